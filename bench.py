@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- merge_path_flat CSR SpMV on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one SpMV y = A x of the workload with inputs resident in HBM and the merge-path
+plan (per-workgroup coordinates) prebuilt -- the region the reference times
+(algorithms/spmv/merge_path_flat.cuh:121-136: its timer starts after the coordinate pre-pass):
+fused merge-tile kernel + carry-out fix-up, and for N > 1 the allgatherv of y.  The time of a
+step WITH the coordinate pre-pass is reported next to it (config.ms_per_step_with_prepass).
+
+Workload at N = 1: BASELINE config C2 -- synthetic power-law CSR, 2^20 rows, 2^24 nnz, max
+degree 2^14, fp32 (SURVEY 8d generator).  At N > 1 (weak scaling): N * 2^20 rows,
+N * 2^24 nnz of the same generator, contiguous row ranges balanced by rows + nnz, one range
+per GPU, x replicated, allgatherv(y) over RCCL every step.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured float4 copy
+
+
+def algorithmic_bytes(rows, cols, nnz, vbytes=4):
+    # nnz * (4 + 4) + (rows + 1) * 4 + rows * 4 + cols * 4 for fp32
+    return nnz * (4 + vbytes) + (rows + 1) * 4 + rows * vbytes + cols * vbytes
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--log2-rows", type=int, default=20, help="rows per GPU = 2^this (C2: 20)")
+    ap.add_argument("--log2-nnz", type=int, default=24, help="nnz per GPU = 2^this (C2: 24)")
+    ap.add_argument("--tile", default="256x8")
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from loops_amd import generate as G, partition as P, spmv as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ------------------------------------------------------------------ workload (synthetic)
+    rows = world << args.log2_rows
+    cols = rows
+    nnz = world << args.log2_nnz
+    t0 = time.time()
+    degrees = G.powerlaw_degrees(rows, nnz)
+    bounds = P.row_ranges_from_degrees(degrees, world)
+    shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
+    off, idx, val = G.csr_from_degrees(degrees[shard.row_begin:shard.row_end], cols, seed=1, row_begin=shard.row_begin)
+    x_h = G.uniform_distribution_int(cols)
+    csr = S.CSR.from_numpy(shard.row_end - shard.row_begin, cols, off, idx, val)
+    x = torch.from_numpy(x_h).cuda()
+    y_full = torch.zeros(rows, dtype=torch.float32, device="cuda")
+    y_loc = y_full[shard.row_begin:shard.row_end]
+    gen_s = time.time() - t0
+    plan = S.MergePathPlan(csr, args.tile)
+    torch.cuda.synchronize()
+
+    def step():
+        S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
+        if world > 1:
+            P.allgatherv_(y_full, shard)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ parity (outside timing)
+    parity = None
+    if not args.no_check:
+        from oracle import oracle as O  # checker only
+        step()
+        torch.cuda.synchronize()
+        ref = O.spmv_f32(off, idx, val, x_h, omp=True)
+        got = y_loc.cpu().numpy()
+        parity = bool(np.array_equal(got, ref))
+        if world > 1:  # the gathered vector: checksum of all ranks' oracle results
+            s = torch.tensor([float(ref.astype(np.float64).sum())], dtype=torch.float64, device="cuda")
+            dist.all_reduce(s)
+            parity = parity and abs(float(y_full.double().sum()) - float(s)) == 0.0
+        assert parity, "GPU result differs from the oracle"
+
+    # ------------------------------------------------------------------ timed region
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    gflops = 2.0 * nnz / (ms_per_step * 1e-3) / 1e9
+
+    # ------------------------------------------------------------------ per-kernel durations (HIP events
+    # on the launch stream = torch's current stream) for the dominant kernel's roofline
+    def event_time(fn, iters):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        return float(np.mean(ts)), float(ts[len(ts) // 2])
+
+    iters = max(20, min(args.steps, 200))
+    k_main_avg, k_main_med = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 0, args.variant), iters)
+    k_fix_avg, _ = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 1, args.variant), iters)
+
+    def with_prepass():
+        plan.refresh(csr)
+        S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
+
+    for _ in range(5):
+        with_prepass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        with_prepass()
+    torch.cuda.synchronize()
+    ms_with_prepass = (time.perf_counter() - t0) / iters * 1e3
+
+    # calibration probes: achievable streaming rate and gather rate on this box
+    n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
+    src = torch.empty(n_copy, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    copy_avg, _ = event_time(lambda: S.stream_copy(src, dst), 20)
+    copy_gbps = 2 * n_copy * 4 / (copy_avg * 1e-3) / 1e9
+    del src, dst
+    gidx = torch.from_numpy(idx[: 1 << 24]).cuda() if idx.size >= 1 << 24 else csr.indices
+    gout = torch.empty(gidx.numel(), dtype=torch.float32, device="cuda")
+    gat_avg, _ = event_time(lambda: S.gather(x, gidx, gout), 20)
+    gather_gps = gidx.numel() / (gat_avg * 1e-3) / 1e9
+
+    loc_rows, loc_nnz = csr.rows, csr.nnzs
+    abytes = algorithmic_bytes(loc_rows, cols, loc_nnz)
+    achieved = abytes / (k_main_avg * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "loops::kernels::merge_path_spmv_fused", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(k_main_avg, 5),
+                "median_launch_ms": round(k_main_med, 5), "fixup_avg_launch_ms": round(k_fix_avg, 5),
+                "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 4),
+                "measured_gather_Gelem_per_s": round(gather_gps, 2)}
+
+    if args.sweep and rank == 0:
+        for tile in ("256x8", "256x7", "128x7", "512x8"):
+            p2 = S.MergePathPlan(csr, tile)
+            for variant in (0, 1, 2, 3):
+                avg, med = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, p2, 0, variant), 50)
+                print(f"[sweep] tile={tile} variant={variant} main kernel avg {avg*1e3:.1f} us med {med*1e3:.1f} us "
+                      f"-> {abytes/avg/1e6:.0f} GB/s", file=sys.stderr)
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        reps1 = 8
+        t0 = time.perf_counter()
+        for _ in range(reps1):
+            O.spmv_f32(off, idx, val, x_h)
+        t1 = (time.perf_counter() - t0) / reps1
+        threads = O.lib().oracle_num_threads()
+        repsn = 16
+        O.spmv_f32(off, idx, val, x_h, omp=True)
+        t0 = time.perf_counter()
+        for _ in range(repsn):
+            O.spmv_f32(off, idx, val, x_h, omp=True)
+        tn = (time.perf_counter() - t0) / repsn
+        cpu = {"value": round(2.0 * loc_nnz / t1 / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+               "sample": f"{reps1} full passes of the same C2 matrix ({loc_rows} rows, {loc_nnz} nnz), "
+                         "oracle/loops_oracle.c oracle_spmv_f32 (restatement of reference::spmv, "
+                         "util/reference.hxx:57-76), gcc -O3 -march=native",
+               "all_cores": {"value": round(2.0 * loc_nnz / tn / 1e9, 3), "cores": int(threads),
+                             "note": "same loop, OpenMP row-parallel schedule(dynamic,1024)"}}
+
+    if rank == 0:
+        out = {
+            "metric": "CSR SpMV GFLOP/s, merge_path_flat", "value": round(gflops, 2), "unit": "GFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic power-law CSR, {rows} rows / {nnz} nnz total "
+                                   f"({world} x 2^{args.log2_rows} rows / 2^{args.log2_nnz} nnz per GPU), max degree 2^14, "
+                                   "fp32, merge_path_flat" + (", row-range sharded + allgatherv(y) over RCCL" if world > 1 else ""),
+                       "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
+                       "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
+                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + allgatherv(y)" if world > 1 else ""),
+                       "ms_per_step_with_prepass": round(ms_with_prepass, 5),
+                       "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
+                       "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,220 @@
+/**
+ * @file csr_spmv.hxx
+ * @brief CSR SpMV kernels written against the public schedule API (raw-pointer interface).
+ *
+ * These are the "a user would write this" kernels: each is a couple of range-for loops over
+ * what a `schedule::setup<...>` hands out.  They double as the executable specification of
+ * the schedules (tests dump their (tile, atom) -> thread assignment and compare it with the
+ * oracle / the reference's device code).  The tuned, atomics-free paths live next door:
+ * merge_path_spmv.hxx (merge_path_flat, work_oriented) and wave_spmv.hxx (group_mapped).
+ *
+ * Kernel semantics follow the reference kernels:
+ *   thread_mapped   algorithms/spmv/thread_mapped.cuh:27-56     y[row] = sum
+ *   original        algorithms/spmv/original.cuh:26-46          y[row] = sum (no schedule)
+ *   merge_path_flat algorithms/spmv/merge_path_flat.cuh:38-83   atomicAdd per nonzero, y pre-zeroed
+ *   work_oriented   algorithms/spmv/work_oriented.cuh:33-89     store / atomicAdd mix, y pre-zeroed
+ *   group_mapped    algorithms/spmv/group_mapped.cuh:27-61      atomicAdd per nonzero, y pre-zeroed
+ *   flat_partitioned algorithms/spmv/flat_partitioned.cuh:46-60 atomicAdd per nonzero, y pre-zeroed
+ */
+#pragma once
+
+#include <cstddef>
+
+#include <hip/hip_runtime.h>
+
+#include <loops/schedule.hxx>
+#include <loops/container/layout.hxx>
+
+namespace loops {
+namespace kernels {
+
+template <typename setup_t, typename index_t, typename offset_t, typename type_t>
+__global__ void thread_mapped_spmv(setup_t config, const std::size_t rows, const std::size_t cols,
+                                   const std::size_t nnz, const offset_t* offsets, const index_t* indices,
+                                   const type_t* values, const type_t* x, type_t* y) {
+  for (auto row : config.tiles()) {
+    type_t sum = 0;
+    for (auto nz : config.atoms(row)) sum += values[nz] * x[indices[nz]];
+    y[row] = sum;
+  }
+}
+
+template <typename index_t, typename offset_t, typename type_t>
+__global__ void original_spmv(const std::size_t rows, const std::size_t cols, const std::size_t nnz,
+                              const offset_t* offsets, const index_t* indices, const type_t* values,
+                              const type_t* x, type_t* y) {
+  for (std::size_t row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
+    type_t sum = 0;
+    for (offset_t nz = offsets[row]; nz < offsets[row + 1]; ++nz) sum += values[nz] * x[indices[nz]];
+    y[row] = sum;
+  }
+}
+
+/// Reference-shaped merge-path kernel through the public schedule (one atomic per nonzero).
+template <std::size_t threads_per_block, std::size_t items_per_thread, typename meta_t, typename index_t,
+          typename offset_t, typename type_t>
+__global__ void __launch_bounds__(int(threads_per_block))
+merge_path_flat_atomic_spmv(meta_t meta, std::size_t rows, std::size_t cols, std::size_t nnz, offset_t* offsets,
+                            index_t* indices, const type_t* values, const type_t* x, type_t* y) {
+  using setup_t = schedule::setup<schedule::algorithms_t::merge_path_flat, threads_per_block, items_per_thread,
+                                  index_t, offset_t, std::size_t, std::size_t>;
+  __shared__ typename setup_t::storage_t temporary_storage;
+  setup_t config(meta, temporary_storage, offsets, rows, nnz);
+  auto map = config.init();
+  if (!config.is_valid_accessor(map)) return;
+#pragma unroll
+  for (auto item : config.virtual_idx()) {
+    auto nz = config.atom_idx(item, map);
+    auto row = config.tile_idx(map);
+    if (config.atoms_counting_it[map.y] < temporary_storage.tile_end_offset[map.x]) {
+      atomicAdd(&(y[row]), values[nz] * x[indices[nz]]);
+      map.y++;
+    } else {
+      map.x++;
+    }
+  }
+}
+
+/// Records which thread the merge_path_flat schedule gives every atom to (test / parity hook).
+template <std::size_t threads_per_block, std::size_t items_per_thread, typename meta_t, typename offset_t>
+__global__ void __launch_bounds__(int(threads_per_block))
+merge_path_flat_dump(meta_t meta, std::size_t rows, std::size_t nnz, offset_t* offsets, unsigned int* thread_start,
+                     int* atom_owner, int* atom_row, int* atom_visits) {
+  using setup_t = schedule::setup<schedule::algorithms_t::merge_path_flat, threads_per_block, items_per_thread, int,
+                                  offset_t, std::size_t, std::size_t>;
+  __shared__ typename setup_t::storage_t temporary_storage;
+  setup_t config(meta, temporary_storage, offsets, rows, nnz);
+  auto map = config.init();
+  if (!config.is_valid_accessor(map)) return;
+  const std::size_t gt = (static_cast<std::size_t>(blockIdx.x) * gridDim.y + blockIdx.y) * threads_per_block + threadIdx.x;
+  thread_start[2 * gt] = map.x;
+  thread_start[2 * gt + 1] = map.y;
+  for (auto item : config.virtual_idx()) {
+    auto nz = config.atom_idx(item, map);
+    auto row = config.tile_idx(map);
+    if (config.atoms_counting_it[map.y] < temporary_storage.tile_end_offset[map.x]) {
+      atom_owner[nz] = static_cast<int>(gt);
+      atom_row[nz] = row;
+      atomicAdd(&atom_visits[nz], 1);
+      map.y++;
+    } else {
+      map.x++;
+    }
+  }
+}
+
+/// Reference-shaped work_oriented kernel (first complete row and the remainder are folded in
+/// atomically, rows owned outright are stored).  y must be zero-filled.
+template <std::size_t threads_per_block, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(threads_per_block)
+work_oriented_atomic_spmv(std::size_t rows, std::size_t cols, std::size_t nnz, offset_t* offsets, index_t* indices,
+                          const type_t* values, const type_t* x, type_t* y) {
+  using setup_t = schedule::setup<schedule::algorithms_t::work_oriented, threads_per_block, 1, index_t, offset_t,
+                                  std::size_t, std::size_t>;
+  setup_t config(offsets, rows, nnz);
+  auto map = config.init();
+  type_t sum = 0;
+  bool first_tile = true;
+  for (auto row : config.tiles(map)) {
+    for (auto nz : config.atoms(row, map)) sum += values[nz] * x[indices[nz]];
+    if (first_tile) {
+      if (sum != 0) atomicAdd(&(y[row]), sum);
+      first_tile = false;
+    } else {
+      y[row] = sum;
+    }
+    sum = 0;
+  }
+  __syncthreads();
+  for (auto row : config.remainder_tiles(map)) {
+    for (auto nz : config.remainder_atoms(map)) sum += values[nz] * x[indices[nz]];
+    if (sum != 0) atomicAdd(&(y[row]), sum);
+  }
+}
+
+template <std::size_t threads_per_block, typename offset_t>
+__global__ void __launch_bounds__(threads_per_block)
+work_oriented_dump(std::size_t rows, std::size_t nnz, offset_t* offsets, int* thread_map, int* atom_owner,
+                   int* atom_row, int* atom_visits) {
+  using setup_t = schedule::setup<schedule::algorithms_t::work_oriented, threads_per_block, 1, int, offset_t,
+                                  std::size_t, std::size_t>;
+  setup_t config(offsets, rows, nnz);
+  auto map = config.init();
+  const int g = threadIdx.x + blockIdx.x * blockDim.x;
+  thread_map[4 * g + 0] = static_cast<int>(map.first.first);
+  thread_map[4 * g + 1] = static_cast<int>(map.first.second);
+  thread_map[4 * g + 2] = static_cast<int>(map.second.first);
+  thread_map[4 * g + 3] = static_cast<int>(map.second.second);
+  for (auto row : config.tiles(map)) {
+    for (auto nz : config.atoms(row, map)) {
+      atom_owner[nz] = g;
+      atom_row[nz] = row;
+      atomicAdd(&atom_visits[nz], 1);
+    }
+  }
+  for (auto row : config.remainder_tiles(map)) {
+    for (auto nz : config.remainder_atoms(map)) {
+      atom_owner[nz] = g;
+      atom_row[nz] = row;
+      atomicAdd(&atom_visits[nz], 1);
+    }
+  }
+}
+
+/// Reference-shaped group_mapped kernel (block_mapped: the workgroup is the group).
+template <std::size_t threads_per_block, std::size_t threads_per_tile, typename index_t, typename offset_t,
+          typename type_t>
+__global__ void __launch_bounds__(threads_per_block)
+group_mapped_atomic_spmv(std::size_t rows, std::size_t cols, std::size_t nnz, offset_t* offsets, index_t* indices,
+                         const type_t* values, const type_t* x, type_t* y) {
+  using setup_t = schedule::setup<schedule::algorithms_t::group_mapped, threads_per_block, threads_per_tile, index_t,
+                                  offset_t>;
+  __shared__ typename setup_t::storage_t temporary_storage;
+  setup_t config(temporary_storage, offsets, rows, nnz);
+  auto p = config.partition();
+  for (auto virtual_atom : config.atom_accessor(p)) {
+    auto virtual_tile = config.tile_accessor(virtual_atom, p);
+    if (!(config.is_valid_accessor(virtual_tile, p))) continue;
+    auto row = config.tile_id(virtual_tile, p);
+    auto nz_idx = config.atom_id(virtual_atom, row, virtual_tile, p);
+    atomicAdd(&(y[row]), values[nz_idx] * x[indices[nz_idx]]);
+  }
+}
+
+template <std::size_t threads_per_block, std::size_t threads_per_tile, typename offset_t>
+__global__ void __launch_bounds__(threads_per_block)
+group_mapped_dump(std::size_t rows, std::size_t nnz, offset_t* offsets, int* atom_owner, int* atom_row,
+                  int* atom_visits) {
+  using setup_t = schedule::setup<schedule::algorithms_t::group_mapped, threads_per_block, threads_per_tile, int,
+                                  offset_t>;
+  __shared__ typename setup_t::storage_t temporary_storage;
+  setup_t config(temporary_storage, offsets, rows, nnz);
+  auto p = config.partition();
+  for (auto virtual_atom : config.atom_accessor(p)) {
+    auto virtual_tile = config.tile_accessor(virtual_atom, p);
+    if (!(config.is_valid_accessor(virtual_tile, p))) continue;
+    auto row = config.tile_id(virtual_tile, p);
+    auto nz_idx = config.atom_id(virtual_atom, row, virtual_tile, p);
+    atom_owner[nz_idx] = static_cast<int>(p.grid_rank());
+    atom_row[nz_idx] = row;
+    atomicAdd(&atom_visits[nz_idx], 1);
+  }
+}
+
+/// thread_mapped over flat_uniform_occupancy<K, csr>: perfectly balanced K-atom tiles, the
+/// original row of every atom recovered with base().tile_of (y must be zero-filled).
+template <typename setup_t, typename index_t, typename type_t>
+__global__ void flat_partitioned_spmv(setup_t config, const index_t* indices, const type_t* values, const type_t* x,
+                                      type_t* y) {
+  const auto& part = config.layout();
+  const auto& base = part.base();
+  for (auto chunk : config.tiles()) {
+    for (auto nz : config.atoms(chunk)) {
+      const auto row = base.tile_of(nz);
+      atomicAdd(&y[row], values[nz] * x[indices[nz]]);
+    }
+  }
+}
+
+}  // namespace kernels
+}  // namespace loops

@@ -1,0 +1,302 @@
+/**
+ * @file merge_path_spmv.hxx
+ * @brief The headline kernel: fused merge-path CSR SpMV for CDNA4 (gfx950, 64-lane wavefronts).
+ *
+ * Same decomposition as `schedule::setup<merge_path_flat, TPB, IPT>` -- workgroup b owns merge
+ * tile b = diagonals [b*TPB*IPT, (b+1)*TPB*IPT) of the (row-ends, nonzeros) merge path and
+ * thread t owns IPT consecutive merge items of it, i.e. the SAME (tile, atom) -> (workgroup,
+ * thread) assignment the reference's schedule hands out (schedule/merge_path_flat.hxx:267-335,
+ * algorithms/spmv/merge_path_flat.cuh:71-82) -- but the per-nonzero global atomicAdd of the
+ * reference kernel is gone:
+ *
+ *  1. STREAM   the tile's col_idx / values are read from HBM once, coalesced, 16 bytes per lane
+ *              (global_load_dwordx4 from a 16-byte aligned base), x is gathered through L2 /
+ *              Infinity Cache, and the products land in LDS (2048 x 4 B per workgroup).
+ *              Row-end offsets of the tile are staged in LDS next to them.
+ *  2. SPLIT    each thread finds its start on the merge path with a halving search over the
+ *              LDS-resident row ends (<= 11 LDS probes).
+ *  3. WALK     IPT merge steps per thread out of LDS: accumulate in a register, store y[row]
+ *              directly for every row that both starts and ends inside the thread.
+ *  4. STITCH   partial rows crossing thread boundaries are combined with a 6-step 64-lane
+ *              segmented prefix sum (wave::segmented_inclusive_sum), wavefronts are stitched
+ *              through 4 LDS words, and the one partial row leaving the workgroup goes to a
+ *              {row, value} carry-out slot.
+ *  5. FIX-UP   a tiny second kernel adds the carry-outs to y (rows longer than a merge tile
+ *              span several workgroups: max degree 2^14 vs 2048-item tiles).
+ *
+ * y needs NO zero-fill: every row is stored exactly once by the thread that consumes its
+ * row-end item; the summation order is deterministic (no floating-point atomics).
+ *
+ * HBM traffic per merge tile: natoms * (4 + sizeof(T)) streamed + (nrows + IPT) * 4 row ends +
+ * nrows * sizeof(T) stores (+ 8 B coordinates, + 12 B carry-out) -- the algorithmic minimum of
+ * SURVEY 8(d) plus ~1 %; x is served by L2 / MALL.
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+#include <loops/container/coordinate.hxx>
+#include <loops/util/math.hxx>
+#include <loops/util/wave.hxx>
+
+namespace loops {
+namespace kernels {
+
+using coord_t = coordinate_t<unsigned int>;
+
+namespace detail {
+
+/// 16-byte (4 x 32-bit) or 2 x 16-byte (4 x 64-bit) vector load of 4 consecutive elements.
+template <typename T, bool NT>
+__device__ __forceinline__ void load4(const T* __restrict__ p, T (&out)[4]) {
+  if constexpr (sizeof(T) == 4) {
+    using v4 = __attribute__((__vector_size__(4 * sizeof(int)))) int;
+    v4 v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+    else v = *reinterpret_cast<const v4*>(p);
+    out[0] = __builtin_bit_cast(T, v[0]);
+    out[1] = __builtin_bit_cast(T, v[1]);
+    out[2] = __builtin_bit_cast(T, v[2]);
+    out[3] = __builtin_bit_cast(T, v[3]);
+  } else {
+    static_assert(sizeof(T) == 8, "load4: 4- or 8-byte elements");
+    using v2 = __attribute__((__vector_size__(2 * sizeof(long long)))) long long;
+    v2 a, b;
+    if constexpr (NT) {
+      a = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
+      b = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p) + 1);
+    } else {
+      a = *reinterpret_cast<const v2*>(p);
+      b = *(reinterpret_cast<const v2*>(p) + 1);
+    }
+    out[0] = __builtin_bit_cast(T, a[0]);
+    out[1] = __builtin_bit_cast(T, a[1]);
+    out[2] = __builtin_bit_cast(T, b[0]);
+    out[3] = __builtin_bit_cast(T, b[1]);
+  }
+}
+
+/// LDS index of product slot i.  With PAD one word of padding every 32 slots turns the
+/// stride-IPT (IPT = 8) per-thread walk into a conflict-free ds_read_b32 pattern.
+template <bool PAD>
+__device__ __forceinline__ int slot(int i) {
+  if constexpr (PAD) return i + (i >> 5);
+  else return i;
+}
+
+}  // namespace detail
+
+/// coord[i] = merge-path split at diagonal i * tile_items, i in [0, M]  (one lane each).
+template <typename offset_t>
+__global__ void merge_path_coordinates(const offset_t* __restrict__ offsets, int rows, int nnz, int tile_items,
+                                       int num_merge_tiles, coord_t* __restrict__ coords) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > num_merge_tiles) return;
+  const long long dl = static_cast<long long>(i) * tile_items;
+  const int d = static_cast<int>(dl);  // int, like the reference (search.hxx:46-47)
+  const offset_t* a = offsets + 1;
+  int lo = d - nnz > 0 ? d - nnz : 0;
+  int count = (d < rows ? d : rows) - lo;
+  while (count > 0) {
+    const int half = count >> 1;
+    const int mid = lo + half;
+    if (a[mid] <= d - mid - 1) {
+      lo = mid + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  coords[i] = coord_t{static_cast<unsigned int>(lo < rows ? lo : rows), static_cast<unsigned int>(d - lo)};
+}
+
+/**
+ * Fused merge-path SpMV, one merge tile per workgroup.
+ * @tparam TPB threads per workgroup (multiple of 64), IPT merge items per thread.
+ * @tparam PAD  pad the LDS product array (conflict-free walk for even IPT).
+ * @tparam NT   stream col_idx / values with non-temporal loads (keeps x resident in L2).
+ * Requires: `indices` and `values` 16-byte aligned (checked by the host launcher; the
+ * unaligned case uses VEC = false).
+ */
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                      const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                      const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                      int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
+  constexpr int TILE = TPB * IPT;
+  constexpr int WAVES = TPB / wave::size;
+  constexpr int NPROD = TILE + 4;                      // + alignment slack (abase <= c0.y)
+  constexpr int KV = (NPROD + 4 * TPB - 1) / (4 * TPB);  // vector-load rounds per thread
+
+  __shared__ type_t s_prod[PAD ? NPROD + (NPROD >> 5) + 1 : NPROD];
+  __shared__ offset_t s_re[TILE + IPT + 1];
+  __shared__ type_t s_wave_val[WAVES];
+  __shared__ int s_wave_head[WAVES];
+
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+
+  // ---- tile coordinates (wave-uniform: scalar loads) -------------------------------------
+  const coord_t c0 = coords[b];
+  const coord_t c1 = coords[b + 1];
+  const int row0 = static_cast<int>(c0.x);
+  const int nz0 = static_cast<int>(c0.y);
+  const int nz1 = static_cast<int>(c1.y);
+  const int nrows = static_cast<int>(c1.x) - row0;
+  const int natoms = nz1 - nz0;
+
+  // ---- 1. STREAM --------------------------------------------------------------------------
+  // Row ends first (they are short and the SPLIT phase needs them right after the barrier).
+  for (int i = tid; i < nrows + IPT; i += TPB) {
+    int r = row0 + i;
+    r = r < rows - 1 ? r : rows - 1;
+    s_re[i] = offsets[r + 1];
+  }
+
+  const int abase = VEC ? (nz0 & ~3) : nz0;  // 16-byte aligned element base of the tile
+  const int shift = nz0 - abase;             // 0..3 leading elements that belong to tile b-1
+
+  if constexpr (VEC) {
+    const bool interior = abase + KV * 4 * TPB <= nnz;  // every vector load in-bounds (block-uniform)
+    index_t col[KV][4];
+    type_t val[KV][4];
+    bool live[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const int e = abase + (k * TPB + tid) * 4;
+      live[k] = e < nz1;
+      if (live[k]) {
+        if (interior || e + 3 < nnz) {
+          detail::load4<index_t, NT>(indices + e, col[k]);
+          detail::load4<type_t, NT>(values + e, val[k]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = e + j < nnz;
+            col[k][j] = ok ? indices[e + j] : index_t(0);
+            val[k][j] = ok ? values[e + j] : type_t(0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      if (live[k]) {
+        type_t xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = x[col[k][j]];
+        const int i = (k * TPB + tid) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[j];
+      }
+    }
+  } else {
+    // Unaligned arrays: coalesced 4-byte loads, one element per lane per round.
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const int i = k * TPB + tid;
+      if (i < natoms) {
+        const int e = nz0 + i;
+        s_prod[detail::slot<PAD>(i)] = values[e] * x[indices[e]];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. SPLIT: this thread's start on the merge path (search.hxx semantics, in LDS) ------
+  const int total = nrows + natoms;  // == TILE except in the last merge tile
+  const int diag = tid * IPT;
+  int tx, ty;
+  {
+    int lo = diag - natoms > 0 ? diag - natoms : 0;
+    int count = (diag < nrows ? diag : nrows) - lo;
+    while (count > 0) {
+      const int half = count >> 1;
+      const int mid = lo + half;
+      if (s_re[mid] <= nz0 + (diag - mid - 1)) {
+        lo = mid + 1;
+        count -= half + 1;
+      } else {
+        count = half;
+      }
+    }
+    tx = lo < nrows ? lo : nrows;
+    ty = diag - lo;
+  }
+
+  // ---- 3. WALK: IPT merge steps out of LDS ----------------------------------------------------
+  type_t sum = type_t(0);
+  type_t first_sum = type_t(0);
+  int first_row = 0;
+  bool closed = false;
+  int re = s_re[tx];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    if (diag + j < total) {
+      if (nz0 + ty < re) {  // merge step consumes a nonzero
+        sum += s_prod[detail::slot<PAD>(ty + shift)];
+        ++ty;
+      } else {  // merge step consumes a row end: row (row0 + tx) is complete
+        if (!closed) {
+          first_sum = sum;
+          first_row = tx;
+          closed = true;
+        } else {
+          y[row0 + tx] = sum;
+        }
+        sum = type_t(0);
+        ++tx;
+        re = s_re[tx];
+      }
+    }
+  }
+
+  // ---- 4. STITCH: partial rows across threads / wavefronts / workgroups -------------------------
+  const int lane = wave::lane();
+  const int w = tid / wave::size;
+  type_t run = sum;      // tail partial (row row0 + tx, still open)
+  bool head = closed;    // a thread that closed a row starts a new segment with its tail
+  wave::segmented_inclusive_sum(run, head);
+  type_t prev_run = __shfl_up(run, 1);
+  int prev_head = __shfl_up(static_cast<int>(head), 1);
+  if (lane == 0) {
+    prev_run = type_t(0);
+    prev_head = 0;
+  }
+  if (lane == wave::size - 1) {
+    s_wave_val[w] = run;
+    s_wave_head[w] = head ? 1 : 0;
+  }
+  __syncthreads();
+  type_t wave_in = type_t(0);  // open partial entering this wavefront from earlier ones
+  for (int i = w - 1; i >= 0; --i) {
+    wave_in += s_wave_val[i];
+    if (s_wave_head[i]) break;
+  }
+  if (closed) y[row0 + first_row] = first_sum + prev_run + (prev_head ? type_t(0) : wave_in);
+  if (tid == TPB - 1) {
+    carry_row[b] = row0 + tx;  // == c1.x: the row still open when the tile ends
+    carry_val[b] = run + (head ? type_t(0) : wave_in);
+  }
+}
+
+/// y[row] += sum of the carry-outs of the run of merge tiles that ended inside `row`.
+template <typename type_t>
+__global__ void merge_path_spmv_fixup(const int* __restrict__ carry_row, const type_t* __restrict__ carry_val,
+                                      int num_merge_tiles, int rows, type_t* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num_merge_tiles) return;
+  const int r = carry_row[i];
+  if (r >= rows) return;
+  if (i > 0 && carry_row[i - 1] == r) return;  // not the first tile of the run
+  type_t s = carry_val[i];
+  for (int j = i + 1; j < num_merge_tiles && carry_row[j] == r; ++j) s += carry_val[j];
+  y[r] += s;
+}
+
+}  // namespace kernels
+}  // namespace loops

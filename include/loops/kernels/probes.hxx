@@ -1,0 +1,55 @@
+/**
+ * @file probes.hxx
+ * @brief Two measurement kernels that calibrate the roofline on the box the SpMV runs on:
+ * a 16-byte-per-lane streaming copy (achievable HBM rate; the guide's 6.3 TB/s figure) and a
+ * 4-byte random gather (the L2 / Infinity-Cache request rate that bounds x[col] reads).
+ */
+#pragma once
+
+#include <cstddef>
+
+#include <hip/hip_runtime.h>
+
+namespace loops {
+namespace kernels {
+
+__global__ void __launch_bounds__(256) stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                          size_t n4) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(256) gather_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                                     float* __restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
+  for (size_t i = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i + 3 < n; i += stride) {
+    const int4 c = *reinterpret_cast<const int4*>(idx + i);
+    float4 v;
+    v.x = table[c.x];
+    v.y = table[c.y];
+    v.z = table[c.z];
+    v.w = table[c.w];
+    *reinterpret_cast<float4*>(out + i) = v;
+  }
+}
+
+inline int launch_stream_copy(hipStream_t stream, const float* src, float* dst, size_t n) {
+  const size_t n4 = n / 4;
+  if (n4 == 0) return 0;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
+  return static_cast<int>(hipGetLastError());
+}
+
+inline int launch_gather(hipStream_t stream, const float* table, const int* idx, float* out, size_t n) {
+  if (n < 4) return 0;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+  hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, table, idx, out, n);
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace kernels
+}  // namespace loops

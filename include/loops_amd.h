@@ -1,0 +1,150 @@
+/*
+ * loops_amd.h -- C ABI of libloops_amd.so: the drop-in boundary of the MI355X-native
+ * load-balanced CSR SpMV path (gunrock/loops hot path), for hosts that cannot consume the
+ * C++ header API in include/loops/ directly (ctypes, cgo, JNI, N-API, ...).
+ *
+ * The reference has no C ABI: its boundary is the header-only C++ template API
+ * (SURVEY 8b).  Every entry point below is a thin wrapper over the corresponding C++
+ * template in include/loops/ instantiated for index_t = offset_t = int and
+ * type_t = float | double -- the instantiation all reference examples use
+ * (examples/spmv/merge_path.cu:18-20).  The reference interface each one replaces is cited
+ * as file:line under the reference tree.
+ *
+ * Conventions: all array pointers are DEVICE pointers unless the name starts with `h_`;
+ * `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous
+ * on `stream` unless stated otherwise; the return value is 0 on success, a hipError_t (> 0)
+ * from the runtime, or a negative LOOPS_E_* argument error.  No entry point falls back to a
+ * CPU implementation.
+ */
+#ifndef LOOPS_AMD_H_
+#define LOOPS_AMD_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOOPS_E_BADARG (-1)   /* null pointer / negative size / unknown enum value        */
+#define LOOPS_E_RANGE (-2)    /* rows + nnz does not fit the int search arithmetic (2^31) */
+#define LOOPS_E_CONFIG (-3)   /* tile configuration not compiled into the library         */
+
+/* schedule::algorithms_t (include/loops/schedule.hxx:26-32) + the two non-schedule kernels */
+enum loops_schedule {
+  LOOPS_MERGE_PATH_FLAT = 0,
+  LOOPS_WORK_ORIENTED = 1,
+  LOOPS_THREAD_MAPPED = 2,
+  LOOPS_GROUP_MAPPED = 3,
+  LOOPS_ORIGINAL = 4,        /* algorithms/spmv/original.cuh:26-46          */
+  LOOPS_FLAT_PARTITIONED = 5 /* algorithms/spmv/flat_partitioned.cuh:46-110 */
+};
+
+/* Compiled (threads-per-block, items-per-thread) merge-tile shapes.  LOOPS_TILE_DEFAULT is
+ * the gfx950 launch box (algorithms/spmv/launch_box.hxx:75-77 in the reference: 256 x 8). */
+enum loops_tile_config {
+  LOOPS_TILE_256x8 = 0,
+  LOOPS_TILE_128x7 = 1, /* the reference's NVIDIA / fallback box, launch_box.hxx:63-90 */
+  LOOPS_TILE_4x2 = 2,   /* tiny: lets small fixtures span many merge tiles             */
+  LOOPS_TILE_256x7 = 3,
+  LOOPS_TILE_512x8 = 4,
+  LOOPS_TILE_DEFAULT = 0
+};
+
+/* ---- library / device ------------------------------------------------------------------ */
+const char* loops_version(void);                 /* "0.2.0-mi355x" (CMakeLists.txt:41: 0.2.0) */
+int loops_device_compute_units(int* out);        /* util/device.hxx:93-108 multi_processor_count */
+
+/* ---- merge-path plan ---------------------------------------------------------------------
+ * Replaces schedule::merge_path::preprocess_t (schedule/merge_path_flat.hxx:99-172) and its
+ * pre-pass kernel generate_search_coordinates (:45-76).  A plan holds the M + 1 per-workgroup
+ * start coordinates for (offsets, rows, nnz, tile shape) and the carry-out scratch of the
+ * fused kernel; it depends on the sparsity structure only and may be reused for any number
+ * of SpMVs with the same offsets array. */
+typedef struct loops_merge_plan loops_merge_plan_t;
+
+int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_config, void* stream,
+                            loops_merge_plan_t** out);
+int loops_merge_plan_destroy(loops_merge_plan_t* plan);
+/* Recompute the coordinates on `stream` (what constructing a new preprocess_t does). */
+int loops_merge_plan_refresh(loops_merge_plan_t* plan, const int* offsets, void* stream);
+int loops_merge_plan_num_tiles(const loops_merge_plan_t* plan);
+/* Synchronous copy of the 2 * (M + 1) unsigned coordinates {x0, y0, x1, y1, ...} to the host. */
+int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
+
+/* ---- CSR SpMV, tuned paths: y = A * x  (y need not be initialised) --------------------------
+ * Replaces algorithms::spmv::{merge_path_flat, work_oriented, thread_mapped, group_mapped,
+ * original, flat_partitioned}(csr, x, y, stream)
+ *   (algorithms/spmv/merge_path_flat.cuh:97-139, work_oriented.cuh:103-121,
+ *    thread_mapped.cuh:70-91, group_mapped.cuh:72-105, original.cuh:58-75,
+ *    flat_partitioned.cuh:70-110).
+ * Unlike the reference wrappers these do NOT block on the stream. */
+int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const float* values, const float* x, float* y, void* stream);
+int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const double* values, const double* x, double* y, void* stream);
+
+/* merge_path_flat with a prebuilt plan: exactly the region the reference times
+ * (merge_path_flat.cuh:121-136 starts its timer after the pre-pass).  `variant` selects a
+ * compiled code variant of the fused kernel (0 = default). */
+int loops_spmv_merge_path_f32(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
+                              const int* offsets, const int* indices, const float* values, const float* x,
+                              float* y, void* stream);
+int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
+                              const int* offsets, const int* indices, const double* values, const double* x,
+                              double* y, void* stream);
+
+/* The two kernels of loops_spmv_merge_path_f32 one at a time, so a harness can bracket each with
+ * its own hipEvents: stage 0 = fused merge-tile kernel (writes y and the carry-outs),
+ * stage 1 = carry-out fix-up.  Running stage 0 then stage 1 == loops_spmv_merge_path_f32. */
+int loops_spmv_merge_path_stage_f32(const loops_merge_plan_t* plan, int variant, int stage, int rows, int cols,
+                                    int nnz, const int* offsets, const int* indices, const float* values,
+                                    const float* x, float* y, void* stream);
+
+/* ---- CSR SpMV through the public schedule API (reference-shaped kernels) --------------------
+ * The kernels a user of schedule::setup<> would write (and the reference ships): one global
+ * atomicAdd per nonzero for merge_path_flat / group_mapped / flat_partitioned, store+atomic mix
+ * for work_oriented.  y MUST be zero-filled by the caller for every schedule except
+ * thread_mapped / original (flat_partitioned.cuh:95-97).  `tile_config` applies to
+ * merge_path_flat only. */
+int loops_spmv_csr_schedule_api_f32(int schedule, int tile_config, int rows, int cols, int nnz,
+                                    const int* offsets, const int* indices, const float* values,
+                                    const float* x, float* y, void* stream);
+
+/* ---- schedule introspection (parity hooks) ---------------------------------------------------
+ * Run a schedule and record what it hands out; outputs are device arrays.
+ *   thread_start : 2 * M * TPB unsigned, the per-thread LOCAL start coordinates
+ *                  (schedule/merge_path_flat.hxx:328-330)
+ *   thread_map   : 4 * grid * 256 ints {st.tile, st.atom, en.tile, en.atom}
+ *                  (schedule/work_oriented.hxx:93-114)
+ *   atom_owner / atom_row / atom_visits : nnz ints (global thread id that visits the atom, the
+ *                  tile it is attributed to, visit count -- visits must be zero-filled). */
+int loops_schedule_dump_merge_path(int tile_config, int use_plan, int rows, int nnz, const int* offsets,
+                                   unsigned* thread_start, int* atom_owner, int* atom_row, int* atom_visits,
+                                   void* stream);
+int loops_schedule_dump_work_oriented(int grid_blocks, int rows, int nnz, const int* offsets, int* thread_map,
+                                      int* atom_owner, int* atom_row, int* atom_visits, void* stream);
+int loops_schedule_dump_group_mapped(int group_size /* 64 or 256 */, int rows, int nnz, const int* offsets,
+                                     int* atom_owner, int* atom_row, int* atom_visits, void* stream);
+/* Grid algorithms::spmv::work_oriented launches: occupancy x CUs (util/launch_box.hxx:228-239). */
+int loops_work_oriented_grid(int* out_blocks);
+
+/* ---- BCSR SpMV (R x C dense blocks), thread-per-block-row and the MFMA path -------------------
+ * Replaces algorithms::spmv::bcsr_thread_mapped<R, C> (algorithms/spmv/bcsr_thread_mapped.cuh:91-123).
+ * x must be padded to num_block_cols * C; rows of y >= `rows` are not written.
+ * mode 0: register accumulation (any of 2x2, 3x3, 4x4); mode 1: MFMA 4x4x1 block inner product
+ * (4x4 only). */
+int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
+                        const int* block_offsets, const int* block_cols, const float* block_values,
+                        const float* x_padded, float* y, void* stream);
+
+/* ---- device-side measurement helpers ---------------------------------------------------------- */
+/* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
+ * roofline fraction is also quoted against. */
+int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
+/* out[i] = table[idx[i]] -- measures the L2 / Infinity-Cache gather rate that bounds x reads. */
+int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOOPS_AMD_H_ */

@@ -1,0 +1,102 @@
+"""ctypes binding of libloops_amd.so -- the C ABI declared in include/loops_amd.h.
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is no CPU
+fallback anywhere in this package: if the shared library is missing, or a kernel cannot be
+launched, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libloops_amd.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "loops_c_abi.hip")
+INCLUDE_DIR = os.path.join(_ROOT, "include")
+
+# enum loops_schedule (include/loops_amd.h)
+MERGE_PATH_FLAT, WORK_ORIENTED, THREAD_MAPPED, GROUP_MAPPED, ORIGINAL, FLAT_PARTITIONED = range(6)
+SCHEDULES = {
+    "merge_path_flat": MERGE_PATH_FLAT, "work_oriented": WORK_ORIENTED, "thread_mapped": THREAD_MAPPED,
+    "group_mapped": GROUP_MAPPED, "original": ORIGINAL, "flat_partitioned": FLAT_PARTITIONED,
+}
+# enum loops_tile_config: name -> (id, threads per block, items per thread)
+TILES = {"256x8": (0, 256, 8), "128x7": (1, 128, 7), "4x2": (2, 4, 2), "256x7": (3, 256, 7), "512x8": (4, 512, 8)}
+
+# every symbol include/loops_amd.h declares (tests/test_c_abi.py checks the export table)
+SYMBOLS = [
+    "loops_version", "loops_device_compute_units",
+    "loops_merge_plan_create", "loops_merge_plan_destroy", "loops_merge_plan_refresh",
+    "loops_merge_plan_num_tiles", "loops_merge_plan_coords",
+    "loops_spmv_csr_f32", "loops_spmv_csr_f64", "loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64",
+    "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
+    "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
+    "loops_work_oriented_grid", "loops_spmv_bcsr_f32", "loops_stream_copy_f32", "loops_gather_f32",
+]
+
+
+class LoopsError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libloops_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    deps = [SRC_PATH]
+    for base, _, files in os.walk(INCLUDE_DIR):
+        deps += [os.path.join(base, f) for f in files]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DLOOPS_TARGET_GFX=0x950",
+           "-I" + INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises LoopsError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LoopsError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.loops_version.restype = C.c_char_p
+        vp, ci = C.c_void_p, C.c_int
+        L.loops_merge_plan_create.argtypes = [ci, ci, vp, ci, vp, C.POINTER(vp)]
+        L.loops_merge_plan_destroy.argtypes = [vp]
+        L.loops_merge_plan_refresh.argtypes = [vp, vp, vp]
+        L.loops_merge_plan_num_tiles.argtypes = [vp]
+        L.loops_merge_plan_coords.argtypes = [vp, vp]
+        for name in ("loops_spmv_csr_f32", "loops_spmv_csr_f64"):
+            getattr(L, name).argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        for name in ("loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64"):
+            getattr(L, name).argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_spmv_merge_path_stage_f32.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_spmv_csr_schedule_api_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_schedule_dump_merge_path.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_schedule_dump_work_oriented.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_schedule_dump_group_mapped.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp]
+        L.loops_work_oriented_grid.argtypes = [C.POINTER(ci)]
+        L.loops_device_compute_units.argtypes = [C.POINTER(ci)]
+        L.loops_spmv_bcsr_f32.argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
+        L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        _lib = L
+    return _lib
+
+
+_ERRORS = {-1: "LOOPS_E_BADARG", -2: "LOOPS_E_RANGE (rows + nnz must stay below 2^31)", -3: "LOOPS_E_CONFIG"}
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise LoopsError(f"{what} failed: {_ERRORS.get(code, 'hipError_t ' + str(code))}")

@@ -1,0 +1,464 @@
+// loops_c_abi.hip -- extern "C" surface of libloops_amd.so (declared in include/loops_amd.h).
+//
+// Thin wrappers: every entry point instantiates the C++ templates of include/loops/ for
+// index_t = offset_t = int, type_t = float | double and launches them on the caller's
+// stream.  No CPU fallbacks live here: if a kernel cannot be launched the hipError_t is
+// returned.  Built by __graft_entry__.build() with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude loops_c_abi.hip
+#include <loops_amd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <limits>
+#include <new>
+
+#include <hip/hip_runtime.h>
+
+#include <loops/schedule.hxx>
+#include <loops/util/launch.hxx>
+#include <loops/util/launch_box.hxx>
+#include <loops/util/math.hxx>
+#include <loops/kernels/csr_spmv.hxx>
+#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/kernels/bcsr_spmv.hxx>
+#include <loops/kernels/probes.hxx>
+
+using namespace loops;
+using kernels::coord_t;
+
+namespace {
+
+constexpr int kSpmvBlock = 256;  // launch_t<T>::block_size on gfx950 (launch_box.hxx:75-77)
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+inline int last_error() { return static_cast<int>(hipGetLastError()); }
+
+struct tile_shape {
+  int tpb, ipt;
+};
+inline bool shape_of(int cfg, tile_shape* s) {
+  switch (cfg) {
+    case LOOPS_TILE_256x8: *s = {256, 8}; return true;
+    case LOOPS_TILE_128x7: *s = {128, 7}; return true;
+    case LOOPS_TILE_4x2: *s = {4, 2}; return true;
+    case LOOPS_TILE_256x7: *s = {256, 7}; return true;
+    case LOOPS_TILE_512x8: *s = {512, 8}; return true;
+    default: return false;
+  }
+}
+
+inline int check_csr(int rows, int cols, int nnz, const void* off, const void* idx, const void* val, const void* x,
+                     const void* y) {
+  if (rows < 0 || cols < 0 || nnz < 0) return LOOPS_E_BADARG;
+  if (!off || !y || (nnz > 0 && (!idx || !val || !x))) return LOOPS_E_BADARG;
+  if (static_cast<long long>(rows) + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ plan
+struct loops_merge_plan {
+  int rows, nnz, cfg, tpb, ipt, num_tiles;
+  int capacity;        // merge tiles the allocation can hold (>= num_tiles)
+  coord_t* coords;     // M + 1
+  double* carry_val;   // M + 2 (8 B slots: float or double)
+  int* carry_row;      // M + 2
+  void* base;
+};
+
+namespace {
+
+int plan_compute(loops_merge_plan* p, const int* offsets, hipStream_t stream) {
+  const int n = p->num_tiles + 1;
+  hipLaunchKernelGGL(kernels::merge_path_coordinates<int>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream,
+                     offsets, p->rows, p->nnz, p->tpb * p->ipt, p->num_tiles, p->coords);
+  return last_error();
+}
+
+int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
+  tile_shape s;
+  if (!shape_of(cfg, &s)) return LOOPS_E_CONFIG;
+  if (rows < 0 || nnz < 0) return LOOPS_E_BADARG;
+  if (static_cast<long long>(rows) + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  auto* p = new (std::nothrow) loops_merge_plan();
+  if (!p) return static_cast<int>(hipErrorOutOfMemory);
+  p->rows = rows; p->nnz = nnz; p->cfg = cfg; p->tpb = s.tpb; p->ipt = s.ipt;
+  p->num_tiles = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(s.tpb) * s.ipt));
+  p->capacity = p->num_tiles;
+  const size_t m = static_cast<size_t>(p->num_tiles);
+  const size_t bytes = (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int));
+  hipError_t e = hipMalloc(&p->base, bytes);
+  if (e != hipSuccess) { delete p; return static_cast<int>(e); }
+  p->coords = static_cast<coord_t*>(p->base);
+  p->carry_val = reinterpret_cast<double*>(p->coords + (m + 1));
+  p->carry_row = reinterpret_cast<int*>(p->carry_val + (m + 2));
+  *out = p;
+  return 0;
+}
+
+// One lazily grown scratch plan per (host thread, tile config) for the plan-less entry points:
+// they rebuild the coordinates on every call, exactly like the reference wrapper constructs a
+// preprocess_t per call (merge_path_flat.cuh:111-114), but without a hipMalloc per call.
+loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
+  thread_local loops_merge_plan* cache[8] = {};
+  loops_merge_plan*& p = cache[cfg];
+  tile_shape s;
+  if (!shape_of(cfg, &s)) { *err = LOOPS_E_CONFIG; return nullptr; }
+  const int need = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(s.tpb) * s.ipt));
+  if (p && p->capacity < need) { (void)hipFree(p->base); delete p; p = nullptr; }
+  if (!p) {
+    *err = plan_alloc(rows, nnz, cfg, &p);
+    if (*err) return nullptr;
+  }
+  // re-target the (possibly larger) allocation at this problem; the array bases were laid out
+  // for `capacity` tiles and stay put
+  p->rows = rows; p->nnz = nnz; p->num_tiles = need;
+  return p;
+}
+
+// ------------------------------------------------------------------------- fused merge path
+// stages: bit 0 = fused tile kernel, bit 1 = fix-up (3 = the whole SpMV)
+template <int TPB, int IPT, bool PAD, bool NT, typename T>
+int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, const int* off, const int* idx,
+                 const T* val, const T* x, T* y, hipStream_t stream, int stages) {
+  if (num_tiles == 0) return 0;
+  T* carry_val = reinterpret_cast<T*>(p->carry_val);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(val)) & 15u) == 0;
+  if (!(stages & 1)) {
+  } else if (aligned)
+    hipLaunchKernelGGL((kernels::merge_path_spmv_fused<TPB, IPT, PAD, NT, true, int, int, T>), dim3(num_tiles),
+                       dim3(TPB), 0, stream, p->coords, rows, nnz, off, idx, val, x, y, p->carry_row, carry_val);
+  else
+    hipLaunchKernelGGL((kernels::merge_path_spmv_fused<TPB, IPT, PAD, NT, false, int, int, T>), dim3(num_tiles),
+                       dim3(TPB), 0, stream, p->coords, rows, nnz, off, idx, val, x, y, p->carry_row, carry_val);
+  if (stages & 2)
+    hipLaunchKernelGGL(kernels::merge_path_spmv_fixup<T>, dim3(math::ceil_div(num_tiles, 256)), dim3(256), 0, stream,
+                       p->carry_row, carry_val, num_tiles, rows, y);
+  return last_error();
+}
+
+template <typename T>
+int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, const int* off, const int* idx,
+                    const T* val, const T* x, T* y, hipStream_t stream, int stages = 3) {
+  const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(p->tpb) * p->ipt));
+  if (rows != p->rows || nnz != p->nnz) return LOOPS_E_BADARG;
+  // variant: bit 0 = non-temporal streaming loads, bit 1 = unpadded LDS product array
+  const bool nt = variant & 1, nopad = variant & 2;
+#define LOOPS_FUSED(TPB, IPT)                                                                                    \
+  if (!nopad && !nt) return launch_fused<TPB, IPT, true, false, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
+  if (!nopad && nt) return launch_fused<TPB, IPT, true, true, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages);   \
+  if (nopad && !nt) return launch_fused<TPB, IPT, false, false, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
+  return launch_fused<TPB, IPT, false, true, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages);
+  switch (p->cfg) {
+    case LOOPS_TILE_256x8: { LOOPS_FUSED(256, 8) }
+    case LOOPS_TILE_128x7: { LOOPS_FUSED(128, 7) }
+    case LOOPS_TILE_256x7: { LOOPS_FUSED(256, 7) }
+    case LOOPS_TILE_512x8: { LOOPS_FUSED(512, 8) }
+    case LOOPS_TILE_4x2: {
+      // tiny tiles are for parity fixtures only: 64-thread workgroups, 4 "real" lanes would waste
+      // the wavefront, so the fused kernel is not built for it; use the schedule-API kernel.
+      return LOOPS_E_CONFIG;
+    }
+    default: return LOOPS_E_CONFIG;
+  }
+#undef LOOPS_FUSED
+}
+
+// ------------------------------------------------------------------- schedule-API launchers
+template <std::size_t TPB, std::size_t IPT, typename T>
+int launch_merge_atomic(int rows, int cols, int nnz, const int* off, const int* idx, const T* val, const T* x, T* y,
+                        hipStream_t stream) {
+  using pre_t = schedule::merge_path::preprocess_t<TPB, IPT, int, int, std::size_t, std::size_t>;
+  pre_t meta(const_cast<int*>(off), std::size_t(rows), std::size_t(nnz), stream);
+  const std::size_t m = meta.merge_tiles();
+  if (m == 0) return 0;
+  launch::non_cooperative(stream, kernels::merge_path_flat_atomic_spmv<TPB, IPT, pre_t, int, int, T>,
+                          dim3(static_cast<unsigned>(m)), dim3(TPB), meta, std::size_t(rows), std::size_t(cols),
+                          std::size_t(nnz), const_cast<int*>(off), const_cast<int*>(idx), val, x, y);
+  (void)hipStreamSynchronize(stream);  // meta owns device scratch freed at scope exit
+  return last_error();
+}
+
+template <std::size_t TPB, std::size_t IPT>
+int launch_merge_dump(bool use_plan, int rows, int nnz, const int* off, unsigned* ts, int* owner, int* arow,
+                      int* visits, hipStream_t stream) {
+  using pre_t = schedule::merge_path::preprocess_t<TPB, IPT, int, int, std::size_t, std::size_t>;
+  using layout_t = layout::csr<int, int>;
+  pre_t meta(layout_t(off, rows, nnz), stream, use_plan);
+  if (!use_plan && meta.data() != nullptr) return LOOPS_E_BADARG;  // wanted the in-kernel search path
+  const std::size_t m = meta.merge_tiles();
+  if (m == 0) return 0;
+  launch::non_cooperative(stream, kernels::merge_path_flat_dump<TPB, IPT, pre_t, int>, dim3(static_cast<unsigned>(m)),
+                          dim3(TPB), meta, std::size_t(rows), std::size_t(nnz), const_cast<int*>(off), ts, owner, arow,
+                          visits);
+  (void)hipStreamSynchronize(stream);
+  return last_error();
+}
+
+template <typename T>
+int spmv_schedule_api(int schedule, int cfg, int rows, int cols, int nnz, const int* off, const int* idx,
+                      const T* val, const T* x, T* y, hipStream_t stream) {
+  if (rows == 0) return 0;
+  const std::size_t R = rows, C = cols, N = nnz;
+  int* o = const_cast<int*>(off);
+  int* i = const_cast<int*>(idx);
+  switch (schedule) {
+    case LOOPS_THREAD_MAPPED: {
+      using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, int, int>;
+      setup_t config(o, R, N);
+      launch::non_cooperative(stream, kernels::thread_mapped_spmv<setup_t, int, int, T>,
+                              dim3(math::ceil_div(rows, kSpmvBlock)), dim3(kSpmvBlock), config, R, C, N, off, idx, val,
+                              x, y);
+      return last_error();
+    }
+    case LOOPS_ORIGINAL: {
+      launch::non_cooperative(stream, kernels::original_spmv<int, int, T>, dim3(math::ceil_div(rows, 128)), dim3(128),
+                              R, C, N, off, idx, val, x, y);
+      return last_error();
+    }
+    case LOOPS_GROUP_MAPPED: {
+      launch::non_cooperative(stream, kernels::group_mapped_atomic_spmv<kSpmvBlock, kSpmvBlock, int, int, T>,
+                              dim3(math::ceil_div(rows, kSpmvBlock)), dim3(kSpmvBlock), R, C, N, o, i, val, x, y);
+      return last_error();
+    }
+    case LOOPS_WORK_ORIENTED: {
+      auto kernel = kernels::work_oriented_atomic_spmv<kSpmvBlock, int, int, T>;
+      const std::size_t grid = launch_box::occupancy_grid(kernel, kSpmvBlock);
+      launch::non_cooperative(stream, kernel, dim3(static_cast<unsigned>(grid)), dim3(kSpmvBlock), R, C, N, o, i, val,
+                              x, y);
+      return last_error();
+    }
+    case LOOPS_FLAT_PARTITIONED: {
+      constexpr std::size_t K = 8;  // flat_partitioned.cuh:70 default
+      using base_t = layout::csr<int, int>;
+      using part_t = layout::flat_uniform_occupancy<K, base_t>;
+      using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, int, int, std::size_t, std::size_t,
+                                      part_t>;
+      part_t part(base_t(off, rows, nnz));
+      setup_t config(part);
+      const int chunks = part.num_tiles();
+      if (chunks == 0) return 0;
+      launch::non_cooperative(stream, kernels::flat_partitioned_spmv<setup_t, int, T>,
+                              dim3(math::ceil_div(chunks, kSpmvBlock)), dim3(kSpmvBlock), config, idx, val, x, y);
+      return last_error();
+    }
+    case LOOPS_MERGE_PATH_FLAT: {
+      switch (cfg) {
+        case LOOPS_TILE_256x8: return launch_merge_atomic<256, 8, T>(rows, cols, nnz, off, idx, val, x, y, stream);
+        case LOOPS_TILE_128x7: return launch_merge_atomic<128, 7, T>(rows, cols, nnz, off, idx, val, x, y, stream);
+        case LOOPS_TILE_4x2: return launch_merge_atomic<4, 2, T>(rows, cols, nnz, off, idx, val, x, y, stream);
+        case LOOPS_TILE_256x7: return launch_merge_atomic<256, 7, T>(rows, cols, nnz, off, idx, val, x, y, stream);
+        case LOOPS_TILE_512x8: return launch_merge_atomic<512, 8, T>(rows, cols, nnz, off, idx, val, x, y, stream);
+        default: return LOOPS_E_CONFIG;
+      }
+    }
+    default: return LOOPS_E_BADARG;
+  }
+}
+
+template <typename T>
+int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const int* idx, const T* val, const T* x,
+               T* y, hipStream_t stream) {
+  int err = check_csr(rows, cols, nnz, off, idx, val, x, y);
+  if (err) return err;
+  if (rows == 0) return 0;
+  switch (schedule) {
+    case LOOPS_MERGE_PATH_FLAT: {
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
+      if (!p) return err;
+      err = plan_compute(p, off, stream);
+      if (!err) err = spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
+      return err;
+    }
+    case LOOPS_THREAD_MAPPED:
+    case LOOPS_ORIGINAL:
+      return spmv_schedule_api<T>(schedule, 0, rows, cols, nnz, off, idx, val, x, y, stream);
+    case LOOPS_WORK_ORIENTED:
+    case LOOPS_GROUP_MAPPED:
+    case LOOPS_FLAT_PARTITIONED: {
+      // atomic kernels accumulate into y: zero it on the stream first
+      hipError_t e = hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), stream);
+      if (e != hipSuccess) return static_cast<int>(e);
+      return spmv_schedule_api<T>(schedule, 0, rows, cols, nnz, off, idx, val, x, y, stream);
+    }
+    default: return LOOPS_E_BADARG;
+  }
+}
+
+}  // namespace
+
+// =============================================================================== extern "C"
+extern "C" {
+
+const char* loops_version(void) { return "0.2.0-mi355x"; }
+
+int loops_device_compute_units(int* out) {
+  if (!out) return LOOPS_E_BADARG;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return static_cast<int>(hipDeviceGetAttribute(out, hipDeviceAttributeMultiprocessorCount, dev));
+}
+
+int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_config, void* stream,
+                            loops_merge_plan_t** out) {
+  if (!out || !offsets) return LOOPS_E_BADARG;
+  loops_merge_plan* p = nullptr;
+  int err = plan_alloc(rows, nnz, tile_config, &p);
+  if (err) return err;
+  err = plan_compute(p, offsets, as_stream(stream));
+  if (err) { (void)hipFree(p->base); delete p; return err; }
+  *out = p;
+  return 0;
+}
+
+int loops_merge_plan_destroy(loops_merge_plan_t* plan) {
+  if (!plan) return 0;
+  hipError_t e = hipFree(plan->base);
+  delete plan;
+  return static_cast<int>(e);
+}
+
+int loops_merge_plan_refresh(loops_merge_plan_t* plan, const int* offsets, void* stream) {
+  if (!plan || !offsets) return LOOPS_E_BADARG;
+  return plan_compute(plan, offsets, as_stream(stream));
+}
+
+int loops_merge_plan_num_tiles(const loops_merge_plan_t* plan) { return plan ? plan->num_tiles : LOOPS_E_BADARG; }
+
+int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords) {
+  if (!plan || !h_coords) return LOOPS_E_BADARG;
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return static_cast<int>(e);
+  return static_cast<int>(hipMemcpy(h_coords, plan->coords, sizeof(coord_t) * (static_cast<size_t>(plan->num_tiles) + 1),
+                                    hipMemcpyDeviceToHost));
+}
+
+int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const float* values, const float* x, float* y, void* stream) {
+  return spmv_tuned<float>(schedule, rows, cols, nnz, offsets, indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const double* values, const double* x, double* y, void* stream) {
+  return spmv_tuned<double>(schedule, rows, cols, nnz, offsets, indices, values, x, y, as_stream(stream));
+}
+
+int loops_spmv_merge_path_f32(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
+                              const int* offsets, const int* indices, const float* values, const float* x, float* y,
+                              void* stream) {
+  if (!plan) return LOOPS_E_BADARG;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  return spmv_merge_path<float>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
+                              const int* offsets, const int* indices, const double* values, const double* x,
+                              double* y, void* stream) {
+  if (!plan) return LOOPS_E_BADARG;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  return spmv_merge_path<double>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream));
+}
+
+int loops_spmv_merge_path_stage_f32(const loops_merge_plan_t* plan, int variant, int stage, int rows, int cols,
+                                    int nnz, const int* offsets, const int* indices, const float* values,
+                                    const float* x, float* y, void* stream) {
+  if (!plan || stage < 0 || stage > 1) return LOOPS_E_BADARG;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  return spmv_merge_path<float>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream),
+                                1 << stage);
+}
+
+int loops_spmv_csr_schedule_api_f32(int schedule, int tile_config, int rows, int cols, int nnz, const int* offsets,
+                                    const int* indices, const float* values, const float* x, float* y, void* stream) {
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  return spmv_schedule_api<float>(schedule, tile_config, rows, cols, nnz, offsets, indices, values, x, y,
+                                  as_stream(stream));
+}
+
+int loops_schedule_dump_merge_path(int tile_config, int use_plan, int rows, int nnz, const int* offsets,
+                                   unsigned* thread_start, int* atom_owner, int* atom_row, int* atom_visits,
+                                   void* stream) {
+  if (!offsets || !thread_start || rows < 0 || nnz < 0) return LOOPS_E_BADARG;
+  hipStream_t s = as_stream(stream);
+  switch (tile_config) {
+    case LOOPS_TILE_256x8: return launch_merge_dump<256, 8>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
+    case LOOPS_TILE_128x7: return launch_merge_dump<128, 7>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
+    case LOOPS_TILE_4x2: return launch_merge_dump<4, 2>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
+    case LOOPS_TILE_256x7: return launch_merge_dump<256, 7>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
+    case LOOPS_TILE_512x8: return launch_merge_dump<512, 8>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
+    default: return LOOPS_E_CONFIG;
+  }
+}
+
+int loops_schedule_dump_work_oriented(int grid_blocks, int rows, int nnz, const int* offsets, int* thread_map,
+                                      int* atom_owner, int* atom_row, int* atom_visits, void* stream) {
+  if (!offsets || !thread_map || grid_blocks <= 0 || rows < 0 || nnz < 0) return LOOPS_E_BADARG;
+  launch::non_cooperative(as_stream(stream), kernels::work_oriented_dump<kSpmvBlock, int>, dim3(grid_blocks),
+                          dim3(kSpmvBlock), std::size_t(rows), std::size_t(nnz), const_cast<int*>(offsets), thread_map,
+                          atom_owner, atom_row, atom_visits);
+  return last_error();
+}
+
+int loops_schedule_dump_group_mapped(int group_size, int rows, int nnz, const int* offsets, int* atom_owner,
+                                     int* atom_row, int* atom_visits, void* stream) {
+  if (!offsets || rows < 0 || nnz < 0) return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  const dim3 grid(math::ceil_div(rows, kSpmvBlock)), block(kSpmvBlock);
+  if (group_size == 256)
+    launch::non_cooperative(as_stream(stream), kernels::group_mapped_dump<kSpmvBlock, 256, int>, grid, block,
+                            std::size_t(rows), std::size_t(nnz), const_cast<int*>(offsets), atom_owner, atom_row,
+                            atom_visits);
+  else if (group_size == 64)
+    launch::non_cooperative(as_stream(stream), kernels::group_mapped_dump<kSpmvBlock, 64, int>, grid, block,
+                            std::size_t(rows), std::size_t(nnz), const_cast<int*>(offsets), atom_owner, atom_row,
+                            atom_visits);
+  else if (group_size == 16)
+    launch::non_cooperative(as_stream(stream), kernels::group_mapped_dump<kSpmvBlock, 16, int>, grid, block,
+                            std::size_t(rows), std::size_t(nnz), const_cast<int*>(offsets), atom_owner, atom_row,
+                            atom_visits);
+  else
+    return LOOPS_E_CONFIG;
+  return last_error();
+}
+
+int loops_work_oriented_grid(int* out_blocks) {
+  if (!out_blocks) return LOOPS_E_BADARG;
+  auto kernel = kernels::work_oriented_atomic_spmv<kSpmvBlock, int, int, float>;
+  *out_blocks = static_cast<int>(launch_box::occupancy_grid(kernel, kSpmvBlock));
+  return 0;
+}
+
+int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
+                        const int* block_cols, const float* block_values, const float* x_padded, float* y,
+                        void* stream) {
+  if (!block_offsets || !y || rows < 0 || num_block_rows < 0 || num_blocks < 0) return LOOPS_E_BADARG;
+  if (num_blocks > 0 && (!block_cols || !block_values || !x_padded)) return LOOPS_E_BADARG;
+  if (num_block_rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  if (mode == 1) {
+    if (R != 4 || C != 4) return LOOPS_E_CONFIG;
+    return kernels::launch_bcsr4x4_mfma(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values,
+                                        x_padded, y);
+  }
+  if (mode != 0) return LOOPS_E_BADARG;
+  if (R == 2 && C == 2) return kernels::launch_bcsr_thread_mapped<2, 2>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  if (R == 3 && C == 3) return kernels::launch_bcsr_thread_mapped<3, 3>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  if (R == 4 && C == 4) return kernels::launch_bcsr_thread_mapped<4, 4>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  return LOOPS_E_CONFIG;
+}
+
+int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) {
+  if (!src || !dst) return LOOPS_E_BADARG;
+  return kernels::launch_stream_copy(as_stream(stream), src, dst, n);
+}
+
+int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, void* stream) {
+  if (!table || !idx || !out) return LOOPS_E_BADARG;
+  return kernels::launch_gather(as_stream(stream), table, idx, out, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+"""Synthetic inputs of the hot path (host side, numpy): the x-vector generator of the
+reference's examples and the power-law CSR / uniform BCSR workloads named by BASELINE.json.
+
+* ``uniform_distribution_int``  restates ``generate::random::uniform_distribution`` for INT
+  bounds (reference include/loops/util/generate.hxx:33-79; every example calls it with
+  (1, 10, seed 42): examples/spmv/merge_path.cu:33) -- vectorised; pinned against the
+  reference build and the oracle in tests/test_generate.py.
+* ``powerlaw_csr``  the C2 / C5 workload of SURVEY 8(d): clamped-Zipf row degrees
+  (alpha = 0.8, cap 2^14), rows scattered by a fixed permutation, per-row distinct hashed
+  columns sorted ascending, values k/8 and integer x so every row sum is exactly
+  representable in fp32 (any summation order gives the same bits).  Counter-based: any row
+  range can be generated independently (each rank of a multi-GPU run builds only its shard).
+* ``uniform_bcsr``  the C4 workload: 4x4 blocks, a fixed number of blocks per block-row.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(z):
+    """SplitMix64 finaliser, vectorised over uint64 arrays."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(z, np.uint64) + np.uint64(0x9E3779B97F4A7C15)) & _M
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M
+        return z ^ (z >> np.uint64(31))
+
+
+# ------------------------------------------------------------------------------ x generator
+def hash32(a):
+    """generate.hxx:33-41 integer mix, vectorised (uint32 wrap-around)."""
+    a = np.asarray(a, np.uint64)
+    m = np.uint64(0xFFFFFFFF)
+    a = ((a + np.uint64(0x7ED55D16)) + (a << np.uint64(12))) & m
+    a = ((a ^ np.uint64(0xC761C23C)) ^ (a >> np.uint64(19))) & m
+    a = ((a + np.uint64(0x165667B1)) + (a << np.uint64(5))) & m
+    a = ((a + np.uint64(0xD3A2646C)) ^ (a << np.uint64(9))) & m
+    a = ((a + np.uint64(0xFD7046C5)) + (a << np.uint64(3))) & m
+    a = ((a ^ np.uint64(0xB55A4F09)) ^ (a >> np.uint64(16))) & m
+    return a
+
+
+def uniform_distribution_int(n, lo=1, hi=10, seed=42, dtype=np.float32, start=0):
+    """x[i] for i in [start, start + n): minstd_rand seeded with hash(i) * seed, one draw, mapped
+    through uniform_int_distribution<int>(lo, hi) (rocThrust semantics)."""
+    m = np.uint64(2147483647)
+    i = np.arange(start, start + n, dtype=np.uint64)
+    s = (hash32(i & np.uint64(0xFFFFFFFF)) * np.uint64(seed & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)
+    s = s % m
+    s[s == 0] = 1
+    u = (np.uint64(48271) * s) % m
+    r = (u - np.uint64(1)).astype(np.float64) / (1.0 + float(int(m) - 2))
+    v = r * ((float(hi) + 1.0) - float(lo)) + float(lo)
+    return v.astype(np.int64).astype(dtype)
+
+
+# ------------------------------------------------------------------------------ power-law CSR
+def powerlaw_degrees(rows, nnz, alpha=0.8, cap=1 << 14, perm_seed=0x5EED):
+    """Row degrees d = clamp(floor(c / (rank + 1)^alpha), 1, cap) with c bisected so sum(d) == nnz,
+    assigned to rows through the fixed permutation argsort(splitmix64(perm_seed ^ r))."""
+    rank = np.arange(1, rows + 1, dtype=np.float64) ** (-alpha)
+
+    def total(c):
+        return int(np.clip(np.floor(c * rank), 1, cap).sum())
+
+    lo, hi = 0.0, float(cap) * rows
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if total(mid) < nnz:
+            lo = mid
+        else:
+            hi = mid
+    d = np.clip(np.floor(hi * rank), 1, cap).astype(np.int64)
+    diff = int(d.sum()) - nnz  # hi gives total >= nnz: shave the residual off the largest uncapped rows
+    if diff:
+        idx = np.flatnonzero((d < cap) & (d > 1)) if diff > 0 else np.flatnonzero(d < cap)
+        assert idx.size >= abs(diff), "cannot fix degree residual"
+        d[idx[: abs(diff)]] -= np.sign(diff)
+    assert int(d.sum()) == nnz
+    perm = np.argsort(splitmix64(np.uint64(perm_seed) ^ np.arange(rows, dtype=np.uint64)), kind="stable")
+    out = np.empty(rows, np.int64)
+    out[perm] = d  # rank k's degree lands on row perm[k]
+    return out
+
+
+def _hash_cols(seed, rows_abs, k, attempt, cols):
+    h = splitmix64(splitmix64(np.uint64(seed) + rows_abs.astype(np.uint64)) + k.astype(np.uint64)
+                   + (np.uint64(attempt) << np.uint64(40)))
+    return (h % np.uint64(cols)).astype(np.int64)
+
+
+def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True):
+    """Rows [row_begin, row_begin + len(degrees)) of the hashed matrix: per-row distinct columns
+    sorted ascending; values k/8 (exact) or U[0.5, 1.5) (realistic)."""
+    nrows = degrees.size
+    offsets = np.zeros(nrows + 1, np.int64)
+    np.cumsum(degrees, out=offsets[1:])
+    nnz = int(offsets[-1])
+    assert int(degrees.max(initial=0)) <= cols
+    rloc = np.repeat(np.arange(nrows, dtype=np.int64), degrees)
+    k = np.arange(nnz, dtype=np.int64) - np.repeat(offsets[:-1], degrees)
+    rabs = rloc + row_begin
+    col = _hash_cols(seed, rabs, k, 0, cols)
+    attempt = 0
+    while True:
+        key = (rloc.astype(np.uint64) << np.uint64(32)) | col.astype(np.uint64)
+        order = np.argsort(key, kind="stable")
+        sk = key[order]
+        dup = np.flatnonzero(sk[1:] == sk[:-1]) + 1
+        if dup.size == 0:
+            break
+        attempt += 1
+        bad = order[dup]
+        col[bad] = _hash_cols(seed, rabs[bad], k[bad], attempt, cols)
+    indices = (sk & np.uint64(0xFFFFFFFF)).astype(np.int32)  # sorted by (row, col)
+    rsorted = rloc  # rows are already grouped: sorting by (row, col) keeps row order
+    vh = splitmix64((rsorted + row_begin).astype(np.uint64) * np.uint64(0x100000001B3) + indices.astype(np.uint64)
+                    + np.uint64(seed) * np.uint64(7919))
+    if exact:
+        values = (((vh >> np.uint64(33)) % np.uint64(8)) + np.uint64(1)).astype(np.float32) / np.float32(8)
+    else:
+        values = (0.5 + (vh >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+    return offsets.astype(np.int32), indices, values
+
+
+def powerlaw_csr(rows, cols, nnz, alpha=0.8, cap=1 << 14, seed=1, row_begin=0, row_end=None, exact=True,
+                 degrees=None):
+    """(offsets, indices, values) of rows [row_begin, row_end) of the power-law matrix
+    (offsets rebased to 0, global column ids)."""
+    if degrees is None:
+        degrees = powerlaw_degrees(rows, nnz, alpha, min(cap, cols))
+    row_end = rows if row_end is None else row_end
+    return csr_from_degrees(degrees[row_begin:row_end], cols, seed, row_begin, exact)
+
+
+def realistic_x(n, seed=7, start=0):
+    h = splitmix64(np.arange(start, start + n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B9))
+    return (0.5 + (h >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------ BCSR
+def uniform_bcsr(num_block_rows, num_block_cols, blocks_per_row, R=4, C=4, seed=3):
+    """C4: every block-row holds `blocks_per_row` blocks at distinct hashed block columns (sorted),
+    block cells k/8."""
+    deg = np.full(num_block_rows, blocks_per_row, np.int64)
+    boff, bcols, _ = csr_from_degrees(deg, num_block_cols, seed)
+    nb = bcols.size
+    cell = np.arange(nb * R * C, dtype=np.uint64)
+    vh = splitmix64(cell + np.uint64(seed) * np.uint64(104729))
+    vals = (((vh >> np.uint64(33)) % np.uint64(8)) + np.uint64(1)).astype(np.float32) / np.float32(8)
+    return boff, bcols, vals
+
+
+# ------------------------------------------------------------------------------ small fixtures
+def random_csr(rows, cols, density, seed, empty_every=0, values="uniform"):
+    """Small hermetic matrices for parity tests (numpy Generator, committed seeds)."""
+    rng = np.random.default_rng(seed)
+    mask = rng.random((rows, cols)) < density
+    if empty_every:
+        mask[::empty_every] = False
+    r, c = np.nonzero(mask)
+    offsets = np.zeros(rows + 1, np.int32)
+    np.add.at(offsets, r + 1, 1)
+    offsets = np.cumsum(offsets).astype(np.int32)
+    if values == "uniform":
+        v = (rng.random(r.size) * 2 - 1).astype(np.float32)
+    else:
+        v = (rng.integers(1, 9, r.size) / 8).astype(np.float32)
+    return offsets, c.astype(np.int32), v

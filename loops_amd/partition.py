@@ -1,0 +1,100 @@
+"""Row-range sharding of a CSR matrix across the GPUs of one node + allgatherv of y.
+
+The reference is single-GPU (no collective call site anywhere); this is the new
+multi-GPU leg BASELINE.json asks for (config C5).  y = A x is independent per row, so the CSR is
+cut into contiguous row ranges balanced by (rows + nnz) -- the same merge-path diagonal split
+the kernels use, applied at GPU granularity -- every rank keeps x replicated, runs
+the single-GPU kernel on its slice (offsets rebased to 0, global column ids) and the slices of y
+are exchanged with ONE collective step: an allgatherv.
+
+RCCL has no native allgatherv.  The exchange is issued as a single batched group of
+point-to-point sends/receives (``torch.distributed.batch_isend_irecv`` -> ncclGroupStart /
+ncclSend / ncclRecv / ncclGroupEnd on the "nccl" = RCCL backend): every shard crosses every xGMI
+link exactly once, all 7 links of a GPU busy at the same time (direct pattern), instead of a
+ring's 7 serial per-link-bound hops.  The same code runs on gloo for the CPU tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def merge_path_split(offsets: np.ndarray, diagonal: int) -> tuple[int, int]:
+    """Merge-path split of (row ends, nonzeros) at `diagonal` (util/search.hxx:35-60 semantics,
+    host side, numpy): returns (rows consumed, nonzeros consumed)."""
+    rows = offsets.size - 1
+    nnz = int(offsets[-1])
+    lo = max(diagonal - nnz, 0)
+    hi = min(diagonal, rows)
+    ends = offsets[1:]
+    while lo < hi:
+        mid = (lo + hi) >> 1
+        if int(ends[mid]) <= diagonal - mid - 1:
+            lo = mid + 1
+        else:
+            hi = mid
+    return min(lo, rows), diagonal - lo
+
+
+def row_ranges(offsets: np.ndarray, parts: int) -> np.ndarray:
+    """parts + 1 row boundaries: range p = [b[p], b[p+1]) holds ~ (rows + nnz) / parts merge items.
+    A boundary that falls inside a row moves to that row's start (rows are never split)."""
+    rows = offsets.size - 1
+    total = rows + int(offsets[-1])
+    b = np.zeros(parts + 1, np.int64)
+    for p in range(1, parts):
+        r, _ = merge_path_split(offsets, (total * p) // parts)
+        b[p] = max(r, b[p - 1])
+    b[parts] = rows
+    return b
+
+
+def row_ranges_from_degrees(degrees: np.ndarray, parts: int) -> np.ndarray:
+    off = np.zeros(degrees.size + 1, np.int64)
+    np.cumsum(degrees, out=off[1:])
+    return row_ranges(off, parts)
+
+
+@dataclass
+class Shard:
+    """One rank's slice: rows [row_begin, row_end) of the global matrix."""
+    rank: int
+    world: int
+    row_begin: int
+    row_end: int
+    bounds: np.ndarray  # all ranks' boundaries (world + 1)
+
+    @property
+    def counts(self):
+        return np.diff(self.bounds)
+
+
+def slice_csr(offsets, indices, values, row_begin, row_end):
+    """Rows [row_begin, row_end) as a standalone CSR (offsets rebased to 0, global column ids)."""
+    a, b = int(offsets[row_begin]), int(offsets[row_end])
+    return (offsets[row_begin:row_end + 1] - offsets[row_begin]).astype(np.int32), indices[a:b], values[a:b]
+
+
+def allgatherv_(y_full: torch.Tensor, shard: Shard, group=None) -> torch.Tensor:
+    """In-place allgatherv: on entry rank r has written y_full[bounds[r]:bounds[r+1]]; on return
+    every rank holds the whole vector.  One batched group of direct sends / receives."""
+    if shard.world == 1:
+        return y_full
+    b = shard.bounds
+    mine = y_full[int(b[shard.rank]):int(b[shard.rank + 1])]
+    ops = []
+    for peer in range(shard.world):
+        if peer == shard.rank:
+            continue
+        if mine.numel():
+            ops.append(dist.P2POp(dist.isend, mine, peer, group))
+        theirs = y_full[int(b[peer]):int(b[peer + 1])]
+        if theirs.numel():
+            ops.append(dist.P2POp(dist.irecv, theirs, peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return y_full

@@ -1,0 +1,267 @@
+"""Host-side mirror of the reference's SpMV operator interface, over the C ABI.
+
+Names follow ``loops::algorithms::spmv::*`` (reference include/loops/algorithms/spmv/*.cuh):
+``merge_path_flat(csr, x, y)``, ``work_oriented``, ``thread_mapped``, ``group_mapped``,
+``original``, ``flat_partitioned``, ``bcsr_thread_mapped``; ``MergePathPlan`` mirrors
+``schedule::merge_path::preprocess_t``.  torch is used for device memory and streams only;
+every array crosses the boundary as a raw device pointer + size.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else C.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+@dataclass
+class CSR:
+    """csr_t<int, int, T> on the device (reference include/loops/container/csr.hxx:36-95)."""
+    rows: int
+    cols: int
+    offsets: torch.Tensor   # int32 [rows + 1]
+    indices: torch.Tensor   # int32 [nnz]
+    values: torch.Tensor    # float32 | float64 [nnz]
+
+    @property
+    def nnzs(self) -> int:
+        return int(self.indices.numel())
+
+    @staticmethod
+    def from_numpy(rows, cols, offsets, indices, values, device="cuda"):
+        return CSR(int(rows), int(cols),
+                   torch.from_numpy(np.ascontiguousarray(offsets, np.int32)).to(device),
+                   torch.from_numpy(np.ascontiguousarray(indices, np.int32)).to(device),
+                   torch.from_numpy(np.ascontiguousarray(values)).to(device))
+
+    def check(self, x, y):
+        assert self.offsets.dtype == torch.int32 and self.indices.dtype == torch.int32
+        assert self.offsets.is_cuda and self.offsets.is_contiguous() and self.offsets.numel() == self.rows + 1
+        assert self.indices.is_contiguous() and self.values.is_contiguous()
+        assert x.dtype == self.values.dtype == y.dtype and x.is_contiguous() and y.is_contiguous()
+        assert x.numel() >= self.cols and y.numel() >= self.rows
+
+
+class MergePathPlan:
+    """Per-workgroup merge-path start coordinates for (csr.offsets, tile shape); reusable across
+    SpMVs on the same sparsity structure (mirrors schedule::merge_path::preprocess_t)."""
+
+    def __init__(self, csr: CSR, tile: str = "256x8"):
+        self.tile = tile
+        self.cfg, self.tpb, self.ipt = L.TILES[tile]
+        self.rows, self.nnz = csr.rows, csr.nnzs
+        self._h = C.c_void_p()
+        L.check(L.lib().loops_merge_plan_create(csr.rows, csr.nnzs, _ptr(csr.offsets), self.cfg, _stream(),
+                                                C.byref(self._h)), "loops_merge_plan_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def num_tiles(self) -> int:
+        return int(L.lib().loops_merge_plan_num_tiles(self._h))
+
+    def coords(self) -> np.ndarray:
+        out = np.zeros((self.num_tiles + 1, 2), np.uint32)
+        L.check(L.lib().loops_merge_plan_coords(self._h, out.ctypes.data_as(C.c_void_p)), "loops_merge_plan_coords")
+        return out
+
+    def refresh(self, csr: CSR):
+        L.check(L.lib().loops_merge_plan_refresh(self._h, _ptr(csr.offsets), _stream()), "loops_merge_plan_refresh")
+
+    def close(self):
+        if self._h:
+            L.lib().loops_merge_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _suffix(t):
+    if t.dtype == torch.float32:
+        return "f32"
+    if t.dtype == torch.float64:
+        return "f64"
+    raise TypeError("values must be float32 or float64")
+
+
+def spmv(schedule: str, csr: CSR, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+    """y = A x with the tuned path of the named schedule (asynchronous on the current stream)."""
+    if y is None:
+        y = torch.empty(csr.rows, dtype=csr.values.dtype, device=csr.values.device)
+    csr.check(x, y)
+    fn = getattr(L.lib(), "loops_spmv_csr_" + _suffix(csr.values))
+    L.check(fn(L.SCHEDULES[schedule], csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+               _ptr(csr.values), _ptr(x), _ptr(y), _stream()), "loops_spmv_csr(" + schedule + ")")
+    return y
+
+
+def merge_path_flat(csr: CSR, x, y=None, plan: MergePathPlan | None = None, variant: int = 0):
+    """algorithms::spmv::merge_path_flat.  With ``plan`` only the fused kernel + fix-up run (the
+    region the reference times); without, the coordinates are rebuilt first, as the reference
+    wrapper does on every call."""
+    if plan is None:
+        return spmv("merge_path_flat", csr, x, y)
+    if y is None:
+        y = torch.empty(csr.rows, dtype=csr.values.dtype, device=csr.values.device)
+    csr.check(x, y)
+    fn = getattr(L.lib(), "loops_spmv_merge_path_" + _suffix(csr.values))
+    L.check(fn(plan.handle, variant, csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+               _ptr(csr.values), _ptr(x), _ptr(y), _stream()), "loops_spmv_merge_path")
+    return y
+
+
+def merge_path_flat_stage(csr: CSR, x, y, plan: MergePathPlan, stage: int, variant: int = 0):
+    """One kernel of the planned merge_path_flat SpMV (0: fused tile kernel, 1: fix-up)."""
+    L.check(L.lib().loops_spmv_merge_path_stage_f32(plan.handle, variant, stage, csr.rows, csr.cols, csr.nnzs,
+                                                    _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), _ptr(x),
+                                                    _ptr(y), _stream()), "loops_spmv_merge_path_stage_f32")
+    return y
+
+
+def work_oriented(csr, x, y=None):
+    return spmv("work_oriented", csr, x, y)
+
+
+def thread_mapped(csr, x, y=None):
+    return spmv("thread_mapped", csr, x, y)
+
+
+def group_mapped(csr, x, y=None):
+    return spmv("group_mapped", csr, x, y)
+
+
+def original(csr, x, y=None):
+    return spmv("original", csr, x, y)
+
+
+def flat_partitioned(csr, x, y=None):
+    return spmv("flat_partitioned", csr, x, y)
+
+
+def spmv_schedule_api(schedule: str, csr: CSR, x, y=None, tile: str = "256x8"):
+    """The reference-shaped kernels written against schedule::setup<> (atomics; y is zero-filled
+    here, as the reference's callers do)."""
+    assert csr.values.dtype == torch.float32
+    if y is None:
+        y = torch.zeros(csr.rows, dtype=torch.float32, device=csr.values.device)
+    else:
+        y.zero_()
+    csr.check(x, y)
+    L.check(L.lib().loops_spmv_csr_schedule_api_f32(L.SCHEDULES[schedule], L.TILES[tile][0], csr.rows, csr.cols,
+                                                    csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values),
+                                                    _ptr(x), _ptr(y), _stream()), "loops_spmv_csr_schedule_api")
+    return y
+
+
+# ------------------------------------------------------------------------------- schedule dumps
+def dump_merge_path(csr: CSR, tile: str = "256x8", use_plan: bool = True):
+    cfg, tpb, ipt = L.TILES[tile]
+    total = csr.rows + csr.nnzs
+    m = total // (tpb * ipt) + (1 if total % (tpb * ipt) else 0)
+    dev = csr.offsets.device
+    ts = torch.zeros(max(2 * m * tpb, 1), dtype=torch.int32, device=dev)
+    owner = torch.full((max(csr.nnzs, 1),), -1, dtype=torch.int32, device=dev)
+    row = torch.full((max(csr.nnzs, 1),), -1, dtype=torch.int32, device=dev)
+    visits = torch.zeros(max(csr.nnzs, 1), dtype=torch.int32, device=dev)
+    L.check(L.lib().loops_schedule_dump_merge_path(cfg, int(use_plan), csr.rows, csr.nnzs, _ptr(csr.offsets), _ptr(ts),
+                                                   _ptr(owner), _ptr(row), _ptr(visits), _stream()),
+            "loops_schedule_dump_merge_path")
+    torch.cuda.synchronize()
+    n = csr.nnzs
+    return (ts.cpu().numpy().view(np.uint32).reshape(-1, 2)[: m * tpb], owner.cpu().numpy()[:n],
+            row.cpu().numpy()[:n], visits.cpu().numpy()[:n])
+
+
+def dump_work_oriented(csr: CSR, grid_blocks: int):
+    dev = csr.offsets.device
+    tm = torch.zeros(4 * grid_blocks * 256, dtype=torch.int32, device=dev)
+    owner = torch.full((max(csr.nnzs, 1),), -1, dtype=torch.int32, device=dev)
+    row = torch.full((max(csr.nnzs, 1),), -1, dtype=torch.int32, device=dev)
+    visits = torch.zeros(max(csr.nnzs, 1), dtype=torch.int32, device=dev)
+    L.check(L.lib().loops_schedule_dump_work_oriented(grid_blocks, csr.rows, csr.nnzs, _ptr(csr.offsets), _ptr(tm),
+                                                      _ptr(owner), _ptr(row), _ptr(visits), _stream()),
+            "loops_schedule_dump_work_oriented")
+    torch.cuda.synchronize()
+    n = csr.nnzs
+    return tm.cpu().numpy().reshape(-1, 4), owner.cpu().numpy()[:n], row.cpu().numpy()[:n], visits.cpu().numpy()[:n]
+
+
+def dump_group_mapped(csr: CSR, group_size: int = 256):
+    dev = csr.offsets.device
+    owner = torch.full((max(csr.nnzs, 1),), -1, dtype=torch.int32, device=dev)
+    row = torch.full((max(csr.nnzs, 1),), -1, dtype=torch.int32, device=dev)
+    visits = torch.zeros(max(csr.nnzs, 1), dtype=torch.int32, device=dev)
+    L.check(L.lib().loops_schedule_dump_group_mapped(group_size, csr.rows, csr.nnzs, _ptr(csr.offsets), _ptr(owner),
+                                                     _ptr(row), _ptr(visits), _stream()),
+            "loops_schedule_dump_group_mapped")
+    torch.cuda.synchronize()
+    n = csr.nnzs
+    return owner.cpu().numpy()[:n], row.cpu().numpy()[:n], visits.cpu().numpy()[:n]
+
+
+def work_oriented_grid() -> int:
+    out = C.c_int()
+    L.check(L.lib().loops_work_oriented_grid(C.byref(out)), "loops_work_oriented_grid")
+    return out.value
+
+
+# ------------------------------------------------------------------------------- BCSR
+@dataclass
+class BCSR:
+    """bcsr_t<R, C, int, int, float> on the device (reference include/loops/container/bcsr.hxx:60)."""
+    R: int
+    C: int
+    rows: int
+    cols: int
+    block_offsets: torch.Tensor
+    block_cols: torch.Tensor
+    values: torch.Tensor
+
+    @property
+    def num_block_rows(self):
+        return int(self.block_offsets.numel()) - 1
+
+    @property
+    def num_blocks(self):
+        return int(self.block_cols.numel())
+
+    @property
+    def num_block_cols(self):
+        return (self.cols + self.C - 1) // self.C
+
+
+def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool = False):
+    """algorithms::spmv::bcsr_thread_mapped<R, C>; ``mfma=True`` selects the 4x4 MFMA kernel."""
+    if y is None:
+        y = torch.empty(b.rows, dtype=torch.float32, device=b.values.device)
+    assert x_padded.numel() >= b.num_block_cols * b.C and x_padded.dtype == torch.float32
+    L.check(L.lib().loops_spmv_bcsr_f32(b.R, b.C, int(mfma), b.rows, b.num_block_rows, b.num_blocks,
+                                        _ptr(b.block_offsets), _ptr(b.block_cols), _ptr(b.values), _ptr(x_padded),
+                                        _ptr(y), _stream()), "loops_spmv_bcsr_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------- probes
+def stream_copy(src, dst):
+    L.check(L.lib().loops_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "loops_stream_copy_f32")
+
+
+def gather(table, idx, out):
+    L.check(L.lib().loops_gather_f32(_ptr(table), _ptr(idx), _ptr(out), idx.numel(), _stream()), "loops_gather_f32")

@@ -1,0 +1,51 @@
+"""The C-ABI library builds, loads, and exports exactly what include/loops_amd.h declares
+(no compute calls: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+from loops_amd import _lib
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "loops_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(loops_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    so = _lib.build()
+    assert os.path.exists(so)
+    L = ctypes.CDLL(so)
+    declared = _declared()
+    assert declared, "no declarations parsed"
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(L, name), name
+    L.loops_version.restype = ctypes.c_char_p
+    assert L.loops_version().decode().startswith("0.2.0")
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    L = _lib.lib()
+    # null pointers / bad sizes are rejected before any runtime call
+    assert L.loops_spmv_csr_f32(0, -1, 1, 1, None, None, None, None, None, None) == -1
+    assert L.loops_spmv_csr_f32(0, 4, 4, 4, None, None, None, None, None, None) == -1
+    assert L.loops_merge_plan_create(4, 4, None, 0, None, None) == -1
+    assert L.loops_merge_plan_num_tiles(None) == -1
+    assert L.loops_spmv_merge_path_f32(None, 0, 1, 1, 1, None, None, None, None, None, None) == -1
+    assert L.loops_spmv_bcsr_f32(4, 4, 0, 4, 1, 1, None, None, None, None, None, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through oracle/ (or any CPU fallback)."""
+    for base, _, files in os.walk(os.path.join(ROOT, "loops_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hxx", ".h")):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r"(import\s+oracle|from\s+oracle|liboracle|loops_oracle|oracle/|oracle\.)", src), f
+    for base, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            src = open(os.path.join(base, f)).read()
+            assert "liboracle" not in src and "loops_oracle" not in src, f

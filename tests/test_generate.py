@@ -1,0 +1,44 @@
+"""Host-side generators: the reference's x generator (vectorised) and the synthetic workloads."""
+import numpy as np
+
+from conftest import load_golden
+from loops_amd import generate as G
+
+
+def test_x_generator_matches_reference_golden():
+    g = load_golden("xgen.npz")
+    assert np.array_equal(G.uniform_distribution_int(4096, 1, 10, 42), g["x_1_10_42"])
+    assert np.array_equal(G.uniform_distribution_int(4096, 0, 1, 7), g["x_0_1_7"])
+    assert np.array_equal(G.uniform_distribution_int(4096, -5, 5, 12345), g["x_m5_5_12345"])
+    assert np.array_equal(G.uniform_distribution_int(96, 1, 10, 42, start=4000), g["x_1_10_42"][4000:])
+    assert list(G.hash32(np.array([0, 1, 2, 41, 12345, 2**32 - 1])).astype(np.uint32)) == list(g["hash"])
+    c = load_golden("chesapeake.npz")
+    assert np.array_equal(G.uniform_distribution_int(39), c["x"])
+
+
+def test_powerlaw_generator_properties():
+    rows, nnz = 1 << 14, 1 << 18
+    deg = G.powerlaw_degrees(rows, nnz, cap=1 << 12)
+    assert deg.sum() == nnz and deg.min() >= 1 and deg.max() == 1 << 12
+    off, idx, val = G.powerlaw_csr(rows, rows, nnz, degrees=deg)
+    assert off[-1] == nnz and idx.min() >= 0 and idx.max() < rows
+    r = np.repeat(np.arange(rows), np.diff(off))
+    key = (r.astype(np.int64) << 32) | idx
+    assert (np.diff(key) > 0).all()  # per-row distinct, ascending
+    assert set(np.unique(val * 8)) <= set(range(1, 9))
+    # counter-based: a row range generated alone equals the slice of the whole
+    o2, i2, v2 = G.powerlaw_csr(rows, rows, nnz, degrees=deg, row_begin=100, row_end=900)
+    assert np.array_equal(i2, idx[off[100]:off[900]]) and np.array_equal(v2, val[off[100]:off[900]])
+    assert np.array_equal(o2, off[100:901] - off[100])
+    # every row sum is exactly representable: f32 and f64 accumulation agree bit-for-bit
+    from oracle import oracle as O
+    x = G.uniform_distribution_int(rows)
+    assert np.array_equal(O.spmv_f32(off, idx, val, x), O.spmv_f64acc_f32(off, idx, val, x))
+
+
+def test_uniform_bcsr():
+    boff, bcols, bvals = G.uniform_bcsr(64, 64, 16)
+    assert np.array_equal(np.diff(boff), np.full(64, 16)) and bvals.size == 64 * 16 * 16
+    for br in range(64):
+        c = bcols[boff[br]:boff[br + 1]]
+        assert (np.diff(c) > 0).all()

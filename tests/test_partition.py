@@ -1,0 +1,74 @@
+"""Row-range sharding + allgatherv(y): host logic on CPU, N > 1 path on gloo, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import battery
+
+
+def test_row_ranges_balance_and_cover():
+    from loops_amd import generate as G, partition as P
+    deg = G.powerlaw_degrees(1 << 14, 1 << 18, cap=1 << 12)
+    off = np.zeros(deg.size + 1, np.int64)
+    np.cumsum(deg, out=off[1:])
+    for parts in (1, 2, 3, 8):
+        b = P.row_ranges(off, parts)
+        assert b[0] == 0 and b[-1] == deg.size and (np.diff(b) >= 0).all()
+        work = np.array([(b[i + 1] - b[i]) + (off[b[i + 1]] - off[b[i]]) for i in range(parts)])
+        assert work.sum() == deg.size + off[-1]
+        assert work.max() <= work.sum() / parts + (1 << 12) + 1  # within one max-degree row of even
+    # the split is the kernels' merge-path split
+    from oracle import oracle as O
+    for d in (0, 1, 77, 5000, int(off[-1]) + deg.size):
+        assert P.merge_path_split(off, d) == O.diag_search(d, off[1:].astype(np.int32), 0, deg.size, int(off[-1]))
+
+
+def test_slices_reassemble_spmv():
+    from loops_amd import partition as P
+    from oracle import oracle as O
+    for name, (r, c, off, idx, val) in battery().items():
+        if r < 2:
+            continue
+        x = O.xgen_int(c)
+        want = O.spmv_f32(off, idx, val, x)
+        b = P.row_ranges(off.astype(np.int64), 3)
+        got = np.concatenate([O.spmv_f32(*P.slice_csr(off, idx, val, int(b[p]), int(b[p + 1])), x) for p in range(3)])
+        assert np.array_equal(got, want), name
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from loops_amd import partition as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bounds = np.array([0, 5, 12], np.int64) if world == 2 else np.array([0, 4, 4, 12], np.int64)
+        shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
+        y = torch.full((12,), -1.0)
+        y[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1)
+        P.allgatherv_(y, shard)
+        want = torch.cat([torch.arange(int(bounds[r]), int(bounds[r + 1]), dtype=torch.float32) * (r + 1) for r in range(world)])
+        q.put((rank, bool(torch.equal(y, want))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allgatherv_gloo(world):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok in res) and len(res) == world

@@ -1,0 +1,85 @@
+"""Pins the oracle's restatement of the reference's DEVICE-ONLY schedule code against the
+reference's own HIP device path executed on the MI355X (oracle/_ref/libloops_ref_gpu.so, built
+in the dev container from /root/reference in place; shipped prebuilt to the GPU box)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, battery, load_golden
+
+pytestmark = pytest.mark.gpu
+SO = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
+needs_ref = pytest.mark.skipif(not os.path.exists(SO), reason="oracle/_ref/libloops_ref_gpu.so not shipped")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _cases():
+    from loops_amd import generate as G
+    cases = dict(battery())
+    rows = cols = 1 << 12
+    deg = G.powerlaw_degrees(rows, 1 << 16, cap=1 << 11)
+    cases["powerlaw4096"] = (rows, cols) + G.powerlaw_csr(rows, cols, 1 << 16, degrees=deg)
+    return cases
+
+
+@needs_ref
+def test_reference_device_merge_path_matches_oracle():
+    from oracle import oracle as O
+    R = C.CDLL(SO)
+    for name, (r, c, off, idx, val) in _cases().items():
+        nnz = idx.size
+        for cfg, (tpb, ipt) in enumerate([(256, 8), (128, 7), (4, 2)]):
+            M = O.merge_path_num_tiles(r, nnz, tpb, ipt)
+            ts = np.zeros((max(M * tpb, 1), 2), np.uint32)
+            owner = np.full(max(nnz, 1), -1, np.int32)
+            row = np.full(max(nnz, 1), -1, np.int32)
+            vis = np.zeros(max(nnz, 1), np.int32)
+            assert R.refgpu_merge_path_dump(cfg, C.c_long(r), C.c_long(nnz), _p(off), _p(ts), _p(owner), _p(row), _p(vis)) == 0
+            want = O.merge_path_assign(off, tpb, ipt)
+            assert np.array_equal(ts[: M * tpb], want[0]), (name, tpb, ipt)
+            assert np.array_equal(owner[:nnz], want[1]) and np.array_equal(row[:nnz], want[2])
+            assert np.array_equal(vis[:nnz], want[3])
+        M = O.merge_path_num_tiles(r, nnz, 256, 8)
+        coords = np.zeros((M + 1, 2), np.uint32)
+        assert R.refgpu_merge_path_coords(C.c_long(r), C.c_long(nnz), _p(off), _p(coords)) == 0
+        assert np.array_equal(coords, O.merge_path_coords(off, 256, 8)), name
+
+
+@needs_ref
+def test_reference_device_work_oriented_matches_oracle():
+    from oracle import oracle as O
+    R = C.CDLL(SO)
+    for name, (r, c, off, idx, val) in _cases().items():
+        nnz = idx.size
+        for grid in (1, 3, 64):
+            tm = np.zeros((grid * 256, 4), np.int32)
+            owner = np.full(max(nnz, 1), -1, np.int32)
+            row = np.full(max(nnz, 1), -1, np.int32)
+            vis = np.zeros(max(nnz, 1), np.int32)
+            assert R.refgpu_work_oriented_dump(C.c_long(r), C.c_long(nnz), _p(off), grid, _p(tm), _p(owner), _p(row), _p(vis)) == 0
+            want = O.work_oriented_assign(off, grid * 256)
+            assert np.array_equal(tm, want[0]), (name, grid)
+            assert np.array_equal(owner[:nnz], want[1]) and np.array_equal(row[:nnz], want[2])
+            assert np.array_equal(vis[:nnz], want[3])
+
+
+@needs_ref
+def test_reference_device_spmv_matches_golden():
+    """The reference's own HIP kernels on this GPU reproduce the golden y (sanity of the pin)."""
+    R = C.CDLL(SO)
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        if r == 0 or idx.size == 0:
+            continue
+        x = g[name + ".x_int"]
+        for kind in (0, 1, 2):
+            y = np.zeros(r, np.float32)
+            ms = C.c_float()
+            assert R.refgpu_spmv_f32(kind, C.c_long(r), C.c_long(c), C.c_long(idx.size), _p(off), _p(idx), _p(val),
+                                     _p(x), _p(y), 1, C.byref(ms)) == 0
+            assert np.allclose(y, g[name + ".y_int"], rtol=1e-4, atol=1e-3), (name, kind)

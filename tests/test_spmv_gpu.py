@@ -1,0 +1,195 @@
+"""GPU parity tests proper: every call goes through the C ABI (libloops_amd.so) and is compared
+with the CPU oracle / the committed golden vectors.  Integer-valued and dyadic inputs are
+exactly summable in fp32, so those comparisons are BIT-EXACT whatever the summation order;
+real-valued inputs are held to the north star's 1e-6 relative bound (scaled by the row's L1
+mass, i.e. the reference's own Wilkinson-style criterion, util/reference.hxx:278-337)."""
+import numpy as np
+import pytest
+
+from conftest import battery, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+TUNED = ["merge_path_flat", "work_oriented", "thread_mapped", "group_mapped", "original", "flat_partitioned"]
+
+
+def _dev(off, idx, val, rows, cols):
+    from loops_amd import spmv as S
+    return S.CSR.from_numpy(rows, cols, off, idx, val)
+
+
+def _close(y, ref, l1, rel=1e-6):
+    # |y - ref| <= rel * sum_k |a_k x_k|  (+ tiny floor): order-independent fp32 bound
+    return np.all(np.abs(y.astype(np.float64) - ref.astype(np.float64)) <= rel * l1.astype(np.float64) * 8 + 1e-30)
+
+
+def test_library_is_the_hip_extension():
+    from loops_amd import _lib
+    assert _lib.lib().loops_version().decode().endswith("mi355x")
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("schedule", TUNED)
+def test_chesapeake_bit_exact(schedule):
+    """BASELINE config C1: chesapeake.mtx, reference x generator, Errors == 0 and bit-exact y."""
+    from loops_amd import spmv as S
+    g = load_golden("chesapeake.npz")
+    csr = _dev(g["offsets"], g["indices"], g["values"], 39, 39)
+    x = torch.from_numpy(g["x"]).cuda()
+    y = S.spmv(schedule, csr, x).cpu().numpy()
+    assert np.array_equal(y, g["y"]), schedule
+    assert y.sum() == 1794
+
+
+@pytest.mark.parametrize("schedule", TUNED)
+def test_battery_tuned_paths(schedule):
+    from loops_amd import spmv as S
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val, r, c)
+        for tag in ("int", "real"):
+            x = torch.from_numpy(g[f"{name}.x_{tag}"]).cuda()
+            y = torch.full((r,), 7.0, device="cuda")  # tuned paths must not need a zeroed y
+            S.spmv(schedule, csr, x, y)
+            y = y.cpu().numpy()
+            ref, l1 = g[f"{name}.y_{tag}"], g[f"{name}.l1_{tag}"]
+            if tag == "int" and name in ("identity16", "all_empty6"):
+                assert np.array_equal(y, ref), (schedule, name)
+            assert _close(y, ref, l1), (schedule, name, tag, np.abs(y - ref).max())
+
+
+@pytest.mark.parametrize("tile", ["256x8", "128x7", "256x7", "512x8"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_merge_path_fused_variants(tile, variant):
+    """Every compiled tile shape / code variant of the fused kernel, with a prebuilt plan."""
+    from loops_amd import spmv as S, generate as G
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val, r, c)
+        plan = S.MergePathPlan(csr, tile)
+        x = torch.from_numpy(g[f"{name}.x_real"]).cuda()
+        y = S.merge_path_flat(csr, x, plan=plan, variant=variant).cpu().numpy()
+        assert _close(y, g[f"{name}.y_real"], g[f"{name}.l1_real"]), (name, tile, variant)
+    # exactly-summable power-law matrix: bit-exact, rows spanning several merge tiles
+    rows = cols = 1 << 13
+    deg = G.powerlaw_degrees(rows, 1 << 17, cap=1 << 12)
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 17, degrees=deg)
+    xi = G.uniform_distribution_int(cols)
+    from oracle import oracle as O
+    ref = O.spmv_f32(off, idx, val, xi)
+    csr = _dev(off, idx, val, rows, cols)
+    plan = S.MergePathPlan(csr, tile)
+    y = S.merge_path_flat(csr, torch.from_numpy(xi).cuda(), plan=plan, variant=variant).cpu().numpy()
+    assert np.array_equal(y, ref), (tile, variant)
+
+
+def test_merge_path_unaligned_views_and_f64():
+    """Row-range shards hand the kernel arbitrarily aligned indices/values pointers."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows = cols = 4096
+    deg = G.powerlaw_degrees(rows, 1 << 16, cap=1 << 11)
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 16, degrees=deg)
+    xi = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xi)
+    for shift in (1, 2, 3):
+        pad_i = torch.zeros(idx.size + shift, dtype=torch.int32, device="cuda")
+        pad_v = torch.zeros(val.size + shift, dtype=torch.float32, device="cuda")
+        pad_i[shift:] = torch.from_numpy(idx).cuda()
+        pad_v[shift:] = torch.from_numpy(val).cuda()
+        csr = S.CSR(rows, cols, torch.from_numpy(off).cuda(), pad_i[shift:], pad_v[shift:])
+        y = S.merge_path_flat(csr, torch.from_numpy(xi).cuda(), plan=S.MergePathPlan(csr)).cpu().numpy()
+        assert np.array_equal(y, ref), shift
+    csr64 = S.CSR.from_numpy(rows, cols, off, idx, val.astype(np.float64))
+    x64 = torch.from_numpy(xi.astype(np.float64)).cuda()
+    for sched in ("merge_path_flat", "thread_mapped", "work_oriented"):
+        y = S.spmv(sched, csr64, x64).cpu().numpy()
+        assert np.array_equal(y, ref.astype(np.float64)), sched
+
+
+@pytest.mark.parametrize("schedule,tile", [("merge_path_flat", "256x8"), ("merge_path_flat", "128x7"),
+                                           ("merge_path_flat", "4x2"), ("work_oriented", "256x8"),
+                                           ("group_mapped", "256x8"), ("thread_mapped", "256x8"),
+                                           ("flat_partitioned", "256x8"), ("original", "256x8")])
+def test_schedule_api_kernels(schedule, tile):
+    """The reference-shaped kernels written against schedule::setup<> (atomics, pre-zeroed y):
+    tolerance is the reference's own test tolerance (unittests/test_helpers.hxx:242-247,
+    rtol 1e-4 / atol 1e-3) -- atomic accumulation order is not deterministic."""
+    from loops_amd import spmv as S
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val, r, c)
+        xi = torch.from_numpy(g[f"{name}.x_int"]).cuda()
+        y = S.spmv_schedule_api(schedule, csr, xi, tile=tile).cpu().numpy()
+        assert np.allclose(y, g[f"{name}.y_int"], rtol=1e-4, atol=1e-3), (schedule, name)
+
+
+def test_bcsr_thread_mapped_and_mfma():
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        for R in (2, 3, 4):
+            if f"{name}.bcsr{R}.offsets" not in g:
+                continue
+            b = S.BCSR(R, R, r, c, torch.from_numpy(g[f"{name}.bcsr{R}.offsets"]).cuda(),
+                       torch.from_numpy(g[f"{name}.bcsr{R}.cols"]).cuda(),
+                       torch.from_numpy(g[f"{name}.bcsr{R}.values"]).cuda())
+            xp = np.zeros(b.num_block_cols * R, np.float32)
+            xp[:c] = g[name + ".x_int"]
+            want = O.bcsr_spmv_f32(R, R, r, g[f"{name}.bcsr{R}.offsets"], g[f"{name}.bcsr{R}.cols"],
+                                   g[f"{name}.bcsr{R}.values"], xp)
+            modes = (False, True) if R == 4 else (False,)
+            for mfma in modes:
+                y = S.bcsr_thread_mapped(b, torch.from_numpy(xp).cuda(), mfma=mfma).cpu().numpy()
+                assert np.allclose(y, want, rtol=1e-6, atol=1e-6), (name, R, mfma)
+                assert np.allclose(y, g[name + ".y_int"], rtol=1e-5, atol=1e-5), (name, R, mfma)
+    # C4-shaped (scaled down), asymmetric blocks, exact inputs: bit-exact incl. the MFMA layout
+    nbr, per = 1 << 12, 16
+    boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, per)
+    x = G.uniform_distribution_int(nbr * 4)
+    want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, x)
+    b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(),
+               torch.from_numpy(bvals).cuda())
+    for mfma in (False, True):
+        y = S.bcsr_thread_mapped(b, torch.from_numpy(x).cuda(), mfma=mfma).cpu().numpy()
+        assert np.array_equal(y, want), mfma
+
+
+def test_full_size_c2_bit_exact_and_properties():
+    """BASELINE config C2 at full size (2^20 rows, 2^24 nnz, max degree 2^14): bit-exact vs the
+    oracle (exactly-summable inputs) + size-independent properties (linearity, plan reuse)."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows = cols = 1 << 20
+    deg = G.powerlaw_degrees(rows, 1 << 24)
+    assert deg.max() == 1 << 14
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 24, degrees=deg)
+    x = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, x, omp=True)
+    csr = _dev(off, idx, val, rows, cols)
+    xd = torch.from_numpy(x).cuda()
+    plan = S.MergePathPlan(csr)
+    assert np.array_equal(plan.coords(), O.merge_path_coords(off, 256, 8))
+    for variant in (0, 1, 2, 3):
+        y = S.merge_path_flat(csr, xd, plan=plan, variant=variant)
+        assert np.array_equal(y.cpu().numpy(), ref), variant
+    for sched in ("merge_path_flat", "work_oriented", "thread_mapped", "group_mapped"):
+        assert np.array_equal(S.spmv(sched, csr, xd).cpu().numpy(), ref), sched
+    # linearity: A(2x) == 2 A x exactly (power-of-two scaling), A(x + x2) == Ax + Ax2 (integers)
+    y1 = S.merge_path_flat(csr, xd, plan=plan)
+    y2 = S.merge_path_flat(csr, xd * 2, plan=plan)
+    assert torch.equal(y2, y1 * 2)
+    x2 = torch.from_numpy(G.uniform_distribution_int(cols, 1, 10, 7)).cuda()
+    assert torch.equal(S.merge_path_flat(csr, xd + x2, plan=plan), y1 + S.merge_path_flat(csr, x2, plan=plan))
+    # realistic values: the reference's rigorous validator (Wilkinson K = 8, floor 1e-3)
+    off_r, idx_r, val_r = G.powerlaw_csr(rows, cols, 1 << 24, degrees=deg, exact=False)
+    xr = G.realistic_x(cols)
+    csr_r = _dev(off_r, idx_r, val_r, rows, cols)
+    yr = S.merge_path_flat(csr_r, torch.from_numpy(xr).cuda(), plan=plan).cpu().numpy()
+    rep = O.rigorous_validate_f32(off_r, idx_r, val_r, xr, yr)
+    assert rep.gpu_overruns == 0 and rep.naive_mismatches == 0
+    y64 = O.spmv_f64acc_f32(off_r, idx_r, val_r, xr)
+    rel = np.abs(yr - y64) / np.maximum(np.abs(y64), 1.0)
+    assert rel.max() < 1e-6 * 16, rel.max()
