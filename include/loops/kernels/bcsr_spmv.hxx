@@ -65,7 +65,7 @@ int launch_bcsr_thread_mapped(hipStream_t stream, int rows, int num_block_rows, 
   return static_cast<int>(hipGetLastError());
 }
 
-using f32x4 = __attribute__((__vector_size__(4 * sizeof(float)))) float;
+using f32x4 = float __attribute__((ext_vector_type(4)));
 
 template <int TPB>
 __global__ void __launch_bounds__(TPB)
@@ -99,10 +99,10 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
     const int bc = block_cols[b];
     f32x4 xv = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc) * 4);
     if (!live) a = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], xv[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], xv[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], xv[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], xv[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, xv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, xv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, xv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, xv.w, acc, 0, 0, 0);
   }
   // D layout of the 4x4x1 16-block form: lane (slot, col) register v = D[v][col]; every column
   // holds the same y (B was broadcast), so column 0's lane stores the block-row's 4 outputs.
@@ -111,9 +111,9 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
     if (r0 + 3 < rows) {
       *reinterpret_cast<f32x4*>(y + r0) = acc;
     } else {
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        if (r0 + v < rows) y[r0 + v] = acc[v];
+      if (r0 + 0 < rows) y[r0 + 0] = acc.x;
+      if (r0 + 1 < rows) y[r0 + 1] = acc.y;
+      if (r0 + 2 < rows) y[r0 + 2] = acc.z;
     }
   }
 }

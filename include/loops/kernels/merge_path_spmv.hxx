@@ -49,33 +49,34 @@ using coord_t = coordinate_t<unsigned int>;
 
 namespace detail {
 
-/// 16-byte (4 x 32-bit) or 2 x 16-byte (4 x 64-bit) vector load of 4 consecutive elements.
+/// 4 consecutive elements with the widest loads the element size allows: one 16-byte
+/// global_load_dwordx4 for 32-bit elements, two for 64-bit ones.  (Written against the native
+/// ext-vector types: element-wise bit_cast of a __vector_size__ vector miscompiles on ROCm 7.2
+/// -- every lane of the result aliases element 0.)
+template <typename V, bool NT>
+__device__ __forceinline__ V load_vec(const void* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(static_cast<const V*>(p));
+  else return *static_cast<const V*>(p);
+}
+
 template <typename T, bool NT>
 __device__ __forceinline__ void load4(const T* __restrict__ p, T (&out)[4]) {
   if constexpr (sizeof(T) == 4) {
-    using v4 = __attribute__((__vector_size__(4 * sizeof(int)))) int;
-    v4 v;
-    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
-    else v = *reinterpret_cast<const v4*>(p);
-    out[0] = __builtin_bit_cast(T, v[0]);
-    out[1] = __builtin_bit_cast(T, v[1]);
-    out[2] = __builtin_bit_cast(T, v[2]);
-    out[3] = __builtin_bit_cast(T, v[3]);
+    using v4 = T __attribute__((ext_vector_type(4)));
+    const v4 v = load_vec<v4, NT>(p);
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
   } else {
     static_assert(sizeof(T) == 8, "load4: 4- or 8-byte elements");
-    using v2 = __attribute__((__vector_size__(2 * sizeof(long long)))) long long;
-    v2 a, b;
-    if constexpr (NT) {
-      a = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p));
-      b = __builtin_nontemporal_load(reinterpret_cast<const v2*>(p) + 1);
-    } else {
-      a = *reinterpret_cast<const v2*>(p);
-      b = *(reinterpret_cast<const v2*>(p) + 1);
-    }
-    out[0] = __builtin_bit_cast(T, a[0]);
-    out[1] = __builtin_bit_cast(T, a[1]);
-    out[2] = __builtin_bit_cast(T, b[0]);
-    out[3] = __builtin_bit_cast(T, b[1]);
+    using v2 = T __attribute__((ext_vector_type(2)));
+    const v2 a = load_vec<v2, NT>(p);
+    const v2 b = load_vec<v2, NT>(p + 2);
+    out[0] = a.x;
+    out[1] = a.y;
+    out[2] = b.x;
+    out[3] = b.y;
   }
 }
 
@@ -255,6 +256,12 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
     }
   }
 
+#ifdef LOOPS_DEBUG_FUSED
+  if (b == 0 && tid < 6)
+    printf("tid %d diag %d start(%d,%d) end(tx %d ty %d) sum %f closed %d first_sum %f first_row %d re %d nrows %d natoms %d shift %d sprod0..3 %f %f %f %f sre0..2 %d %d %d\n",
+           tid, diag, tx, ty, tx, ty, (double)sum, (int)closed, (double)first_sum, first_row, re, nrows, natoms, shift,
+           (double)s_prod[detail::slot<PAD>(0)], (double)s_prod[detail::slot<PAD>(1)], (double)s_prod[detail::slot<PAD>(2)], (double)s_prod[detail::slot<PAD>(3)], s_re[0], s_re[1], s_re[2]);
+#endif
   // ---- 4. STITCH: partial rows across threads / wavefronts / workgroups -------------------------
   const int lane = wave::lane();
   const int w = tid / wave::size;

@@ -83,11 +83,13 @@ class preprocess_t {
   static constexpr std::size_t items_per_tile = THREADS_PER_BLOCK * ITEMS_PER_THREAD;
   /// Below this many merge tiles the per-workgroup search is done in-kernel (two lanes).
   static constexpr std::size_t min_tiles_for_prepass = 256;
+  /// Third constructor argument: when to run the coordinate pre-pass kernel.
+  enum : int { prepass_auto = -1, prepass_never = 0, prepass_always = 1 };
 
   preprocess_t(tiles_iterator_t _tiles, tile_size_t _num_tiles, atom_size_t _num_atoms, xpu::stream_t stream = 0)
       : preprocess_t(layout_t(_tiles, _num_tiles, _num_atoms), stream) {}
 
-  explicit preprocess_t(layout_t _layout, xpu::stream_t stream = 0, bool force_prepass = false)
+  explicit preprocess_t(layout_t _layout, xpu::stream_t stream = 0, int prepass = prepass_auto)
       : total_work(static_cast<std::size_t>(_layout.num_tiles()) + static_cast<std::size_t>(_layout.num_atoms())),
         num_merge_tiles(math::ceil_div(total_work, items_per_tile)),
         d_tile_coordinates(nullptr),
@@ -97,7 +99,7 @@ class preprocess_t {
     const std::size_t coord_bytes = (num_merge_tiles + 1) * sizeof(coord_t);
     const std::size_t bytes = coord_bytes + (num_merge_tiles + 2) * (sizeof(double) + sizeof(int));
     error::throw_if_exception(xpu::malloc(&d_scratch, bytes), "merge_path::preprocess_t: allocation failed.");
-    if (force_prepass || num_merge_tiles >= min_tiles_for_prepass) {
+    if (prepass == prepass_always || (prepass == prepass_auto && num_merge_tiles >= min_tiles_for_prepass)) {
       d_tile_coordinates = static_cast<coord_t*>(d_scratch);
       constexpr std::size_t block = 256;
       launch::non_cooperative(

@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libloops_amd.so")
+LIB_PATH = os.environ.get("LOOPS_AMD_LIB", os.path.join(_HERE, "libloops_amd.so"))
 SRC_PATH = os.path.join(_HERE, "csrc", "loops_c_abi.hip")
 INCLUDE_DIR = os.path.join(_ROOT, "include")
 
@@ -60,6 +60,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _lib = None
 
 
+def load_shared(path: str) -> C.CDLL:
+    """dlopen a HIP shared library so that it shares ONE HIP runtime with PyTorch.
+
+    PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so; a second copy of
+    the runtime in the same process (e.g. /opt/rocm's, pulled in by an extension that is loaded
+    before torch) cannot open the device again (hipErrorNoDevice / "No HIP GPUs are available").
+    Importing torch first makes the loader bind our DT_NEEDED libamdhip64.so.7 to the copy that
+    is already resident."""
+    import torch  # noqa: F401  (side effect: torch's HIP runtime is loaded first)
+    return C.CDLL(path)
+
+
 def lib() -> C.CDLL:
     """The loaded library; raises LoopsError (never falls back) when it has not been built."""
     global _lib
@@ -68,7 +80,7 @@ def lib() -> C.CDLL:
             raise LoopsError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = load_shared(LIB_PATH)
         L.loops_version.restype = C.c_char_p
         vp, ci = C.c_void_p, C.c_int
         L.loops_merge_plan_create.argtypes = [ci, ci, vp, ci, vp, C.POINTER(vp)]

@@ -185,8 +185,7 @@ int launch_merge_dump(bool use_plan, int rows, int nnz, const int* off, unsigned
                       int* visits, hipStream_t stream) {
   using pre_t = schedule::merge_path::preprocess_t<TPB, IPT, int, int, std::size_t, std::size_t>;
   using layout_t = layout::csr<int, int>;
-  pre_t meta(layout_t(off, rows, nnz), stream, use_plan);
-  if (!use_plan && meta.data() != nullptr) return LOOPS_E_BADARG;  // wanted the in-kernel search path
+  pre_t meta(layout_t(off, rows, nnz), stream, use_plan ? pre_t::prepass_always : pre_t::prepass_never);
   const std::size_t m = meta.merge_tiles();
   if (m == 0) return 0;
   launch::non_cooperative(stream, kernels::merge_path_flat_dump<TPB, IPT, pre_t, int>, dim3(static_cast<unsigned>(m)),

@@ -61,6 +61,13 @@ def ref() -> C.CDLL | None:
         so = os.path.join(_HERE, "_ref", "libloops_ref.so")
         if not os.path.exists(so):
             return None
+        # libloops_ref.so is hipcc-built and DT_NEEDs libamdhip64.so.7: import torch first so the
+        # process keeps ONE HIP runtime (torch bundles its own copy; a second copy loaded before
+        # it leaves torch with "No HIP GPUs are available").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _REF = C.CDLL(so)
         _REF.ref_hash.restype = C.c_uint
         _REF.ref_hash.argtypes = [C.c_uint]

@@ -17,7 +17,7 @@ def _declared():
 def test_library_builds_and_exports_every_declared_symbol():
     so = _lib.build()
     assert os.path.exists(so)
-    L = ctypes.CDLL(so)
+    L = _lib.load_shared(so)
     declared = _declared()
     assert declared, "no declarations parsed"
     assert sorted(_lib.SYMBOLS) == declared

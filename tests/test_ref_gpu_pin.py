@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, battery, load_golden
+from loops_amd import _lib
 
 pytestmark = pytest.mark.gpu
 SO = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
@@ -30,7 +31,7 @@ def _cases():
 @needs_ref
 def test_reference_device_merge_path_matches_oracle():
     from oracle import oracle as O
-    R = C.CDLL(SO)
+    R = _lib.load_shared(SO)
     for name, (r, c, off, idx, val) in _cases().items():
         nnz = idx.size
         for cfg, (tpb, ipt) in enumerate([(256, 8), (128, 7), (4, 2)]):
@@ -53,7 +54,7 @@ def test_reference_device_merge_path_matches_oracle():
 @needs_ref
 def test_reference_device_work_oriented_matches_oracle():
     from oracle import oracle as O
-    R = C.CDLL(SO)
+    R = _lib.load_shared(SO)
     for name, (r, c, off, idx, val) in _cases().items():
         nnz = idx.size
         for grid in (1, 3, 64):
@@ -71,7 +72,7 @@ def test_reference_device_work_oriented_matches_oracle():
 @needs_ref
 def test_reference_device_spmv_matches_golden():
     """The reference's own HIP kernels on this GPU reproduce the golden y (sanity of the pin)."""
-    R = C.CDLL(SO)
+    R = _lib.load_shared(SO)
     g = load_golden("battery.npz")
     for name, (r, c, off, idx, val) in battery().items():
         if r == 0 or idx.size == 0:
