@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--window", type=int, default=0,
+                    help="0: uniform hashed columns (SURVEY 8d, the headline); W > 0: columns in a band of W around "
+                         "the diagonal (locality variant, reported for context)")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
     args = ap.parse_args()
 
@@ -71,7 +74,8 @@ def main():
     degrees = G.powerlaw_degrees(rows, nnz)
     bounds = P.row_ranges_from_degrees(degrees, world)
     shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
-    off, idx, val = G.csr_from_degrees(degrees[shard.row_begin:shard.row_end], cols, seed=1, row_begin=shard.row_begin)
+    off, idx, val = G.csr_from_degrees(degrees[shard.row_begin:shard.row_end], cols, seed=1, row_begin=shard.row_begin,
+                                       window=args.window or None)
     x_h = G.uniform_distribution_int(cols)
     csr = S.CSR.from_numpy(shard.row_end - shard.row_begin, cols, off, idx, val)
     x = torch.from_numpy(x_h).cuda()
@@ -211,7 +215,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic power-law CSR, {rows} rows / {nnz} nnz total "
                                    f"({world} x 2^{args.log2_rows} rows / 2^{args.log2_nnz} nnz per GPU), max degree 2^14, "
-                                   "fp32, merge_path_flat" + (", row-range sharded + allgatherv(y) over RCCL" if world > 1 else ""),
+                                   "fp32, merge_path_flat" + (f", columns banded (window {args.window})" if args.window else ", columns uniform")
+                                   + (", row-range sharded + allgatherv(y) over RCCL" if world > 1 else ""),
                        "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
                        "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
                        "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + allgatherv(y)" if world > 1 else ""),

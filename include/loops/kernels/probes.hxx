@@ -19,16 +19,27 @@ __global__ void __launch_bounds__(256) stream_copy_kernel(const float4* __restri
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
 }
 
+/// How the gathered word is requested: 0 plain, 1 non-temporal, 2 agent-scope (sc1, bypasses the
+/// CU's vector L1), 3 system-scope (sc0 sc1).
+template <int MODE>
+__device__ __forceinline__ float gather_load(const float* p) {
+  if constexpr (MODE == 1) return __builtin_nontemporal_load(p);
+  else if constexpr (MODE == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else if constexpr (MODE == 3) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  else return *p;
+}
+
+template <int MODE>
 __global__ void __launch_bounds__(256) gather_kernel(const float* __restrict__ table, const int* __restrict__ idx,
                                                      float* __restrict__ out, size_t n) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
   for (size_t i = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i + 3 < n; i += stride) {
     const int4 c = *reinterpret_cast<const int4*>(idx + i);
     float4 v;
-    v.x = table[c.x];
-    v.y = table[c.y];
-    v.z = table[c.z];
-    v.w = table[c.w];
+    v.x = gather_load<MODE>(table + c.x);
+    v.y = gather_load<MODE>(table + c.y);
+    v.z = gather_load<MODE>(table + c.z);
+    v.w = gather_load<MODE>(table + c.w);
     *reinterpret_cast<float4*>(out + i) = v;
   }
 }
@@ -43,11 +54,17 @@ inline int launch_stream_copy(hipStream_t stream, const float* src, float* dst, 
   return static_cast<int>(hipGetLastError());
 }
 
-inline int launch_gather(hipStream_t stream, const float* table, const int* idx, float* out, size_t n) {
+inline int launch_gather(hipStream_t stream, const float* table, const int* idx, float* out, size_t n, int mode) {
   if (n < 4) return 0;
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
-  hipLaunchKernelGGL(gather_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, table, idx, out, n);
+  const dim3 g(static_cast<unsigned>(blocks)), b(256);
+  switch (mode) {
+    case 1: hipLaunchKernelGGL(gather_kernel<1>, g, b, 0, stream, table, idx, out, n); break;
+    case 2: hipLaunchKernelGGL(gather_kernel<2>, g, b, 0, stream, table, idx, out, n); break;
+    case 3: hipLaunchKernelGGL(gather_kernel<3>, g, b, 0, stream, table, idx, out, n); break;
+    default: hipLaunchKernelGGL(gather_kernel<0>, g, b, 0, stream, table, idx, out, n); break;
+  }
   return static_cast<int>(hipGetLastError());
 }
 

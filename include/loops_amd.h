@@ -141,8 +141,9 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against. */
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
-/* out[i] = table[idx[i]] -- measures the L2 / Infinity-Cache gather rate that bounds x reads. */
-int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, void* stream);
+/* out[i] = table[idx[i]] -- measures the L2 / Infinity-Cache gather rate that bounds x reads.
+ * mode: 0 plain loads, 1 non-temporal, 2 agent-scope (sc1: bypass the CU's L1), 3 system-scope. */
+int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,7 @@ def lib() -> C.CDLL:
         L.loops_device_compute_units.argtypes = [C.POINTER(ci)]
         L.loops_spmv_bcsr_f32.argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
-        L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, vp]
+        L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         _lib = L
     return _lib
 

@@ -455,9 +455,9 @@ int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) 
   return kernels::launch_stream_copy(as_stream(stream), src, dst, n);
 }
 
-int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, void* stream) {
+int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream) {
   if (!table || !idx || !out) return LOOPS_E_BADARG;
-  return kernels::launch_gather(as_stream(stream), table, idx, out, n);
+  return kernels::launch_gather(as_stream(stream), table, idx, out, n, mode);
 }
 
 }  // extern "C"

@@ -85,15 +85,23 @@ def powerlaw_degrees(rows, nnz, alpha=0.8, cap=1 << 14, perm_seed=0x5EED):
     return out
 
 
-def _hash_cols(seed, rows_abs, k, attempt, cols):
+def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None):
     h = splitmix64(splitmix64(np.uint64(seed) + rows_abs.astype(np.uint64)) + k.astype(np.uint64)
                    + (np.uint64(attempt) << np.uint64(40)))
-    return (h % np.uint64(cols)).astype(np.int64)
+    if window is None:
+        return (h % np.uint64(cols)).astype(np.int64)
+    # locality variant: columns fall in a window centred on the diagonal, at least 4x the row's
+    # degree wide (so distinct columns always exist) and never wider than the matrix
+    w = np.minimum(np.maximum(np.int64(window), 4 * deg), np.int64(cols)).astype(np.uint64)
+    off = (h % w).astype(np.int64) - (w // np.uint64(2)).astype(np.int64)
+    return (rows_abs + off) % np.int64(cols)
 
 
-def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True):
+def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None):
     """Rows [row_begin, row_begin + len(degrees)) of the hashed matrix: per-row distinct columns
-    sorted ascending; values k/8 (exact) or U[0.5, 1.5) (realistic)."""
+    sorted ascending; values k/8 (exact) or U[0.5, 1.5) (realistic).  `window` = None draws
+    columns uniformly over [0, cols); an integer draws them from a band of that many
+    columns around the diagonal (web-graph-like locality of the x gather)."""
     nrows = degrees.size
     offsets = np.zeros(nrows + 1, np.int64)
     np.cumsum(degrees, out=offsets[1:])
@@ -102,7 +110,8 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True):
     rloc = np.repeat(np.arange(nrows, dtype=np.int64), degrees)
     k = np.arange(nnz, dtype=np.int64) - np.repeat(offsets[:-1], degrees)
     rabs = rloc + row_begin
-    col = _hash_cols(seed, rabs, k, 0, cols)
+    dk = np.repeat(degrees.astype(np.int64), degrees) if window is not None else None
+    col = _hash_cols(seed, rabs, k, 0, cols, window, dk)
     attempt = 0
     while True:
         key = (rloc.astype(np.uint64) << np.uint64(32)) | col.astype(np.uint64)
@@ -113,7 +122,7 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True):
             break
         attempt += 1
         bad = order[dup]
-        col[bad] = _hash_cols(seed, rabs[bad], k[bad], attempt, cols)
+        col[bad] = _hash_cols(seed, rabs[bad], k[bad], attempt, cols, window, None if dk is None else dk[bad])
     indices = (sk & np.uint64(0xFFFFFFFF)).astype(np.int32)  # sorted by (row, col)
     rsorted = rloc  # rows are already grouped: sorting by (row, col) keeps row order
     vh = splitmix64((rsorted + row_begin).astype(np.uint64) * np.uint64(0x100000001B3) + indices.astype(np.uint64)
@@ -126,13 +135,13 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True):
 
 
 def powerlaw_csr(rows, cols, nnz, alpha=0.8, cap=1 << 14, seed=1, row_begin=0, row_end=None, exact=True,
-                 degrees=None):
+                 degrees=None, window=None):
     """(offsets, indices, values) of rows [row_begin, row_end) of the power-law matrix
     (offsets rebased to 0, global column ids)."""
     if degrees is None:
         degrees = powerlaw_degrees(rows, nnz, alpha, min(cap, cols))
     row_end = rows if row_end is None else row_end
-    return csr_from_degrees(degrees[row_begin:row_end], cols, seed, row_begin, exact)
+    return csr_from_degrees(degrees[row_begin:row_end], cols, seed, row_begin, exact, window)
 
 
 def realistic_x(n, seed=7, start=0):

@@ -263,5 +263,6 @@ def stream_copy(src, dst):
     L.check(L.lib().loops_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "loops_stream_copy_f32")
 
 
-def gather(table, idx, out):
-    L.check(L.lib().loops_gather_f32(_ptr(table), _ptr(idx), _ptr(out), idx.numel(), _stream()), "loops_gather_f32")
+def gather(table, idx, out, mode: int = 0):
+    L.check(L.lib().loops_gather_f32(_ptr(table), _ptr(idx), _ptr(out), idx.numel(), mode, _stream()),
+            "loops_gather_f32")
