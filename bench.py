@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--window", type=int, default=0,
                     help="0: uniform hashed columns (SURVEY 8d, the headline); W > 0: columns in a band of W around "
                          "the diagonal (locality variant, reported for context)")
+    ap.add_argument("--ref-gpu", action="store_true",
+                    help="also time the reference's own HIP kernels on this GPU (oracle/_ref/libloops_ref_gpu.so)")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
     args = ap.parse_args()
 
@@ -185,6 +187,23 @@ def main():
                 print(f"[sweep] tile={tile} variant={variant} main kernel avg {avg*1e3:.1f} us med {med*1e3:.1f} us "
                       f"-> {abytes/avg/1e6:.0f} GB/s", file=sys.stderr)
 
+    # ------------------------------------------------------------------ the reference's own HIP path on this GPU
+    ref_gpu = None
+    so = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
+    if args.ref_gpu and rank == 0 and world == 1 and os.path.exists(so):
+        import ctypes as C
+        from loops_amd import _lib
+        R = _lib.load_shared(so)
+        ref_gpu = {}
+        for kind, name in ((2, "merge_path_flat"), (0, "thread_mapped"), (1, "work_oriented")):
+            yr = np.zeros(csr.rows, np.float32)
+            ms = C.c_float()
+            p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            rc = R.refgpu_spmv_f32(kind, C.c_long(csr.rows), C.c_long(cols), C.c_long(csr.nnzs), p(off), p(idx), p(val),
+                                   p(x_h), p(yr), 10, C.byref(ms))
+            ref_gpu[name] = {"rc": rc, "best_kernel_ms": round(ms.value, 5),
+                             "GFLOPs": round(2.0 * csr.nnzs / (ms.value * 1e-3) / 1e9, 2) if ms.value > 0 else None}
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -222,7 +241,8 @@ def main():
                        "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + allgatherv(y)" if world > 1 else ""),
                        "ms_per_step_with_prepass": round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
-                       "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1)},
+                       "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
+                       "reference_hip_backend_on_this_gpu": ref_gpu},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -1,0 +1,57 @@
+"""Times every schedule's SpMV (tuned C-ABI path and the reference-shaped schedule-API kernels)
+on the C2 workload and on a C3-sized scale-free stand-in; prints a table + JSON (stderr/stdout).
+Also times the reference's own HIP kernels on the same GPU when oracle/_ref is present."""
+import argparse, json, os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from loops_amd import generate as G, spmv as S, _lib
+
+def ev(fn, iters=30, warm=3):
+    for _ in range(warm): fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--log2-rows", type=int, default=20)
+ap.add_argument("--log2-nnz", type=int, default=24)
+ap.add_argument("--window", type=int, default=0)
+ap.add_argument("--ref-gpu", action="store_true")
+ap.add_argument("--tag", default="c2")
+args = ap.parse_args()
+rows = cols = 1 << args.log2_rows
+nnz = 1 << args.log2_nnz
+deg = G.powerlaw_degrees(rows, nnz)
+off, idx, val = G.powerlaw_csr(rows, cols, nnz, degrees=deg, window=args.window or None)
+xh = G.uniform_distribution_int(cols)
+csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+x = torch.from_numpy(xh).cuda()
+y = torch.empty(rows, device="cuda")
+from oracle import oracle as O
+ref = O.spmv_f32(off, idx, val, xh, omp=True)
+abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
+res = {"workload": f"{args.tag}: 2^{args.log2_rows} rows, 2^{args.log2_nnz} nnz, window={args.window}", "rows": {}}
+plan = S.MergePathPlan(csr)
+def rec(name, fn, check=True):
+    ms = ev(fn)
+    ok = bool(np.array_equal(y.cpu().numpy(), ref)) if check else None
+    res["rows"][name] = {"ms": round(ms, 4), "GFLOPs": round(2 * nnz / ms / 1e6, 1), "GBps": round(abytes / ms / 1e6, 1), "bit_exact": ok}
+    print(f"{name:42s} {ms*1e3:9.1f} us {2*nnz/ms/1e6:8.1f} GFLOP/s {abytes/ms/1e6:8.1f} GB/s exact={ok}", file=sys.stderr, flush=True)
+rec("merge_path_flat (planned, fused+fixup)", lambda: S.merge_path_flat(csr, x, y, plan=plan))
+for sched in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "original", "flat_partitioned"):
+    rec(f"tuned {sched}", lambda: S.spmv(sched, csr, x, y))
+for sched in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "flat_partitioned"):
+    rec(f"schedule-API {sched} (incl. y zero-fill)", lambda: S.spmv_schedule_api(sched, csr, x, y))
+so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libloops_ref_gpu.so")
+if args.ref_gpu and os.path.exists(so):
+    R = _lib.load_shared(so)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for kind, name in ((2, "merge_path_flat"), (0, "thread_mapped"), (1, "work_oriented")):
+        yr = np.zeros(rows, np.float32); ms = C.c_float()
+        rc = R.refgpu_spmv_f32(kind, C.c_long(rows), C.c_long(cols), C.c_long(nnz), p(off), p(idx), p(val), p(xh), p(yr), 10, C.byref(ms))
+        ok = bool(np.allclose(yr, ref, rtol=1e-4, atol=1e-3))
+        res["rows"][f"REFERENCE HIP backend {name}"] = {"ms": round(ms.value, 4), "GFLOPs": round(2 * nnz / ms.value / 1e6, 1), "GBps": round(abytes / ms.value / 1e6, 1), "ok": ok, "rc": rc}
+        print(f"{'REFERENCE HIP backend ' + name:42s} {ms.value*1e3:9.1f} us {2*nnz/ms.value/1e6:8.1f} GFLOP/s {abytes/ms.value/1e6:8.1f} GB/s ok={ok}", file=sys.stderr, flush=True)
+print(json.dumps(res))
