@@ -1,0 +1,53 @@
+/**
+ * @file csc_thread_mapped.cuh
+ * @brief `algorithms::spmv::csc_thread_mapped(csc, x, y, stream) -> util::timer_t`: one thread per
+ * column over `layout::csc`, x[col] read once, atomicAdd per nonzero (reference
+ * include/loops/algorithms/spmv/csc_thread_mapped.cuh:37-96).  y must be zero-filled.
+ */
+#pragma once
+
+#include <loops/schedule.hxx>
+#include <loops/container/formats.hxx>
+#include <loops/container/vector.hxx>
+#include <loops/util/launch.hxx>
+#include <loops/util/device.hxx>
+#include <loops/util/math.hxx>
+#include <loops/util/timer.hxx>
+#include <loops/algorithms/spmv/launch_box.hxx>
+#include <loops/memory.hxx>
+
+namespace loops {
+namespace algorithms {
+namespace spmv {
+
+template <typename setup_t, typename index_t, typename type_t>
+__global__ void __csc_thread_mapped(setup_t config, const index_t* row_indices, const type_t* values,
+                                    const type_t* x, type_t* y) {
+  for (auto col : config.tiles()) {
+    const type_t x_col = x[col];
+    for (auto atom : config.atoms(col)) atomicAdd(&y[row_indices[atom]], values[atom] * x_col);
+  }
+}
+
+template <typename index_t, typename offset_t, typename type_t>
+util::timer_t csc_thread_mapped(csc_t<index_t, offset_t, type_t>& csc, vector_t<type_t>& x, vector_t<type_t>& y,
+                                xpu::stream_t stream = 0) {
+  using layout_t = layout::csc<index_t, offset_t>;
+  using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t, std::size_t,
+                                  std::size_t, layout_t>;
+  setup_t config(layout_t(csc.offsets.data().get(), static_cast<index_t>(csc.cols), static_cast<offset_t>(csc.nnzs)));
+  constexpr std::size_t block_size = 128;
+  util::timer_t timer(stream);
+  timer.start();
+  if (csc.cols > 0)
+    launch::non_cooperative(stream, __csc_thread_mapped<setup_t, index_t, type_t>,
+                            dim3(static_cast<unsigned>(math::ceil_div(csc.cols, block_size))), dim3(block_size), config,
+                            csc.indices.data().get(), csc.values.data().get(), x.data().get(), y.data().get());
+  (void)xpu::stream_synchronize(stream);
+  timer.stop();
+  return timer;
+}
+
+}  // namespace spmv
+}  // namespace algorithms
+}  // namespace loops

@@ -1,0 +1,67 @@
+/**
+ * @file merge_path_flat.cuh
+ * @brief `algorithms::spmv::merge_path_flat(csr, x, y, stream) -> util::timer_t`: the headline
+ * load-balanced CSR SpMV.  Same signature and timing convention as the reference wrapper
+ * (include/loops/algorithms/spmv/merge_path_flat.cuh:97-139: the coordinate pre-pass is built
+ * first and NOT timed; the returned timer brackets the SpMV kernels only), but the work is done
+ * by the fused CDNA4 kernel (loops/kernels/merge_path_spmv.hxx) -- no per-nonzero atomics, y
+ * needs no zero-fill, deterministic summation order.
+ *
+ * `merge_path_flat(plan, csr, x, y, stream)` reuses a caller-held `preprocess_t` (the plan only
+ * depends on csr.offsets), which is how an iterative solver should call it.
+ */
+#pragma once
+
+#include <loops/schedule.hxx>
+#include <loops/container/formats.hxx>
+#include <loops/container/vector.hxx>
+#include <loops/util/launch.hxx>
+#include <loops/util/device.hxx>
+#include <loops/util/math.hxx>
+#include <loops/util/timer.hxx>
+#include <loops/algorithms/spmv/launch_box.hxx>
+#include <loops/kernels/launch.hxx>
+#include <loops/memory.hxx>
+
+namespace loops {
+namespace algorithms {
+namespace spmv {
+
+template <typename index_t, typename offset_t, typename type_t>
+using merge_path_plan_t =
+    schedule::merge_path::preprocess_t<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread, index_t,
+                                       offset_t, std::size_t, std::size_t>;
+
+/// SpMV with a prebuilt plan; asynchronous on `stream`.
+template <typename index_t, typename offset_t, typename type_t>
+void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,
+                           csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
+                           xpu::stream_t stream = 0) {
+  constexpr int block_size = launch_t<type_t>::block_size;
+  constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
+  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                static_cast<int>(plan.merge_tiles())};
+  kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
+      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
+}
+
+template <typename index_t, typename offset_t, typename type_t>
+util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
+                              xpu::stream_t stream = 0) {
+  using plan_t = merge_path_plan_t<index_t, offset_t, type_t>;
+  // Coordinates for every merge tile (the fused kernel always consumes the table).
+  plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows),
+                                        static_cast<offset_t>(csr.nnzs)),
+              stream, plan_t::prepass_always);
+  util::timer_t timer(stream);
+  timer.start();
+  merge_path_flat_async(plan, csr, x, y, stream);
+  (void)xpu::stream_synchronize(stream);
+  timer.stop();
+  return timer;
+}
+
+}  // namespace spmv
+}  // namespace algorithms
+}  // namespace loops

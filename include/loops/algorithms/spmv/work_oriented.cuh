@@ -1,0 +1,36 @@
+/**
+ * @file work_oriented.cuh
+ * @brief `algorithms::spmv::work_oriented(csr, x, y, stream)`: even share of (rows + nonzeros)
+ * per thread of an occupancy-sized grid (reference include/loops/algorithms/spmv/work_oriented.cuh:33-121).
+ * Unlike the reference, y does not have to be zero-filled by the caller.
+ */
+#pragma once
+
+#include <loops/schedule.hxx>
+#include <loops/container/formats.hxx>
+#include <loops/container/vector.hxx>
+#include <loops/util/launch.hxx>
+#include <loops/util/device.hxx>
+#include <loops/util/math.hxx>
+#include <loops/util/timer.hxx>
+#include <loops/algorithms/spmv/launch_box.hxx>
+#include <loops/kernels/launch.hxx>
+#include <loops/memory.hxx>
+
+namespace loops {
+namespace algorithms {
+namespace spmv {
+
+template <typename index_t, typename offset_t, typename type_t>
+void work_oriented(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
+                   xpu::stream_t stream = 0) {
+  (void)xpu::memset_async(y.data().get(), 0, sizeof(type_t) * csr.rows, stream);
+  kernels::launch_work_oriented_atomic(stream, csr.rows, csr.cols, csr.nnzs, csr.offsets.data().get(),
+                                       csr.indices.data().get(), csr.values.data().get(), x.data().get(),
+                                       y.data().get());
+  (void)xpu::stream_synchronize(stream);
+}
+
+}  // namespace spmv
+}  // namespace algorithms
+}  // namespace loops

@@ -1,0 +1,154 @@
+/**
+ * @file launch.hxx
+ * @brief Raw-pointer launchers of the CSR SpMV kernels.  Both front ends -- the container
+ * wrappers `algorithms::spmv::*` (include/loops/algorithms/spmv/*.cuh) and the C ABI
+ * (loops_amd/csrc/loops_c_abi.hip) -- go through these, so there is exactly one launch
+ * configuration per kernel.  All launchers are asynchronous on `stream` and return the
+ * hipError_t of the launch (0 = success).
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+#include <loops/schedule.hxx>
+#include <loops/algorithms/spmv/launch_box.hxx>
+#include <loops/kernels/csr_spmv.hxx>
+#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/util/launch.hxx>
+#include <loops/util/launch_box.hxx>
+#include <loops/util/math.hxx>
+
+namespace loops {
+namespace kernels {
+
+inline int launch_status() { return static_cast<int>(hipGetLastError()); }
+
+/// Device-side scratch of the fused merge-path SpMV for one (matrix structure, tile shape).
+struct merge_plan_view {
+  coord_t* coords;      ///< M + 1 per-workgroup start coordinates
+  int* carry_row;       ///< M carry-out rows
+  void* carry_val;      ///< M carry-out partial sums (value type of the SpMV)
+  int num_merge_tiles;  ///< M
+};
+
+/// coords[i] = merge-path split at diagonal i * tpb * ipt, i in [0, M].
+template <typename offset_t>
+int launch_merge_path_coordinates(hipStream_t stream, const offset_t* offsets, int rows, int nnz, int tile_items,
+                                  int num_merge_tiles, coord_t* coords) {
+  const int n = num_merge_tiles + 1;
+  hipLaunchKernelGGL(merge_path_coordinates<offset_t>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream, offsets,
+                     rows, nnz, tile_items, num_merge_tiles, coords);
+  return launch_status();
+}
+
+/// Fused merge-path SpMV (+ fix-up).  stages: bit 0 = tile kernel, bit 1 = fix-up.
+template <int TPB, int IPT, bool PAD, bool NT, typename index_t, typename offset_t, typename T>
+int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
+                            const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
+                            int stages = 3) {
+  const int m = plan.num_merge_tiles;
+  if (m == 0) return 0;
+  T* carry_val = static_cast<T*>(plan.carry_val);
+  if (stages & 1) {
+    const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+    if (aligned)
+      hipLaunchKernelGGL((merge_path_spmv_fused<TPB, IPT, PAD, NT, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
+                         stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val);
+    else
+      hipLaunchKernelGGL((merge_path_spmv_fused<TPB, IPT, PAD, NT, false, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
+                         stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val);
+  }
+  if (stages & 2)
+    hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,
+                       carry_val, m, rows, y);
+  return launch_status();
+}
+
+template <typename index_t, typename offset_t, typename T>
+int launch_thread_mapped(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz,
+                         const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
+  if (rows == 0) return 0;
+  constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
+  using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t>;
+  setup_t config(const_cast<offset_t*>(offsets), rows, nnz);
+  launch::non_cooperative(stream, thread_mapped_spmv<setup_t, index_t, offset_t, T>,
+                          dim3(static_cast<unsigned>(math::ceil_div(rows, block))), dim3(block), config, rows, cols,
+                          nnz, offsets, indices, values, x, y);
+  return launch_status();
+}
+
+template <typename index_t, typename offset_t, typename T>
+int launch_original(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz, const offset_t* offsets,
+                    const index_t* indices, const T* values, const T* x, T* y) {
+  if (rows == 0) return 0;
+  launch::non_cooperative(stream, original_spmv<index_t, offset_t, T>,
+                          dim3(static_cast<unsigned>(math::ceil_div(rows, std::size_t(128)))), dim3(128), rows, cols,
+                          nnz, offsets, indices, values, x, y);
+  return launch_status();
+}
+
+/// Reference-shaped group_mapped (block_mapped) kernel: atomics, y must be zero-filled.
+template <typename index_t, typename offset_t, typename T>
+int launch_group_mapped_atomic(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz,
+                               const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
+  if (rows == 0) return 0;
+  constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
+  launch::non_cooperative(stream, group_mapped_atomic_spmv<block, block, index_t, offset_t, T>,
+                          dim3(static_cast<unsigned>(math::ceil_div(rows, block))), dim3(block), rows, cols, nnz,
+                          const_cast<offset_t*>(offsets), const_cast<index_t*>(indices), values, x, y);
+  return launch_status();
+}
+
+/// Reference-shaped work_oriented kernel: store/atomic mix, y must be zero-filled.
+template <typename index_t, typename offset_t, typename T>
+int launch_work_oriented_atomic(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz,
+                                const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
+  if (rows == 0) return 0;
+  constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
+  auto kernel = work_oriented_atomic_spmv<block, index_t, offset_t, T>;
+  const std::size_t grid = launch_box::occupancy_grid(kernel, block);
+  launch::non_cooperative(stream, kernel, dim3(static_cast<unsigned>(grid)), dim3(block), rows, cols, nnz,
+                          const_cast<offset_t*>(offsets), const_cast<index_t*>(indices), values, x, y);
+  return launch_status();
+}
+
+/// thread_mapped over flat_uniform_occupancy<K, csr>: atomics, y must be zero-filled.
+template <std::size_t K, typename index_t, typename offset_t, typename T>
+int launch_flat_partitioned(hipStream_t stream, std::size_t rows, std::size_t nnz, const offset_t* offsets,
+                            const index_t* indices, const T* values, const T* x, T* y) {
+  using base_t = layout::csr<index_t, offset_t>;
+  using part_t = layout::flat_uniform_occupancy<K, base_t>;
+  using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t, std::size_t,
+                                  std::size_t, part_t>;
+  part_t part(base_t(offsets, static_cast<index_t>(rows), static_cast<offset_t>(nnz)));
+  const std::size_t chunks = static_cast<std::size_t>(part.num_tiles());
+  if (chunks == 0) return 0;
+  constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
+  setup_t config(part);
+  launch::non_cooperative(stream, flat_partitioned_spmv<setup_t, index_t, T>,
+                          dim3(static_cast<unsigned>(math::ceil_div(chunks, block))), dim3(block), config, indices,
+                          values, x, y);
+  return launch_status();
+}
+
+/// Reference-shaped merge_path_flat kernel through the schedule API: atomics, y zero-filled.
+/// Blocks until the kernel is done (the temporary preprocess_t owns device scratch).
+template <std::size_t TPB, std::size_t IPT, typename index_t, typename offset_t, typename T>
+int launch_merge_path_atomic(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz,
+                             const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
+  using pre_t = schedule::merge_path::preprocess_t<TPB, IPT, index_t, offset_t, std::size_t, std::size_t>;
+  pre_t meta(const_cast<offset_t*>(offsets), rows, nnz, stream);
+  const std::size_t m = meta.merge_tiles();
+  if (m == 0) return 0;
+  launch::non_cooperative(stream, merge_path_flat_atomic_spmv<TPB, IPT, pre_t, index_t, offset_t, T>,
+                          dim3(static_cast<unsigned>(m)), dim3(TPB), meta, rows, cols, nnz,
+                          const_cast<offset_t*>(offsets), const_cast<index_t*>(indices), values, x, y);
+  (void)hipStreamSynchronize(stream);
+  return launch_status();
+}
+
+}  // namespace kernels
+}  // namespace loops
