@@ -3,7 +3,8 @@
  * @brief `algorithms::spmv::group_mapped(csr, x, y, stream)`: a workgroup owns 256 consecutive rows
  * and sweeps their concatenated nonzeros lane-strided (reference
  * include/loops/algorithms/spmv/group_mapped.cuh:27-105 -- CUDA-only there; this is the CDNA4
- * implementation).  y does not have to be zero-filled by the caller.
+ * implementation: group_mapped_spmv_fused, the merge-tile engine over the workgroup's own rows --
+ * no atomics, no plan).  y does not have to be zero-filled by the caller.
  */
 #pragma once
 
@@ -25,10 +26,11 @@ namespace spmv {
 template <typename index_t, typename offset_t, typename type_t>
 void group_mapped(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                   xpu::stream_t stream = 0) {
-  (void)xpu::memset_async(y.data().get(), 0, sizeof(type_t) * csr.rows, stream);
-  kernels::launch_group_mapped_atomic(stream, csr.rows, csr.cols, csr.nnzs, csr.offsets.data().get(),
-                                      csr.indices.data().get(), csr.values.data().get(), x.data().get(),
-                                      y.data().get());
+  constexpr int block_size = launch_t<type_t>::block_size;
+  constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
+  kernels::launch_group_mapped_fused<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
+      stream, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
   (void)xpu::stream_synchronize(stream);
 }
 

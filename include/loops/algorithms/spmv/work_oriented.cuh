@@ -2,7 +2,9 @@
  * @file work_oriented.cuh
  * @brief `algorithms::spmv::work_oriented(csr, x, y, stream)`: even share of (rows + nonzeros)
  * per thread of an occupancy-sized grid (reference include/loops/algorithms/spmv/work_oriented.cuh:33-121).
- * Unlike the reference, y does not have to be zero-filled by the caller.
+ * Runs the fused persistent kernel (loops/kernels/merge_path_spmv.hxx: work_oriented_spmv_fused): a
+ * fixed occupancy-sized grid, each workgroup walking an even contiguous share of merge tiles with
+ * the open row carried in registers.  No atomics; y does not have to be zero-filled.
  */
 #pragma once
 
@@ -24,10 +26,18 @@ namespace spmv {
 template <typename index_t, typename offset_t, typename type_t>
 void work_oriented(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                    xpu::stream_t stream = 0) {
-  (void)xpu::memset_async(y.data().get(), 0, sizeof(type_t) * csr.rows, stream);
-  kernels::launch_work_oriented_atomic(stream, csr.rows, csr.cols, csr.nnzs, csr.offsets.data().get(),
-                                       csr.indices.data().get(), csr.values.data().get(), x.data().get(),
-                                       y.data().get());
+  constexpr int block_size = launch_t<type_t>::block_size;
+  constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
+  using plan_t = schedule::merge_path::preprocess_t<block_size, items_per_thread, index_t, offset_t, std::size_t,
+                                                    std::size_t>;
+  plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows),
+                                        static_cast<offset_t>(csr.nnzs)),
+              stream, plan_t::prepass_always);
+  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                static_cast<int>(plan.merge_tiles())};
+  kernels::launch_work_oriented_fused<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
+      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
   (void)xpu::stream_synchronize(stream);
 }
 

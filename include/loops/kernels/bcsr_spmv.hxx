@@ -91,7 +91,6 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int safe = len > 0 ? beg : 0;  // any valid block index for masked-off steps
-#pragma unroll 4
   for (int k = 0; k < maxlen; ++k) {
     const bool live = k < len;
     const int b = live ? beg + k : safe;

@@ -1,7 +1,7 @@
 /**
  * @file launch.hxx
  * @brief Raw-pointer launchers of the CSR SpMV kernels.  Both front ends -- the container
- * wrappers `algorithms::spmv::*` (include/loops/algorithms/spmv/*.cuh) and the C ABI
+ * wrappers `algorithms::spmv::*` (the .cuh files under include/loops/algorithms/spmv) and the C ABI
  * (loops_amd/csrc/loops_c_abi.hip) -- go through these, so there is exactly one launch
  * configuration per kernel.  All launchers are asynchronous on `stream` and return the
  * hipError_t of the launch (0 = success).
@@ -64,6 +64,46 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,
                        carry_val, m, rows, y);
+  return launch_status();
+}
+
+/// Tuned work_oriented: fixed occupancy-sized grid, even share of plan tiles per workgroup.
+template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T>
+int launch_work_oriented_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
+                               const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
+  const int m = plan.num_merge_tiles;
+  if (m == 0) return 0;
+  T* carry_val = static_cast<T*>(plan.carry_val);
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  auto k_vec = work_oriented_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T>;
+  auto k_scl = work_oriented_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T>;
+  static const int resident = static_cast<int>(launch_box::occupancy_grid(k_vec, TPB));  // blocks per CU x CUs
+  const int tiles_per_group = math::ceil_div(m, resident < 1 ? 1 : resident);
+  const int groups = math::ceil_div(m, tiles_per_group);
+  if (aligned)
+    hipLaunchKernelGGL(k_vec, dim3(groups), dim3(TPB), 0, stream, plan.coords, m, tiles_per_group, rows, nnz, offsets,
+                       indices, values, x, y, plan.carry_row, carry_val);
+  else
+    hipLaunchKernelGGL(k_scl, dim3(groups), dim3(TPB), 0, stream, plan.coords, m, tiles_per_group, rows, nnz, offsets,
+                       indices, values, x, y, plan.carry_row, carry_val);
+  hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(groups, 256)), dim3(256), 0, stream, plan.carry_row,
+                     carry_val, groups, rows, y);
+  return launch_status();
+}
+
+/// Tuned group_mapped: one workgroup per TPB consecutive rows, no plan, no atomics.
+template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T>
+int launch_group_mapped_fused(hipStream_t stream, int rows, int nnz, const offset_t* offsets, const index_t* indices,
+                              const T* values, const T* x, T* y) {
+  if (rows == 0) return 0;
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  const dim3 grid(math::ceil_div(rows, TPB)), block(TPB);
+  if (aligned)
+    hipLaunchKernelGGL((group_mapped_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T>), grid, block, 0,
+                       stream, rows, nnz, offsets, indices, values, x, y);
+  else
+    hipLaunchKernelGGL((group_mapped_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T>), grid, block, 0,
+                       stream, rows, nnz, offsets, indices, values, x, y);
   return launch_status();
 }
 

@@ -24,6 +24,11 @@
  *  5. FIX-UP   a tiny second kernel adds the carry-outs to y (rows longer than a merge tile
  *              span several workgroups: max degree 2^14 vs 2048-item tiles).
  *
+ * Steps 1-4 are the `merge_tile_engine`; the three tuned CSR kernels differ only in how they
+ * cut the merge path into tiles: merge_path_flat (one plan tile per workgroup), work_oriented
+ * (a fixed grid, an even contiguous share of plan tiles per workgroup, carried in registers) and
+ * group_mapped (the tiles of the workgroup's own 256 rows, found in LDS -- no plan, no fix-up).
+ *
  * y needs NO zero-fill: every row is stored exactly once by the thread that consumes its
  * row-end item; the summation order is deterministic (no floating-point atomics).
  *
@@ -115,12 +120,185 @@ __global__ void merge_path_coordinates(const offset_t* __restrict__ offsets, int
 }
 
 /**
- * Fused merge-path SpMV, one merge tile per workgroup.
+ * The merge-tile engine shared by the three tuned CSR SpMV kernels.  One call processes ONE
+ * merge tile -- `nrows` row ends and `natoms` nonzeros starting at (row0, nz0) on the merge path,
+ * nrows + natoms <= TPB * IPT -- with the whole workgroup:
+ *
+ *   STREAM  col_idx / values of [nz0, nz0 + natoms) -> products in LDS (16 B per lane loads)
+ *   SPLIT   per-thread start on the merge path (halving search over the LDS row ends `re`)
+ *   WALK    IPT merge steps per thread out of LDS; rows that start and end inside a thread are
+ *           stored straight to y
+ *   STITCH  partial rows across threads (64-lane segmented prefix sum) and wavefronts (LDS)
+ *
+ * `re[i]` must hold the end offset of row (row0 + i) for i < nrows + IPT (clamped past the
+ * last row), in LDS, visible to the whole workgroup once the engine's first barrier is passed.
+ * `carry_in` is the partial sum of row `row0` accumulated by earlier tiles of the SAME workgroup
+ * (0 for the first); the return value is the partial sum of the row still open when the tile
+ * ends (row0 + nrows), uniform across the workgroup.  Collective: every thread of the workgroup
+ * must call it; contains 3 workgroup barriers.
+ */
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+struct merge_tile_engine {
+  static constexpr int TILE = TPB * IPT;
+  static constexpr int WAVES = TPB / wave::size;
+  static constexpr int NPROD = TILE + 4;                            // + alignment slack
+  static constexpr int KV = (NPROD + 4 * TPB - 1) / (4 * TPB);      // vector-load rounds per thread
+
+  struct storage_t {
+    type_t prod[PAD ? NPROD + (NPROD >> 5) + 1 : NPROD];
+    type_t wave_val[WAVES];
+    int wave_head[WAVES];
+    type_t carry;
+  };
+
+  static __device__ __forceinline__ type_t run(storage_t& s, const offset_t* re, const int row0, const int nz0,
+                                               const int nrows, const int natoms, const int nnz,
+                                               const index_t* __restrict__ indices,
+                                               const type_t* __restrict__ values, const type_t* __restrict__ x,
+                                               type_t* __restrict__ y, const type_t carry_in) {
+    const int tid = threadIdx.x;
+    const int nz1 = nz0 + natoms;
+
+    // ---- 1. STREAM ------------------------------------------------------------------------
+    const int abase = VEC ? (nz0 & ~3) : nz0;  // 16-byte aligned element base of the tile
+    const int shift = nz0 - abase;             // 0..3 leading elements owned by the previous tile
+    if constexpr (VEC) {
+      const bool interior = abase + KV * 4 * TPB <= nnz;  // every vector load in-bounds (uniform)
+      index_t col[KV][4];
+      type_t val[KV][4];
+      bool live[KV];
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const int e = abase + (k * TPB + tid) * 4;
+        live[k] = e < nz1;
+        if (live[k]) {
+          if (interior || e + 3 < nnz) {
+            detail::load4<index_t, NT>(indices + e, col[k]);
+            detail::load4<type_t, NT>(values + e, val[k]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool ok = e + j < nnz;
+              col[k][j] = ok ? indices[e + j] : index_t(0);
+              val[k][j] = ok ? values[e + j] : type_t(0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        if (live[k]) {
+          type_t xv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = x[col[k][j]];
+          const int i = (k * TPB + tid) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[j];
+        }
+      }
+    } else {
+      // Unaligned arrays: coalesced 4-byte loads, one element per lane per round.
+#pragma unroll
+      for (int k = 0; k < IPT; ++k) {
+        const int i = k * TPB + tid;
+        if (i < natoms) {
+          const int e = nz0 + i;
+          s.prod[detail::slot<PAD>(i)] = values[e] * x[indices[e]];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- 2. SPLIT: this thread's start on the merge path (search.hxx semantics, in LDS) ------
+    const int total = nrows + natoms;  // == TILE except in a last / short tile
+    const int diag = tid * IPT;
+    int tx, ty;
+    {
+      int lo = diag - natoms > 0 ? diag - natoms : 0;
+      int count = (diag < nrows ? diag : nrows) - lo;
+      while (count > 0) {
+        const int half = count >> 1;
+        const int mid = lo + half;
+        if (re[mid] <= nz0 + (diag - mid - 1)) {
+          lo = mid + 1;
+          count -= half + 1;
+        } else {
+          count = half;
+        }
+      }
+      tx = lo < nrows ? lo : nrows;
+      ty = diag - lo;
+    }
+
+    // ---- 3. WALK: IPT merge steps out of LDS ------------------------------------------------
+    type_t sum = type_t(0);
+    type_t first_sum = type_t(0);
+    int first_row = 0;
+    bool closed = false;
+    int row_end = re[tx];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+      if (diag + j < total) {
+        if (nz0 + ty < row_end) {  // merge step consumes a nonzero
+          sum += s.prod[detail::slot<PAD>(ty + shift)];
+          ++ty;
+        } else {  // merge step consumes a row end: row (row0 + tx) is complete
+          if (!closed) {
+            first_sum = sum;
+            first_row = tx;
+            closed = true;
+          } else {
+            y[row0 + tx] = sum;
+          }
+          sum = type_t(0);
+          ++tx;
+          row_end = re[tx];
+        }
+      }
+    }
+
+    // ---- 4. STITCH: partial rows across threads / wavefronts ----------------------------------
+    const int lane = wave::lane();
+    const int w = tid / wave::size;
+    type_t run_sum = sum;  // tail partial (row row0 + tx, still open)
+    bool head = closed;    // a thread that closed a row starts a new segment with its tail
+    wave::segmented_inclusive_sum(run_sum, head);
+    type_t prev_run = __shfl_up(run_sum, 1);
+    int prev_head = __shfl_up(static_cast<int>(head), 1);
+    if (lane == 0) {
+      prev_run = type_t(0);
+      prev_head = 0;
+    }
+    if (lane == wave::size - 1) {
+      s.wave_val[w] = run_sum;
+      s.wave_head[w] = head ? 1 : 0;
+    }
+    __syncthreads();
+    // open partial entering this wavefront: earlier wavefronts back to the last one that closed a
+    // row, and -- if none of them did -- the workgroup's carry-in.
+    type_t wave_in = type_t(0);
+    bool reaches_tile_start = true;
+    for (int i = w - 1; i >= 0; --i) {
+      wave_in += s.wave_val[i];
+      if (s.wave_head[i]) {
+        reaches_tile_start = false;
+        break;
+      }
+    }
+    if (reaches_tile_start) wave_in += carry_in;
+    if (closed) y[row0 + first_row] = first_sum + prev_run + (prev_head ? type_t(0) : wave_in);
+    if (tid == TPB - 1) s.carry = run_sum + (head ? type_t(0) : wave_in);
+    __syncthreads();
+    return s.carry;
+  }
+};
+
+/**
+ * merge_path_flat: one merge tile per workgroup, tile b = coords[b] .. coords[b + 1].
  * @tparam TPB threads per workgroup (multiple of 64), IPT merge items per thread.
  * @tparam PAD  pad the LDS product array (conflict-free walk for even IPT).
- * @tparam NT   stream col_idx / values with non-temporal loads (keeps x resident in L2).
- * Requires: `indices` and `values` 16-byte aligned (checked by the host launcher; the
- * unaligned case uses VEC = false).
+ * @tparam NT   stream col_idx / values with non-temporal loads.
+ * @tparam VEC  `indices` and `values` are 16-byte aligned (checked by the host launcher).
  */
 template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
 __global__ void __launch_bounds__(TPB)
@@ -128,166 +306,135 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
                       const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                       const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
                       int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  constexpr int TILE = TPB * IPT;
-  constexpr int WAVES = TPB / wave::size;
-  constexpr int NPROD = TILE + 4;                      // + alignment slack (abase <= c0.y)
-  constexpr int KV = (NPROD + 4 * TPB - 1) / (4 * TPB);  // vector-load rounds per thread
-
-  __shared__ type_t s_prod[PAD ? NPROD + (NPROD >> 5) + 1 : NPROD];
-  __shared__ offset_t s_re[TILE + IPT + 1];
-  __shared__ type_t s_wave_val[WAVES];
-  __shared__ int s_wave_head[WAVES];
+  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t>;
+  __shared__ typename engine_t::storage_t s_engine;
+  __shared__ offset_t s_re[TPB * IPT + IPT + 1];
 
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-
-  // ---- tile coordinates (wave-uniform: scalar loads) -------------------------------------
+  // tile coordinates (wave-uniform: scalar loads)
   const coord_t c0 = coords[b];
   const coord_t c1 = coords[b + 1];
   const int row0 = static_cast<int>(c0.x);
   const int nz0 = static_cast<int>(c0.y);
-  const int nz1 = static_cast<int>(c1.y);
   const int nrows = static_cast<int>(c1.x) - row0;
-  const int natoms = nz1 - nz0;
+  const int natoms = static_cast<int>(c1.y) - nz0;
 
-  // ---- 1. STREAM --------------------------------------------------------------------------
-  // Row ends first (they are short and the SPLIT phase needs them right after the barrier).
+  // row ends of the tile -> LDS (visible after the engine's first barrier)
   for (int i = tid; i < nrows + IPT; i += TPB) {
     int r = row0 + i;
     r = r < rows - 1 ? r : rows - 1;
     s_re[i] = offsets[r + 1];
   }
+  const type_t carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, type_t(0));
+  if (tid == 0) {
+    carry_row[b] = row0 + nrows;  // == c1.x: the row still open when the tile ends
+    carry_val[b] = carry;
+  }
+}
 
-  const int abase = VEC ? (nz0 & ~3) : nz0;  // 16-byte aligned element base of the tile
-  const int shift = nz0 - abase;             // 0..3 leading elements that belong to tile b-1
+/**
+ * work_oriented: a FIXED, occupancy-sized grid; every workgroup owns an even, contiguous share
+ * of the merge tiles (hence of rows + nonzeros) and walks it tile after tile, carrying the open
+ * row's partial sum in a register -- one carry-out per workgroup instead of one per tile.
+ * (Even-share semantics of schedule::setup<work_oriented>, reference work_oriented.hxx:79-91,
+ * at merge-tile granularity.)
+ */
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge_tiles, const int tiles_per_group,
+                         const int rows, const int nnz, const offset_t* __restrict__ offsets,
+                         const index_t* __restrict__ indices, const type_t* __restrict__ values,
+                         const type_t* __restrict__ x, type_t* __restrict__ y, int* __restrict__ carry_row,
+                         type_t* __restrict__ carry_val) {
+  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t>;
+  __shared__ typename engine_t::storage_t s_engine;
+  __shared__ offset_t s_re[TPB * IPT + IPT + 1];
 
-  if constexpr (VEC) {
-    const bool interior = abase + KV * 4 * TPB <= nnz;  // every vector load in-bounds (block-uniform)
-    index_t col[KV][4];
-    type_t val[KV][4];
-    bool live[KV];
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-      const int e = abase + (k * TPB + tid) * 4;
-      live[k] = e < nz1;
-      if (live[k]) {
-        if (interior || e + 3 < nnz) {
-          detail::load4<index_t, NT>(indices + e, col[k]);
-          detail::load4<type_t, NT>(values + e, val[k]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const bool ok = e + j < nnz;
-            col[k][j] = ok ? indices[e + j] : index_t(0);
-            val[k][j] = ok ? values[e + j] : type_t(0);
-          }
-        }
-      }
+  const int tid = threadIdx.x;
+  const int t_begin = blockIdx.x * tiles_per_group;
+  int t_end = t_begin + tiles_per_group;
+  t_end = t_end < num_merge_tiles ? t_end : num_merge_tiles;
+  type_t carry = type_t(0);
+  int open_row = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const coord_t c0 = coords[t];
+    const coord_t c1 = coords[t + 1];
+    const int row0 = static_cast<int>(c0.x);
+    const int nz0 = static_cast<int>(c0.y);
+    const int nrows = static_cast<int>(c1.x) - row0;
+    const int natoms = static_cast<int>(c1.y) - nz0;
+    for (int i = tid; i < nrows + IPT; i += TPB) {
+      int r = row0 + i;
+      r = r < rows - 1 ? r : rows - 1;
+      s_re[i] = offsets[r + 1];
     }
-#pragma unroll
-    for (int k = 0; k < KV; ++k) {
-      if (live[k]) {
-        type_t xv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xv[j] = x[col[k][j]];
-        const int i = (k * TPB + tid) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s_prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[j];
-      }
-    }
-  } else {
-    // Unaligned arrays: coalesced 4-byte loads, one element per lane per round.
-#pragma unroll
-    for (int k = 0; k < IPT; ++k) {
-      const int i = k * TPB + tid;
-      if (i < natoms) {
-        const int e = nz0 + i;
-        s_prod[detail::slot<PAD>(i)] = values[e] * x[indices[e]];
-      }
-    }
+    // carry-in of the share's FIRST tile belongs to an earlier workgroup: it goes through the fix-up
+    carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, carry);
+    open_row = row0 + nrows;
+  }
+  if (tid == 0 && t_begin < t_end) {
+    carry_row[blockIdx.x] = open_row;
+    carry_val[blockIdx.x] = carry;
+  }
+}
+
+/**
+ * group_mapped: workgroup b owns the TPB consecutive rows [b * TPB, (b + 1) * TPB) and sweeps the
+ * concatenation of their nonzeros cooperatively (semantics of schedule::setup<group_mapped, TPB, TPB>,
+ * reference group_mapped.hxx:104-192), here as a sequence of merge tiles over the workgroup's OWN
+ * row offsets, which sit in LDS once: no global search, no plan, no cross-workgroup carry (a
+ * workgroup owns whole rows), no atomics, no zero-fill of y.
+ */
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restrict__ offsets,
+                        const index_t* __restrict__ indices, const type_t* __restrict__ values,
+                        const type_t* __restrict__ x, type_t* __restrict__ y) {
+  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t>;
+  constexpr int TILE = TPB * IPT;
+  __shared__ typename engine_t::storage_t s_engine;
+  __shared__ offset_t s_off[TPB + 1 + IPT];  // offsets of the group's rows (+ clamped slack)
+
+  const int tid = threadIdx.x;
+  const int group_row0 = blockIdx.x * TPB;
+  int group_rows = rows - group_row0;
+  group_rows = group_rows < TPB ? group_rows : TPB;
+  for (int i = tid; i < TPB + 1 + IPT; i += TPB) {
+    int r = group_row0 + i;
+    r = r < rows ? r : rows;
+    s_off[i] = offsets[r];
   }
   __syncthreads();
+  const int nz_begin = s_off[0];
+  const int group_atoms = s_off[group_rows] - nz_begin;
+  const int total = group_rows + group_atoms;
+  const offset_t* row_end = s_off + 1;  // row_end[i] = end of row group_row0 + i
 
-  // ---- 2. SPLIT: this thread's start on the merge path (search.hxx semantics, in LDS) ------
-  const int total = nrows + natoms;  // == TILE except in the last merge tile
-  const int diag = tid * IPT;
-  int tx, ty;
-  {
-    int lo = diag - natoms > 0 ? diag - natoms : 0;
-    int count = (diag < nrows ? diag : nrows) - lo;
+  type_t carry = type_t(0);
+  int tx0 = 0, ty0 = 0;  // merge-path position (rows, atoms consumed) at the start of the tile
+  for (int d0 = 0; d0 < total; d0 += TILE) {
+    // end of this tile on the group's merge path: split at min(d0 + TILE, total), every lane
+    // does the same <= log2(TPB) LDS probes (broadcast reads)
+    const int d1 = d0 + TILE < total ? d0 + TILE : total;
+    int lo = d1 - group_atoms > 0 ? d1 - group_atoms : 0;
+    int count = (d1 < group_rows ? d1 : group_rows) - lo;
     while (count > 0) {
       const int half = count >> 1;
       const int mid = lo + half;
-      if (s_re[mid] <= nz0 + (diag - mid - 1)) {
+      if (row_end[mid] <= nz_begin + (d1 - mid - 1)) {
         lo = mid + 1;
         count -= half + 1;
       } else {
         count = half;
       }
     }
-    tx = lo < nrows ? lo : nrows;
-    ty = diag - lo;
-  }
-
-  // ---- 3. WALK: IPT merge steps out of LDS ----------------------------------------------------
-  type_t sum = type_t(0);
-  type_t first_sum = type_t(0);
-  int first_row = 0;
-  bool closed = false;
-  int re = s_re[tx];
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {
-    if (diag + j < total) {
-      if (nz0 + ty < re) {  // merge step consumes a nonzero
-        sum += s_prod[detail::slot<PAD>(ty + shift)];
-        ++ty;
-      } else {  // merge step consumes a row end: row (row0 + tx) is complete
-        if (!closed) {
-          first_sum = sum;
-          first_row = tx;
-          closed = true;
-        } else {
-          y[row0 + tx] = sum;
-        }
-        sum = type_t(0);
-        ++tx;
-        re = s_re[tx];
-      }
-    }
-  }
-
-#ifdef LOOPS_DEBUG_FUSED
-  if (b == 0 && tid < 6)
-    printf("tid %d diag %d start(%d,%d) end(tx %d ty %d) sum %f closed %d first_sum %f first_row %d re %d nrows %d natoms %d shift %d sprod0..3 %f %f %f %f sre0..2 %d %d %d\n",
-           tid, diag, tx, ty, tx, ty, (double)sum, (int)closed, (double)first_sum, first_row, re, nrows, natoms, shift,
-           (double)s_prod[detail::slot<PAD>(0)], (double)s_prod[detail::slot<PAD>(1)], (double)s_prod[detail::slot<PAD>(2)], (double)s_prod[detail::slot<PAD>(3)], s_re[0], s_re[1], s_re[2]);
-#endif
-  // ---- 4. STITCH: partial rows across threads / wavefronts / workgroups -------------------------
-  const int lane = wave::lane();
-  const int w = tid / wave::size;
-  type_t run = sum;      // tail partial (row row0 + tx, still open)
-  bool head = closed;    // a thread that closed a row starts a new segment with its tail
-  wave::segmented_inclusive_sum(run, head);
-  type_t prev_run = __shfl_up(run, 1);
-  int prev_head = __shfl_up(static_cast<int>(head), 1);
-  if (lane == 0) {
-    prev_run = type_t(0);
-    prev_head = 0;
-  }
-  if (lane == wave::size - 1) {
-    s_wave_val[w] = run;
-    s_wave_head[w] = head ? 1 : 0;
-  }
-  __syncthreads();
-  type_t wave_in = type_t(0);  // open partial entering this wavefront from earlier ones
-  for (int i = w - 1; i >= 0; --i) {
-    wave_in += s_wave_val[i];
-    if (s_wave_head[i]) break;
-  }
-  if (closed) y[row0 + first_row] = first_sum + prev_run + (prev_head ? type_t(0) : wave_in);
-  if (tid == TPB - 1) {
-    carry_row[b] = row0 + tx;  // == c1.x: the row still open when the tile ends
-    carry_val[b] = run + (head ? type_t(0) : wave_in);
+    const int tx1 = lo < group_rows ? lo : group_rows;
+    const int ty1 = d1 - lo;
+    carry = engine_t::run(s_engine, row_end + tx0, group_row0 + tx0, nz_begin + ty0, tx1 - tx0, ty1 - ty0, nnz,
+                          indices, values, x, y, carry);
+    tx0 = tx1;
+    ty0 = ty1;
   }
 }
 

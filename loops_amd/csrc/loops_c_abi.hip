@@ -18,8 +18,7 @@
 #include <loops/util/launch.hxx>
 #include <loops/util/launch_box.hxx>
 #include <loops/util/math.hxx>
-#include <loops/kernels/csr_spmv.hxx>
-#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/kernels/launch.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 #include <loops/kernels/probes.hxx>
 
@@ -70,10 +69,8 @@ struct loops_merge_plan {
 namespace {
 
 int plan_compute(loops_merge_plan* p, const int* offsets, hipStream_t stream) {
-  const int n = p->num_tiles + 1;
-  hipLaunchKernelGGL(kernels::merge_path_coordinates<int>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream,
-                     offsets, p->rows, p->nnz, p->tpb * p->ipt, p->num_tiles, p->coords);
-  return last_error();
+  return kernels::launch_merge_path_coordinates(stream, offsets, p->rows, p->nnz, p->tpb * p->ipt, p->num_tiles,
+                                                p->coords);
 }
 
 int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
@@ -122,20 +119,8 @@ loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
 template <int TPB, int IPT, bool PAD, bool NT, typename T>
 int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, const int* off, const int* idx,
                  const T* val, const T* x, T* y, hipStream_t stream, int stages) {
-  if (num_tiles == 0) return 0;
-  T* carry_val = reinterpret_cast<T*>(p->carry_val);
-  const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(val)) & 15u) == 0;
-  if (!(stages & 1)) {
-  } else if (aligned)
-    hipLaunchKernelGGL((kernels::merge_path_spmv_fused<TPB, IPT, PAD, NT, true, int, int, T>), dim3(num_tiles),
-                       dim3(TPB), 0, stream, p->coords, rows, nnz, off, idx, val, x, y, p->carry_row, carry_val);
-  else
-    hipLaunchKernelGGL((kernels::merge_path_spmv_fused<TPB, IPT, PAD, NT, false, int, int, T>), dim3(num_tiles),
-                       dim3(TPB), 0, stream, p->coords, rows, nnz, off, idx, val, x, y, p->carry_row, carry_val);
-  if (stages & 2)
-    hipLaunchKernelGGL(kernels::merge_path_spmv_fixup<T>, dim3(math::ceil_div(num_tiles, 256)), dim3(256), 0, stream,
-                       p->carry_row, carry_val, num_tiles, rows, y);
-  return last_error();
+  kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles};
+  return kernels::launch_merge_path_fused<TPB, IPT, PAD, NT>(stream, view, rows, nnz, off, idx, val, x, y, stages);
 }
 
 template <typename T>
@@ -166,20 +151,6 @@ int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, c
 }
 
 // ------------------------------------------------------------------- schedule-API launchers
-template <std::size_t TPB, std::size_t IPT, typename T>
-int launch_merge_atomic(int rows, int cols, int nnz, const int* off, const int* idx, const T* val, const T* x, T* y,
-                        hipStream_t stream) {
-  using pre_t = schedule::merge_path::preprocess_t<TPB, IPT, int, int, std::size_t, std::size_t>;
-  pre_t meta(const_cast<int*>(off), std::size_t(rows), std::size_t(nnz), stream);
-  const std::size_t m = meta.merge_tiles();
-  if (m == 0) return 0;
-  launch::non_cooperative(stream, kernels::merge_path_flat_atomic_spmv<TPB, IPT, pre_t, int, int, T>,
-                          dim3(static_cast<unsigned>(m)), dim3(TPB), meta, std::size_t(rows), std::size_t(cols),
-                          std::size_t(nnz), const_cast<int*>(off), const_cast<int*>(idx), val, x, y);
-  (void)hipStreamSynchronize(stream);  // meta owns device scratch freed at scope exit
-  return last_error();
-}
-
 template <std::size_t TPB, std::size_t IPT>
 int launch_merge_dump(bool use_plan, int rows, int nnz, const int* off, unsigned* ts, int* owner, int* arow,
                       int* visits, hipStream_t stream) {
@@ -200,55 +171,19 @@ int spmv_schedule_api(int schedule, int cfg, int rows, int cols, int nnz, const 
                       const T* val, const T* x, T* y, hipStream_t stream) {
   if (rows == 0) return 0;
   const std::size_t R = rows, C = cols, N = nnz;
-  int* o = const_cast<int*>(off);
-  int* i = const_cast<int*>(idx);
   switch (schedule) {
-    case LOOPS_THREAD_MAPPED: {
-      using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, int, int>;
-      setup_t config(o, R, N);
-      launch::non_cooperative(stream, kernels::thread_mapped_spmv<setup_t, int, int, T>,
-                              dim3(math::ceil_div(rows, kSpmvBlock)), dim3(kSpmvBlock), config, R, C, N, off, idx, val,
-                              x, y);
-      return last_error();
-    }
-    case LOOPS_ORIGINAL: {
-      launch::non_cooperative(stream, kernels::original_spmv<int, int, T>, dim3(math::ceil_div(rows, 128)), dim3(128),
-                              R, C, N, off, idx, val, x, y);
-      return last_error();
-    }
-    case LOOPS_GROUP_MAPPED: {
-      launch::non_cooperative(stream, kernels::group_mapped_atomic_spmv<kSpmvBlock, kSpmvBlock, int, int, T>,
-                              dim3(math::ceil_div(rows, kSpmvBlock)), dim3(kSpmvBlock), R, C, N, o, i, val, x, y);
-      return last_error();
-    }
-    case LOOPS_WORK_ORIENTED: {
-      auto kernel = kernels::work_oriented_atomic_spmv<kSpmvBlock, int, int, T>;
-      const std::size_t grid = launch_box::occupancy_grid(kernel, kSpmvBlock);
-      launch::non_cooperative(stream, kernel, dim3(static_cast<unsigned>(grid)), dim3(kSpmvBlock), R, C, N, o, i, val,
-                              x, y);
-      return last_error();
-    }
-    case LOOPS_FLAT_PARTITIONED: {
-      constexpr std::size_t K = 8;  // flat_partitioned.cuh:70 default
-      using base_t = layout::csr<int, int>;
-      using part_t = layout::flat_uniform_occupancy<K, base_t>;
-      using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, int, int, std::size_t, std::size_t,
-                                      part_t>;
-      part_t part(base_t(off, rows, nnz));
-      setup_t config(part);
-      const int chunks = part.num_tiles();
-      if (chunks == 0) return 0;
-      launch::non_cooperative(stream, kernels::flat_partitioned_spmv<setup_t, int, T>,
-                              dim3(math::ceil_div(chunks, kSpmvBlock)), dim3(kSpmvBlock), config, idx, val, x, y);
-      return last_error();
-    }
+    case LOOPS_THREAD_MAPPED: return kernels::launch_thread_mapped(stream, R, C, N, off, idx, val, x, y);
+    case LOOPS_ORIGINAL: return kernels::launch_original(stream, R, C, N, off, idx, val, x, y);
+    case LOOPS_GROUP_MAPPED: return kernels::launch_group_mapped_atomic(stream, R, C, N, off, idx, val, x, y);
+    case LOOPS_WORK_ORIENTED: return kernels::launch_work_oriented_atomic(stream, R, C, N, off, idx, val, x, y);
+    case LOOPS_FLAT_PARTITIONED: return kernels::launch_flat_partitioned<8>(stream, R, N, off, idx, val, x, y);
     case LOOPS_MERGE_PATH_FLAT: {
       switch (cfg) {
-        case LOOPS_TILE_256x8: return launch_merge_atomic<256, 8, T>(rows, cols, nnz, off, idx, val, x, y, stream);
-        case LOOPS_TILE_128x7: return launch_merge_atomic<128, 7, T>(rows, cols, nnz, off, idx, val, x, y, stream);
-        case LOOPS_TILE_4x2: return launch_merge_atomic<4, 2, T>(rows, cols, nnz, off, idx, val, x, y, stream);
-        case LOOPS_TILE_256x7: return launch_merge_atomic<256, 7, T>(rows, cols, nnz, off, idx, val, x, y, stream);
-        case LOOPS_TILE_512x8: return launch_merge_atomic<512, 8, T>(rows, cols, nnz, off, idx, val, x, y, stream);
+        case LOOPS_TILE_256x8: return kernels::launch_merge_path_atomic<256, 8>(stream, R, C, N, off, idx, val, x, y);
+        case LOOPS_TILE_128x7: return kernels::launch_merge_path_atomic<128, 7>(stream, R, C, N, off, idx, val, x, y);
+        case LOOPS_TILE_4x2: return kernels::launch_merge_path_atomic<4, 2>(stream, R, C, N, off, idx, val, x, y);
+        case LOOPS_TILE_256x7: return kernels::launch_merge_path_atomic<256, 7>(stream, R, C, N, off, idx, val, x, y);
+        case LOOPS_TILE_512x8: return kernels::launch_merge_path_atomic<512, 8>(stream, R, C, N, off, idx, val, x, y);
         default: return LOOPS_E_CONFIG;
       }
     }
@@ -273,8 +208,16 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
     case LOOPS_THREAD_MAPPED:
     case LOOPS_ORIGINAL:
       return spmv_schedule_api<T>(schedule, 0, rows, cols, nnz, off, idx, val, x, y, stream);
-    case LOOPS_WORK_ORIENTED:
+    case LOOPS_WORK_ORIENTED: {
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
+      if (!p) return err;
+      err = plan_compute(p, off, stream);
+      if (err) return err;
+      kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, p->num_tiles};
+      return kernels::launch_work_oriented_fused<256, 8, true>(stream, view, rows, nnz, off, idx, val, x, y);
+    }
     case LOOPS_GROUP_MAPPED:
+      return kernels::launch_group_mapped_fused<256, 8, true>(stream, rows, nnz, off, idx, val, x, y);
     case LOOPS_FLAT_PARTITIONED: {
       // atomic kernels accumulate into y: zero it on the stream first
       hipError_t e = hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), stream);
