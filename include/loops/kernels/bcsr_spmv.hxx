@@ -67,7 +67,7 @@ int launch_bcsr_thread_mapped(hipStream_t stream, int rows, int num_block_rows, 
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
-template <int TPB>
+template <int TPB, int UNROLL>
 __global__ void __launch_bounds__(TPB)
 bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
                   const int* __restrict__ block_cols, const float* __restrict__ values, const float* __restrict__ x,
@@ -82,7 +82,7 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
     beg = block_offsets[br];
     end = block_offsets[br + 1];
   }
-  int len = end - beg;
+  const int len = end - beg;
   int maxlen = len;
 #pragma unroll
   for (int d = 32; d >= 4; d >>= 1) {
@@ -91,17 +91,29 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int safe = len > 0 ? beg : 0;  // any valid block index for masked-off steps
-  for (int k = 0; k < maxlen; ++k) {
-    const bool live = k < len;
-    const int b = live ? beg + k : safe;
-    f32x4 a = *reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4);
-    const int bc = block_cols[b];
-    f32x4 xv = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc) * 4);
-    if (!live) a = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, xv.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, xv.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, xv.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, xv.w, acc, 0, 0, 0);
+  for (int k0 = 0; k0 < maxlen; k0 += UNROLL) {
+    // issue every load of the UNROLL steps before the first MFMA: UNROLL x (16 B block row +
+    // 4 B block column + 16 B of x) in flight per lane
+    f32x4 a[UNROLL];
+    int bc[UNROLL];
+    f32x4 xv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const bool live = k0 + u < len;
+      const int b = live ? beg + k0 + u : safe;
+      a[u] = *reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4);
+      bc[u] = block_cols[b];
+      if (!live) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc[u]) * 4);
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, xv[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].y, xv[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].z, xv[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].w, xv[u].w, acc, 0, 0, 0);
+    }
   }
   // D layout of the 4x4x1 16-block form: lane (slot, col) register v = D[v][col]; every column
   // holds the same y (B was broadcast), so column 0's lane stores the block-row's 4 outputs.
@@ -119,12 +131,17 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
 
 inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows, int num_blocks,
                                const int* block_offsets, const int* block_cols, const float* values, const float* x,
-                               float* y) {
+                               float* y, int unroll = 8) {
   (void)num_blocks;
   constexpr int TPB = 256;                      // 4 wavefronts = 64 block-rows per workgroup
   constexpr int rows_per_block = TPB / 64 * 16;
-  hipLaunchKernelGGL(bcsr4x4_mfma_spmv<TPB>, dim3(math::ceil_div(num_block_rows, rows_per_block)), dim3(TPB), 0,
-                     stream, rows, num_block_rows, block_offsets, block_cols, values, x, y);
+  const dim3 grid(math::ceil_div(num_block_rows, rows_per_block)), block(TPB);
+  switch (unroll) {
+    case 1: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 1>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
+    case 2: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 2>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
+    default: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 8>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
+    case 4: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 4>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
+  }
   return static_cast<int>(hipGetLastError());
 }
 

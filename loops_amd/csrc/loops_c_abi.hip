@@ -381,10 +381,10 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
   if (num_blocks > 0 && (!block_cols || !block_values || !x_padded)) return LOOPS_E_BADARG;
   if (num_block_rows == 0) return 0;
   hipStream_t s = as_stream(stream);
-  if (mode == 1) {
+  if (mode == 1 || (mode > 10 && mode < 20)) {  // 1x: MFMA path with x steps in flight per lane (tuning aid)
     if (R != 4 || C != 4) return LOOPS_E_CONFIG;
     return kernels::launch_bcsr4x4_mfma(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values,
-                                        x_padded, y);
+                                        x_padded, y, mode == 1 ? 8 : mode - 10);
   }
   if (mode != 0) return LOOPS_E_BADARG;
   if (R == 2 && C == 2) return kernels::launch_bcsr_thread_mapped<2, 2>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);

@@ -247,7 +247,7 @@ class BCSR:
         return (self.cols + self.C - 1) // self.C
 
 
-def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool = False):
+def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool | int = False):
     """algorithms::spmv::bcsr_thread_mapped<R, C>; ``mfma=True`` selects the 4x4 MFMA kernel."""
     if y is None:
         y = torch.empty(b.rows, dtype=torch.float32, device=b.values.device)
