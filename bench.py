@@ -37,6 +37,23 @@ def algorithmic_bytes(rows, cols, nnz, vbytes=4):
     return nnz * (4 + vbytes) + (rows + 1) * 4 + rows * vbytes + cols * vbytes
 
 
+def pmc_traffic(args):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
+    THIS command (profiles/r01_c2_pmc_summary.json; separate --pmc FETCH_SIZE / WRITE_SIZE runs):
+    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE counts the 128-B requests of this kernel at
+    64 B on gfx950 (MI355X_MICROARCH.md, HBM section; checked here against TCC_MISS * 128 B).
+    None when the configuration differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json")
+    if not os.path.exists(path) or args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 \
+            or args.tile != "256x8" or args.variant != 0:
+        return None
+    d = json.load(open(path))
+    for k, v in d.items():
+        if "merge_path_spmv_fused" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return int((2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,10 +104,25 @@ def main():
     plan = S.MergePathPlan(csr, args.tile)
     torch.cuda.synchronize()
 
+    gather_mode = {"mode": "p2p"}
+
     def step():
         S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
         if world > 1:
-            P.allgatherv_(y_full, shard)
+            P.allgatherv_(y_full, shard, mode=gather_mode["mode"])
+
+    if world > 1:  # grouped p2p is the design; fall back to the library collective if this build refuses it
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] batched p2p allgatherv unavailable ({type(e).__name__}: {e}); using padded all_gather",
+                  file=sys.stderr)
+            gather_mode["mode"] = "padded"
+        flag = torch.tensor([1.0 if gather_mode["mode"] == "padded" else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if float(flag) > 0:
+            gather_mode["mode"] = "padded"
 
     def barrier():
         if world > 1:
@@ -173,7 +205,7 @@ def main():
     abytes = algorithmic_bytes(loc_rows, cols, loc_nnz)
     achieved = abytes / (k_main_avg * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": "loops::kernels::merge_path_spmv_fused", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args),
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(k_main_avg, 5),
                 "median_launch_ms": round(k_main_med, 5), "fixup_avg_launch_ms": round(k_fix_avg, 5),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 4),
@@ -238,7 +270,7 @@ def main():
                                    + (", row-range sharded + allgatherv(y) over RCCL" if world > 1 else ""),
                        "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
                        "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
-                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + allgatherv(y)" if world > 1 else ""),
+                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (f" + allgatherv(y) [{gather_mode['mode']}]" if world > 1 else ""),
                        "ms_per_step_with_prepass": round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) stream_copy_kernel(const float4* __restri
 }
 
 /// How the gathered word is requested: 0 plain, 1 non-temporal, 2 agent-scope (sc1, bypasses the
-/// CU's vector L1), 3 system-scope (sc0 sc1).
+/// CU's vector L1), 3 system-scope (sc0 sc1), 4 plain gather but non-temporal index / output streams.
 template <int MODE>
 __device__ __forceinline__ float gather_load(const float* p) {
   if constexpr (MODE == 1) return __builtin_nontemporal_load(p);
@@ -34,13 +34,18 @@ __global__ void __launch_bounds__(256) gather_kernel(const float* __restrict__ t
                                                      float* __restrict__ out, size_t n) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4;
   for (size_t i = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) * 4; i + 3 < n; i += stride) {
-    const int4 c = *reinterpret_cast<const int4*>(idx + i);
-    float4 v;
+    using i4 = int __attribute__((ext_vector_type(4)));
+    using f4 = float __attribute__((ext_vector_type(4)));
+    i4 c;
+    if constexpr (MODE == 4) c = __builtin_nontemporal_load(reinterpret_cast<const i4*>(idx + i));  // streams nt, gather plain
+    else c = *reinterpret_cast<const i4*>(idx + i);
+    f4 v;
     v.x = gather_load<MODE>(table + c.x);
     v.y = gather_load<MODE>(table + c.y);
     v.z = gather_load<MODE>(table + c.z);
     v.w = gather_load<MODE>(table + c.w);
-    *reinterpret_cast<float4*>(out + i) = v;
+    if constexpr (MODE == 4) __builtin_nontemporal_store(v, reinterpret_cast<f4*>(out + i));
+    else *reinterpret_cast<f4*>(out + i) = v;
   }
 }
 
@@ -63,6 +68,7 @@ inline int launch_gather(hipStream_t stream, const float* table, const int* idx,
     case 1: hipLaunchKernelGGL(gather_kernel<1>, g, b, 0, stream, table, idx, out, n); break;
     case 2: hipLaunchKernelGGL(gather_kernel<2>, g, b, 0, stream, table, idx, out, n); break;
     case 3: hipLaunchKernelGGL(gather_kernel<3>, g, b, 0, stream, table, idx, out, n); break;
+    case 4: hipLaunchKernelGGL(gather_kernel<4>, g, b, 0, stream, table, idx, out, n); break;
     default: hipLaunchKernelGGL(gather_kernel<0>, g, b, 0, stream, table, idx, out, n); break;
   }
   return static_cast<int>(hipGetLastError());

@@ -78,23 +78,43 @@ def slice_csr(offsets, indices, values, row_begin, row_end):
     return (offsets[row_begin:row_end + 1] - offsets[row_begin]).astype(np.int32), indices[a:b], values[a:b]
 
 
-def allgatherv_(y_full: torch.Tensor, shard: Shard, group=None) -> torch.Tensor:
+def allgatherv_(y_full: torch.Tensor, shard: Shard, group=None, mode: str = "p2p", scratch=None) -> torch.Tensor:
     """In-place allgatherv: on entry rank r has written y_full[bounds[r]:bounds[r+1]]; on return
-    every rank holds the whole vector.  One batched group of direct sends / receives."""
+    every rank holds the whole vector.
+
+    mode "p2p" (default): one batched group of direct sends / receives (all xGMI links at once).
+    mode "padded": ``all_gather_into_tensor`` on max-count-padded slots + a local compaction -- the
+    library collective, kept as the fallback for backends / builds where grouped p2p is
+    unavailable."""
     if shard.world == 1:
         return y_full
     b = shard.bounds
     mine = y_full[int(b[shard.rank]):int(b[shard.rank + 1])]
-    ops = []
+    if mode == "p2p":
+        ops = []
+        for peer in range(shard.world):
+            if peer == shard.rank:
+                continue
+            if mine.numel():
+                ops.append(dist.P2POp(dist.isend, mine, peer, group))
+            theirs = y_full[int(b[peer]):int(b[peer + 1])]
+            if theirs.numel():
+                ops.append(dist.P2POp(dist.irecv, theirs, peer, group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return y_full
+    if mode != "padded":
+        raise ValueError(mode)
+    slot = int(shard.counts.max())
+    if scratch is None or scratch.numel() < slot * (shard.world + 1):
+        scratch = torch.empty(slot * (shard.world + 1), dtype=y_full.dtype, device=y_full.device)
+    send = scratch[:slot]
+    send[: mine.numel()].copy_(mine)
+    recv = scratch[slot: slot * (shard.world + 1)]
+    dist.all_gather_into_tensor(recv, send, group=group)
     for peer in range(shard.world):
-        if peer == shard.rank:
-            continue
-        if mine.numel():
-            ops.append(dist.P2POp(dist.isend, mine, peer, group))
-        theirs = y_full[int(b[peer]):int(b[peer + 1])]
-        if theirs.numel():
-            ops.append(dist.P2POp(dist.irecv, theirs, peer, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        if peer != shard.rank:
+            n = int(b[peer + 1] - b[peer])
+            y_full[int(b[peer]):int(b[peer + 1])].copy_(recv[peer * slot: peer * slot + n])
     return y_full

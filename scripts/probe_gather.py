@@ -23,7 +23,7 @@ for logt in (14, 16, 18, 20, 22, 24, 26):
     sidx = torch.sort(idx.view(-1, 64), dim=1).values.view(-1).contiguous()  # sorted within a wavefront's 64
     line = (torch.arange(n, device="cuda", dtype=torch.int32) % t)             # perfectly coalesced
     row = []
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         ms = ev(lambda: S.gather(table, idx, out, mode))
         row.append(f"m{mode} {n/ms/1e6:7.1f}")
     ms = ev(lambda: S.gather(table, sidx, out, 0)); row.append(f"sorted64 {n/ms/1e6:7.1f}")

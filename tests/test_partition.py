@@ -47,11 +47,14 @@ def _worker(rank, world, port, q):
     try:
         bounds = np.array([0, 5, 12], np.int64) if world == 2 else np.array([0, 4, 4, 12], np.int64)
         shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
-        y = torch.full((12,), -1.0)
-        y[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1)
-        P.allgatherv_(y, shard)
         want = torch.cat([torch.arange(int(bounds[r]), int(bounds[r + 1]), dtype=torch.float32) * (r + 1) for r in range(world)])
-        q.put((rank, bool(torch.equal(y, want))))
+        ok = True
+        for mode in ("p2p", "padded"):
+            y = torch.full((12,), -1.0)
+            y[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1)
+            P.allgatherv_(y, shard, mode=mode)
+            ok = ok and bool(torch.equal(y, want))
+        q.put((rank, ok))
     finally:
         dist.destroy_process_group()
 
