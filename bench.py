@@ -212,7 +212,7 @@ def main():
                 "measured_gather_Gelem_per_s": round(gather_gps, 2)}
 
     if args.sweep and rank == 0:
-        for tile in ("256x8", "256x7", "128x7", "512x8"):
+        for tile in ("256x8", "256x7", "128x7", "512x8", "256x16"):
             p2 = S.MergePathPlan(csr, tile)
             for variant in (0, 1, 2, 3):
                 avg, med = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, p2, 0, variant), 50)

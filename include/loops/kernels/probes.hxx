@@ -49,6 +49,35 @@ __global__ void __launch_bounds__(256) gather_kernel(const float* __restrict__ t
   }
 }
 
+/// Address-rate probe: no index / output streams, every lane issues `reps` 4-byte loads from a
+/// table that fits L1 (pattern 0: consecutive lanes -> consecutive words; 1: hashed within the
+/// table; 2: all lanes the same word).  Measures what the CU's address path (TA/TCP) sustains.
+template <int PATTERN>
+__global__ void __launch_bounds__(256) address_rate_kernel(const float* __restrict__ table, int mask, int reps,
+                                                           float* __restrict__ out) {
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = 0.f;
+  unsigned h = gid * 2654435761u;
+  for (int k = 0; k < reps; ++k) {
+    unsigned j;
+    if constexpr (PATTERN == 0) j = (gid + k * 64u) & mask;
+    else if constexpr (PATTERN == 1) { h = h * 1664525u + 1013904223u; j = (h >> 8) & mask; }
+    else j = (k * 17u) & mask;
+    acc += table[j];
+  }
+  if (acc == 123.456f) out[gid] = acc;  // keep the loads alive
+}
+
+inline int launch_address_rate(hipStream_t stream, const float* table, int table_words, int reps, int pattern,
+                               int blocks, float* out) {
+  const dim3 g(blocks), b(256);
+  const int mask = table_words - 1;
+  if (pattern == 0) hipLaunchKernelGGL(address_rate_kernel<0>, g, b, 0, stream, table, mask, reps, out);
+  else if (pattern == 1) hipLaunchKernelGGL(address_rate_kernel<1>, g, b, 0, stream, table, mask, reps, out);
+  else hipLaunchKernelGGL(address_rate_kernel<2>, g, b, 0, stream, table, mask, reps, out);
+  return static_cast<int>(hipGetLastError());
+}
+
 inline int launch_stream_copy(hipStream_t stream, const float* src, float* dst, size_t n) {
   const size_t n4 = n / 4;
   if (n4 == 0) return 0;

@@ -47,6 +47,7 @@ enum loops_tile_config {
   LOOPS_TILE_4x2 = 2,   /* tiny: lets small fixtures span many merge tiles             */
   LOOPS_TILE_256x7 = 3,
   LOOPS_TILE_512x8 = 4,
+  LOOPS_TILE_256x16 = 5, /* 4096-item tiles: twice the bytes in flight per lane */
   LOOPS_TILE_DEFAULT = 0
 };
 
@@ -144,6 +145,11 @@ int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
 /* out[i] = table[idx[i]] -- measures the L2 / Infinity-Cache gather rate that bounds x reads.
  * mode: 0 plain loads, 1 non-temporal, 2 agent-scope (sc1: bypass the CU's L1), 3 system-scope. */
 int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream);
+
+/* `blocks` x 256 lanes each issue `reps` 4-byte loads from a power-of-two table (pattern 0
+ * consecutive, 1 hashed, 2 broadcast): the address rate of the CU's vector-memory path. */
+int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ SCHEDULES = {
     "group_mapped": GROUP_MAPPED, "original": ORIGINAL, "flat_partitioned": FLAT_PARTITIONED,
 }
 # enum loops_tile_config: name -> (id, threads per block, items per thread)
-TILES = {"256x8": (0, 256, 8), "128x7": (1, 128, 7), "4x2": (2, 4, 2), "256x7": (3, 256, 7), "512x8": (4, 512, 8)}
+TILES = {"256x8": (0, 256, 8), "128x7": (1, 128, 7), "4x2": (2, 4, 2), "256x7": (3, 256, 7), "512x8": (4, 512, 8), "256x16": (5, 256, 16)}
 
 # every symbol include/loops_amd.h declares (tests/test_c_abi.py checks the export table)
 SYMBOLS = [
@@ -33,7 +33,7 @@ SYMBOLS = [
     "loops_spmv_csr_f32", "loops_spmv_csr_f64", "loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64",
     "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
-    "loops_work_oriented_grid", "loops_spmv_bcsr_f32", "loops_stream_copy_f32", "loops_gather_f32",
+    "loops_work_oriented_grid", "loops_spmv_bcsr_f32", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
 ]
 
 
@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
         L.loops_device_compute_units.argtypes = [C.POINTER(ci)]
         L.loops_spmv_bcsr_f32.argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
+        L.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         _lib = L
     return _lib

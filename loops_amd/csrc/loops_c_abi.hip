@@ -42,6 +42,7 @@ inline bool shape_of(int cfg, tile_shape* s) {
     case LOOPS_TILE_4x2: *s = {4, 2}; return true;
     case LOOPS_TILE_256x7: *s = {256, 7}; return true;
     case LOOPS_TILE_512x8: *s = {512, 8}; return true;
+    case LOOPS_TILE_256x16: *s = {256, 16}; return true;
     default: return false;
   }
 }
@@ -140,6 +141,7 @@ int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, c
     case LOOPS_TILE_128x7: { LOOPS_FUSED(128, 7) }
     case LOOPS_TILE_256x7: { LOOPS_FUSED(256, 7) }
     case LOOPS_TILE_512x8: { LOOPS_FUSED(512, 8) }
+    case LOOPS_TILE_256x16: { LOOPS_FUSED(256, 16) }
     case LOOPS_TILE_4x2: {
       // tiny tiles are for parity fixtures only: 64-thread workgroups, 4 "real" lanes would waste
       // the wavefront, so the fused kernel is not built for it; use the schedule-API kernel.
@@ -184,6 +186,7 @@ int spmv_schedule_api(int schedule, int cfg, int rows, int cols, int nnz, const 
         case LOOPS_TILE_4x2: return kernels::launch_merge_path_atomic<4, 2>(stream, R, C, N, off, idx, val, x, y);
         case LOOPS_TILE_256x7: return kernels::launch_merge_path_atomic<256, 7>(stream, R, C, N, off, idx, val, x, y);
         case LOOPS_TILE_512x8: return kernels::launch_merge_path_atomic<512, 8>(stream, R, C, N, off, idx, val, x, y);
+        case LOOPS_TILE_256x16: return kernels::launch_merge_path_atomic<256, 16>(stream, R, C, N, off, idx, val, x, y);
         default: return LOOPS_E_CONFIG;
       }
     }
@@ -332,6 +335,7 @@ int loops_schedule_dump_merge_path(int tile_config, int use_plan, int rows, int 
     case LOOPS_TILE_4x2: return launch_merge_dump<4, 2>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
     case LOOPS_TILE_256x7: return launch_merge_dump<256, 7>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
     case LOOPS_TILE_512x8: return launch_merge_dump<512, 8>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
+    case LOOPS_TILE_256x16: return launch_merge_dump<256, 16>(use_plan, rows, nnz, offsets, thread_start, atom_owner, atom_row, atom_visits, s);
     default: return LOOPS_E_CONFIG;
   }
 }
@@ -401,6 +405,13 @@ int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) 
 int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream) {
   if (!table || !idx || !out) return LOOPS_E_BADARG;
   return kernels::launch_gather(as_stream(stream), table, idx, out, n, mode);
+}
+
+int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
+                           void* stream) {
+  if (!table || !out || table_words <= 0 || (table_words & (table_words - 1)) || reps < 0 || blocks <= 0)
+    return LOOPS_E_BADARG;
+  return kernels::launch_address_rate(as_stream(stream), table, table_words, reps, pattern, blocks, out);
 }
 
 }  // extern "C"

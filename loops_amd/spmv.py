@@ -266,3 +266,8 @@ def stream_copy(src, dst):
 def gather(table, idx, out, mode: int = 0):
     L.check(L.lib().loops_gather_f32(_ptr(table), _ptr(idx), _ptr(out), idx.numel(), mode, _stream()),
             "loops_gather_f32")
+
+
+def address_rate(table, reps: int, pattern: int, blocks: int, out):
+    L.check(L.lib().loops_address_rate_f32(_ptr(table), table.numel(), reps, pattern, blocks, _ptr(out), _stream()),
+            "loops_address_rate_f32")

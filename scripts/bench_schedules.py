@@ -20,11 +20,21 @@ ap.add_argument("--log2-nnz", type=int, default=24)
 ap.add_argument("--window", type=int, default=0)
 ap.add_argument("--ref-gpu", action="store_true")
 ap.add_argument("--tag", default="c2")
+ap.add_argument("--rows", type=int, default=0, help="exact row count (overrides --log2-rows)")
+ap.add_argument("--nnz", type=int, default=0, help="exact nonzero count (overrides --log2-nnz)")
+ap.add_argument("--cap", type=int, default=1 << 14)
 args = ap.parse_args()
-rows = cols = 1 << args.log2_rows
-nnz = 1 << args.log2_nnz
-deg = G.powerlaw_degrees(rows, nnz)
-off, idx, val = G.powerlaw_csr(rows, cols, nnz, degrees=deg, window=args.window or None)
+rows = cols = args.rows or (1 << args.log2_rows)
+nnz = args.nnz or (1 << args.log2_nnz)
+deg = G.powerlaw_degrees(rows, nnz, cap=args.cap)
+# generate in row chunks to bound host memory on big stand-ins
+chunks, parts = max(1, nnz >> 25), []
+bounds = np.linspace(0, rows, chunks + 1).astype(np.int64)
+for a, b in zip(bounds[:-1], bounds[1:]):
+    parts.append(G.csr_from_degrees(deg[a:b], cols, 1, int(a), True, args.window or None))
+off = np.concatenate([[0]] + [p[0][1:].astype(np.int64) + sum(int(q[0][-1]) for q in parts[:i]) for i, p in enumerate(parts)]).astype(np.int32)
+idx = np.concatenate([p[1] for p in parts]); val = np.concatenate([p[2] for p in parts])
+del parts
 xh = G.uniform_distribution_int(cols)
 csr = S.CSR.from_numpy(rows, cols, off, idx, val)
 x = torch.from_numpy(xh).cuda()
@@ -32,7 +42,7 @@ y = torch.empty(rows, device="cuda")
 from oracle import oracle as O
 ref = O.spmv_f32(off, idx, val, xh, omp=True)
 abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
-res = {"workload": f"{args.tag}: 2^{args.log2_rows} rows, 2^{args.log2_nnz} nnz, window={args.window}", "rows": {}}
+res = {"workload": f"{args.tag}: {rows} rows, {nnz} nnz, max degree {int(deg.max())}, window={args.window}", "rows": {}}
 plan = S.MergePathPlan(csr)
 def rec(name, fn, check=True):
     ms = ev(fn)

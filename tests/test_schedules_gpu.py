@@ -18,7 +18,7 @@ def _cases():
     return cases
 
 
-@pytest.mark.parametrize("tile", ["256x8", "128x7", "4x2", "256x7", "512x8"])
+@pytest.mark.parametrize("tile", ["256x8", "128x7", "4x2", "256x7", "512x8", "256x16"])
 def test_merge_path_coordinates_and_thread_assignment(tile):
     from loops_amd import spmv as S, _lib
     from oracle import oracle as O
