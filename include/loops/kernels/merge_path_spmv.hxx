@@ -190,7 +190,13 @@ struct merge_tile_engine {
         if (live[k]) {
           type_t xv[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xv[j] = x[col[k][j]];
+          for (int j = 0; j < 4; ++j) {
+#ifdef LOOPS_PROBE_NO_GATHER  // measurement aid (never defined in a product build): cost with x[col] free
+            xv[j] = static_cast<type_t>(col[k][j] & 1);
+#else
+            xv[j] = x[col[k][j]];
+#endif
+          }
           const int i = (k * TPB + tid) * 4;
 #pragma unroll
           for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[j];

@@ -90,6 +90,9 @@ def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None):
                    + (np.uint64(attempt) << np.uint64(40)))
     if window is None:
         return (h % np.uint64(cols)).astype(np.int64)
+    if window < 0:  # "runs": the row's columns are consecutive from a hashed start (perfectly coalesced gather)
+        start = splitmix64(np.uint64(seed) * np.uint64(31) + rows_abs.astype(np.uint64)) % np.uint64(cols)
+        return ((start.astype(np.int64) + k) % np.int64(cols))
     # locality variant: columns fall in a window centred on the diagonal, at least 4x the row's
     # degree wide (so distinct columns always exist) and never wider than the matrix
     w = np.minimum(np.maximum(np.int64(window), 4 * deg), np.int64(cols)).astype(np.uint64)
