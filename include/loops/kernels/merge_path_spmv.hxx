@@ -18,7 +18,8 @@
  *  3. WALK     IPT merge steps per thread out of LDS: accumulate in a register, store y[row]
  *              directly for every row that both starts and ends inside the thread.
  *  4. STITCH   partial rows crossing thread boundaries are combined with a 6-step 64-lane
- *              segmented prefix sum (wave::segmented_inclusive_sum), wavefronts are stitched
+ *              segmented prefix sum on the VALU (DPP row_shr / row_bcast, wave::segmented_inclusive_sum),
+ *              wavefronts are stitched
  *              through 4 LDS words, and the one partial row leaving the workgroup goes to a
  *              {row, value} carry-out slot.
  *  5. FIX-UP   a tiny second kernel adds the carry-outs to y (rows longer than a merge tile
@@ -215,6 +216,10 @@ struct merge_tile_engine {
     }
     __syncthreads();
 
+#ifdef LOOPS_PROBE_STREAM_ONLY  // measurement aid: stop after the products are in LDS
+    if (s.prod[detail::slot<PAD>(tid)] == type_t(-12345.678)) y[tid] = type_t(1);
+    return type_t(0);
+#endif
     // ---- 2. SPLIT: this thread's start on the merge path (search.hxx semantics, in LDS) ------
     const int total = nrows + natoms;  // == TILE except in a last / short tile
     const int diag = tid * IPT;
@@ -263,18 +268,18 @@ struct merge_tile_engine {
       }
     }
 
+#ifdef LOOPS_PROBE_NO_STITCH  // measurement aid: skip the cross-thread combination
+    if (closed) y[row0 + first_row] = first_sum + sum;
+    return type_t(0);
+#endif
     // ---- 4. STITCH: partial rows across threads / wavefronts ----------------------------------
     const int lane = wave::lane();
     const int w = tid / wave::size;
     type_t run_sum = sum;  // tail partial (row row0 + tx, still open)
     bool head = closed;    // a thread that closed a row starts a new segment with its tail
     wave::segmented_inclusive_sum(run_sum, head);
-    type_t prev_run = __shfl_up(run_sum, 1);
-    int prev_head = __shfl_up(static_cast<int>(head), 1);
-    if (lane == 0) {
-      prev_run = type_t(0);
-      prev_head = 0;
-    }
+    const type_t prev_run = wave::shift_up1(run_sum, type_t(0));  // lane 0: nothing before it
+    const int prev_head = wave::shift_up1(static_cast<int>(head), 0);
     if (lane == wave::size - 1) {
       s.wave_val[w] = run_sum;
       s.wave_head[w] = head ? 1 : 0;
