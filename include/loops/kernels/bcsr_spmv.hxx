@@ -91,22 +91,31 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int safe = len > 0 ? beg : 0;  // any valid block index for masked-off steps
-  for (int k0 = 0; k0 < maxlen; k0 += UNROLL) {
-    // issue every load of the UNROLL steps before the first MFMA: UNROLL x (16 B block row +
-    // 4 B block column + 16 B of x) in flight per lane
-    f32x4 a[UNROLL];
-    int bc[UNROLL];
-    f32x4 xv[UNROLL];
+  // Software pipeline over batches of UNROLL blocks: the 16-byte block rows and block columns of
+  // batch n + 1 are requested BEFORE the x gathers and MFMAs of batch n, so a wavefront always has
+  // one batch of HBM reads in flight behind the batch it is multiplying.
+  f32x4 a_next[UNROLL];
+  int bc_next[UNROLL];
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const bool live = k0 + u < len;
       const int b = live ? beg + k0 + u : safe;
-      a[u] = *reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4);
-      bc[u] = block_cols[b];
-      if (!live) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      a_next[u] = *reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4);
+      bc_next[u] = block_cols[b];
+      if (!live) a_next[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  if (maxlen > 0) fetch(0);
+  for (int k0 = 0; k0 < maxlen; k0 += UNROLL) {
+    f32x4 a[UNROLL];
+    f32x4 xv[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc[u]) * 4);
+    for (int u = 0; u < UNROLL; ++u) {
+      a[u] = a_next[u];
+      xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4);
+    }
+    if (k0 + UNROLL < maxlen) fetch(k0 + UNROLL);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, xv[u].x, acc, 0, 0, 0);

@@ -78,9 +78,29 @@ inline int launch_address_rate(hipStream_t stream, const float* table, int table
   return static_cast<int>(hipGetLastError());
 }
 
+/// Read-only stream: every lane sums its float4s (one store per thread at the very end, only if the
+/// sum is a magic value) -- the achievable READ rate of HBM / Infinity Cache.
+__global__ void __launch_bounds__(256) stream_read_kernel(const float4* __restrict__ src, float* __restrict__ sink,
+                                                          size_t n4) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  float acc = 0.f;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = src[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  if (acc == -1.2345e30f) sink[0] = acc;
+}
+
 inline int launch_stream_copy(hipStream_t stream, const float* src, float* dst, size_t n) {
   const size_t n4 = n / 4;
   if (n4 == 0) return 0;
+  if (src == dst) {  // read-only probe: dst doubles as the (never written) sink
+    size_t rb = (n4 + 255) / 256;
+    if (rb > 256 * 8 * 4) rb = 256 * 8 * 4;
+    hipLaunchKernelGGL(stream_read_kernel, dim3(static_cast<unsigned>(rb)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(src), dst, n4);
+    return static_cast<int>(hipGetLastError());
+  }
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
   hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream,

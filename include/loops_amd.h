@@ -140,7 +140,8 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
 
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
- * roofline fraction is also quoted against. */
+ * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream
+ * (per-lane sums, nothing written): the achievable read rate. */
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
 /* out[i] = table[idx[i]] -- measures the L2 / Infinity-Cache gather rate that bounds x reads.
  * mode: 0 plain loads, 1 non-temporal, 2 agent-scope (sc1: bypass the CU's L1), 3 system-scope. */

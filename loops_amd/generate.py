@@ -90,6 +90,14 @@ def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None):
                    + (np.uint64(attempt) << np.uint64(40)))
     if window is None:
         return (h % np.uint64(cols)).astype(np.int64)
+    if window <= -2:  # power-law COLUMN popularity too (scale-free in both dimensions, like R-MAT graphs):
+        # column rank = cols * u^5 (Zipf-like, alpha = 0.8); -2: popular columns scattered by a fixed
+        # multiplicative permutation, -3: popular columns adjacent (labels sorted by popularity)
+        u = (h >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+        rank = np.minimum((np.float64(cols) * u ** 5).astype(np.int64), np.int64(cols - 1))
+        if window == -3:
+            return rank
+        return (rank * np.int64(2654435761)) % np.int64(cols)  # odd multiplier: a permutation of [0, 2^k)
     if window < 0:  # "runs": the row's columns are consecutive from a hashed start (perfectly coalesced gather)
         start = splitmix64(np.uint64(seed) * np.uint64(31) + rows_abs.astype(np.uint64)) % np.uint64(cols)
         return ((start.astype(np.int64) + k) % np.int64(cols))

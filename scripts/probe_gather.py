@@ -30,9 +30,10 @@ for logt in (14, 16, 18, 20, 22, 24, 26):
     ms = ev(lambda: S.gather(table, line, out, 0)); row.append(f"coalesced {n/ms/1e6:7.1f}")
     print(f"table 2^{logt} floats ({t*4/2**20:8.2f} MiB): Gelem/s " + "  ".join(row), flush=True)
 # streaming copy at several sizes
-for logn in (22, 24, 26, 28):
+for logn in (22, 24, 25, 26, 27, 28):
     n2 = 1 << logn
     src = torch.rand(n2, device="cuda"); dst = torch.empty_like(src)
     ms = ev(lambda: S.stream_copy(src, dst))
     ms2 = ev(lambda: dst.copy_(src))
-    print(f"copy 2^{logn} floats: ours {2*n2*4/ms/1e6:7.1f} GB/s  torch {2*n2*4/ms2/1e6:7.1f} GB/s", flush=True)
+    ms3 = ev(lambda: S.stream_copy(src, src))
+    print(f"copy 2^{logn} floats: ours {2*n2*4/ms/1e6:7.1f} GB/s  torch {2*n2*4/ms2/1e6:7.1f} GB/s  read-only {n2*4/ms3/1e6:7.1f} GB/s", flush=True)
