@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--window", type=int, default=0,
                     help="0: uniform hashed columns (SURVEY 8d, the headline); W > 0: columns in a band of W around "
                          "the diagonal (locality variant, reported for context)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="functional test: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--ref-gpu", action="store_true",
                     help="also time the reference's own HIP kernels on this GPU (oracle/_ref/libloops_ref_gpu.so)")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
@@ -81,9 +85,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     # ------------------------------------------------------------------ workload (synthetic)
     rows = world << args.log2_rows
@@ -119,7 +128,8 @@ def main():
             print(f"[rank {rank}] batched p2p allgatherv unavailable ({type(e).__name__}: {e}); using padded all_gather",
                   file=sys.stderr)
             gather_mode["mode"] = "padded"
-        flag = torch.tensor([1.0 if gather_mode["mode"] == "padded" else 0.0], device="cuda")
+        flag = torch.tensor([1.0 if gather_mode["mode"] == "padded" else 0.0],
+                            device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if float(flag) > 0:
             gather_mode["mode"] = "padded"
@@ -139,7 +149,8 @@ def main():
         got = y_loc.cpu().numpy()
         parity = bool(np.array_equal(got, ref))
         if world > 1:  # the gathered vector: checksum of all ranks' oracle results
-            s = torch.tensor([float(ref.astype(np.float64).sum())], dtype=torch.float64, device="cuda")
+            s = torch.tensor([float(ref.astype(np.float64).sum())], dtype=torch.float64,
+                             device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(s)
             parity = parity and abs(float(y_full.double().sum()) - float(s)) == 0.0
         assert parity, "GPU result differs from the oracle"
@@ -154,7 +165,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     ms_per_step = elapsed / args.steps * 1e3
@@ -267,7 +278,7 @@ def main():
             "config": {"workload": f"synthetic power-law CSR, {rows} rows / {nnz} nnz total "
                                    f"({world} x 2^{args.log2_rows} rows / 2^{args.log2_nnz} nnz per GPU), max degree 2^14, "
                                    "fp32, merge_path_flat" + (f", columns banded (window {args.window})" if args.window else ", columns uniform")
-                                   + (", row-range sharded + allgatherv(y) over RCCL" if world > 1 else ""),
+                                   + (f", row-range sharded + allgatherv(y) over {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'}" if world > 1 else ""),
                        "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
                        "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
                        "step_includes": "fused merge-tile kernel + carry-out fix-up" + (f" + allgatherv(y) [{gather_mode['mode']}]" if world > 1 else ""),

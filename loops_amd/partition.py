@@ -89,6 +89,12 @@ def allgatherv_(y_full: torch.Tensor, shard: Shard, group=None, mode: str = "p2p
     if shard.world == 1:
         return y_full
     b = shard.bounds
+    if y_full.is_cuda and dist.get_backend(group) == "gloo":
+        # functional-test path only (two ranks sharing one GPU, no RCCL): stage through the host
+        host = y_full.cpu()
+        allgatherv_(host, shard, group, mode)
+        y_full.copy_(host)
+        return y_full
     mine = y_full[int(b[shard.rank]):int(b[shard.rank + 1])]
     if mode == "p2p":
         ops = []

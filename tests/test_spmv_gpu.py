@@ -3,6 +3,8 @@ with the CPU oracle / the committed golden vectors.  Integer-valued and dyadic i
 exactly summable in fp32, so those comparisons are BIT-EXACT whatever the summation order;
 real-valued inputs are held to the north star's 1e-6 relative bound (scaled by the row's L1
 mass, i.e. the reference's own Wilkinson-style criterion, util/reference.hxx:278-337)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -248,3 +250,29 @@ def test_c5_shard_size_properties():
     assert np.array_equal(y.cpu().numpy(), ref)
     for sched in ("work_oriented", "group_mapped"):
         assert np.array_equal(S.spmv(sched, csr, xd).cpu().numpy(), ref), sched
+
+
+def test_bench_two_ranks_functional():
+    """bench.py's N > 1 control flow end to end -- row-range shards, per-rank plans and kernels,
+    allgatherv(y), gathered-vector checksum, max-over-ranks timing, one JSON line from rank 0 --
+    with two ranks sharing cuda:0 and gloo standing in for RCCL (a 1-GPU box cannot run RCCL with
+    two ranks).  The collective itself on gloo: tests/test_partition.py."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "2", "--backend", "gloo", "--single-device", "--log2-rows", "16", "--log2-nnz", "20"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parity_vs_oracle_bit_exact"] is True
+    assert d["value"] > 0 and d["cpu_baseline"] is None
