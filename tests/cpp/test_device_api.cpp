@@ -1,0 +1,180 @@
+// Device-side tests of the C++ header API (include/loops) -- the counterpart of the reference's
+// SpMV battery (unittests/test_spmv_{csr,coo,csc,dia,ell,bcsr,partitioned}.cu + test_spmv_battery.hxx,
+// restated, not copied): every `algorithms::spmv::*` wrapper, on a battery of small matrices, in
+// f32 and f64, against `reference::spmv` on the host; plus plan reuse, device-side COO->CSR,
+// duplicate removal, the device generator and SpMM.  Built in the dev container by
+// tests/test_cpp_device_api.py (hipcc), run on the GPU box.
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include <loops/container/formats.hxx>
+#include <loops/container/matrix.cuh>
+#include <loops/util/generate.hxx>
+#include <loops/util/reference.hxx>
+#include <loops/util/sample.hxx>
+#include <loops/algorithms/spmv/original.cuh>
+#include <loops/algorithms/spmv/thread_mapped.cuh>
+#include <loops/algorithms/spmv/group_mapped.cuh>
+#include <loops/algorithms/spmv/work_oriented.cuh>
+#include <loops/algorithms/spmv/merge_path_flat.cuh>
+#include <loops/algorithms/spmv/flat_partitioned.cuh>
+#include <loops/algorithms/spmv/bcsr_thread_mapped.cuh>
+#include <loops/algorithms/spmv/coo_thread_mapped.cuh>
+#include <loops/algorithms/spmv/csc_thread_mapped.cuh>
+#include <loops/algorithms/spmv/dia_thread_mapped.cuh>
+#include <loops/algorithms/spmv/ell_thread_mapped.cuh>
+#include <loops/algorithms/spmv/ell_merge_path.cuh>
+#include <loops/algorithms/spmm/thread_mapped.cuh>
+
+using namespace loops;
+static int g_fail = 0, g_checks = 0;
+#define CHECK(...) do { ++g_checks; if (!(__VA_ARGS__)) { ++g_fail; std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #__VA_ARGS__); } } while (0)
+constexpr auto H = memory_space_t::host;
+
+template <typename T>
+using hcsr_t = csr_t<int, int, T, H>;
+
+template <typename T>
+static hcsr_t<T> from_dense(const std::vector<std::vector<double>>& d) {
+  const std::size_t rows = d.size(), cols = rows ? d[0].size() : 0;
+  std::size_t nnz = 0;
+  for (auto& r : d) for (double v : r) nnz += v != 0.0;
+  hcsr_t<T> m(rows, cols, nnz);
+  std::size_t k = 0;
+  for (std::size_t r = 0; r < rows; ++r) {
+    m.offsets[r] = static_cast<int>(k);
+    for (std::size_t c = 0; c < cols; ++c)
+      if (d[r][c] != 0.0) { m.indices[k] = static_cast<int>(c); m.values[k] = static_cast<T>(d[r][c]); ++k; }
+  }
+  m.offsets[rows] = static_cast<int>(k);
+  return m;
+}
+
+// identity, banded, block-diagonal, skewed (one heavy row), empty rows, random, one long row
+// spanning several 2048-item merge tiles, all-empty.
+static std::vector<std::vector<std::vector<double>>> battery() {
+  std::mt19937 rng(12345);
+  std::uniform_real_distribution<double> u(0.5, 1.5);
+  std::vector<std::vector<std::vector<double>>> out;
+  auto zeros = [](std::size_t r, std::size_t c) { return std::vector<std::vector<double>>(r, std::vector<double>(c, 0.0)); };
+  { auto d = zeros(16, 16); for (int i = 0; i < 16; ++i) d[i][i] = 1.0; out.push_back(d); }
+  { auto d = zeros(32, 32); for (int i = 0; i < 32; ++i) for (int j = std::max(0, i - 3); j <= std::min(31, i + 4); ++j) d[i][j] = u(rng); out.push_back(d); }
+  { auto d = zeros(9, 9); for (int b = 0; b < 3; ++b) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) d[3 * b + i][3 * b + j] = u(rng); out.push_back(d); }
+  { auto d = zeros(20, 50); for (int j = 0; j < 50; ++j) d[0][j] = u(rng); for (int i = 1; i < 20; ++i) { d[i][(7 * i) % 50] = u(rng); d[i][(13 * i + 5) % 50] = u(rng); } out.push_back(d); }
+  { auto d = zeros(20, 12); for (int i = 0; i < 20; ++i) if (i % 4) for (int j = 0; j < 12; ++j) if (u(rng) < 0.8) d[i][j] = u(rng); out.push_back(d); }
+  { auto d = zeros(50, 50); for (auto& r : d) for (auto& v : r) if (u(rng) < 0.55) v = u(rng) - 1.0; out.push_back(d); }
+  { auto d = zeros(300, 6000); for (int j = 0; j < 6000; ++j) d[7][j] = u(rng); for (int i = 0; i < 300; ++i) d[i][(37 * i) % 6000] = u(rng); for (int i = 100; i < 140; ++i) for (auto& v : d[i]) v = 0.0; out.push_back(d); }
+  { out.push_back(zeros(6, 4)); }
+  return out;
+}
+
+template <typename T>
+static void check_y(const char* what, int m, const thrust::device_vector<T>& y, const thrust::host_vector<T>& ref) {
+  const std::size_t errors = reference::count_errors(y.data().get(), ref.data(), ref.size());
+  ++g_checks;
+  if (errors) { ++g_fail; std::printf("FAIL %s on matrix %d: %zu rows differ\n", what, m, errors); }
+}
+
+template <typename T>
+static void run_battery() {
+  int m = 0;
+  for (auto& dense : battery()) {
+    hcsr_t<T> h = from_dense<T>(dense);
+    csr_t<int, int, T> csr(h);
+    vector_t<T, H> xh(h.cols);
+    generate::random::uniform_distribution(xh.begin(), xh.end(), 1, 10, 42u);
+    vector_t<T> x(xh);
+    const auto ref = reference::spmv(h, xh);
+    {
+      vector_t<T> xd(h.cols);  // device generator == host generator
+      generate::random::uniform_distribution(xd.begin(), xd.end(), 1, 10, 42u);
+      vector_t<T, H> back(xd);
+      bool same = true;
+      for (std::size_t i = 0; i < back.size(); ++i) same = same && back[i] == xh[i];
+      CHECK(same);
+    }
+    auto fresh = [&] { return vector_t<T>(h.rows, T(0)); };
+    { auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::original(csr, x, y); check_y("original", m, y, ref); }
+    { auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::thread_mapped(csr, x, y); check_y("thread_mapped", m, y, ref); }
+    { auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::group_mapped(csr, x, y); check_y("group_mapped", m, y, ref); }
+    { auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::work_oriented(csr, x, y); check_y("work_oriented", m, y, ref); }
+    { auto y = vector_t<T>(h.rows, T(7)); auto t = algorithms::spmv::merge_path_flat(csr, x, y); CHECK(t.milliseconds() >= 0.f); check_y("merge_path_flat", m, y, ref); }
+    { auto y = fresh(); algorithms::spmv::flat_partitioned(csr, x, y); check_y("flat_partitioned<8>", m, y, ref); }
+    { auto y = fresh(); algorithms::spmv::flat_partitioned<4>(csr, x, y); check_y("flat_partitioned<4>", m, y, ref); }
+    if (h.rows && h.nnzs) {
+      { coo_t<int, T> coo(csr); auto y = fresh(); algorithms::spmv::coo_thread_mapped(coo, x, y); check_y("coo_thread_mapped", m, y, ref);
+        csr_t<int, int, T> again(coo);  // device-side COO -> CSR (radix sort + lower_bound)
+        vector_t<int, H> o2(again.offsets); bool same = true; for (std::size_t i = 0; i <= h.rows; ++i) same = same && o2[i] == h.offsets[i]; CHECK(same); }
+      { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_thread_mapped(csc, x, y); check_y("csc_thread_mapped", m, y, ref); }
+      { ell_t<int, T> ell(csr); auto y = fresh(); algorithms::spmv::ell_thread_mapped(ell, x, y); check_y("ell_thread_mapped", m, y, ref);
+        auto y2 = fresh(); algorithms::spmv::ell_merge_path(ell, x, y2); check_y("ell_merge_path", m, y2, ref); }
+      if (h.cols <= 64) { dia_t<int, int, T> dia(csr); auto y = fresh(); algorithms::spmv::dia_thread_mapped(dia, x, y); check_y("dia_thread_mapped", m, y, ref); }
+      auto bcsr_case = [&](auto b, const char* what) {
+        vector_t<T, H> xp(b.num_block_cols * b.kBlockCols, T(0));
+        for (std::size_t i = 0; i < h.cols; ++i) xp[i] = xh[i];
+        vector_t<T> xpd(xp);
+        auto y = fresh();
+        algorithms::spmv::bcsr_thread_mapped(b, xpd, y);
+        check_y(what, m, y, ref);
+      };
+      bcsr_case(bcsr_t<2, 2, int, int, T>(csr), "bcsr<2,2>");
+      bcsr_case(bcsr_t<3, 3, int, int, T>(csr), "bcsr<3,3>");
+      bcsr_case(bcsr_t<4, 4, int, int, T>(csr), "bcsr<4,4> (MFMA for f32)");
+    }
+    // plan reuse: one preprocess_t, several x (what an iterative solver does)
+    if (h.rows) {
+      using plan_t = algorithms::spmv::merge_path_plan_t<int, int, T>;
+      plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<int>(csr.rows), static_cast<int>(csr.nnzs)), 0, plan_t::prepass_always);
+      for (unsigned seed : {7u, 8u, 9u}) {
+        generate::random::uniform_distribution(xh.begin(), xh.end(), 1, 10, seed);
+        vector_t<T> x2(xh);
+        auto y = vector_t<T>(h.rows, T(-1));
+        algorithms::spmv::merge_path_flat_async(plan, csr, x2, y);
+        (void)xpu::stream_synchronize(0);
+        check_y("merge_path_flat_async(plan)", m, y, reference::spmv(h, xh));
+      }
+    }
+    ++m;
+  }
+}
+
+static void misc() {
+  auto s = sample::csr<>();  // device
+  vector_t<float> x(4, 1.0f), y(4);
+  algorithms::spmv::merge_path_flat(s, x, y);
+  vector_t<float, H> yh(y);
+  CHECK(yh[0] == 0.f && yh[1] == 13.f && yh[2] == 3.f && yh[3] == 6.f);
+  coo_t<int, float> dup(3, 3, 4);  // device-side duplicate removal
+  { coo_t<int, float, H> hd(3, 3, 4); const int r[] = {1, 0, 1, 0}, c[] = {2, 0, 2, 0};
+    for (int i = 0; i < 4; ++i) { hd.row_indices[i] = r[i]; hd.col_indices[i] = c[i]; hd.values[i] = float(i + 1); } dup = coo_t<int, float>(hd); }
+  dup.remove_duplicates();
+  CHECK(dup.nnzs == 2);
+  csr_t<int, int, float> rnd;
+  generate::random::csr(64, 64, 0.1f, rnd);
+  CHECK(rnd.rows == 64 && rnd.nnzs > 0 && rnd.nnzs <= 409);
+  // SpMM vs host
+  hcsr_t<float> h = from_dense<float>(battery()[1]);
+  csr_t<int, int, float> csr(h);
+  matrix_t<float> B(h.cols, 10), C(h.rows, 10);
+  generate::random::uniform_distribution(B.m_data.begin(), B.m_data.end(), 1, 10, 3u);
+  algorithms::spmm::thread_mapped(csr, B, C);
+  vector_t<float, H> Bh(B.m_data), Ch(C.m_data);
+  bool ok = true;
+  for (std::size_t r = 0; r < h.rows; ++r)
+    for (int j = 0; j < 10; ++j) {
+      float sum = 0;
+      for (int k = h.offsets[r]; k < h.offsets[r + 1]; ++k) sum += h.values[k] * Bh[h.indices[k] * 10 + j];
+      ok = ok && std::fabs(sum - Ch[r * 10 + j]) <= 1e-3f + 1e-4f * std::fabs(sum);
+    }
+  CHECK(ok);
+}
+
+int main() {
+  run_battery<float>();
+  run_battery<double>();
+  misc();
+  std::printf("%d checks, %d failures\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}
