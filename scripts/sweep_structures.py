@@ -1,0 +1,70 @@
+"""Load-balance robustness sweep (the reference's evaluation runs its schedules over 4 830 SuiteSparse
+matrices, plots/data/*.csv; none of them is available here): the tuned schedules + the reference's own
+HIP backend on synthetic matrices of very different row-length / column structure, all ~2^24 nnz."""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from loops_amd import generate as G, spmv as S, _lib
+from oracle import oracle as O
+
+def ev(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs]))
+
+def chunked(deg, cols, window):
+    rows = deg.size; nnz = int(deg.sum())
+    chunks = max(1, nnz >> 24); parts = []
+    b = np.linspace(0, rows, chunks + 1).astype(np.int64)
+    for a0, a1 in zip(b[:-1], b[1:]):
+        parts.append(G.csr_from_degrees(deg[a0:a1], cols, 1, int(a0), True, window))
+    off = np.concatenate([[0]] + [p[0][1:].astype(np.int64) + sum(int(q[0][-1]) for q in parts[:i]) for i, p in enumerate(parts)]).astype(np.int32)
+    return off, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
+
+N = 1 << 24
+rng = np.random.default_rng(1)
+cases = {}
+cases["power-law rows, uniform cols (C2)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, None)
+cases["power-law rows, banded cols (w=8192)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, 8192)
+cases["power-law rows, consecutive cols (runs)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, -1)
+cases["uniform degree 16, uniform cols"] = (np.full(1 << 20, 16, np.int64), 1 << 20, None)
+cases["uniform degree 16, banded (FEM-like, w=64)"] = (np.full(1 << 20, 16, np.int64), 1 << 20, 64)
+cases["short rows: degree 1-3, 8M rows"] = (rng.integers(1, 4, 1 << 23).astype(np.int64), 1 << 23, None)
+d = np.ones(1 << 18, np.int64); d[rng.choice(1 << 18, 64, replace=False)] = 1 << 18; d = (d * (N / d.sum())).astype(np.int64).clip(1, 1 << 18)
+cases["extreme skew: 64 rows hold ~all nnz"] = (d, 1 << 18, None)
+d = np.where(np.arange(1 << 21) % 4 == 0, 32, 0).astype(np.int64)
+cases["75 % empty rows, degree 32 otherwise"] = (d, 1 << 21, None)
+
+so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libloops_ref_gpu.so")
+R = _lib.load_shared(so) if os.path.exists(so) else None
+out = {}
+for name, (deg, cols, window) in cases.items():
+    off, idx, val = chunked(deg, cols, window)
+    rows, nnz = deg.size, int(off[-1])
+    xh = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    x = torch.from_numpy(xh).cuda(); y = torch.empty(rows, device="cuda")
+    abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
+    row = {"rows": rows, "cols": cols, "nnz": nnz, "max_degree": int(deg.max())}
+    plan = S.MergePathPlan(csr)
+    for label, fn in (("merge_path_flat", lambda: S.merge_path_flat(csr, x, y, plan=plan)),
+                      ("work_oriented", lambda: S.spmv("work_oriented", csr, x, y)),
+                      ("group_mapped", lambda: S.spmv("group_mapped", csr, x, y)),
+                      ("thread_mapped", lambda: S.spmv("thread_mapped", csr, x, y))):
+        ms = ev(fn, iters=10 if label == "thread_mapped" else 20)
+        ok = bool(np.array_equal(y.cpu().numpy(), ref))
+        row[label] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "bit_exact": ok}
+    if R is not None:
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        for kind, label in ((2, "ref_hip_merge_path"), (1, "ref_hip_work_oriented"), (0, "ref_hip_thread_mapped")):
+            yr = np.zeros(rows, np.float32); ms = C.c_float()
+            R.refgpu_spmv_f32(kind, C.c_long(rows), C.c_long(cols), C.c_long(nnz), p(off), p(idx), p(val), p(xh), p(yr), 3, C.byref(ms))
+            row[label] = {"us": round(ms.value * 1e3, 1)}
+    out[name] = row
+    print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict)), file=sys.stderr, flush=True)
+    del csr, x, y, plan
+print(json.dumps(out))
