@@ -26,7 +26,7 @@ nb = bcols.size
 abytes = nb * (16 * 4 + 4) + (nbr + 1) * 4 + nbr * 4 * 4 + nbr * 4 * 4
 flops = 2 * 16 * nb
 out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks ({nb} blocks), fp32", "algorithmic_bytes": abytes, "flops": flops, "rows": {}}
-for name, mfma in (("bcsr_thread_mapped (registers)", 0), ("bcsr_thread_mapped (MFMA 4x4x1)", 1), ("MFMA unroll 1", 11), ("MFMA unroll 2", 12), ("MFMA unroll 8", 18)):
+for name, mfma in (("bcsr_thread_mapped (registers)", 0), ("bcsr_thread_mapped (MFMA 4x4x1)", 1), ("MFMA unroll 1", 11), ("MFMA unroll 2", 12), ("MFMA unroll 4", 14), ("MFMA unroll 8", 18)):
     avg, med = ev(lambda: S.bcsr_thread_mapped(b, xd, y, mfma=mfma))
     ok = bool(np.array_equal(y.cpu().numpy(), want))
     out["rows"][name] = {"avg_ms": round(avg, 5), "median_ms": round(med, 5), "GFLOPs": round(flops / avg / 1e6, 1),
