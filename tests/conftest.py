@@ -77,5 +77,14 @@ def matrices():
     return battery()
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_extension():
+    """The HIP extension is built in-tree before any test runs (hipcc cross-compiles without a GPU;
+    a no-op when libloops_amd.so is newer than its sources).  There is no fallback path to test:
+    if this fails, every product call would raise LoopsError."""
+    from loops_amd import _lib
+    _lib.build()
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
