@@ -156,9 +156,11 @@ int launch_work_oriented_atomic(hipStream_t stream, std::size_t rows, std::size_
 }
 
 /// thread_mapped over flat_uniform_occupancy<K, csr>: atomics, y must be zero-filled.
+/// `per_atom` selects the reference-shaped kernel (one tile_of search + one atomic per nonzero);
+/// the default walks row runs (one search per thread, one atomic per run).
 template <std::size_t K, typename index_t, typename offset_t, typename T>
 int launch_flat_partitioned(hipStream_t stream, std::size_t rows, std::size_t nnz, const offset_t* offsets,
-                            const index_t* indices, const T* values, const T* x, T* y) {
+                            const index_t* indices, const T* values, const T* x, T* y, bool per_atom = false) {
   using base_t = layout::csr<index_t, offset_t>;
   using part_t = layout::flat_uniform_occupancy<K, base_t>;
   using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t, std::size_t,
@@ -168,9 +170,13 @@ int launch_flat_partitioned(hipStream_t stream, std::size_t rows, std::size_t nn
   if (chunks == 0) return 0;
   constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
   setup_t config(part);
-  launch::non_cooperative(stream, flat_partitioned_spmv<setup_t, index_t, T>,
-                          dim3(static_cast<unsigned>(math::ceil_div(chunks, block))), dim3(block), config, indices,
-                          values, x, y);
+  const dim3 grid(static_cast<unsigned>(math::ceil_div(chunks, block)));
+  if (per_atom)
+    launch::non_cooperative(stream, flat_partitioned_spmv<setup_t, index_t, T>, grid, dim3(block), config, indices,
+                            values, x, y);
+  else
+    launch::non_cooperative(stream, flat_partitioned_runs_spmv<setup_t, index_t, T>, grid, dim3(block), config,
+                            indices, values, x, y);
   return launch_status();
 }
 

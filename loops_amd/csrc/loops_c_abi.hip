@@ -178,7 +178,7 @@ int spmv_schedule_api(int schedule, int cfg, int rows, int cols, int nnz, const 
     case LOOPS_ORIGINAL: return kernels::launch_original(stream, R, C, N, off, idx, val, x, y);
     case LOOPS_GROUP_MAPPED: return kernels::launch_group_mapped_atomic(stream, R, C, N, off, idx, val, x, y);
     case LOOPS_WORK_ORIENTED: return kernels::launch_work_oriented_atomic(stream, R, C, N, off, idx, val, x, y);
-    case LOOPS_FLAT_PARTITIONED: return kernels::launch_flat_partitioned<8>(stream, R, N, off, idx, val, x, y);
+    case LOOPS_FLAT_PARTITIONED: return kernels::launch_flat_partitioned<8>(stream, R, N, off, idx, val, x, y, true);
     case LOOPS_MERGE_PATH_FLAT: {
       switch (cfg) {
         case LOOPS_TILE_256x8: return kernels::launch_merge_path_atomic<256, 8>(stream, R, C, N, off, idx, val, x, y);
@@ -222,10 +222,10 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
     case LOOPS_GROUP_MAPPED:
       return kernels::launch_group_mapped_fused<256, 8, true>(stream, rows, nnz, off, idx, val, x, y);
     case LOOPS_FLAT_PARTITIONED: {
-      // atomic kernels accumulate into y: zero it on the stream first
+      // atomic kernel accumulates into y: zero it on the stream first
       hipError_t e = hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), stream);
       if (e != hipSuccess) return static_cast<int>(e);
-      return spmv_schedule_api<T>(schedule, 0, rows, cols, nnz, off, idx, val, x, y, stream);
+      return kernels::launch_flat_partitioned<8>(stream, std::size_t(rows), std::size_t(nnz), off, idx, val, x, y);
     }
     default: return LOOPS_E_BADARG;
   }
