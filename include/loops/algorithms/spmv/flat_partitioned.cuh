@@ -2,7 +2,9 @@
  * @file flat_partitioned.cuh
  * @brief `algorithms::spmv::flat_partitioned<K = 8>(csr, x, y, stream) -> util::timer_t`:
  * thread_mapped over `layout::flat_uniform_occupancy<K, layout::csr>` -- perfectly balanced
- * K-nonzero tiles, original row recovered with `base().tile_of`, one atomicAdd per nonzero
+ * K-nonzero tiles; the original row is recovered with `base().tile_of` once per thread and followed
+ * along the thread's K atoms, one atomicAdd per run of same-row atoms (the reference-shaped per-atom
+ * kernel stays available as kernels::flat_partitioned_spmv)
  * (reference include/loops/algorithms/spmv/flat_partitioned.cuh:46-110).  y must be zero-filled
  * (a freshly constructed vector_t is).
  */
