@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -17,6 +18,7 @@
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/kernels/csr_spmv.hxx>
 #include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/kernels/merge_path_spmm.hxx>
 #include <loops/util/launch.hxx>
 #include <loops/util/launch_box.hxx>
 #include <loops/util/math.hxx>
@@ -64,6 +66,64 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,
                        carry_val, m, rows, y);
+  return launch_status();
+}
+
+/// Merge-path SpMM C = A * B (+ fix-up).  `carry_mat` holds plan.num_merge_tiles * n values.
+/// V (columns per lane) = the widest of 4 / 2 / 1 that divides n and the base alignments allow;
+/// G (lanes per sub-group) = the smallest power of two >= n / V, capped at 64 -- wider B is
+/// covered by grid.y slabs of 64 * V columns.
+template <int TPB, int IPT, typename index_t, typename offset_t, typename T>
+int launch_merge_path_spmm(hipStream_t stream, const merge_plan_view& plan, T* carry_mat, int rows, int cols, int nnz,
+                           const offset_t* offsets, const index_t* indices, const T* values, const T* B, int n,
+                           std::size_t ldb, T* C, std::size_t ldc) {
+  const int m = plan.num_merge_tiles;
+  if (m == 0 || n <= 0) return 0;
+  // B-row offsets are staged as 32-bit counts of per-lane vectors: cols * (ldb / V) must fit
+  if (static_cast<unsigned long long>(cols) * ldb >= (1ull << 32)) return static_cast<int>(hipErrorInvalidValue);
+#ifndef LOOPS_SPMM_U
+#define LOOPS_SPMM_U 8
+#endif
+  constexpr int U = LOOPS_SPMM_U;
+  auto go = [&](auto width, auto per_lane) {
+    constexpr int G = decltype(width)::value;
+    constexpr int V = decltype(per_lane)::value;
+    hipLaunchKernelGGL((merge_path_spmm<TPB, IPT, G, V, U, index_t, offset_t, T>), dim3(m, math::ceil_div(n, G * V)),
+                       dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, B, n, ldb, C, ldc,
+                       plan.carry_row, carry_mat);
+  };
+  auto pick_width = [&](auto per_lane) {
+    constexpr int V = decltype(per_lane)::value;
+    const int w = n / V;  // lanes needed for one row of B
+    if (w <= 2) go(std::integral_constant<int, 2>{}, per_lane);
+    else if (w <= 4) go(std::integral_constant<int, 4>{}, per_lane);
+    else if (w <= 8) go(std::integral_constant<int, 8>{}, per_lane);
+    else if (w <= 16) go(std::integral_constant<int, 16>{}, per_lane);
+    else if (w <= 32) go(std::integral_constant<int, 32>{}, per_lane);
+    else go(std::integral_constant<int, 64>{}, per_lane);
+  };
+  const std::uintptr_t bases = reinterpret_cast<std::uintptr_t>(B) | reinterpret_cast<std::uintptr_t>(C) |
+                               reinterpret_cast<std::uintptr_t>(carry_mat);
+  auto fits = [&](int v) {
+    const std::size_t bytes = sizeof(T) * v;
+    return n % v == 0 && ldb % v == 0 && ldc % v == 0 && bases % (bytes < 16 ? bytes : 16) == 0;
+  };
+  if (fits(4)) pick_width(std::integral_constant<int, 4>{});
+  else if (fits(2)) pick_width(std::integral_constant<int, 2>{});
+  else pick_width(std::integral_constant<int, 1>{});
+  const std::size_t work = static_cast<std::size_t>(m) * n;
+  hipLaunchKernelGGL(merge_path_spmm_fixup<T>, dim3(static_cast<unsigned>(math::ceil_div(work, std::size_t(256)))),
+                     dim3(256), 0, stream, plan.carry_row, carry_mat, m, rows, n, C, ldc);
+  return launch_status();
+}
+
+/// Reference-shaped SpMM: thread per row of A, columns of B in the outer loop.
+template <typename index_t, typename offset_t, typename T>
+int launch_thread_mapped_spmm(hipStream_t stream, int rows, const offset_t* offsets, const index_t* indices,
+                              const T* values, const T* B, int n, std::size_t ldb, T* C, std::size_t ldc) {
+  if (rows == 0 || n <= 0) return 0;
+  hipLaunchKernelGGL((thread_mapped_spmm<index_t, offset_t, T>), dim3(math::ceil_div(rows, 128)), dim3(128), 0, stream,
+                     rows, offsets, indices, values, B, n, ldb, C, ldc);
   return launch_status();
 }
 

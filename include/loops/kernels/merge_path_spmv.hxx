@@ -86,6 +86,21 @@ __device__ __forceinline__ void load4(const T* __restrict__ p, T (&out)[4]) {
   }
 }
 
+/// Tile owned by workgroup `i` of `m` when XCD (i mod 8) is to work on one contiguous run of
+/// tiles.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2 each): a contiguous run
+/// per XCD keeps the x / B rows that neighbouring tiles share (banded, clustered, web-graph
+/// matrices) in ONE L2 instead of all eight.
+__device__ __forceinline__ int xcd_contiguous(int i, int m) {
+#ifdef LOOPS_PROBE_NO_XCD_SWIZZLE  // measurement aid (never defined in a product build): round-robin tiles
+  return i;
+#else
+  constexpr int XCDS = 8;
+  const int k = i % XCDS, j = i / XCDS;
+  const int base = m / XCDS, rem = m % XCDS;
+  return k * base + (k < rem ? k : rem) + j;
+#endif
+}
+
 /// LDS index of product slot i.  With PAD one word of padding every 32 slots turns the
 /// stride-IPT (IPT = 8) per-thread walk into a conflict-free ds_read_b32 pattern.
 template <bool PAD>
@@ -322,7 +337,7 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
   __shared__ offset_t s_re[TPB * IPT + IPT + 1];
 
   const int tid = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
   // tile coordinates (wave-uniform: scalar loads)
   const coord_t c0 = coords[b];
   const coord_t c1 = coords[b + 1];
@@ -363,7 +378,8 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
   __shared__ offset_t s_re[TPB * IPT + IPT + 1];
 
   const int tid = threadIdx.x;
-  const int t_begin = blockIdx.x * tiles_per_group;
+  const int g = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int t_begin = g * tiles_per_group;
   int t_end = t_begin + tiles_per_group;
   t_end = t_end < num_merge_tiles ? t_end : num_merge_tiles;
   type_t carry = type_t(0);
@@ -385,8 +401,8 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
     open_row = row0 + nrows;
   }
   if (tid == 0 && t_begin < t_end) {
-    carry_row[blockIdx.x] = open_row;
-    carry_val[blockIdx.x] = carry;
+    carry_row[g] = open_row;
+    carry_val[g] = carry;
   }
 }
 
@@ -408,7 +424,7 @@ group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restric
   __shared__ offset_t s_off[TPB + 1 + IPT];  // offsets of the group's rows (+ clamped slack)
 
   const int tid = threadIdx.x;
-  const int group_row0 = blockIdx.x * TPB;
+  const int group_row0 = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x)) * TPB;
   int group_rows = rows - group_row0;
   group_rows = group_rows < TPB ? group_rows : TPB;
   for (int i = tid; i < TPB + 1 + IPT; i += TPB) {

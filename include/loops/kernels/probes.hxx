@@ -123,5 +123,49 @@ inline int launch_gather(hipStream_t stream, const float* table, const int* idx,
   return static_cast<int>(hipGetLastError());
 }
 
+/// Row-gather probe: the B access pattern of the SpMM in isolation.  Sub-groups of LANES lanes
+/// read rows of LANES * 16 bytes of `table` (row ids from `idx`, `count` of them), U rows in
+/// flight per sub-group, and keep a per-lane sum.  Measures the row-gather bandwidth the memory
+/// system sustains (L2 / Infinity Cache / HBM by table size and index pattern).
+template <int LANES, int U>
+__global__ void __launch_bounds__(256) row_gather_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                                         size_t count, float* __restrict__ out) {
+  using f4 = float __attribute__((ext_vector_type(4)));
+  const size_t gid = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const size_t sub = gid / LANES, l = gid % LANES;
+  const size_t subs = static_cast<size_t>(gridDim.x) * blockDim.x / LANES;
+  const size_t per = (count + subs - 1) / subs;
+  size_t a = sub * per;
+  const size_t end = a + per < count ? a + per : count;
+  const f4* __restrict__ base = reinterpret_cast<const f4*>(table) + l;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; a + U <= end; a += U) {
+    int r[U];
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = idx[a + u];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = base[static_cast<size_t>(r[u]) * LANES];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += v[u];
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[gid] = acc.x;  // keep the loads alive
+}
+
+inline int launch_row_gather(hipStream_t stream, const float* table, const int* idx, size_t count, int row_floats,
+                             int blocks, float* out) {
+  const dim3 g(blocks), b(256);
+  switch (row_floats) {
+    case 8: hipLaunchKernelGGL((row_gather_kernel<2, 8>), g, b, 0, stream, table, idx, count, out); break;
+    case 16: hipLaunchKernelGGL((row_gather_kernel<4, 8>), g, b, 0, stream, table, idx, count, out); break;
+    case 32: hipLaunchKernelGGL((row_gather_kernel<8, 8>), g, b, 0, stream, table, idx, count, out); break;
+    case 64: hipLaunchKernelGGL((row_gather_kernel<16, 8>), g, b, 0, stream, table, idx, count, out); break;
+    case 128: hipLaunchKernelGGL((row_gather_kernel<32, 8>), g, b, 0, stream, table, idx, count, out); break;
+    case 256: hipLaunchKernelGGL((row_gather_kernel<64, 8>), g, b, 0, stream, table, idx, count, out); break;
+    default: return -1;
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace kernels
 }  // namespace loops

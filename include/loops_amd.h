@@ -138,6 +138,21 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
                         const int* block_offsets, const int* block_cols, const float* block_values,
                         const float* x_padded, float* y, void* stream);
 
+/* ---- CSR SpMM  C[rows x n] = A[rows x cols] * B[cols x n], dense row-major B and C ------------
+ * Replaces algorithms::spmm::thread_mapped (algorithms/spmm/thread_mapped.cuh:28-90; caller:
+ * examples/spmm/thread_mapped.cu:30-41).  schedule LOOPS_MERGE_PATH_FLAT = the tuned kernel
+ * (merge tiles x 64-column slabs of B, coalesced B rows, no atomics, C needs no zero-fill);
+ * LOOPS_THREAD_MAPPED = the reference-shaped kernel (thread per row, columns outer).  Leading
+ * dimensions are n (packed), as matrix_t stores them (container/matrix.cuh:28-36). */
+int loops_spmm_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const float* values, const float* B, int n, float* C, void* stream);
+int loops_spmm_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const double* values, const double* B, int n, double* C, void* stream);
+/* Same with a held plan (tile config LOOPS_TILE_256x8 only): no coordinate pre-pass per call. */
+int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                              const int* indices, const float* values, const float* B, int n, float* C,
+                              void* stream);
+
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream
@@ -151,6 +166,12 @@ int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, i
  * consecutive, 1 hashed, 2 broadcast): the address rate of the CU's vector-memory path. */
 int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
                            void* stream);
+
+/* Row-gather probe (the SpMM's B access pattern in isolation): sub-groups of row_floats / 4 lanes
+ * read `count` rows of row_floats floats (8..256, power of two) of `table` selected by `idx`, 16 B
+ * per lane, 8 rows in flight; `out` needs blocks * 256 floats. */
+int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
+                         void* stream);
 
 #ifdef __cplusplus
 }

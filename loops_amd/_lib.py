@@ -33,7 +33,8 @@ SYMBOLS = [
     "loops_spmv_csr_f32", "loops_spmv_csr_f64", "loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64",
     "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
-    "loops_work_oriented_grid", "loops_spmv_bcsr_f32", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
+    "loops_work_oriented_grid", "loops_spmv_bcsr_f32",
+    "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_row_gather_f32", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
 ]
 
 
@@ -100,6 +101,10 @@ def lib() -> C.CDLL:
         L.loops_work_oriented_grid.argtypes = [C.POINTER(ci)]
         L.loops_device_compute_units.argtypes = [C.POINTER(ci)]
         L.loops_spmv_bcsr_f32.argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_spmm_csr_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
+        L.loops_spmm_csr_f64.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
+        L.loops_spmm_merge_path_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
+        L.loops_row_gather_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, vp, vp]
         L.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
         L.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]

@@ -65,6 +65,8 @@ struct loops_merge_plan {
   double* carry_val;   // M + 2 (8 B slots: float or double)
   int* carry_row;      // M + 2
   void* base;
+  mutable void* wide_carry;         // SpMM carry-outs, M x n values, grown on demand
+  mutable size_t wide_carry_bytes;
 };
 
 namespace {
@@ -104,7 +106,7 @@ loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
   tile_shape s;
   if (!shape_of(cfg, &s)) { *err = LOOPS_E_CONFIG; return nullptr; }
   const int need = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(s.tpb) * s.ipt));
-  if (p && p->capacity < need) { (void)hipFree(p->base); delete p; p = nullptr; }
+  if (p && p->capacity < need) { (void)hipFree(p->base); (void)hipFree(p->wide_carry); delete p; p = nullptr; }
   if (!p) {
     *err = plan_alloc(rows, nnz, cfg, &p);
     if (*err) return nullptr;
@@ -231,6 +233,49 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
   }
 }
 
+// ------------------------------------------------------------------------------------- SpMM
+template <typename T>
+int spmm_merge_path(const loops_merge_plan* p, int rows, int cols, int nnz, const int* off, const int* idx, const T* val,
+                    const T* B, int n, T* C, hipStream_t stream) {
+  if (rows != p->rows || nnz != p->nnz) return LOOPS_E_BADARG;
+  if (p->tpb != 256 || p->ipt != 8) return LOOPS_E_CONFIG;
+  if (static_cast<unsigned long long>(cols) * static_cast<unsigned long long>(n) >= (1ull << 32)) return LOOPS_E_RANGE;
+  const size_t need = static_cast<size_t>(p->num_tiles) * static_cast<size_t>(n) * sizeof(T);
+  if (need > p->wide_carry_bytes) {
+    (void)hipFree(p->wide_carry);
+    p->wide_carry = nullptr;
+    p->wide_carry_bytes = 0;
+    hipError_t e = hipMalloc(&p->wide_carry, need);
+    if (e != hipSuccess) return static_cast<int>(e);
+    p->wide_carry_bytes = need;
+  }
+  kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, p->num_tiles};
+  return kernels::launch_merge_path_spmm<256, 8>(stream, view, static_cast<T*>(p->wide_carry), rows, cols, nnz, off, idx, val,
+                                                 B, n, static_cast<size_t>(n), C, static_cast<size_t>(n));
+}
+
+template <typename T>
+int spmm_tuned(int schedule, int rows, int cols, int nnz, const int* off, const int* idx, const T* val, const T* B,
+               int n, T* C, hipStream_t stream) {
+  if (n < 0 || rows < 0) return LOOPS_E_BADARG;
+  if (n == 0 || rows == 0) return 0;  // C is empty: nothing to check, nothing to write
+  int err = check_csr(rows, cols, nnz, off, idx, val, B, C);
+  if (err) return err;
+  switch (schedule) {
+    case LOOPS_MERGE_PATH_FLAT: {
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
+      if (!p) return err;
+      err = plan_compute(p, off, stream);
+      if (!err) err = spmm_merge_path<T>(p, rows, cols, nnz, off, idx, val, B, n, C, stream);
+      return err;
+    }
+    case LOOPS_THREAD_MAPPED:
+      return kernels::launch_thread_mapped_spmm(stream, rows, off, idx, val, B, n, static_cast<size_t>(n), C,
+                                                static_cast<size_t>(n));
+    default: return LOOPS_E_CONFIG;
+  }
+}
+
 }  // namespace
 
 // =============================================================================== extern "C"
@@ -260,6 +305,7 @@ int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_conf
 
 int loops_merge_plan_destroy(loops_merge_plan_t* plan) {
   if (!plan) return 0;
+  (void)hipFree(plan->wide_carry);
   hipError_t e = hipFree(plan->base);
   delete plan;
   return static_cast<int>(e);
@@ -412,6 +458,31 @@ int loops_address_rate_f32(const float* table, int table_words, int reps, int pa
   if (!table || !out || table_words <= 0 || (table_words & (table_words - 1)) || reps < 0 || blocks <= 0)
     return LOOPS_E_BADARG;
   return kernels::launch_address_rate(as_stream(stream), table, table_words, reps, pattern, blocks, out);
+}
+
+int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
+                         void* stream) {
+  if (!table || !idx || !out || blocks <= 0) return LOOPS_E_BADARG;
+  const int rc = kernels::launch_row_gather(as_stream(stream), table, idx, count, row_floats, blocks, out);
+  return rc == -1 ? LOOPS_E_CONFIG : rc;
+}
+
+int loops_spmm_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const float* values, const float* B, int n, float* C, void* stream) {
+  return spmm_tuned<float>(schedule, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
+}
+int loops_spmm_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                       const double* values, const double* B, int n, double* C, void* stream) {
+  return spmm_tuned<double>(schedule, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
+}
+int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                              const int* indices, const float* values, const float* B, int n, float* C,
+                              void* stream) {
+  if (!plan || n < 0 || rows < 0) return LOOPS_E_BADARG;
+  if (n == 0 || rows == 0) return 0;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, B, C);
+  if (err) return err;
+  return spmm_merge_path<float>(plan, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
 }
 
 }  // extern "C"

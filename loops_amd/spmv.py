@@ -170,6 +170,29 @@ def spmv_schedule_api(schedule: str, csr: CSR, x, y=None, tile: str = "256x8"):
     return y
 
 
+# ------------------------------------------------------------------------------------------ SpMM
+def spmm(csr: CSR, B: torch.Tensor, Cm: torch.Tensor | None = None, schedule: str = "merge_path_flat",
+         plan: MergePathPlan | None = None) -> torch.Tensor:
+    """C = A B with dense row-major B [cols, n] and C [rows, n] (algorithms::spmm).  ``schedule``:
+    "merge_path_flat" (tuned) or "thread_mapped" (reference-shaped).  With ``plan`` the coordinate
+    pre-pass is skipped (merge_path_flat, f32)."""
+    assert B.dim() == 2 and B.is_contiguous() and B.shape[0] == csr.cols and B.dtype == csr.values.dtype
+    n = B.shape[1]
+    if Cm is None:
+        Cm = torch.empty((csr.rows, n), dtype=B.dtype, device=B.device)
+    assert Cm.is_contiguous() and tuple(Cm.shape) == (csr.rows, n) and Cm.dtype == B.dtype
+    if plan is not None:
+        assert schedule == "merge_path_flat" and B.dtype == torch.float32
+        L.check(L.lib().loops_spmm_merge_path_f32(plan.handle, csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets),
+                                                  _ptr(csr.indices), _ptr(csr.values), _ptr(B), n, _ptr(Cm), _stream()),
+                "loops_spmm_merge_path_f32")
+        return Cm
+    fn = getattr(L.lib(), "loops_spmm_csr_" + _suffix(csr.values))
+    L.check(fn(L.SCHEDULES[schedule], csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+               _ptr(csr.values), _ptr(B), n, _ptr(Cm), _stream()), "loops_spmm_csr(" + schedule + ")")
+    return Cm
+
+
 # ------------------------------------------------------------------------------- schedule dumps
 def dump_merge_path(csr: CSR, tile: str = "256x8", use_plan: bool = True):
     cfg, tpb, ipt = L.TILES[tile]
@@ -271,3 +294,9 @@ def gather(table, idx, out, mode: int = 0):
 def address_rate(table, reps: int, pattern: int, blocks: int, out):
     L.check(L.lib().loops_address_rate_f32(_ptr(table), table.numel(), reps, pattern, blocks, _ptr(out), _stream()),
             "loops_address_rate_f32")
+
+
+def row_gather(table, idx, row_floats: int, blocks: int, out):
+    """Row-gather probe: see loops_row_gather_f32."""
+    L.check(L.lib().loops_row_gather_f32(_ptr(table), _ptr(idx), idx.numel(), row_floats, blocks, _ptr(out), _stream()),
+            "loops_row_gather_f32")

@@ -252,6 +252,20 @@ def bcsr_spmv_f32(R, Cc, rows, block_offsets, block_cols, block_values, x_padded
     return y
 
 
+def spmm(offsets, indices, values, B):
+    """C = A * B, the reference's SpMM semantics (spmm/thread_mapped.cuh:38-51); f32 or f64 by values.dtype."""
+    offsets, indices = _i32(offsets), _i32(indices)
+    f64 = np.asarray(values).dtype == np.float64
+    dt = np.float64 if f64 else np.float32
+    values = np.ascontiguousarray(values, dt)
+    B = np.ascontiguousarray(B, dt)
+    rows, n = offsets.size - 1, B.shape[1]
+    out = np.zeros((rows, n), dt)
+    fn = lib().oracle_spmm_f64 if f64 else lib().oracle_spmm_f32
+    fn(C.c_long(rows), _p(offsets), _p(indices), _p(values), _p(B), C.c_long(n), _p(out))
+    return out
+
+
 # --------------------------------------------------------------------------- reference (real)
 def ref_load_mtx(path):
     r = ref()

@@ -18,6 +18,7 @@
 //   schedule::setup<merge_path_flat>    include/loops/schedule/merge_path_flat.hxx:193-390
 //   schedule::setup<work_oriented>      include/loops/schedule/work_oriented.hxx:45-190
 //   merge_path::preprocess_t            include/loops/schedule/merge_path_flat.hxx:99-172
+//   algorithms::spmm::thread_mapped     include/loops/algorithms/spmm/thread_mapped.cuh:68-94
 // (group_mapped is excluded from the reference's HIP build: schedule.hxx:69-74.)
 #include <loops/schedule.hxx>
 #include <loops/container/formats.hxx>
@@ -27,6 +28,7 @@
 #include <loops/algorithms/spmv/merge_path_flat.cuh>
 #include <loops/algorithms/spmv/thread_mapped.cuh>
 #include <loops/algorithms/spmv/work_oriented.cuh>
+#include <loops/algorithms/spmm/thread_mapped.cuh>
 
 #include <algorithm>
 
@@ -149,6 +151,29 @@ int refgpu_spmv_f32(int kind, long rows, long cols, long nnz, const int* off, co
     }
     if (ms) *ms = best;
     thrust::copy(dy.begin(), dy.end(), y);
+    return 0;
+  } catch (...) { return 1; }
+}
+
+// The reference's SpMM (C = A * B, dense row-major B [cols x n], C [rows x n]) on this GPU,
+// bracketed with util::timer_t the way examples/spmm/thread_mapped.cu:36-41 does.
+int refgpu_spmm_f32(long rows, long cols, long nnz, const int* off, const int* idx, const float* val,
+                    const float* B, long n, float* Cm, int iters, float* ms) {
+  try {
+    host_csr h = make_host(rows, cols, nnz, off, idx, val);
+    dev_csr csr(h);
+    matrix_t<float> dB(cols, n), dC(rows, n);
+    thrust::copy(B, B + cols * n, dB.m_data.begin());
+    float best = 1e30f;
+    for (int it = 0; it < iters; ++it) {
+      util::timer_t timer;
+      timer.start();
+      algorithms::spmm::thread_mapped(csr, dB, dC);
+      timer.stop();
+      best = std::min(best, timer.milliseconds());
+    }
+    if (ms) *ms = best;
+    thrust::copy(dC.m_data.begin(), dC.m_data.end(), Cm);
     return 0;
   } catch (...) { return 1; }
 }

@@ -27,6 +27,7 @@
 #include <loops/algorithms/spmv/ell_thread_mapped.cuh>
 #include <loops/algorithms/spmv/ell_merge_path.cuh>
 #include <loops/algorithms/spmm/thread_mapped.cuh>
+#include <loops/algorithms/spmm/merge_path_flat.cuh>
 
 using namespace loops;
 static int g_fail = 0, g_checks = 0;
@@ -169,6 +170,31 @@ static void misc() {
       ok = ok && std::fabs(sum - Ch[r * 10 + j]) <= 1e-3f + 1e-4f * std::fabs(sum);
     }
   CHECK(ok);
+  // tuned SpMM == reference-shaped SpMM (every battery matrix, several widths of B, f32 + f64)
+  for (auto& dense : battery())
+    for (int n : {1, 4, 10, 32, 70}) {
+      hcsr_t<float> hf = from_dense<float>(dense);
+      csr_t<int, int, float> a(hf);
+      matrix_t<float> Bn(hf.cols, n), C0(hf.rows, n), C1(hf.rows, n);
+      generate::random::uniform_distribution(Bn.m_data.begin(), Bn.m_data.end(), 1, 10, 5u);
+      algorithms::spmm::thread_mapped(a, Bn, C0);
+      auto timer = algorithms::spmm::merge_path_flat(a, Bn, C1);
+      CHECK(timer.milliseconds() >= 0.f);
+      vector_t<float, H> c0(C0.m_data), c1(C1.m_data);
+      bool same = true;
+      for (std::size_t i = 0; i < c0.size(); ++i) same = same && std::fabs(c0[i] - c1[i]) <= 1e-3f + 1e-5f * std::fabs(c0[i]);
+      CHECK(same);
+      hcsr_t<double> hd = from_dense<double>(dense);
+      csr_t<int, int, double> ad(hd);
+      matrix_t<double> Bd(hd.cols, n), D0(hd.rows, n), D1(hd.rows, n);
+      generate::random::uniform_distribution(Bd.m_data.begin(), Bd.m_data.end(), 1, 10, 5u);
+      algorithms::spmm::thread_mapped(ad, Bd, D0);
+      algorithms::spmm::merge_path_flat(ad, Bd, D1);
+      vector_t<double, H> d0(D0.m_data), d1(D1.m_data);
+      same = true;
+      for (std::size_t i = 0; i < d0.size(); ++i) same = same && std::fabs(d0[i] - d1[i]) <= 1e-9 + 1e-12 * std::fabs(d0[i]);
+      CHECK(same);
+    }
 }
 
 int main() {
