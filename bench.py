@@ -14,7 +14,10 @@ step WITH the coordinate pre-pass is reported next to it (config.ms_per_step_wit
 Workload at N = 1: BASELINE config C2 -- synthetic power-law CSR, 2^20 rows, 2^24 nnz, max
 degree 2^14, fp32 (SURVEY 8d generator).  At N > 1 (weak scaling): N * 2^20 rows,
 N * 2^24 nnz of the same generator, contiguous row ranges balanced by rows + nnz, one range
-per GPU, x replicated, allgatherv(y) over RCCL every step.
+per GPU, x replicated, allgatherv(y) over RCCL every step.  At N > 1 a rank holds its shard
+COLUMN-BLOCKED by owner (--layout, include/loops/kernels/column_blocked.hxx): x is N * 4 MB there and no
+longer fits the 4 MB per-XCD L2; the blocked layout keeps each XCD inside one x block (same fused
+kernel + a K-way row reduce).  The N = 1 headline runs on the unmodified CSR.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
 """
@@ -45,7 +48,7 @@ def pmc_traffic(args):
     None when the configuration differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json")
     if not os.path.exists(path) or args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 \
-            or args.tile != "256x8" or args.variant != 0:
+            or args.tile != "256x8" or args.variant != 0 or args.layout == "blocked":
         return None
     d = json.load(open(path))
     for k, v in d.items():
@@ -75,6 +78,10 @@ def main():
     ap.add_argument("--ref-gpu", action="store_true",
                     help="also time the reference's own HIP kernels on this GPU (oracle/_ref/libloops_ref_gpu.so)")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
+    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked"],
+                    help="how a rank holds its row-range shard: 'csr' as sliced; 'blocked' = column-blocked by owner "
+                         "(x of N x 4 MB does not fit the per-XCD L2: include/loops/kernels/column_blocked.hxx); "
+                         "auto = csr at N = 1 (the headline is the unmodified CSR), blocked at N > 1")
     args = ap.parse_args()
 
     import torch
@@ -111,12 +118,22 @@ def main():
     y_loc = y_full[shard.row_begin:shard.row_end]
     gen_s = time.time() - t0
     plan = S.MergePathPlan(csr, args.tile)
+    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
+    blocked = None
+    if layout == "blocked":
+        blocked = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds))
     torch.cuda.synchronize()
 
     gather_mode = {"mode": "p2p"}
 
+    def spmv_local():
+        if blocked is not None:
+            blocked.spmv(x, y_loc)
+        else:
+            S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
+
     def step():
-        S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
+        spmv_local()
         if world > 1:
             P.allgatherv_(y_full, shard, mode=gather_mode["mode"])
 
@@ -184,8 +201,14 @@ def main():
         return float(np.mean(ts)), float(ts[len(ts) // 2])
 
     iters = max(20, min(args.steps, 200))
-    k_main_avg, k_main_med = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 0, args.variant), iters)
-    k_fix_avg, _ = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 1, args.variant), iters)
+    k_reduce_avg = None
+    if blocked is not None:
+        k_main_avg, k_main_med = event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
+        k_fix_avg, _ = event_time(lambda: blocked.spmv_stage(1, x, y_loc), iters)
+        k_reduce_avg, _ = event_time(lambda: blocked.spmv_stage(2, x, y_loc), iters)
+    else:
+        k_main_avg, k_main_med = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 0, args.variant), iters)
+        k_fix_avg, _ = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 1, args.variant), iters)
 
     def with_prepass():
         plan.refresh(csr)
@@ -199,6 +222,25 @@ def main():
         with_prepass()
     torch.cuda.synchronize()
     ms_with_prepass = (time.perf_counter() - t0) / iters * 1e3
+
+    # for context at N = 1: the same SpMV with the matrix held column-blocked (never `value`)
+    blocked_info = None
+    if world == 1 and blocked is None and rank == 0:
+        cb = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds))
+        yb = torch.empty_like(y_loc)
+        for _ in range(5):
+            cb.spmv(x, yb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            cb.spmv(x, yb)
+        torch.cuda.synchronize()
+        ms_b = (time.perf_counter() - t0) / iters * 1e3
+        blocked_info = {"blocks": cb.num_blocks, "ms_per_step": round(ms_b, 5),
+                        "GFLOPs": round(2.0 * nnz / (ms_b * 1e-3) / 1e9, 2), "equal_to_csr_result": bool(torch.equal(yb, y_loc)),
+                        "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/column_blocked.hxx); "
+                                "same fused kernel + K-way row reduce; not the headline"}
+        cb.close()
 
     # calibration probes: achievable streaming rate and gather rate on this box
     n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
@@ -221,6 +263,8 @@ def main():
                 "median_launch_ms": round(k_main_med, 5), "fixup_avg_launch_ms": round(k_fix_avg, 5),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 4),
                 "measured_gather_Gelem_per_s": round(gather_gps, 2)}
+    if k_reduce_avg is not None:
+        roofline["block_reduce_avg_launch_ms"] = round(k_reduce_avg, 5)
 
     if args.sweep and rank == 0:
         for tile in ("256x8", "256x7", "128x7", "512x8", "256x16"):
@@ -281,10 +325,13 @@ def main():
                                    + (f", row-range sharded + allgatherv(y) over {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'}" if world > 1 else ""),
                        "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
                        "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
-                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (f" + allgatherv(y) [{gather_mode['mode']}]" if world > 1 else ""),
+                       "shard_layout": "csr" if blocked is None else
+                                       f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)",
+                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}]" if world > 1 else ""),
                        "ms_per_step_with_prepass": round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
+                       "column_blocked_layout_same_matrix": blocked_info,
                        "reference_hip_backend_on_this_gpu": ref_gpu},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -153,6 +153,36 @@ int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols
                               const int* indices, const float* values, const float* B, int n, float* C,
                               void* stream);
 
+/* ---- column-blocked CSR: SpMV for matrices / shards whose x does not fit the per-XCD L2 ---------
+ * No reference counterpart (the reference is single-GPU and leaves the x gather to the cache).
+ * The plan holds a re-ordered COPY of the matrix: the columns are cut into K blocks and stacked row
+ * (k * rows + r) holds the part of row r inside block k -- an ordinary CSR of K * rows rows that the
+ * fused merge_path_flat kernel runs unchanged, each XCD staying inside (about) one column block so its
+ * L2 holds cols * 4 / K bytes of x; a K-way row reduce finishes y (include/loops/kernels/column_blocked.hxx).
+ * num_blocks <= 0: automatic (x[block] ~ 2 MB, at most 8).  block_bounds: NULL for equal blocks, or
+ * num_blocks + 1 ascending HOST ints with [0] = 0 and [num_blocks] = cols (multi-GPU: the owners' row
+ * ranges).  Creation is synchronous on `stream` (device radix sort + scan, O(nnz)).
+ * y = A x is deterministic; it sums each row block by block, so it is bit-identical to the plain
+ * kernels for exactly-summable inputs and within the usual fp32 reordering bound otherwise. */
+typedef struct loops_colblock_plan loops_colblock_plan_t;
+int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                               const float* values, int num_blocks, const int* block_bounds, void* stream,
+                               loops_colblock_plan_t** out);
+void loops_colblock_plan_destroy(loops_colblock_plan_t* plan);
+/* num_blocks and (if non-NULL) the num_blocks + 1 HOST column boundaries */
+int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks, int* block_bounds);
+/* copies of the stacked CSR (K * rows + 1 offsets, nnz indices / values) and of the permutation
+ * (stacked position -> original position) into HOST buffers (any may be NULL); synchronous; for
+ * inspection and tests */
+int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_offsets, int* stacked_indices,
+                               float* stacked_values, int* perm);
+/* new numerical values, same structure */
+int loops_colblock_plan_refresh_values(loops_colblock_plan_t* plan, const float* values, void* stream);
+int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream);
+/* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
+int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
+                                  void* stream);
+
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream

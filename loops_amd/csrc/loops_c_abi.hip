@@ -19,6 +19,7 @@
 #include <loops/util/launch_box.hxx>
 #include <loops/util/math.hxx>
 #include <loops/kernels/launch.hxx>
+#include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 #include <loops/kernels/probes.hxx>
 
@@ -278,6 +279,47 @@ int spmm_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
 
 }  // namespace
 
+// --------------------------------------------------------------------- column-blocked CSR
+struct loops_colblock_plan {
+  int rows, cols, nnz, K;
+  int* bounds_dev;            // K + 1
+  int bounds_host[65];
+  int *soff, *sidx, *perm;    // stacked CSR structure + permutation
+  float* sval;
+  float* ys;                  // K * rows partial results
+  loops_merge_plan* merge;    // merge-path plan of the stacked CSR
+};
+
+namespace {
+
+void colblock_free(loops_colblock_plan* p) {
+  if (!p) return;
+  (void)hipFree(p->bounds_dev); (void)hipFree(p->soff); (void)hipFree(p->sidx); (void)hipFree(p->perm);
+  (void)hipFree(p->sval); (void)hipFree(p->ys);
+  if (p->merge) { (void)hipFree(p->merge->wide_carry); (void)hipFree(p->merge->base); delete p->merge; }
+  delete p;
+}
+
+// K for a column count: x[block] of about 2 MB (half the per-XCD L2), at most 8 blocks (one per XCD)
+int colblock_auto(int cols) {
+  const long long bytes = static_cast<long long>(cols) * 4;
+  int k = 1;
+  while (k < 8 && bytes / k > (2ll << 20)) k *= 2;
+  return k;
+}
+
+int colblock_spmv(const loops_colblock_plan* p, int stages, const float* x, float* y, hipStream_t stream) {
+  if (p->rows == 0) return 0;
+  int err = 0;
+  if (stages & 3)
+    err = spmv_merge_path<float>(p->merge, 0, p->K * p->rows, p->nnz, p->soff, p->sidx, p->sval, x, p->ys, stream,
+                                 stages & 3);
+  if (!err && (stages & 4)) err = kernels::launch_reduce_blocks<float>(stream, p->ys, p->rows, p->K, y);
+  return err;
+}
+
+}  // namespace
+
 // =============================================================================== extern "C"
 extern "C" {
 
@@ -483,6 +525,95 @@ int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols
   int err = check_csr(rows, cols, nnz, offsets, indices, values, B, C);
   if (err) return err;
   return spmm_merge_path<float>(plan, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
+}
+
+int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                               const float* values, int num_blocks, const int* block_bounds, void* stream,
+                               loops_colblock_plan_t** out) {
+  if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
+  int K = num_blocks > 0 ? num_blocks : colblock_auto(cols);
+  if (K > 64) return LOOPS_E_CONFIG;
+  if (K > cols && cols > 0) K = cols;
+  if (K < 1) K = 1;
+  if (static_cast<long long>(K) * rows + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  auto* p = new (std::nothrow) loops_colblock_plan();
+  if (!p) return static_cast<int>(hipErrorOutOfMemory);
+  p->rows = rows; p->cols = cols; p->nnz = nnz; p->K = K;
+  for (int k = 0; k <= K; ++k) {
+    p->bounds_host[k] = block_bounds ? block_bounds[k]
+                                     : static_cast<int>(static_cast<long long>(cols) * k / K);
+    if (k > 0 && p->bounds_host[k] < p->bounds_host[k - 1]) { delete p; return LOOPS_E_BADARG; }
+  }
+  if (p->bounds_host[0] != 0 || p->bounds_host[K] != cols) { delete p; return LOOPS_E_BADARG; }
+  const size_t srows = static_cast<size_t>(K) * rows, n = static_cast<size_t>(nnz);
+  hipStream_t st = as_stream(stream);
+  void* temp = nullptr;
+  const size_t temp_bytes = kernels::column_blocked_temp_bytes(nnz, static_cast<int>(srows));
+  hipError_t e = hipSuccess;
+  auto alloc = [&](auto** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 4); };
+  alloc(&p->bounds_dev, sizeof(int) * (K + 1));
+  alloc(&p->soff, sizeof(int) * (srows + 1));
+  alloc(&p->sidx, sizeof(int) * n);
+  alloc(&p->perm, sizeof(int) * n);
+  alloc(&p->sval, sizeof(float) * n);
+  alloc(&p->ys, sizeof(float) * srows);
+  alloc(&temp, temp_bytes);
+  int err = static_cast<int>(e);
+  if (!err) err = static_cast<int>(hipMemcpyAsync(p->bounds_dev, p->bounds_host, sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
+  if (!err) {
+    kernels::column_blocked_view<int, int, float> view{rows, cols, nnz, K, p->soff, p->sidx, p->sval, p->perm};
+    err = kernels::build_column_blocked(st, offsets, indices, values, p->bounds_dev, view, temp, temp_bytes);
+  }
+  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, LOOPS_TILE_DEFAULT, &p->merge);
+  if (!err) err = plan_compute(p->merge, p->soff, st);
+  if (!err) err = static_cast<int>(hipStreamSynchronize(st));  // the temporaries go away below
+  (void)hipFree(temp);
+  if (err) { colblock_free(p); return err; }
+  *out = p;
+  return 0;
+}
+
+void loops_colblock_plan_destroy(loops_colblock_plan_t* plan) { colblock_free(plan); }
+
+int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks, int* block_bounds) {
+  if (!plan) return LOOPS_E_BADARG;
+  if (num_blocks) *num_blocks = plan->K;
+  if (block_bounds) for (int k = 0; k <= plan->K; ++k) block_bounds[k] = plan->bounds_host[k];
+  return 0;
+}
+
+int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_offsets, int* stacked_indices,
+                               float* stacked_values, int* perm) {
+  if (!plan) return LOOPS_E_BADARG;
+  const size_t srows = static_cast<size_t>(plan->K) * plan->rows, n = static_cast<size_t>(plan->nnz);
+  hipError_t e = hipDeviceSynchronize();
+  auto copy = [&](void* dst, const void* src, size_t bytes) {
+    if (e == hipSuccess && dst && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  };
+  copy(stacked_offsets, plan->soff, sizeof(int) * (srows + 1));
+  copy(stacked_indices, plan->sidx, sizeof(int) * n);
+  copy(stacked_values, plan->sval, sizeof(float) * n);
+  copy(perm, plan->perm, sizeof(int) * n);
+  return static_cast<int>(e);
+}
+
+int loops_colblock_plan_refresh_values(loops_colblock_plan_t* plan, const float* values, void* stream) {
+  if (!plan || (plan->nnz > 0 && !values)) return LOOPS_E_BADARG;
+  if (plan->nnz == 0) return 0;
+  hipLaunchKernelGGL((kernels::colblock::gather_values<float>), dim3(math::ceil_div(plan->nnz, 256)), dim3(256), 0,
+                     as_stream(stream), plan->perm, values, plan->nnz, plan->sval);
+  return static_cast<int>(hipGetLastError());
+}
+
+int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream) {
+  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  return colblock_spmv(plan, 7, x, y, as_stream(stream));
+}
+
+int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
+                                  void* stream) {
+  if (!plan || !y || stage < 0 || stage > 2) return LOOPS_E_BADARG;
+  return colblock_spmv(plan, 1 << stage, x, y, as_stream(stream));
 }
 
 }  // extern "C"

@@ -124,3 +124,20 @@ def allgatherv_(y_full: torch.Tensor, shard: Shard, group=None, mode: str = "p2p
             n = int(b[peer + 1] - b[peer])
             y_full[int(b[peer]):int(b[peer + 1])].copy_(recv[peer * slot: peer * slot + n])
     return y_full
+
+
+def column_block_bounds(owner_bounds, max_blocks: int = 8, target_bytes: int = 2 << 20, elem_bytes: int = 4):
+    """Column boundaries for the column-blocked layout of a shard (spmv.ColumnBlockedPlan): the owners'
+    row ranges (x[block k] = the y slice rank k produces), each cut into s equal pieces so that a block
+    of x is about ``target_bytes`` (half a per-XCD L2) without exceeding ``max_blocks`` (one per XCD)."""
+    owner_bounds = np.asarray(owner_bounds, np.int64)
+    world = owner_bounds.size - 1
+    widest = int(np.diff(owner_bounds).max()) if world else 0
+    s = 1
+    while world * s * 2 <= max_blocks and widest * elem_bytes // s > target_bytes:
+        s *= 2
+    out = [0]
+    for a, b in zip(owner_bounds[:-1], owner_bounds[1:]):
+        for j in range(1, s + 1):
+            out.append(int(a + (b - a) * j // s))
+    return np.asarray(out, np.int32)

@@ -170,6 +170,71 @@ def spmv_schedule_api(schedule: str, csr: CSR, x, y=None, tile: str = "256x8"):
     return y
 
 
+# ------------------------------------------------------------------------- column-blocked CSR
+class ColumnBlockedPlan:
+    """Column-blocked ("stacked") copy of a CSR for matrices / shards whose x does not fit the per-XCD
+    L2 (loops_colblock_plan_*; include/loops/kernels/column_blocked.hxx).  ``num_blocks`` 0 = automatic;
+    ``block_bounds`` = num_blocks + 1 ascending column boundaries (multi-GPU: the owners' row ranges)."""
+
+    def __init__(self, csr: CSR, num_blocks: int = 0, block_bounds=None):
+        assert csr.values.dtype == torch.float32
+        self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
+        self._h = C.c_void_p()
+        bounds = None
+        if block_bounds is not None:
+            bounds = np.ascontiguousarray(block_bounds, np.int32)
+            num_blocks = bounds.size - 1
+        L.check(L.lib().loops_colblock_plan_create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+                                                   _ptr(csr.values), int(num_blocks),
+                                                   None if bounds is None else bounds.ctypes.data_as(C.c_void_p),
+                                                   _stream(), C.byref(self._h)), "loops_colblock_plan_create")
+        k = C.c_int()
+        L.check(L.lib().loops_colblock_plan_info(self._h, C.byref(k), None), "loops_colblock_plan_info")
+        self.num_blocks = k.value
+        b = np.zeros(self.num_blocks + 1, np.int32)
+        L.check(L.lib().loops_colblock_plan_info(self._h, None, b.ctypes.data_as(C.c_void_p)), "loops_colblock_plan_info")
+        self.block_bounds = b
+
+    @property
+    def handle(self):
+        return self._h
+
+    def arrays(self):
+        """(stacked offsets, stacked indices, stacked values, perm) copied to the host."""
+        srows = self.num_blocks * self.rows
+        off, idx = np.zeros(srows + 1, np.int32), np.zeros(self.nnz, np.int32)
+        val, perm = np.zeros(self.nnz, np.float32), np.zeros(self.nnz, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        L.check(L.lib().loops_colblock_plan_arrays(self._h, p(off), p(idx), p(val), p(perm)), "loops_colblock_plan_arrays")
+        return off, idx, val, perm
+
+    def refresh_values(self, values: torch.Tensor):
+        assert values.dtype == torch.float32 and values.numel() == self.nnz
+        L.check(L.lib().loops_colblock_plan_refresh_values(self._h, _ptr(values), _stream()), "loops_colblock_plan_refresh_values")
+
+    def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+        if y is None:
+            y = torch.empty(self.rows, dtype=torch.float32, device=x.device)
+        assert x.dtype == torch.float32 and x.numel() == self.cols and y.numel() == self.rows and x.is_contiguous()
+        L.check(L.lib().loops_spmv_colblock_f32(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock_f32")
+        return y
+
+    def spmv_stage(self, stage: int, x, y):
+        L.check(L.lib().loops_spmv_colblock_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock_stage_f32")
+        return y
+
+    def close(self):
+        if self._h:
+            L.lib().loops_colblock_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------------------------------ SpMM
 def spmm(csr: CSR, B: torch.Tensor, Cm: torch.Tensor | None = None, schedule: str = "merge_path_flat",
          plan: MergePathPlan | None = None) -> torch.Tensor:

@@ -1,0 +1,103 @@
+"""Column-blocked ("stacked") CSR plans through the C ABI (include/loops/kernels/column_blocked.hxx):
+the device-built layout must equal the oracle's specification bit for bit (integer work), and the
+SpMV over it must equal the plain CSR SpMV (bit-exact for exactly-summable inputs)."""
+import numpy as np
+import pytest
+
+from conftest import battery, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev(off, idx, val, rows, cols):
+    from loops_amd import spmv as S
+    return S.CSR.from_numpy(rows, cols, off, idx, val)
+
+
+def _uniform_bounds(cols, K):
+    return np.array([cols * k // K for k in range(K + 1)], np.int64)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 8])
+def test_battery_layout_and_spmv(K):
+    from loops_amd import spmv as S
+    from oracle import oracle as O
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val.astype(np.float32), r, c)
+        plan = S.ColumnBlockedPlan(csr, K)
+        k = plan.num_blocks
+        assert k == max(1, min(K, c)), (name, k)
+        want = O.column_blocked(off, idx, val.astype(np.float32), plan.block_bounds)
+        got = plan.arrays()
+        for a, b, what in zip(got, want, ("offsets", "indices", "values", "perm")):
+            assert np.array_equal(a, b), (name, K, what)
+        x = torch.from_numpy(g[f"{name}.x_int"]).cuda()
+        y = torch.full((r,), 7.0, device="cuda")
+        plan.spmv(x, y)
+        ref, l1 = g[f"{name}.y_int"], g[f"{name}.l1_int"]
+        assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= 8e-6 * l1 + 1e-30), (name, K)
+
+
+def test_powerlaw_auto_blocks_bit_exact_and_refresh():
+    """x of 16 MB -> 8 automatic blocks; exactly-summable values -> bit-exact vs the plain kernel and
+    the oracle; new values through refresh_values."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows, cols, nnz = 1 << 14, 1 << 22, 1 << 18
+    off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, nnz, cap=1 << 12), cols, 1, 0, True, None)
+    csr = _dev(off, idx, val, rows, cols)
+    plan = S.ColumnBlockedPlan(csr)
+    assert plan.num_blocks == O.auto_blocks(cols) == 8
+    assert np.array_equal(plan.block_bounds, _uniform_bounds(cols, 8))
+    want = O.column_blocked(off, idx, val, plan.block_bounds)
+    for a, b in zip(plan.arrays(), want):
+        assert np.array_equal(a, b)
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    y = plan.spmv(x).cpu().numpy()
+    assert np.array_equal(y, O.spmv_f32(off, idx, val, xh))
+    assert np.array_equal(y, S.spmv("merge_path_flat", csr, x).cpu().numpy())
+    val2 = np.roll(val, 7)
+    plan.refresh_values(torch.from_numpy(val2).cuda())
+    assert np.array_equal(plan.spmv(x).cpu().numpy(), O.spmv_f32(off, idx, val2, xh))
+
+
+def test_uneven_bounds_like_row_range_owners():
+    """Explicit, uneven column boundaries (what the owners' nnz-balanced row ranges look like),
+    including an empty block."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows = cols = 1 << 13
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 17, degrees=G.powerlaw_degrees(rows, 1 << 17, cap=1 << 12))
+    csr = _dev(off, idx, val, rows, cols)
+    bounds = np.array([0, 100, 100, 3000, 5000, cols], np.int32)
+    plan = S.ColumnBlockedPlan(csr, block_bounds=bounds)
+    assert plan.num_blocks == 5 and np.array_equal(plan.block_bounds, bounds)
+    for a, b in zip(plan.arrays(), O.column_blocked(off, idx, val, bounds)):
+        assert np.array_equal(a, b)
+    xh = G.uniform_distribution_int(cols)
+    assert np.array_equal(plan.spmv(torch.from_numpy(xh).cuda()).cpu().numpy(), O.spmv_f32(off, idx, val, xh))
+
+
+def test_real_values_and_bad_arguments():
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    rows = cols = 1 << 12
+    off, idx, _ = G.powerlaw_csr(rows, cols, 1 << 16, degrees=G.powerlaw_degrees(rows, 1 << 16, cap=1 << 11))
+    rng = np.random.default_rng(2)
+    val = rng.uniform(0.5, 1.5, idx.size).astype(np.float32)
+    xh = rng.uniform(0.5, 1.5, cols).astype(np.float32)
+    csr = _dev(off, idx, val, rows, cols)
+    y = S.ColumnBlockedPlan(csr, 4).spmv(torch.from_numpy(xh).cuda()).cpu().numpy()
+    ref = O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64))
+    l1 = O.row_l1_f32(off, idx, val, xh)
+    assert np.all(np.abs(y - ref) <= 8e-6 * l1 + 1e-30)
+    with pytest.raises(_lib.LoopsError):
+        S.ColumnBlockedPlan(csr, block_bounds=[0, 10, 5, cols])        # not ascending
+    with pytest.raises(_lib.LoopsError):
+        S.ColumnBlockedPlan(csr, block_bounds=[0, 10, cols - 1])       # does not end at cols
+    with pytest.raises(_lib.LoopsError):
+        S.ColumnBlockedPlan(csr, 65)                                   # too many blocks

@@ -75,3 +75,16 @@ def test_allgatherv_gloo(world):
     for p in procs:
         p.join(60)
     assert all(ok for _, ok in res) and len(res) == world
+
+
+def test_column_block_bounds_follow_owner_ranges():
+    """Blocks never straddle an owner's range; each owner's range is cut into equal pieces until a block
+    of x is <= 2 MB or 8 blocks are reached."""
+    from loops_amd import partition as P
+    owners = np.array([0, 1_000_000, 2_100_000, 3_000_000, 4_194_304], np.int64)   # 4 ranks, x = 16 MB
+    b = P.column_block_bounds(owners)
+    assert b[0] == 0 and b[-1] == owners[-1] and np.all(np.diff(b) >= 0) and b.size - 1 == 8
+    assert set(owners.tolist()) <= set(b.tolist())
+    assert P.column_block_bounds(np.array([0, 1 << 20])).size - 1 == 2            # N = 1: 4 MB -> 2 blocks
+    assert P.column_block_bounds(np.arange(9) << 20).size - 1 == 8                # N = 8: one block per owner
+    assert P.column_block_bounds(np.array([0, 1000, 2000])).tolist() == [0, 1000, 2000]   # small x: owners only

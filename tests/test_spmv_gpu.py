@@ -276,3 +276,8 @@ def test_bench_two_ranks_functional():
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parity_vs_oracle_bit_exact"] is True
     assert d["value"] > 0 and d["cpu_baseline"] is None
+    assert d["config"]["shard_layout"].startswith("column-blocked by owner")  # the N > 1 default
+    r = subprocess.run(cmd + ["--layout", "csr"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["shard_layout"] == "csr" and d["config"]["parity_vs_oracle_bit_exact"] is True
