@@ -28,6 +28,7 @@
 #include <loops/algorithms/spmv/ell_merge_path.cuh>
 #include <loops/algorithms/spmm/thread_mapped.cuh>
 #include <loops/algorithms/spmm/merge_path_flat.cuh>
+#include <loops/algorithms/spmv/column_blocked.cuh>
 
 using namespace loops;
 static int g_fail = 0, g_checks = 0;
@@ -170,6 +171,22 @@ static void misc() {
       ok = ok && std::fabs(sum - Ch[r * 10 + j]) <= 1e-3f + 1e-4f * std::fabs(sum);
     }
   CHECK(ok);
+  // column-blocked layout: same y as the plain merge_path_flat, automatic and explicit block counts
+  for (auto& dense : battery())
+    for (int blocks : {0, 1, 3}) {
+      hcsr_t<float> hf = from_dense<float>(dense);
+      csr_t<int, int, float> a(hf);
+      if (blocks > int(hf.cols)) continue;
+      vector_t<float> xb(hf.cols), y0(hf.rows), y1(hf.rows, -1.f);
+      generate::random::uniform_distribution(xb.begin(), xb.end(), 1, 10, 9u);
+      algorithms::spmv::merge_path_flat(a, xb, y0);
+      algorithms::spmv::column_blocked_t<int, int, float> blocked(a, blocks);
+      blocked.spmv(xb, y1);
+      vector_t<float, H> h0(y0), h1(y1);
+      bool same = true;
+      for (std::size_t i = 0; i < h0.size(); ++i) same = same && std::fabs(h0[i] - h1[i]) <= 1e-3f + 1e-5f * std::fabs(h0[i]);
+      CHECK(same);
+    }
   // tuned SpMM == reference-shaped SpMM (every battery matrix, several widths of B, f32 + f64)
   for (auto& dense : battery())
     for (int n : {1, 4, 10, 32, 70}) {
