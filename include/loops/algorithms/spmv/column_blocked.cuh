@@ -57,7 +57,7 @@ struct column_blocked_t {
                                   static_cast<int>(plan.merge_tiles())};
     kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
         stream, view, static_cast<int>(num_blocks * rows), static_cast<int>(nnzs), offsets.data().get(),
-        indices.data().get(), values.data().get(), x.data().get(), partial.data().get());
+        indices.data().get(), values.data().get(), x.data().get(), partial.data().get(), 3, true);
     kernels::launch_reduce_blocks<type_t>(stream, partial.data().get(), static_cast<int>(rows), num_blocks,
                                           y.data().get());
   }

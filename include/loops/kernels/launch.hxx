@@ -47,21 +47,27 @@ int launch_merge_path_coordinates(hipStream_t stream, const offset_t* offsets, i
 }
 
 /// Fused merge-path SpMV (+ fix-up).  stages: bit 0 = tile kernel, bit 1 = fix-up.
+/// `stacked`: the matrix is a column-blocked CSR -- same code under its own kernel symbol.
 template <int TPB, int IPT, bool PAD, bool NT, typename index_t, typename offset_t, typename T>
 int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
                             const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
-                            int stages = 3) {
+                            int stages = 3, bool stacked = false) {
   const int m = plan.num_merge_tiles;
   if (m == 0) return 0;
   T* carry_val = static_cast<T*>(plan.carry_val);
   if (stages & 1) {
     const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-    if (aligned)
-      hipLaunchKernelGGL((merge_path_spmv_fused<TPB, IPT, PAD, NT, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
-                         stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val);
-    else
-      hipLaunchKernelGGL((merge_path_spmv_fused<TPB, IPT, PAD, NT, false, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
-                         stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val);
+    auto go = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
+                         plan.carry_row, carry_val);
+    };
+    if (stacked) {
+      if (aligned) go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, true, index_t, offset_t, T>);
+      else go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, false, index_t, offset_t, T>);
+    } else {
+      if (aligned) go(merge_path_spmv_fused<TPB, IPT, PAD, NT, true, index_t, offset_t, T>);
+      else go(merge_path_spmv_fused<TPB, IPT, PAD, NT, false, index_t, offset_t, T>);
+    }
   }
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,

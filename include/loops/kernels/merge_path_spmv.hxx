@@ -327,8 +327,8 @@ struct merge_tile_engine {
  * @tparam VEC  `indices` and `values` are 16-byte aligned (checked by the host launcher).
  */
 template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
-__global__ void __launch_bounds__(TPB)
-merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const int nnz,
+__device__ __forceinline__ void
+merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const int nnz,
                       const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                       const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
                       int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
@@ -357,6 +357,26 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
     carry_row[b] = row0 + nrows;  // == c1.x: the row still open when the tile ends
     carry_val[b] = carry;
   }
+}
+
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                      const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                      const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                      int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
+}
+
+/// The same kernel under its own symbol for column-blocked ("stacked") CSRs (column_blocked.hxx), so
+/// that profiles attribute those launches separately from the plain-CSR SpMV.
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                              const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                              const type_t* __restrict__ values, const type_t* __restrict__ x,
+                              type_t* __restrict__ y, int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
 }
 
 /**

@@ -311,9 +311,11 @@ int colblock_auto(int cols) {
 int colblock_spmv(const loops_colblock_plan* p, int stages, const float* x, float* y, hipStream_t stream) {
   if (p->rows == 0) return 0;
   int err = 0;
-  if (stages & 3)
-    err = spmv_merge_path<float>(p->merge, 0, p->K * p->rows, p->nnz, p->soff, p->sidx, p->sval, x, p->ys, stream,
-                                 stages & 3);
+  if (stages & 3) {
+    kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
+    err = kernels::launch_merge_path_fused<256, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
+                                                                p->sval, x, p->ys, stages & 3, /*stacked=*/true);
+  }
   if (!err && (stages & 4)) err = kernels::launch_reduce_blocks<float>(stream, p->ys, p->rows, p->K, y);
   return err;
 }
