@@ -23,5 +23,8 @@ done
 build "$REF/examples/spmm/thread_mapped.cu" "$OUT/loops.spmm.thread_mapped" "-I$REF/examples/spmm" &
 build "$REF/examples/saxpy/saxpy.cu" "$OUT/loops.saxpy" "" &
 build "$REF/examples/range/range.cu" "$OUT/loops.range" "" &
+# this repository's own example drivers for the paths the reference does not have
+build "$ROOT/examples/spmm/merge_path_flat.cu" "$OUT/loops.spmm.merge_path_flat" "" &
+build "$ROOT/examples/spmv/column_blocked.cu" "$OUT/loops.spmv.column_blocked" "" &
 wait
 exit $fail
