@@ -17,6 +17,7 @@
 #pragma once
 
 #include <cstddef>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -67,31 +68,42 @@ int launch_bcsr_thread_mapped(hipStream_t stream, int rows, int num_block_rows, 
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
-template <int TPB, int UNROLL>
+/**
+ * @tparam H blocks of ONE block-row a wavefront multiplies per step: the 64 lanes are 16 MFMA
+ *           batches of 4 lanes; batch q = (slot q / H, h = q % H) works on block (k * H + h) of block-row
+ *           `slot`, so a slot reads H * 64 contiguous bytes per step (H = 1: 64-byte requests from 16
+ *           different rows; H = 4: 256-byte requests from 4 rows; H = 16: 1 KB from one row) and the H
+ *           partial products of a slot are added with log2(H) cross-lane steps after the loop.
+ */
+template <int TPB, int UNROLL, int H>
 __global__ void __launch_bounds__(TPB)
 bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
                   const int* __restrict__ block_cols, const float* __restrict__ values, const float* __restrict__ x,
                   float* __restrict__ y) {
+  static_assert(H == 1 || H == 2 || H == 4 || H == 8 || H == 16, "H: power of two <= 16");
+  constexpr int SLOTS = 16 / H;  // block-rows a wavefront works on at a time
   const int lane = wave::lane();
-  const int slot = lane >> 2;  // which of the wavefront's 16 block-rows
+  const int q = lane >> 2;     // MFMA batch
+  const int slot = q / H;      // which of the wavefront's block-rows
+  const int h = q % H;         // which of the H concurrent blocks of that block-row
   const int i = lane & 3;      // row of the 4 x 4 block this lane feeds
   const long long gwave = (static_cast<long long>(blockIdx.x) * TPB + threadIdx.x) / wave::size;
-  const long long br = gwave * 16 + slot;
+  const long long br = gwave * SLOTS + slot;
   int beg = 0, end = 0;
   if (br < num_block_rows) {
     beg = block_offsets[br];
     end = block_offsets[br + 1];
   }
   const int len = end - beg;
-  int maxlen = len;
+  int steps = (len + H - 1) / H;  // steps this slot needs; the wavefront runs max over slots
 #pragma unroll
   for (int d = 32; d >= 4; d >>= 1) {
-    const int o = __shfl_xor(maxlen, d);
-    maxlen = o > maxlen ? o : maxlen;
+    const int o = __shfl_xor(steps, d);
+    steps = o > steps ? o : steps;
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int safe = len > 0 ? beg : 0;  // any valid block index for masked-off steps
-  // Software pipeline over batches of UNROLL blocks: the 16-byte block rows and block columns of
+  // Software pipeline over batches of UNROLL steps: the 16-byte block rows and block columns of
   // batch n + 1 are requested BEFORE the x gathers and MFMAs of batch n, so a wavefront always has
   // one batch of HBM reads in flight behind the batch it is multiplying.
   f32x4 a_next[UNROLL];
@@ -99,23 +111,41 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
   auto fetch = [&](int k0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const bool live = k0 + u < len;
-      const int b = live ? beg + k0 + u : safe;
-      a_next[u] = *reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4);
-      bc_next[u] = block_cols[b];
+      const int k = (k0 + u) * H + h;
+      const bool live = k < len;
+      const int b = live ? beg + k : safe;
+      // The block stream is read once: with H >= 2 a slot consumes whole 128-byte lines per step, so
+      // it is loaded non-temporally and stops evicting x from L1 / L2 (C4: 73.1 -> 67.7 us).  With
+      // H = 1 the second half of a line is used by the NEXT step and must stay cached.
+      if constexpr (H >= 2) {
+        a_next[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4));
+        bc_next[u] = __builtin_nontemporal_load(block_cols + b);
+      } else {
+        a_next[u] = *reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4);
+        bc_next[u] = block_cols[b];
+      }
       if (!live) a_next[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  if (maxlen > 0) fetch(0);
-  for (int k0 = 0; k0 < maxlen; k0 += UNROLL) {
+  if (steps > 0) fetch(0);
+  for (int k0 = 0; k0 < steps; k0 += UNROLL) {
     f32x4 a[UNROLL];
     f32x4 xv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       a[u] = a_next[u];
+#if defined(LOOPS_PROBE_NO_GATHER)  // measurement aid (never defined in a product build): x free
+      const float f = static_cast<float>(bc_next[u] & 3);
+      xv[u] = f32x4{f, f, f, f};
+#elif defined(LOOPS_PROBE_SMALL_GATHER)  // measurement aid: the gather confined to 4 KB of x
+      xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u] & 255) * 4);
+#elif defined(LOOPS_PROBE_NT_GATHER)  // measurement aid: non-temporal x gather
+      xv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4));
+#else
       xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4);
+#endif
     }
-    if (k0 + UNROLL < maxlen) fetch(k0 + UNROLL);
+    if (k0 + UNROLL < steps) fetch(k0 + UNROLL);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, xv[u].x, acc, 0, 0, 0);
@@ -124,9 +154,16 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
       acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].w, xv[u].w, acc, 0, 0, 0);
     }
   }
-  // D layout of the 4x4x1 16-block form: lane (slot, col) register v = D[v][col]; every column
-  // holds the same y (B was broadcast), so column 0's lane stores the block-row's 4 outputs.
-  if (i == 0 && br < num_block_rows) {
+  // D layout of the 4x4x1 16-block form: lane (batch, col) register v = D[v][col]; every column
+  // holds the same 4 partial outputs (B was broadcast).  Add the H partials of a slot.
+#pragma unroll
+  for (int d = 4; d < 4 * H; d <<= 1) {
+    acc.x += __shfl_xor(acc.x, d);
+    acc.y += __shfl_xor(acc.y, d);
+    acc.z += __shfl_xor(acc.z, d);
+    acc.w += __shfl_xor(acc.w, d);
+  }
+  if (i == 0 && h == 0 && br < num_block_rows) {
     const long long r0 = br * 4;
     if (r0 + 3 < rows) {
       *reinterpret_cast<f32x4*>(y + r0) = acc;
@@ -138,18 +175,40 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
   }
 }
 
+/// `unroll`: steps in flight (1, 2, 4, 8); `h`: blocks of one block-row per step.  0 = automatic from the
+/// mean blocks per block-row m: h = 1 (m < 1.5), 2 (m < 3), else 4; unroll = the power of two covering
+/// m / h, at most 8 (C4, m = 16: h = 4, unroll = 4 -- measured best of the 20 compiled shapes).
 inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows, int num_blocks,
                                const int* block_offsets, const int* block_cols, const float* values, const float* x,
-                               float* y, int unroll = 8) {
-  (void)num_blocks;
-  constexpr int TPB = 256;                      // 4 wavefronts = 64 block-rows per workgroup
-  constexpr int rows_per_block = TPB / 64 * 16;
-  const dim3 grid(math::ceil_div(num_block_rows, rows_per_block)), block(TPB);
+                               float* y, int unroll = 0, int h = 0) {
+  constexpr int TPB = 256;  // 4 wavefronts
+  if (num_block_rows == 0) return 0;
+  const double mean = static_cast<double>(num_blocks) / num_block_rows;
+  if (h == 0) h = mean < 1.5 ? 1 : mean < 3 ? 2 : 4;
+  if (unroll == 0) {
+    unroll = 1;
+    while (unroll < 8 && unroll * h < mean) unroll *= 2;
+  }
+  auto go = [&](auto u_tag, auto h_tag) {
+    constexpr int U = decltype(u_tag)::value, HH = decltype(h_tag)::value;
+    const int rows_per_group = TPB / 64 * (16 / HH);
+    hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, U, HH>), dim3(math::ceil_div(num_block_rows, rows_per_group)), dim3(TPB), 0,
+                       stream, rows, num_block_rows, block_offsets, block_cols, values, x, y);
+  };
+  auto with_h = [&](auto u_tag) {
+    switch (h) {
+      case 1: go(u_tag, std::integral_constant<int, 1>{}); break;
+      case 2: go(u_tag, std::integral_constant<int, 2>{}); break;
+      case 4: go(u_tag, std::integral_constant<int, 4>{}); break;
+      case 8: go(u_tag, std::integral_constant<int, 8>{}); break;
+      default: go(u_tag, std::integral_constant<int, 16>{}); break;
+    }
+  };
   switch (unroll) {
-    case 1: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 1>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
-    case 2: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 2>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
-    default: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 8>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
-    case 4: hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, 4>), grid, block, 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y); break;
+    case 1: with_h(std::integral_constant<int, 1>{}); break;
+    case 2: with_h(std::integral_constant<int, 2>{}); break;
+    case 4: with_h(std::integral_constant<int, 4>{}); break;
+    default: with_h(std::integral_constant<int, 8>{}); break;
   }
   return static_cast<int>(hipGetLastError());
 }

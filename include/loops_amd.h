@@ -133,7 +133,9 @@ int loops_work_oriented_grid(int* out_blocks);
  * Replaces algorithms::spmv::bcsr_thread_mapped<R, C> (algorithms/spmv/bcsr_thread_mapped.cuh:91-123).
  * x must be padded to num_block_cols * C; rows of y >= `rows` are not written.
  * mode 0: register accumulation (any of 2x2, 3x3, 4x4); mode 1: MFMA 4x4x1 block inner product
- * (4x4 only). */
+ * (4x4 only), kernel shape picked from the mean blocks per block-row.  Tuning aids: mode 1u = one block
+ * of a block-row per step with u in {1,2,4,8} steps in flight; mode 100 + 10 h + u = h in {1,2,4,8,16}
+ * consecutive blocks of a block-row per step (h * 64 contiguous bytes per request). */
 int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
                         const int* block_offsets, const int* block_cols, const float* block_values,
                         const float* x_padded, float* y, void* stream);

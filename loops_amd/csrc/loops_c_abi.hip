@@ -475,10 +475,17 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
   if (num_blocks > 0 && (!block_cols || !block_values || !x_padded)) return LOOPS_E_BADARG;
   if (num_block_rows == 0) return 0;
   hipStream_t s = as_stream(stream);
-  if (mode == 1 || (mode > 10 && mode < 20)) {  // 1x: MFMA path with x steps in flight per lane (tuning aid)
+  if (mode == 1 || (mode > 10 && mode < 20) || mode >= 100) {
+    // MFMA path.  1: automatic shape; tuning aids: 1u = one block per block-row per step, u steps in
+    // flight; 100 + 10 h + u = h blocks of a block-row per step (1, 2, 4, 8, 16), u steps in flight
     if (R != 4 || C != 4) return LOOPS_E_CONFIG;
+    int h = 0, u = 0;
+    if (mode > 10 && mode < 20) { h = 1; u = mode - 10; }
+    if (mode >= 100) { h = (mode - 100) / 10; u = (mode - 100) % 10; }
+    if (mode != 1 && ((h != 1 && h != 2 && h != 4 && h != 8 && h != 16) || (u != 1 && u != 2 && u != 4 && u != 8)))
+      return LOOPS_E_BADARG;
     return kernels::launch_bcsr4x4_mfma(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values,
-                                        x_padded, y, mode == 1 ? 8 : mode - 10);
+                                        x_padded, y, u, h);
   }
   if (mode != 0) return LOOPS_E_BADARG;
   if (R == 2 && C == 2) return kernels::launch_bcsr_thread_mapped<2, 2>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);

@@ -26,10 +26,14 @@ nb = bcols.size
 abytes = nb * (16 * 4 + 4) + (nbr + 1) * 4 + nbr * 4 * 4 + nbr * 4 * 4
 flops = 2 * 16 * nb
 out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks ({nb} blocks), fp32", "algorithmic_bytes": abytes, "flops": flops, "rows": {}}
-for name, mfma in (("bcsr_thread_mapped (registers)", 0), ("bcsr_thread_mapped (MFMA 4x4x1)", 1), ("MFMA unroll 1", 11), ("MFMA unroll 2", 12), ("MFMA unroll 4", 14), ("MFMA unroll 8", 18)):
+shapes = [(f"MFMA h={h} unroll={u}", 100 + 10 * h + u) for h in (1, 2, 4, 8, 16) for u in (1, 2, 4, 8)]
+if os.environ.get("BCSR_SHAPES"):  # e.g. BCSR_SHAPES=128,144: only these tuning shapes (profiling runs)
+    keep = {int(t) for t in os.environ["BCSR_SHAPES"].split(",")}
+    shapes = [s for s in shapes if s[1] in keep]
+for name, mfma in [("bcsr_thread_mapped (registers)", 0), ("bcsr_thread_mapped (MFMA 4x4x1, automatic shape)", 1)] + shapes:
     avg, med = ev(lambda: S.bcsr_thread_mapped(b, xd, y, mfma=mfma))
     ok = bool(np.array_equal(y.cpu().numpy(), want))
     out["rows"][name] = {"avg_ms": round(avg, 5), "median_ms": round(med, 5), "GFLOPs": round(flops / avg / 1e6, 1),
                          "GBps": round(abytes / avg / 1e6, 1), "frac_of_8TBps": round(abytes / avg / 1e6 / 8000, 4), "bit_exact": ok}
-    print(f"{name:36s} {avg*1e3:8.1f} us  {flops/avg/1e6:8.1f} GFLOP/s  {abytes/avg/1e6:8.1f} GB/s  frac {abytes/avg/1e6/8000:.3f} exact={ok}", file=sys.stderr)
+    print(f"{name:50s} {avg*1e3:8.1f} us  {flops/avg/1e6:8.1f} GFLOP/s  {abytes/avg/1e6:8.1f} GB/s  frac {abytes/avg/1e6/8000:.3f} exact={ok}", file=sys.stderr)
 print(json.dumps(out))

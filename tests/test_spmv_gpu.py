@@ -142,7 +142,8 @@ def test_bcsr_thread_mapped_and_mfma():
             xp[:c] = g[name + ".x_int"]
             want = O.bcsr_spmv_f32(R, R, r, g[f"{name}.bcsr{R}.offsets"], g[f"{name}.bcsr{R}.cols"],
                                    g[f"{name}.bcsr{R}.values"], xp)
-            modes = (False, True) if R == 4 else (False,)
+            shapes = tuple(100 + 10 * h + u for h in (1, 2, 4, 8, 16) for u in (1, 2, 4, 8))
+            modes = (False, True) + shapes if R == 4 else (False,)   # every compiled MFMA kernel shape
             for mfma in modes:
                 y = S.bcsr_thread_mapped(b, torch.from_numpy(xp).cuda(), mfma=mfma).cpu().numpy()
                 # same accumulation order as the oracle, but the GPU contracts a*b+c into FMAs
@@ -155,7 +156,19 @@ def test_bcsr_thread_mapped_and_mfma():
     want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, x)
     b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(),
                torch.from_numpy(bvals).cuda())
-    for mfma in (False, True):
+    for mfma in (False, True, 118, 124, 144, 182, 261, 262, 268):
+        y = S.bcsr_thread_mapped(b, torch.from_numpy(x).cuda(), mfma=mfma).cpu().numpy()
+        assert np.array_equal(y, want), mfma
+    # ragged block-rows (0 .. 40 blocks, not multiples of any h) through every shape
+    rng = np.random.default_rng(4)
+    lens = rng.integers(0, 41, size=1000)
+    boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    bcols = np.concatenate([np.sort(rng.choice(1000, size=n, replace=False)) for n in lens]).astype(np.int32)
+    bvals = (rng.integers(1, 9, size=bcols.size * 16) / 8.0).astype(np.float32)
+    x = G.uniform_distribution_int(4000)
+    want = O.bcsr_spmv_f32(4, 4, 3998, boff, bcols, bvals, x)   # rows not a multiple of 4: guarded tail
+    b = S.BCSR(4, 4, 3998, 4000, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    for mfma in (0, 1) + tuple(100 + 10 * h + u for h in (1, 2, 4, 8, 16) for u in (1, 8)):
         y = S.bcsr_thread_mapped(b, torch.from_numpy(x).cuda(), mfma=mfma).cpu().numpy()
         assert np.array_equal(y, want), mfma
 
