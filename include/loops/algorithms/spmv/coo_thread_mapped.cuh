@@ -15,6 +15,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/memory.hxx>
+#include <loops/kernels/coo_spmv.hxx>
 
 namespace loops {
 namespace algorithms {
@@ -42,6 +43,21 @@ util::timer_t coo_thread_mapped(coo_t<index_t, type_t>& coo, vector_t<type_t>& x
                             dim3(static_cast<unsigned>(math::ceil_div(coo.nnzs, block_size))), dim3(block_size), config,
                             coo.row_indices.data().get(), coo.col_indices.data().get(), coo.values.data().get(),
                             x.data().get(), y.data().get());
+  (void)xpu::stream_synchronize(stream);
+  timer.stop();
+  return timer;
+}
+
+/// Tuned COO SpMV: a lane owns 8 consecutive triplets (16-byte loads) and issues one atomicAdd per run
+/// of equal row indices (loops/kernels/coo_spmv.hxx).  Same contract as coo_thread_mapped: y zero-filled
+/// by the caller, any triplet order; row-sorted COO is the fast case.
+template <typename index_t, typename type_t>
+util::timer_t coo_run_mapped(coo_t<index_t, type_t>& coo, vector_t<type_t>& x, vector_t<type_t>& y,
+                             xpu::stream_t stream = 0) {
+  util::timer_t timer(stream);
+  timer.start();
+  kernels::launch_coo_runs(stream, coo.nnzs, coo.row_indices.data().get(), coo.col_indices.data().get(),
+                           coo.values.data().get(), x.data().get(), y.data().get());
   (void)xpu::stream_synchronize(stream);
   timer.stop();
   return timer;

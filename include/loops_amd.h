@@ -185,6 +185,14 @@ int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, f
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);
 
+/* ---- COO SpMV ------------------------------------------------------------------------------------
+ * Replaces algorithms::spmv::coo_thread_mapped (algorithms/spmv/coo_thread_mapped.cuh:37-100).
+ * mode 0: the reference shape, one atomicAdd per nonzero, y zero-filled by the CALLER;
+ * mode 1: tuned -- 8 consecutive triplets per lane (16-byte loads), one atomicAdd per run of equal row
+ * indices, y zero-filled here; any triplet order is correct, row-sorted order is the fast case. */
+int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
+                       const float* values, const float* x, float* y, void* stream);
+
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream

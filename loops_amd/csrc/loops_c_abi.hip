@@ -20,6 +20,7 @@
 #include <loops/util/math.hxx>
 #include <loops/kernels/launch.hxx>
 #include <loops/kernels/column_blocked.hxx>
+#include <loops/kernels/coo_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 #include <loops/kernels/probes.hxx>
 
@@ -623,6 +624,20 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
                                   void* stream) {
   if (!plan || !y || stage < 0 || stage > 2) return LOOPS_E_BADARG;
   return colblock_spmv(plan, 1 << stage, x, y, as_stream(stream));
+}
+
+int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
+                       const float* values, const float* x, float* y, void* stream) {
+  if (rows < 0 || cols < 0 || nnz < 0 || !y || (nnz > 0 && (!row_indices || !col_indices || !values || !x)))
+    return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  if (mode == 0)  // reference shape: the caller zero-fills y (coo_thread_mapped.cuh:95-97 convention)
+    return kernels::launch_coo_atom(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
+  if (mode != 1) return LOOPS_E_BADARG;
+  hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return kernels::launch_coo_runs(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
 }
 
 }  // extern "C"

@@ -365,3 +365,15 @@ def row_gather(table, idx, row_floats: int, blocks: int, out):
     """Row-gather probe: see loops_row_gather_f32."""
     L.check(L.lib().loops_row_gather_f32(_ptr(table), _ptr(idx), idx.numel(), row_floats, blocks, _ptr(out), _stream()),
             "loops_row_gather_f32")
+
+
+def coo_spmv(rows: int, cols: int, row_indices, col_indices, values, x, y=None, tuned: bool = True):
+    """COO SpMV (loops_spmv_coo_f32): ``tuned`` = one atomic per run of equal row indices (y zero-filled
+    inside); otherwise the reference shape, one atomic per nonzero into a y zero-filled here."""
+    if y is None:
+        y = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if not tuned:
+        y.zero_()
+    L.check(L.lib().loops_spmv_coo_f32(int(tuned), rows, cols, values.numel(), _ptr(row_indices), _ptr(col_indices),
+                                       _ptr(values), _ptr(x), _ptr(y), _stream()), "loops_spmv_coo_f32")
+    return y

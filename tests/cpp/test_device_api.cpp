@@ -106,6 +106,7 @@ static void run_battery() {
     { auto y = fresh(); algorithms::spmv::flat_partitioned(csr, x, y); check_y("flat_partitioned<8>", m, y, ref); }
     { auto y = fresh(); algorithms::spmv::flat_partitioned<4>(csr, x, y); check_y("flat_partitioned<4>", m, y, ref); }
     if (h.rows && h.nnzs) {
+      { coo_t<int, T> coo(csr); auto y = fresh(); algorithms::spmv::coo_run_mapped(coo, x, y); check_y("coo_run_mapped", m, y, ref); }
       { coo_t<int, T> coo(csr); auto y = fresh(); algorithms::spmv::coo_thread_mapped(coo, x, y); check_y("coo_thread_mapped", m, y, ref);
         csr_t<int, int, T> again(coo);  // device-side COO -> CSR (radix sort + lower_bound)
         vector_t<int, H> o2(again.offsets); bool same = true; for (std::size_t i = 0; i <= h.rows; ++i) same = same && o2[i] == h.offsets[i]; CHECK(same); }
