@@ -15,6 +15,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/memory.hxx>
+#include <loops/kernels/ell_spmv.hxx>
 
 namespace loops {
 namespace algorithms {
@@ -45,6 +46,15 @@ void ell_thread_mapped(ell_t<index_t, type_t>& ell, vector_t<type_t>& x, vector_
     launch::non_cooperative(stream, __ell_thread_mapped<setup_t, index_t, type_t>,
                             dim3(static_cast<unsigned>(math::ceil_div(ell.rows, block_size))), dim3(block_size), config,
                             ell.indices.data().get(), ell.values.data().get(), x.data().get(), y.data().get());
+  (void)xpu::stream_synchronize(stream);
+}
+
+/// Tuned ELL SpMV: G lanes per row read it as contiguous 16-byte pieces and reduce across lanes
+/// (loops/kernels/ell_spmv.hxx); same contract as ell_thread_mapped (y overwritten).
+template <typename index_t, typename type_t>
+void ell_row_mapped(ell_t<index_t, type_t>& ell, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
+  kernels::launch_ell_row_split(stream, ell.rows, ell.pitch, ell.indices.data().get(), ell.values.data().get(),
+                                x.data().get(), y.data().get());
   (void)xpu::stream_synchronize(stream);
 }
 

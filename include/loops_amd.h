@@ -193,6 +193,14 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
 int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
                        const float* values, const float* x, float* y, void* stream);
 
+/* ---- ELL SpMV ------------------------------------------------------------------------------------
+ * Replaces algorithms::spmv::ell_thread_mapped (algorithms/spmv/ell_thread_mapped.cuh:36-85).  ELL as the
+ * reference stores it: ROW-major rows x pitch arrays, padding = negative column index
+ * (container/ell.hxx:31-55).  mode 0: lane per row (reference shape); mode 1: tuned -- a row is read by
+ * G lanes with 16-byte loads (contiguous runs) and reduced across lanes.  y is overwritten. */
+int loops_spmv_ell_f32(int mode, int rows, int cols, int pitch, const int* indices, const float* values,
+                       const float* x, float* y, void* stream);
+
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream

@@ -21,6 +21,7 @@
 #include <loops/kernels/launch.hxx>
 #include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/coo_spmv.hxx>
+#include <loops/kernels/ell_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 #include <loops/kernels/probes.hxx>
 
@@ -638,6 +639,16 @@ int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_ind
   hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), s);
   if (e != hipSuccess) return static_cast<int>(e);
   return kernels::launch_coo_runs(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
+}
+
+int loops_spmv_ell_f32(int mode, int rows, int cols, int pitch, const int* indices, const float* values,
+                       const float* x, float* y, void* stream) {
+  if (rows < 0 || cols < 0 || pitch < 0 || !y || (rows > 0 && pitch > 0 && (!indices || !values || !x))) return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  if (mode == 0) return kernels::launch_ell_thread(s, static_cast<size_t>(rows), static_cast<size_t>(pitch), indices, values, x, y);
+  if (mode == 1) return kernels::launch_ell_row_split(s, static_cast<size_t>(rows), static_cast<size_t>(pitch), indices, values, x, y);
+  return LOOPS_E_BADARG;
 }
 
 }  // extern "C"

@@ -377,3 +377,12 @@ def coo_spmv(rows: int, cols: int, row_indices, col_indices, values, x, y=None, 
     L.check(L.lib().loops_spmv_coo_f32(int(tuned), rows, cols, values.numel(), _ptr(row_indices), _ptr(col_indices),
                                        _ptr(values), _ptr(x), _ptr(y), _stream()), "loops_spmv_coo_f32")
     return y
+
+
+def ell_spmv(rows: int, cols: int, pitch: int, indices, values, x, y=None, tuned: bool = True):
+    """ELL SpMV (loops_spmv_ell_f32) over the reference's row-major rows x pitch arrays (padding: column -1)."""
+    if y is None:
+        y = torch.empty(rows, dtype=torch.float32, device=x.device)
+    L.check(L.lib().loops_spmv_ell_f32(int(tuned), rows, cols, pitch, _ptr(indices), _ptr(values), _ptr(x), _ptr(y), _stream()),
+            "loops_spmv_ell_f32")
+    return y
