@@ -170,6 +170,9 @@ typedef struct loops_colblock_plan loops_colblock_plan_t;
 int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
                                const float* values, int num_blocks, const int* block_bounds, void* stream,
                                loops_colblock_plan_t** out);
+int loops_colblock_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                                   const double* values, int num_blocks, const int* block_bounds, void* stream,
+                                   loops_colblock_plan_t** out);
 void loops_colblock_plan_destroy(loops_colblock_plan_t* plan);
 /* num_blocks and (if non-NULL) the num_blocks + 1 HOST column boundaries */
 int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks, int* block_bounds);
@@ -177,10 +180,13 @@ int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks,
  * (stacked position -> original position) into HOST buffers (any may be NULL); synchronous; for
  * inspection and tests */
 int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_offsets, int* stacked_indices,
-                               float* stacked_values, int* perm);
+                               void* stacked_values /* float or double, as created */, int* perm);
 /* new numerical values, same structure */
 int loops_colblock_plan_refresh_values(loops_colblock_plan_t* plan, const float* values, void* stream);
+int loops_colblock_plan_refresh_values_f64(loops_colblock_plan_t* plan, const double* values, void* stream);
+/* the value type must match the plan's (LOOPS_E_BADARG otherwise) */
 int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream);
+int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, double* y, void* stream);
 /* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);

@@ -36,7 +36,8 @@ SYMBOLS = [
     "loops_work_oriented_grid", "loops_spmv_bcsr_f32",
     "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_row_gather_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32",
     "loops_colblock_plan_create", "loops_colblock_plan_destroy", "loops_colblock_plan_info", "loops_colblock_plan_arrays",
-    "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
+    "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32",
+    "loops_colblock_plan_create_f64", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
 ]
 
 
@@ -108,6 +109,9 @@ def lib() -> C.CDLL:
         L.loops_spmm_merge_path_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_row_gather_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, vp, vp]
         L.loops_colblock_plan_create.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
+        L.loops_colblock_plan_create_f64.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
+        L.loops_colblock_plan_refresh_values_f64.argtypes = [vp, vp, vp]
+        L.loops_spmv_colblock_f64.argtypes = [vp, vp, vp, vp]
         L.loops_colblock_plan_destroy.argtypes = [vp]
         L.loops_colblock_plan_destroy.restype = None
         L.loops_colblock_plan_info.argtypes = [vp, C.POINTER(ci), vp]

@@ -287,8 +287,9 @@ struct loops_colblock_plan {
   int* bounds_dev;            // K + 1
   int bounds_host[65];
   int *soff, *sidx, *perm;    // stacked CSR structure + permutation
-  float* sval;
-  float* ys;                  // K * rows partial results
+  int vbytes;                 // 4 (float) or 8 (double) values
+  void* sval;                 // nnz stacked values
+  void* ys;                   // K * rows partial results
   loops_merge_plan* merge;    // merge-path plan of the stacked CSR
 };
 
@@ -303,23 +304,81 @@ void colblock_free(loops_colblock_plan* p) {
 }
 
 // K for a column count: x[block] of about 2 MB (half the per-XCD L2), at most 8 blocks (one per XCD)
-int colblock_auto(int cols) {
-  const long long bytes = static_cast<long long>(cols) * 4;
+int colblock_auto(int cols, int vbytes) {
+  const long long bytes = static_cast<long long>(cols) * vbytes;
   int k = 1;
   while (k < 8 && bytes / k > (2ll << 20)) k *= 2;
   return k;
 }
 
-int colblock_spmv(const loops_colblock_plan* p, int stages, const float* x, float* y, hipStream_t stream) {
+template <typename T>
+int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hipStream_t stream) {
+  if (p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
   if (p->rows == 0) return 0;
   int err = 0;
+  T* ys = static_cast<T*>(p->ys);
   if (stages & 3) {
     kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
     err = kernels::launch_merge_path_fused<256, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
-                                                                p->sval, x, p->ys, stages & 3, /*stacked=*/true);
+                                                                static_cast<const T*>(p->sval), x, ys, stages & 3,
+                                                                /*stacked=*/true);
   }
-  if (!err && (stages & 4)) err = kernels::launch_reduce_blocks<float>(stream, p->ys, p->rows, p->K, y);
+  if (!err && (stages & 4)) err = kernels::launch_reduce_blocks<T>(stream, ys, p->rows, p->K, y);
   return err;
+}
+
+template <typename T>
+int colblock_create(int rows, int cols, int nnz, const int* offsets, const int* indices, const T* values,
+                    int num_blocks, const int* block_bounds, hipStream_t st, loops_colblock_plan** out) {
+  if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
+  int K = num_blocks > 0 ? num_blocks : colblock_auto(cols, static_cast<int>(sizeof(T)));
+  if (K > 64) return LOOPS_E_CONFIG;
+  if (K > cols && cols > 0) K = cols;
+  if (K < 1) K = 1;
+  if (static_cast<long long>(K) * rows + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  auto* p = new (std::nothrow) loops_colblock_plan();
+  if (!p) return static_cast<int>(hipErrorOutOfMemory);
+  p->rows = rows; p->cols = cols; p->nnz = nnz; p->K = K; p->vbytes = static_cast<int>(sizeof(T));
+  for (int k = 0; k <= K; ++k) {
+    p->bounds_host[k] = block_bounds ? block_bounds[k]
+                                     : static_cast<int>(static_cast<long long>(cols) * k / K);
+    if (k > 0 && p->bounds_host[k] < p->bounds_host[k - 1]) { delete p; return LOOPS_E_BADARG; }
+  }
+  if (p->bounds_host[0] != 0 || p->bounds_host[K] != cols) { delete p; return LOOPS_E_BADARG; }
+  const size_t srows = static_cast<size_t>(K) * rows, n = static_cast<size_t>(nnz);
+  void* temp = nullptr;
+  const size_t temp_bytes = kernels::column_blocked_temp_bytes(nnz, static_cast<int>(srows));
+  hipError_t e = hipSuccess;
+  auto alloc = [&](auto** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 4); };
+  alloc(&p->bounds_dev, sizeof(int) * (K + 1));
+  alloc(&p->soff, sizeof(int) * (srows + 1));
+  alloc(&p->sidx, sizeof(int) * n);
+  alloc(&p->perm, sizeof(int) * n);
+  alloc(&p->sval, sizeof(T) * n);
+  alloc(&p->ys, sizeof(T) * srows);
+  alloc(&temp, temp_bytes);
+  int err = static_cast<int>(e);
+  if (!err) err = static_cast<int>(hipMemcpyAsync(p->bounds_dev, p->bounds_host, sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
+  if (!err) {
+    kernels::column_blocked_view<int, int, T> view{rows, cols, nnz, K, p->soff, p->sidx, static_cast<T*>(p->sval), p->perm};
+    err = kernels::build_column_blocked(st, offsets, indices, values, p->bounds_dev, view, temp, temp_bytes);
+  }
+  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, LOOPS_TILE_DEFAULT, &p->merge);
+  if (!err) err = plan_compute(p->merge, p->soff, st);
+  if (!err) err = static_cast<int>(hipStreamSynchronize(st));  // the temporaries go away below
+  (void)hipFree(temp);
+  if (err) { colblock_free(p); return err; }
+  *out = p;
+  return 0;
+}
+
+template <typename T>
+int colblock_refresh(loops_colblock_plan* plan, const T* values, hipStream_t stream) {
+  if (!plan || (plan->nnz > 0 && !values) || plan->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
+  if (plan->nnz == 0) return 0;
+  hipLaunchKernelGGL((kernels::colblock::gather_values<T>), dim3(math::ceil_div(plan->nnz, 256)), dim3(256), 0, stream,
+                     plan->perm, values, plan->nnz, static_cast<T*>(plan->sval));
+  return static_cast<int>(hipGetLastError());
 }
 
 }  // namespace
@@ -541,47 +600,12 @@ int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols
 int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
                                const float* values, int num_blocks, const int* block_bounds, void* stream,
                                loops_colblock_plan_t** out) {
-  if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
-  int K = num_blocks > 0 ? num_blocks : colblock_auto(cols);
-  if (K > 64) return LOOPS_E_CONFIG;
-  if (K > cols && cols > 0) K = cols;
-  if (K < 1) K = 1;
-  if (static_cast<long long>(K) * rows + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
-  auto* p = new (std::nothrow) loops_colblock_plan();
-  if (!p) return static_cast<int>(hipErrorOutOfMemory);
-  p->rows = rows; p->cols = cols; p->nnz = nnz; p->K = K;
-  for (int k = 0; k <= K; ++k) {
-    p->bounds_host[k] = block_bounds ? block_bounds[k]
-                                     : static_cast<int>(static_cast<long long>(cols) * k / K);
-    if (k > 0 && p->bounds_host[k] < p->bounds_host[k - 1]) { delete p; return LOOPS_E_BADARG; }
-  }
-  if (p->bounds_host[0] != 0 || p->bounds_host[K] != cols) { delete p; return LOOPS_E_BADARG; }
-  const size_t srows = static_cast<size_t>(K) * rows, n = static_cast<size_t>(nnz);
-  hipStream_t st = as_stream(stream);
-  void* temp = nullptr;
-  const size_t temp_bytes = kernels::column_blocked_temp_bytes(nnz, static_cast<int>(srows));
-  hipError_t e = hipSuccess;
-  auto alloc = [&](auto** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 4); };
-  alloc(&p->bounds_dev, sizeof(int) * (K + 1));
-  alloc(&p->soff, sizeof(int) * (srows + 1));
-  alloc(&p->sidx, sizeof(int) * n);
-  alloc(&p->perm, sizeof(int) * n);
-  alloc(&p->sval, sizeof(float) * n);
-  alloc(&p->ys, sizeof(float) * srows);
-  alloc(&temp, temp_bytes);
-  int err = static_cast<int>(e);
-  if (!err) err = static_cast<int>(hipMemcpyAsync(p->bounds_dev, p->bounds_host, sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
-  if (!err) {
-    kernels::column_blocked_view<int, int, float> view{rows, cols, nnz, K, p->soff, p->sidx, p->sval, p->perm};
-    err = kernels::build_column_blocked(st, offsets, indices, values, p->bounds_dev, view, temp, temp_bytes);
-  }
-  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, LOOPS_TILE_DEFAULT, &p->merge);
-  if (!err) err = plan_compute(p->merge, p->soff, st);
-  if (!err) err = static_cast<int>(hipStreamSynchronize(st));  // the temporaries go away below
-  (void)hipFree(temp);
-  if (err) { colblock_free(p); return err; }
-  *out = p;
-  return 0;
+  return colblock_create<float>(rows, cols, nnz, offsets, indices, values, num_blocks, block_bounds, as_stream(stream), out);
+}
+int loops_colblock_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                                   const double* values, int num_blocks, const int* block_bounds, void* stream,
+                                   loops_colblock_plan_t** out) {
+  return colblock_create<double>(rows, cols, nnz, offsets, indices, values, num_blocks, block_bounds, as_stream(stream), out);
 }
 
 void loops_colblock_plan_destroy(loops_colblock_plan_t* plan) { colblock_free(plan); }
@@ -594,7 +618,7 @@ int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks,
 }
 
 int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_offsets, int* stacked_indices,
-                               float* stacked_values, int* perm) {
+                               void* stacked_values, int* perm) {
   if (!plan) return LOOPS_E_BADARG;
   const size_t srows = static_cast<size_t>(plan->K) * plan->rows, n = static_cast<size_t>(plan->nnz);
   hipError_t e = hipDeviceSynchronize();
@@ -603,28 +627,31 @@ int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_o
   };
   copy(stacked_offsets, plan->soff, sizeof(int) * (srows + 1));
   copy(stacked_indices, plan->sidx, sizeof(int) * n);
-  copy(stacked_values, plan->sval, sizeof(float) * n);
+  copy(stacked_values, plan->sval, static_cast<size_t>(plan->vbytes) * n);
   copy(perm, plan->perm, sizeof(int) * n);
   return static_cast<int>(e);
 }
 
 int loops_colblock_plan_refresh_values(loops_colblock_plan_t* plan, const float* values, void* stream) {
-  if (!plan || (plan->nnz > 0 && !values)) return LOOPS_E_BADARG;
-  if (plan->nnz == 0) return 0;
-  hipLaunchKernelGGL((kernels::colblock::gather_values<float>), dim3(math::ceil_div(plan->nnz, 256)), dim3(256), 0,
-                     as_stream(stream), plan->perm, values, plan->nnz, plan->sval);
-  return static_cast<int>(hipGetLastError());
+  return colblock_refresh<float>(plan, values, as_stream(stream));
+}
+int loops_colblock_plan_refresh_values_f64(loops_colblock_plan_t* plan, const double* values, void* stream) {
+  return colblock_refresh<double>(plan, values, as_stream(stream));
 }
 
 int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream) {
   if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
-  return colblock_spmv(plan, 7, x, y, as_stream(stream));
+  return colblock_spmv<float>(plan, 7, x, y, as_stream(stream));
+}
+int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, double* y, void* stream) {
+  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  return colblock_spmv<double>(plan, 7, x, y, as_stream(stream));
 }
 
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream) {
   if (!plan || !y || stage < 0 || stage > 2) return LOOPS_E_BADARG;
-  return colblock_spmv(plan, 1 << stage, x, y, as_stream(stream));
+  return colblock_spmv<float>(plan, 1 << stage, x, y, as_stream(stream));
 }
 
 int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,

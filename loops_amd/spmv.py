@@ -177,14 +177,17 @@ class ColumnBlockedPlan:
     ``block_bounds`` = num_blocks + 1 ascending column boundaries (multi-GPU: the owners' row ranges)."""
 
     def __init__(self, csr: CSR, num_blocks: int = 0, block_bounds=None):
-        assert csr.values.dtype == torch.float32
+        assert csr.values.dtype in (torch.float32, torch.float64)
+        self.dtype = csr.values.dtype
+        self._sfx = "" if self.dtype == torch.float32 else "_f64"
         self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
         self._h = C.c_void_p()
         bounds = None
         if block_bounds is not None:
             bounds = np.ascontiguousarray(block_bounds, np.int32)
             num_blocks = bounds.size - 1
-        L.check(L.lib().loops_colblock_plan_create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+        create = getattr(L.lib(), "loops_colblock_plan_create" + self._sfx)
+        L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
                                                    _ptr(csr.values), int(num_blocks),
                                                    None if bounds is None else bounds.ctypes.data_as(C.c_void_p),
                                                    _stream(), C.byref(self._h)), "loops_colblock_plan_create")
@@ -203,20 +206,24 @@ class ColumnBlockedPlan:
         """(stacked offsets, stacked indices, stacked values, perm) copied to the host."""
         srows = self.num_blocks * self.rows
         off, idx = np.zeros(srows + 1, np.int32), np.zeros(self.nnz, np.int32)
-        val, perm = np.zeros(self.nnz, np.float32), np.zeros(self.nnz, np.int32)
+        val = np.zeros(self.nnz, np.float32 if self.dtype == torch.float32 else np.float64)
+        perm = np.zeros(self.nnz, np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         L.check(L.lib().loops_colblock_plan_arrays(self._h, p(off), p(idx), p(val), p(perm)), "loops_colblock_plan_arrays")
         return off, idx, val, perm
 
     def refresh_values(self, values: torch.Tensor):
-        assert values.dtype == torch.float32 and values.numel() == self.nnz
-        L.check(L.lib().loops_colblock_plan_refresh_values(self._h, _ptr(values), _stream()), "loops_colblock_plan_refresh_values")
+        assert values.dtype == self.dtype and values.numel() == self.nnz
+        fn = getattr(L.lib(), "loops_colblock_plan_refresh_values" + self._sfx)
+        L.check(fn(self._h, _ptr(values), _stream()), "loops_colblock_plan_refresh_values")
 
     def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
         if y is None:
-            y = torch.empty(self.rows, dtype=torch.float32, device=x.device)
-        assert x.dtype == torch.float32 and x.numel() == self.cols and y.numel() == self.rows and x.is_contiguous()
-        L.check(L.lib().loops_spmv_colblock_f32(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock_f32")
+            y = torch.empty(self.rows, dtype=self.dtype, device=x.device)
+        assert x.dtype == self.dtype and y.dtype == self.dtype and x.numel() == self.cols and y.numel() == self.rows
+        assert x.is_contiguous() and y.is_contiguous()
+        fn = L.lib().loops_spmv_colblock_f32 if self.dtype == torch.float32 else L.lib().loops_spmv_colblock_f64
+        L.check(fn(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock")
         return y
 
     def spmv_stage(self, stage: int, x, y):

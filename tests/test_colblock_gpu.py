@@ -101,3 +101,25 @@ def test_real_values_and_bad_arguments():
         S.ColumnBlockedPlan(csr, block_bounds=[0, 10, cols - 1])       # does not end at cols
     with pytest.raises(_lib.LoopsError):
         S.ColumnBlockedPlan(csr, 65)                                   # too many blocks
+
+
+def test_double_precision_plan():
+    """f64 plans: x of 2^20 doubles is 8 MB -> 4 automatic blocks; layout and SpMV vs the oracle; the
+    value type of the call must match the plan's."""
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    rows, cols, nnz = 1 << 13, 1 << 20, 1 << 17
+    off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, nnz, cap=1 << 12), cols, 1, 0, True, None)
+    v64 = val.astype(np.float64)
+    csr = _dev(off, idx, v64, rows, cols)
+    plan = S.ColumnBlockedPlan(csr)
+    assert plan.num_blocks == 4
+    for a, b in zip(plan.arrays(), O.column_blocked(off, idx, v64, plan.block_bounds)):
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    xh = G.uniform_distribution_int(cols).astype(np.float64)
+    y = plan.spmv(torch.from_numpy(xh).cuda()).cpu().numpy()
+    assert np.array_equal(y, O.spmv_f64(off, idx, v64, xh))
+    plan.refresh_values(torch.from_numpy(np.roll(v64, 3)).cuda())
+    assert np.array_equal(plan.spmv(torch.from_numpy(xh).cuda()).cpu().numpy(), O.spmv_f64(off, idx, np.roll(v64, 3), xh))
+    with pytest.raises(_lib.LoopsError):   # f32 call on an f64 plan
+        _lib.check(_lib.lib().loops_spmv_colblock_f32(plan.handle, 1, 1, None), "loops_spmv_colblock_f32")
