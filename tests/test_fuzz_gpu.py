@@ -1,0 +1,76 @@
+"""Randomised shape sweep over every tuned entry point of the C ABI against the CPU oracle: many small
+matrices with empty rows, single huge rows, rows spanning merge tiles, more columns than rows and vice
+versa.  Inputs are exactly summable (values k/8, integer x) so every comparison is BIT-EXACT whatever
+the summation order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _random_csr(rng, rows, cols, kind):
+    if kind == "empty":
+        lens = np.zeros(rows, np.int64)
+    elif kind == "uniform":
+        lens = rng.integers(0, min(cols, 12) + 1, size=rows)
+    elif kind == "skewed":        # a few rows hold most nonzeros (rows longer than a 2048-item merge tile)
+        lens = rng.integers(0, 4, size=rows)
+        for r in rng.choice(rows, size=min(rows, 3), replace=False):
+            lens[r] = min(cols, int(rng.integers(1500, 6000)))
+    else:                         # "ragged": geometric tail
+        lens = np.minimum(rng.geometric(0.08, size=rows) - 1, cols)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([np.sort(rng.choice(cols, size=int(n), replace=False)) for n in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = (rng.integers(-8, 9, size=idx.size) / 8.0).astype(np.float32)
+    return off, idx, val
+
+
+CASES = [(seed, kind) for seed in range(20) for kind in ("empty", "uniform", "skewed", "ragged")]
+
+
+@pytest.mark.parametrize("seed,kind", CASES)
+def test_every_tuned_path_matches_the_oracle(seed, kind):
+    from loops_amd import spmv as S
+    from oracle import oracle as O
+    rng = np.random.default_rng(1000 * seed + len(kind))
+    rows = int(rng.integers(1, 3000))
+    cols = int(rng.integers(1, 7000)) if kind != "skewed" else int(rng.integers(6000, 9000))
+    off, idx, val = _random_csr(rng, rows, cols, kind)
+    xh = rng.integers(1, 11, size=cols).astype(np.float32)
+    want = O.spmv_f32(off, idx, val, xh)
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    x = torch.from_numpy(xh).cuda()
+    tag = (seed, kind, rows, cols, idx.size)
+    # CSR schedules
+    for sch in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "original", "flat_partitioned"):
+        y = torch.full((rows,), 5.0, device="cuda")
+        assert np.array_equal(S.spmv(sch, csr, x, y).cpu().numpy(), want), (sch,) + tag
+    # column-blocked plans
+    for K in (0, 1, 3, 8):
+        if K > cols:
+            continue
+        assert np.array_equal(S.ColumnBlockedPlan(csr, K).spmv(x).cpu().numpy(), want), ("blocked", K) + tag
+    # COO (sorted and shuffled) and ELL
+    ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(off))
+    for perm in (np.arange(idx.size), rng.permutation(idx.size)):
+        y = S.coo_spmv(rows, cols, torch.from_numpy(ri[perm]).cuda(), torch.from_numpy(idx[perm]).cuda(),
+                       torch.from_numpy(val[perm]).cuda(), x)
+        assert np.array_equal(y.cpu().numpy(), want), ("coo",) + tag
+    pitch = int(np.diff(off).max()) if rows else 0
+    if rows * max(pitch, 1) < 4_000_000:
+        ind = np.full((rows, max(pitch, 1)), -1, np.int32)[:, :pitch]
+        ev = np.zeros((rows, pitch), np.float32)
+        for r in range(rows):
+            n = off[r + 1] - off[r]
+            ind[r, :n] = idx[off[r]:off[r + 1]]
+            ev[r, :n] = val[off[r]:off[r + 1]]
+        y = S.ell_spmv(rows, cols, pitch, torch.from_numpy(np.ascontiguousarray(ind)).cuda(),
+                       torch.from_numpy(np.ascontiguousarray(ev)).cuda(), x)
+        assert np.array_equal(y.cpu().numpy(), want), ("ell",) + tag
+    # SpMM, a few widths of B
+    for n in (1, 6, 16, 40):
+        B = rng.integers(1, 11, size=(cols, n)).astype(np.float32)
+        got = S.spmm(csr, torch.from_numpy(B).cuda()).cpu().numpy()
+        assert np.array_equal(got, O.spmm(off, idx, val, B)), ("spmm", n) + tag
