@@ -207,6 +207,17 @@ int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_ind
 int loops_spmv_ell_f32(int mode, int rows, int cols, int pitch, const int* indices, const float* values,
                        const float* x, float* y, void* stream);
 
+/* ---- launch-box autotuner -----------------------------------------------------------
+ * The reference picks (threads per block, items per thread) per architecture from a compile-time
+ * table of "analytical" values (algorithms/spmv/launch_box.hxx:56-90).  This times the planned
+ * merge_path_flat SpMV of THIS matrix with every compiled tile shape (2 warm-up + `repeats` timed
+ * launches each, hipEvents on `stream`) and returns the fastest loops_tile_config, to be passed to
+ * loops_merge_plan_create.  ms_per_config (optional) receives the mean time per config index, -1 for
+ * shapes that are not timed.  y is overwritten with A x.  Synchronous. */
+int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                                  const float* values, const float* x, float* y, int repeats, void* stream,
+                                  int* best_tile_config, float* ms_per_config);
+
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream

@@ -678,4 +678,42 @@ int loops_spmv_ell_f32(int mode, int rows, int cols, int pitch, const int* indic
   return LOOPS_E_BADARG;
 }
 
+int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                                  const float* values, const float* x, float* y, int repeats, void* stream,
+                                  int* best_tile_config, float* ms_per_config /* 6 entries, may be NULL */) {
+  if (!best_tile_config) return LOOPS_E_BADARG;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  if (repeats < 1) repeats = 5;
+  hipStream_t st = as_stream(stream);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return static_cast<int>(hipGetLastError());
+  static const int candidates[] = {LOOPS_TILE_256x8, LOOPS_TILE_256x7, LOOPS_TILE_128x7, LOOPS_TILE_512x8, LOOPS_TILE_256x16};
+  float best = 0.f;
+  *best_tile_config = LOOPS_TILE_DEFAULT;
+  if (ms_per_config) for (int i = 0; i < 6; ++i) ms_per_config[i] = -1.f;
+  for (int cfg : candidates) {
+    loops_merge_plan* p = nullptr;
+    err = plan_alloc(rows, nnz, cfg, &p);
+    if (!err) err = plan_compute(p, offsets, st);
+    for (int it = 0; !err && it < 2; ++it) err = spmv_merge_path<float>(p, 0, rows, nnz, offsets, indices, values, x, y, st);
+    float ms = 0.f;
+    if (!err) {
+      (void)hipEventRecord(e0, st);
+      for (int it = 0; !err && it < repeats; ++it) err = spmv_merge_path<float>(p, 0, rows, nnz, offsets, indices, values, x, y, st);
+      (void)hipEventRecord(e1, st);
+      if (!err) err = static_cast<int>(hipEventSynchronize(e1));
+      if (!err) err = static_cast<int>(hipEventElapsedTime(&ms, e0, e1));
+      ms /= static_cast<float>(repeats);
+    }
+    if (p) { (void)hipFree(p->wide_carry); (void)hipFree(p->base); delete p; }
+    if (err) break;
+    if (ms_per_config) ms_per_config[cfg] = ms;
+    if (best == 0.f || ms < best) { best = ms; *best_tile_config = cfg; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return err;
+}
+
 }  // extern "C"

@@ -393,3 +393,16 @@ def ell_spmv(rows: int, cols: int, pitch: int, indices, values, x, y=None, tuned
     L.check(L.lib().loops_spmv_ell_f32(int(tuned), rows, cols, pitch, _ptr(indices), _ptr(values), _ptr(x), _ptr(y), _stream()),
             "loops_spmv_ell_f32")
     return y
+
+
+def autotune_merge_path(csr: CSR, x, repeats: int = 5):
+    """Times the planned merge_path_flat SpMV with every compiled tile shape on this matrix
+    (loops_autotune_merge_path_f32).  Returns (best tile name, {tile name: ms})."""
+    y = torch.empty(csr.rows, dtype=torch.float32, device=x.device)
+    best = C.c_int()
+    ms = (C.c_float * 6)()
+    L.check(L.lib().loops_autotune_merge_path_f32(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+                                                  _ptr(csr.values), _ptr(x), _ptr(y), repeats, _stream(), C.byref(best), ms),
+            "loops_autotune_merge_path_f32")
+    names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
+    return names[best.value], {names[i]: ms[i] for i in range(6) if ms[i] >= 0 and i in names}

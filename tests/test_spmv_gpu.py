@@ -294,3 +294,17 @@ def test_bench_two_ranks_functional():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["shard_layout"] == "csr" and d["config"]["parity_vs_oracle_bit_exact"] is True
+
+
+def test_launch_box_autotuner():
+    """Every compiled tile shape is timed on the matrix; the winner is one of them and y is A x."""
+    from loops_amd import spmv as S, generate as G, _lib
+    rows = cols = 1 << 14
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 18, degrees=G.powerlaw_degrees(rows, 1 << 18, cap=1 << 12))
+    csr = _dev(off, idx, val, rows, cols)
+    x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
+    best, times = S.autotune_merge_path(csr, x, repeats=3)
+    assert set(times) == {"256x8", "256x7", "128x7", "512x8", "256x16"} and best in times
+    assert all(t > 0 for t in times.values()) and times[best] == min(times.values())
+    plan = S.MergePathPlan(csr, best)
+    assert torch.equal(S.merge_path_flat(csr, x, plan=plan), S.spmv("merge_path_flat", csr, x))
