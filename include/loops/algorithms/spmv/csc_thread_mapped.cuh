@@ -15,6 +15,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/memory.hxx>
+#include <loops/kernels/csc_spmv.hxx>
 
 namespace loops {
 namespace algorithms {
@@ -43,6 +44,21 @@ util::timer_t csc_thread_mapped(csc_t<index_t, offset_t, type_t>& csc, vector_t<
     launch::non_cooperative(stream, __csc_thread_mapped<setup_t, index_t, type_t>,
                             dim3(static_cast<unsigned>(math::ceil_div(csc.cols, block_size))), dim3(block_size), config,
                             csc.indices.data().get(), csc.values.data().get(), x.data().get(), y.data().get());
+  (void)xpu::stream_synchronize(stream);
+  timer.stop();
+  return timer;
+}
+
+/// Tuned CSC SpMV: the nonzeros are split evenly over the lanes (loops/kernels/csc_spmv.hxx); same
+/// contract as csc_thread_mapped (y zero-filled by the caller).
+template <typename index_t, typename offset_t, typename type_t>
+util::timer_t csc_nonzero_mapped(csc_t<index_t, offset_t, type_t>& csc, vector_t<type_t>& x, vector_t<type_t>& y,
+                                 xpu::stream_t stream = 0) {
+  util::timer_t timer(stream);
+  timer.start();
+  kernels::launch_csc_nonzero_split(stream, static_cast<int>(csc.cols), static_cast<int>(csc.nnzs),
+                                    csc.offsets.data().get(), csc.indices.data().get(), csc.values.data().get(),
+                                    x.data().get(), y.data().get());
   (void)xpu::stream_synchronize(stream);
   timer.stop();
   return timer;

@@ -1,0 +1,124 @@
+/**
+ * @file csc_spmv.hxx
+ * @brief CSC SpMV kernels: y[row_indices[k]] += values[k] * x[column of k].
+ *
+ *  - `csc_column_spmv`: one lane per column walking its nonzeros (the shape of the reference kernel,
+ *    algorithms/spmv/csc_thread_mapped.cuh:36-58): adjacent lanes read from unrelated places and a
+ *    long column serialises one lane.
+ *  - `csc_nonzero_split_spmv`: the nonzeros are split evenly -- a lane owns IPT consecutive nonzeros
+ *    whatever column they are in (16-byte loads of row_indices / values), finds the column of its first
+ *    one with a search over the column offsets and walks the offsets from there; x[col] is a broadcast
+ *    read.  One atomicAdd per nonzero remains (the rows of a column are scattered by construction).
+ * y must be zero-filled (same precondition as the reference).
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/util/math.hxx>
+
+namespace loops {
+namespace kernels {
+
+template <typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(256)
+csc_column_spmv(const std::size_t cols, const offset_t* __restrict__ offsets, const index_t* __restrict__ row_indices,
+                const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y) {
+  const std::size_t col = static_cast<std::size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  const type_t xc = x[col];
+  for (offset_t k = offsets[col]; k < offsets[col + 1]; ++k) atomicAdd(&y[row_indices[k]], values[k] * xc);
+}
+
+template <int IPT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(256)
+csc_nonzero_split_spmv(const int cols, const int nnz, const offset_t* __restrict__ offsets,
+                       const index_t* __restrict__ row_indices, const type_t* __restrict__ values,
+                       const type_t* __restrict__ x, type_t* __restrict__ y) {
+  static_assert(IPT % 4 == 0, "IPT: multiple of 4");
+  const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
+  if (base_ll >= nnz) return;
+  const int base = static_cast<int>(base_ll);
+  // column of nonzero `base`: last c with offsets[c] <= base
+  int col = 0, count = cols;
+  while (count > 0) {
+    const int half = count >> 1;
+    const int mid = col + half;
+    if (offsets[mid + 1] <= base) {
+      col = mid + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  index_t r[IPT];
+  type_t v[IPT];
+  const bool full = base + IPT <= nnz;
+  if (VEC && full) {
+#pragma unroll
+    for (int k = 0; k < IPT; k += 4) {
+      index_t r4[4];
+      type_t v4[4];
+      detail::load4<index_t, false>(row_indices + base + k, r4);
+      detail::load4<type_t, false>(values + base + k, v4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[k + j] = r4[j];
+        v[k + j] = v4[j];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+      const bool ok = base + k < nnz;
+      r[k] = ok ? row_indices[base + k] : index_t(0);
+      v[k] = ok ? values[base + k] : type_t(0);
+    }
+  }
+  offset_t col_end = offsets[col + 1];
+  type_t xc = x[col];
+#pragma unroll
+  for (int k = 0; k < IPT; ++k) {
+    if (base + k < nnz) {
+      while (base + k >= col_end) {  // next non-empty column
+        ++col;
+        col_end = offsets[col + 1];
+        xc = x[col];
+      }
+      atomicAdd(&y[r[k]], v[k] * xc);
+    }
+  }
+}
+
+template <typename index_t, typename offset_t, typename type_t>
+int launch_csc_column(hipStream_t stream, std::size_t cols, const offset_t* offsets, const index_t* row_indices,
+                      const type_t* values, const type_t* x, type_t* y) {
+  if (cols == 0) return 0;
+  hipLaunchKernelGGL((csc_column_spmv<index_t, offset_t, type_t>),
+                     dim3(static_cast<unsigned>(math::ceil_div(cols, std::size_t(256)))), dim3(256), 0, stream, cols,
+                     offsets, row_indices, values, x, y);
+  return static_cast<int>(hipGetLastError());
+}
+
+template <typename index_t, typename offset_t, typename type_t>
+int launch_csc_nonzero_split(hipStream_t stream, int cols, int nnz, const offset_t* offsets, const index_t* row_indices,
+                             const type_t* values, const type_t* x, type_t* y) {
+  if (nnz == 0 || cols == 0) return 0;
+  constexpr int IPT = 8;
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(row_indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  const dim3 grid(static_cast<unsigned>(math::ceil_div(static_cast<long long>(nnz), 256ll * IPT))), block(256);
+  if (aligned)
+    hipLaunchKernelGGL((csc_nonzero_split_spmv<IPT, true, index_t, offset_t, type_t>), grid, block, 0, stream, cols, nnz,
+                       offsets, row_indices, values, x, y);
+  else
+    hipLaunchKernelGGL((csc_nonzero_split_spmv<IPT, false, index_t, offset_t, type_t>), grid, block, 0, stream, cols, nnz,
+                       offsets, row_indices, values, x, y);
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace kernels
+}  // namespace loops

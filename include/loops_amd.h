@@ -218,6 +218,14 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
                                   const float* values, const float* x, float* y, int repeats, void* stream,
                                   int* best_tile_config, float* ms_per_config);
 
+/* ---- CSC SpMV ------------------------------------------------------------------------------------
+ * Replaces algorithms::spmv::csc_thread_mapped (algorithms/spmv/csc_thread_mapped.cuh:36-95).
+ * mode 0: lane per column (reference shape), y zero-filled by the CALLER; mode 1: tuned -- the nonzeros
+ * are split evenly over the lanes (8 consecutive ones each, 16-byte loads, column found by a search over
+ * the column offsets), one atomicAdd per nonzero, y zero-filled here. */
+int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
+                       const float* values, const float* x, float* y, void* stream);
+
 /* ---- device-side measurement helpers ---------------------------------------------------------- */
 /* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
  * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream

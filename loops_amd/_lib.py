@@ -34,7 +34,7 @@ SYMBOLS = [
     "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
     "loops_work_oriented_grid", "loops_spmv_bcsr_f32",
-    "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_row_gather_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_autotune_merge_path_f32",
+    "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_row_gather_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_spmv_csc_f32", "loops_autotune_merge_path_f32",
     "loops_colblock_plan_create", "loops_colblock_plan_destroy", "loops_colblock_plan_info", "loops_colblock_plan_arrays",
     "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32",
     "loops_colblock_plan_create_f64", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
         L.loops_spmv_coo_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_spmv_ell_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.loops_autotune_merge_path_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]
+        L.loops_spmv_csc_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
         L.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]

@@ -22,6 +22,7 @@
 #include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/coo_spmv.hxx>
 #include <loops/kernels/ell_spmv.hxx>
+#include <loops/kernels/csc_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 #include <loops/kernels/probes.hxx>
 
@@ -714,6 +715,20 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return err;
+}
+
+int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
+                       const float* values, const float* x, float* y, void* stream) {
+  if (rows < 0 || cols < 0 || nnz < 0 || !y || !col_offsets || (nnz > 0 && (!row_indices || !values || !x)))
+    return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  hipStream_t s = as_stream(stream);
+  if (mode == 0)  // reference shape: the caller zero-fills y
+    return kernels::launch_csc_column(s, static_cast<size_t>(cols), col_offsets, row_indices, values, x, y);
+  if (mode != 1) return LOOPS_E_BADARG;
+  hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return kernels::launch_csc_nonzero_split(s, cols, nnz, col_offsets, row_indices, values, x, y);
 }
 
 }  // extern "C"

@@ -406,3 +406,15 @@ def autotune_merge_path(csr: CSR, x, repeats: int = 5):
             "loops_autotune_merge_path_f32")
     names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
     return names[best.value], {names[i]: ms[i] for i in range(6) if ms[i] >= 0 and i in names}
+
+
+def csc_spmv(rows: int, cols: int, col_offsets, row_indices, values, x, y=None, tuned: bool = True):
+    """CSC SpMV (loops_spmv_csc_f32): ``tuned`` = nonzero-split kernel (y zero-filled inside); otherwise the
+    reference shape, lane per column, into a y zero-filled here."""
+    if y is None:
+        y = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if not tuned:
+        y.zero_()
+    L.check(L.lib().loops_spmv_csc_f32(int(tuned), rows, cols, values.numel(), _ptr(col_offsets), _ptr(row_indices),
+                                       _ptr(values), _ptr(x), _ptr(y), _stream()), "loops_spmv_csc_f32")
+    return y

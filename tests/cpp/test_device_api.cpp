@@ -111,6 +111,7 @@ static void run_battery() {
         csr_t<int, int, T> again(coo);  // device-side COO -> CSR (radix sort + lower_bound)
         vector_t<int, H> o2(again.offsets); bool same = true; for (std::size_t i = 0; i <= h.rows; ++i) same = same && o2[i] == h.offsets[i]; CHECK(same); }
       { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_thread_mapped(csc, x, y); check_y("csc_thread_mapped", m, y, ref); }
+      { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_nonzero_mapped(csc, x, y); check_y("csc_nonzero_mapped", m, y, ref); }
       { ell_t<int, T> ell(csr); auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_row_mapped(ell, x, y); check_y("ell_row_mapped", m, y, ref); }
       { ell_t<int, T> ell(csr); auto y = fresh(); algorithms::spmv::ell_thread_mapped(ell, x, y); check_y("ell_thread_mapped", m, y, ref);
         auto y2 = fresh(); algorithms::spmv::ell_merge_path(ell, x, y2); check_y("ell_merge_path", m, y2, ref); }

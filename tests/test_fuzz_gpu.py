@@ -69,6 +69,13 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         y = S.ell_spmv(rows, cols, pitch, torch.from_numpy(np.ascontiguousarray(ind)).cuda(),
                        torch.from_numpy(np.ascontiguousarray(ev)).cuda(), x)
         assert np.array_equal(y.cpu().numpy(), want), ("ell",) + tag
+    # CSC (built on the host from the CSR), both kernels
+    order = np.lexsort((ri, idx))                      # by column, rows ascending inside a column
+    coff = np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=cols))]).astype(np.int32)
+    for tuned in (False, True):
+        y = S.csc_spmv(rows, cols, torch.from_numpy(coff).cuda(), torch.from_numpy(ri[order]).cuda(),
+                       torch.from_numpy(val[order]).cuda(), x, tuned=tuned)
+        assert np.array_equal(y.cpu().numpy(), want), ("csc", tuned) + tag
     # SpMM, a few widths of B
     for n in (1, 6, 16, 40):
         B = rng.integers(1, 11, size=(cols, n)).astype(np.float32)
