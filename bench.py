@@ -238,7 +238,20 @@ def main():
             cb.spmv(x, yb)
         torch.cuda.synchronize()
         ms_b = (time.perf_counter() - t0) / iters * 1e3
+        kb_avg, _ = event_time(lambda: cb.spmv_stage(0, x, yb), iters)
+        cb.spmv(x, yb)
+        torch.cuda.synchronize()
+        traffic_b = None
+        pb = os.path.join(ROOT, "profiles", "r01_c2_blocked_pmc_summary.json")
+        if os.path.exists(pb) and pmc_traffic(args) is not None:  # same configuration as the profiled one
+            for k, v in json.load(open(pb)).items():
+                if "merge_path_spmv_fused_stacked" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                    traffic_b = int((2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024)
+        ab = algorithmic_bytes(csr.rows, cols, csr.nnzs)
         blocked_info = {"blocks": cb.num_blocks, "ms_per_step": round(ms_b, 5),
+                        "roofline": {"kernel": "loops::kernels::merge_path_spmv_fused_stacked", "avg_launch_ms": round(kb_avg, 5),
+                                     "achieved": round(ab / (kb_avg * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                     "frac": round(ab / (kb_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic_b},
                         "GFLOPs": round(2.0 * nnz / (ms_b * 1e-3) / 1e9, 2), "equal_to_csr_result": bool(torch.equal(yb, y_loc)),
                         "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/column_blocked.hxx); "
                                 "same fused kernel + K-way row reduce; not the headline"}
