@@ -45,12 +45,14 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        bounds = np.array([0, 5, 12], np.int64) if world == 2 else np.array([0, 4, 4, 12], np.int64)
+        bounds = {2: np.array([0, 5, 12], np.int64), 3: np.array([0, 4, 4, 12], np.int64),
+                  8: np.array([0, 3, 3, 10, 11, 20, 25, 31, 40], np.int64)}[world]   # uneven, one empty shard
+        total = int(bounds[-1])
         shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
         want = torch.cat([torch.arange(int(bounds[r]), int(bounds[r + 1]), dtype=torch.float32) * (r + 1) for r in range(world)])
         ok = True
         for mode in ("p2p", "padded"):
-            y = torch.full((12,), -1.0)
+            y = torch.full((total,), -1.0)
             y[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1)
             P.allgatherv_(y, shard, mode=mode)
             ok = ok and bool(torch.equal(y, want))
@@ -59,7 +61,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_allgatherv_gloo(world):
     import torch.multiprocessing as mp
     s = socket.socket()
