@@ -1,13 +1,11 @@
 /**
  * @file launch_box.hxx
  * @brief `launch_t<type_t>`: (workgroup size, merge items per thread) for the SpMV kernels, keyed
- * by the compile target (reference include/loops/algorithms/spmv/launch_box.hxx:63-90).
- *
- * gfx950 (MI355X): 256 threads x 8 items (fp32) / 4 items (fp64) = 2048 / 1024 merge items per
- * workgroup: 8 workgroups of 16.7 KB LDS are resident per CU (32 wavefronts), which keeps
- * ~128 KB of col_idx / value loads in flight per CU.  On this chip the tile shape is NOT the
- * bottleneck of SpMV -- the x gather is (profiles/) -- 256x7, 128x7 and 512x8 measure
- * within 2 % of 256x8 on the C2 workload, so the reference's gfx950 entry is kept.
+ * by the compile target (LOOPS_TARGET_GFX) through `launch_box_t` (util/launch_box.hxx).  The
+ * reference keeps one "analytical" pair per NVIDIA SM generation and per CDNA generation
+ * (algorithms/spmv/launch_box.hxx:56-90); the pairs below are the ones MEASURED on MI355X
+ * (bench.py --sweep, loops_autotune_merge_path_f32): 256 x 8 merge items for 4-byte values -- a
+ * 2048-item tile keeps 16.7 KB of LDS and 8 workgroups per CU -- and 256 x 4 for 8-byte values.
  */
 #pragma once
 
@@ -18,13 +16,27 @@
 namespace loops {
 namespace algorithms {
 namespace spmv {
+namespace detail {
+
+/// Merge items per thread: halve the 4-byte figure for 8-byte values (same LDS footprint per tile).
+template <typename type_t>
+constexpr std::size_t items_for(std::size_t four_byte_items) {
+  return sizeof(type_t) > 4 ? 4 : four_byte_items;
+}
 
 template <typename type_t>
-using launch_t = launch_box::launch_box_t<
-    launch_box::launch_params_t<launch_box::gfx942 | launch_box::gfx950, 256, (sizeof(type_t) > 4 ? 4 : 8)>,
-    launch_box::launch_params_t<launch_box::gfx906 | launch_box::gfx908 | launch_box::gfx90a, 256,
-                                (sizeof(type_t) > 4 ? 4 : 7)>,
-    launch_box::launch_params_t<launch_box::fallback, 256, (sizeof(type_t) > 4 ? 4 : 8)>>;
+using cdna3_cdna4_t = launch_box::launch_params_t<launch_box::gfx942 | launch_box::gfx950, 256, items_for<type_t>(8)>;
+template <typename type_t>
+using earlier_cdna_t =
+    launch_box::launch_params_t<launch_box::gfx906 | launch_box::gfx908 | launch_box::gfx90a, 256, items_for<type_t>(7)>;
+template <typename type_t>
+using anything_else_t = launch_box::launch_params_t<launch_box::fallback, 256, items_for<type_t>(8)>;
+
+}  // namespace detail
+
+template <typename type_t>
+using launch_t = launch_box::launch_box_t<detail::cdna3_cdna4_t<type_t>, detail::earlier_cdna_t<type_t>,
+                                          detail::anything_else_t<type_t>>;
 
 }  // namespace spmv
 }  // namespace algorithms

@@ -1,49 +1,33 @@
 /**
  * @file csc.hxx
- * @brief `csc_t`: compressed sparse column container (reference include/loops/container/csc.hxx:34-120):
- * offsets[cols + 1], indices[nnz] = row ids, values[nnz].
+ * @brief `csc_t<index_t, offset_t, value_t, space>`: compressed sparse COLUMN container -- offsets[cols + 1],
+ * indices[nnz] (row ids), values[nnz] (reference include/loops/container/csc.hxx:36-107).  Storage and
+ * the COO conversion live in detail::compressed_t; a CSR source goes through COO.
  */
 #pragma once
 
-#include <utility>
-
 #include <loops/container/formats.hxx>
-#include <loops/container/detail/convert.hxx>
-#include <loops/container/vector.hxx>
-#include <loops/memory.hxx>
+#include <loops/container/detail/compressed.hxx>
 
 namespace loops {
-using namespace memory;
 
 template <typename index_t, typename offset_t, typename value_t, memory_space_t space = memory_space_t::device>
-struct csc_t {
-  std::size_t rows;
-  std::size_t cols;
-  std::size_t nnzs;
+struct csc_t : detail::compressed_t<detail::major_axis::column, index_t, offset_t, value_t, space> {
+  using storage_t = detail::compressed_t<detail::major_axis::column, index_t, offset_t, value_t, space>;
 
-  vector_t<offset_t, space> offsets;  ///< column offsets, length cols + 1
-  vector_t<index_t, space> indices;   ///< row ids, length nnzs
-  vector_t<value_t, space> values;
+  csc_t() = default;
+  csc_t(std::size_t r, std::size_t c, std::size_t nnz) : storage_t(r, c, nnz) {}
 
-  csc_t() : rows(0), cols(0), nnzs(0) {}
-  csc_t(std::size_t r, std::size_t c, std::size_t nnz)
-      : rows(r), cols(c), nnzs(nnz), offsets(c + 1), indices(nnz), values(nnz) {}
-
+  /// Copy across memory spaces.
   template <auto rhs_space>
   csc_t(const csc_t<index_t, offset_t, value_t, rhs_space>& rhs)
-      : rows(rhs.rows), cols(rhs.cols), nnzs(rhs.nnzs), offsets(rhs.offsets), indices(rhs.indices),
-        values(rhs.values) {}
+      : storage_t(static_cast<const detail::compressed_t<detail::major_axis::column, index_t, offset_t, value_t, rhs_space>&>(rhs)) {}
 
+  /// COO -> CSC (the input is copied; it need not be sorted).
   template <auto rhs_space>
-  csc_t(const coo_t<index_t, value_t, rhs_space>& coo)
-      : rows(coo.rows), cols(coo.cols), nnzs(coo.nnzs), offsets(coo.cols + 1) {
-    coo_t<index_t, value_t, space> sorted(coo);
-    sorted.sort_by_column();
-    indices = std::move(sorted.row_indices);
-    values = std::move(sorted.values);
-    detail::indices_to_offsets(sorted.col_indices, offsets);
-  }
+  csc_t(const coo_t<index_t, value_t, rhs_space>& coo) : storage_t(coo) {}
 
+  /// CSR -> CSC: expand the rows to triplets, then compress by column.
   template <auto rhs_space>
   csc_t(const csr_t<index_t, offset_t, value_t, rhs_space>& csr) : csc_t(coo_t<index_t, value_t, space>(csr)) {}
 };

@@ -1,11 +1,11 @@
 /**
  * @file partitioning.hxx
- * @brief `flat_uniform_occupancy<K, base>`: a layout ADAPTOR that re-bins the atoms of any
- * base layout into uniform tiles of K atoms (last tile clipped), so a tile-per-thread
- * schedule becomes perfectly balanced; `base().tile_of(a)` recovers the original tile (row)
- * of an atom.  Reference: include/loops/container/partitioning.hxx:72-141; known answers in
- * unittests/test_layout_flat_partitioner.cu:24-112 (K=2 over 7 atoms -> 4 tiles of sizes
- * 2,2,2,1; tile_of(a) = a / K).
+ * @brief `layout::flat_uniform_occupancy<K, base_layout_t>`: re-tiles any layout into tiles of exactly K
+ * consecutive atoms (the last one may be short), ignoring the base layout's own tile boundaries -- a
+ * uniform-occupancy work list on top of an irregular one.  It satisfies the layout contract
+ * (num_tiles / num_atoms / tile_begin / tile_end / tile_size / tile_end_iter / tile_of) and keeps the
+ * base view reachable through base(); `flat_partitioned<K>` SpMV asks that for the row of an atom.
+ * Reference: include/loops/container/partitioning.hxx:72-141.
  */
 #pragma once
 
@@ -17,6 +17,23 @@
 
 namespace loops {
 namespace layout {
+namespace detail {
+
+/// Arithmetic of "tiles of K atoms over [0, total)".
+template <typename tile_id_t, typename atom_id_t, atom_id_t K>
+struct fixed_tiling {
+  __host__ __device__ static constexpr tile_id_t count(atom_id_t total) {
+    return static_cast<tile_id_t>(total / K + (total % K != 0 ? 1 : 0));
+  }
+  __host__ __device__ static constexpr atom_id_t first(tile_id_t t) { return static_cast<atom_id_t>(t) * K; }
+  __host__ __device__ static constexpr atom_id_t last(tile_id_t t, atom_id_t total) {
+    const atom_id_t unclipped = first(t) + K;
+    return unclipped < total ? unclipped : total;
+  }
+  __host__ __device__ static constexpr tile_id_t owner(atom_id_t a) { return static_cast<tile_id_t>(a / K); }
+};
+
+}  // namespace detail
 
 template <std::size_t K, typename base_layout_type>
 struct flat_uniform_occupancy {
@@ -28,6 +45,7 @@ struct flat_uniform_occupancy {
   using tile_end_iterator_t = iterator::uniform_tile_end<tile_id_t, atom_id_t>;
 
   static constexpr atom_id_t kAtomsPerTile = static_cast<atom_id_t>(K);
+  using tiling_t = detail::fixed_tiling<tile_id_t, atom_id_t, kAtomsPerTile>;
 
   base_layout_t base_;
 
@@ -36,21 +54,15 @@ struct flat_uniform_occupancy {
 
   __host__ __device__ const base_layout_t& base() const { return base_; }
 
-  __host__ __device__ tile_id_t num_tiles() const {
-    return static_cast<tile_id_t>((base_.num_atoms() + kAtomsPerTile - 1) / kAtomsPerTile);
-  }
   __host__ __device__ atom_id_t num_atoms() const { return base_.num_atoms(); }
-  __host__ __device__ atom_id_t tile_begin(tile_id_t t) const { return static_cast<atom_id_t>(t) * kAtomsPerTile; }
-  __host__ __device__ atom_id_t tile_end(tile_id_t t) const {
-    const atom_id_t e = static_cast<atom_id_t>(t + 1) * kAtomsPerTile;
-    const atom_id_t total = base_.num_atoms();
-    return e < total ? e : total;
-  }
+  __host__ __device__ tile_id_t num_tiles() const { return tiling_t::count(num_atoms()); }
+  __host__ __device__ atom_id_t tile_begin(tile_id_t t) const { return tiling_t::first(t); }
+  __host__ __device__ atom_id_t tile_end(tile_id_t t) const { return tiling_t::last(t, num_atoms()); }
   __host__ __device__ atom_id_t tile_size(tile_id_t t) const { return tile_end(t) - tile_begin(t); }
+  __host__ __device__ tile_id_t tile_of(atom_id_t a) const { return tiling_t::owner(a); }
   __host__ __device__ tile_end_iterator_t tile_end_iter() const {
-    return tile_end_iterator_t{kAtomsPerTile, base_.num_atoms()};
+    return tile_end_iterator_t{kAtomsPerTile, num_atoms()};
   }
-  __host__ __device__ tile_id_t tile_of(atom_id_t a) const { return static_cast<tile_id_t>(a / kAtomsPerTile); }
 };
 
 }  // namespace layout

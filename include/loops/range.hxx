@@ -94,4 +94,38 @@ __host__ __device__ range_proxy<typename std::initializer_list<type_t>::size_typ
   return {0, cont.size()};
 }
 
+// ---------------------------------------------------------------------------- launch-shaped spans
+// The strided spans kernels iterate with (<loops/stride_ranges.hxx> forwards here).  Semantics of the
+// reference's helpers (stride_ranges.hxx:16-62): the span starts at `begin` (+ the caller's global
+// thread rank for the grid flavour) and advances by the stated launch dimension.
+
+template <typename T>
+using step_range_t = typename range_proxy<T>::step_range_proxy;
+
+namespace detail {
+template <typename T, typename S>
+__host__ __device__ __forceinline__ step_range_t<T> span_from(T first, T end, S stride) {
+  return step_range_t<T>(first, end, static_cast<T>(stride));
+}
+}  // namespace detail
+
+/// One element per launched thread, then again one grid further on.
+template <typename T>
+__device__ __forceinline__ step_range_t<T> grid_stride_range(T begin, T end) {
+  const unsigned int rank = blockDim.x * blockIdx.x + threadIdx.x;
+  return detail::span_from(static_cast<T>(begin + static_cast<T>(rank)), end, gridDim.x * blockDim.x);
+}
+
+/// [begin, end) in steps of the workgroup size (the caller adds its own lane offset to `begin`).
+template <typename T>
+__device__ __forceinline__ step_range_t<T> block_stride_range(T begin, T end) {
+  return detail::span_from(begin, end, blockDim.x);
+}
+
+/// [begin, end) in steps of `stride`.
+template <typename T>
+__device__ __forceinline__ step_range_t<T> custom_stride_range(T begin, T end, T stride) {
+  return detail::span_from(begin, end, stride);
+}
+
 }  // namespace loops

@@ -20,7 +20,7 @@
  */
 #pragma once
 
-#include <loops/schedule.hxx>
+#include <loops/schedule/setup.hxx>
 #include <loops/stride_ranges.hxx>
 #include <loops/util/wave.hxx>
 #include <loops/container/layout.hxx>

@@ -30,7 +30,7 @@
 #include <limits>
 
 #include <loops/error.hxx>
-#include <loops/schedule.hxx>
+#include <loops/schedule/setup.hxx>
 #include <loops/stride_ranges.hxx>
 #include <loops/iterator.hxx>
 #include <loops/util/math.hxx>

@@ -2,55 +2,46 @@
  * @file thread_mapped.hxx
  * @brief `setup<thread_mapped, 1, 1, ...>`: thread g visits tiles g, g + G, ... (G = threads in
  * the grid) and walks each tile's atoms sequentially.  Host-constructible POD passed by value
- * into the kernel.  Member surface follows include/loops/schedule/thread_mapped.hxx:40-129 of
- * the reference (tiles(), atoms(t), atoms(t, fn), layout()).
+ * into the kernel.  Member surface (tiles(), atoms(t), atoms(t, fn), layout()) as in the reference,
+ * include/loops/schedule/thread_mapped.hxx:40-129.
  */
 #pragma once
 
-#include <loops/schedule.hxx>
-#include <loops/stride_ranges.hxx>
-#include <loops/container/layout.hxx>
+#include <loops/schedule/setup.hxx>
+#include <loops/range.hxx>
 
 namespace loops {
 namespace schedule {
 
 template <typename tiles_type, typename atoms_type, typename tile_size_type, typename atom_size_type,
           typename layout_type>
-class setup<algorithms_t::thread_mapped, 1, 1, tiles_type, atoms_type, tile_size_type, atom_size_type, layout_type> {
+class setup<algorithms_t::thread_mapped, 1, 1, tiles_type, atoms_type, tile_size_type, atom_size_type, layout_type>
+    : public detail::layout_bound<tiles_type, atoms_type, tile_size_type, atom_size_type, layout_type> {
+  using bound_t = detail::layout_bound<tiles_type, atoms_type, tile_size_type, atom_size_type, layout_type>;
+
  public:
-  using tiles_t = tiles_type;
-  using atoms_t = atoms_type;
-  using tiles_iterator_t = tiles_t*;
-  using atoms_iterator_t = atoms_t*;
-  using tile_size_t = tile_size_type;
-  using atom_size_t = atom_size_type;
-  using layout_t = layout_type;
+  using typename bound_t::tile_size_t;
+  using bound_t::bound_t;  // (), (tile_ends, num_tiles, num_atoms), (layout)
 
-  __host__ __device__ setup() : layout_() {}
-  __host__ __device__ setup(tiles_t* tiles, tile_size_t num_tiles, atom_size_t num_atoms)
-      : layout_(tiles, num_tiles, num_atoms) {}
-  __host__ __device__ explicit setup(layout_t layout) : layout_(layout) {}
-
-  /// Tiles owned by the calling thread.
+  /// Tiles owned by the calling thread: its grid rank, then one grid further, ...
   __device__ step_range_t<tile_size_t> tiles() const {
-    return grid_stride_range(tile_size_t(0), static_cast<tile_size_t>(layout_.num_tiles()));
+    return grid_stride_range(tile_size_t(0), static_cast<tile_size_t>(this->layout_.num_tiles()));
   }
 
   /// Atoms of `tile`, first to last.
-  __device__ auto atoms(const tile_size_t& tile) const {
-    return loops::range(layout_.tile_begin(tile), layout_.tile_end(tile));
-  }
+  __device__ auto atoms(const tile_size_t& tile) const { return span(this->layout_.tile_begin(tile), tile); }
 
-  /// Atoms of `tile` starting from a caller-supplied first atom `first_atom(tile)`.
+  /// Atoms of `tile` from a caller-supplied first atom `first_atom(tile)` on (resuming mid-tile).
   template <typename fn_t>
   __device__ auto atoms(const tile_size_t& tile, fn_t first_atom) const {
-    return loops::range(first_atom(tile), layout_.tile_end(tile));
+    return span(first_atom(tile), tile);
   }
 
-  __host__ __device__ const layout_t& layout() const { return layout_; }
-
  private:
-  layout_t layout_;
+  template <typename first_t>
+  __device__ auto span(first_t first, const tile_size_t& tile) const {
+    return loops::range(first, this->layout_.tile_end(tile));
+  }
 };
 
 }  // namespace schedule

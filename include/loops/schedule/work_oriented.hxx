@@ -17,7 +17,7 @@
  */
 #pragma once
 
-#include <loops/schedule.hxx>
+#include <loops/schedule/setup.hxx>
 #include <loops/memory.hxx>
 #include <loops/stride_ranges.hxx>
 #include <loops/util/math.hxx>

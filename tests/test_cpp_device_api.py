@@ -14,8 +14,9 @@ SRC = os.path.join(ROOT, "tests", "cpp", "test_device_api.cpp")
 
 def build():
     os.makedirs(os.path.dirname(EXE), exist_ok=True)
-    if os.path.exists(EXE) and os.path.getmtime(EXE) >= os.path.getmtime(SRC):
-        return
+    deps = [SRC] + [os.path.join(b, f) for b, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs]
+    if os.path.exists(EXE) and os.path.getmtime(EXE) >= max(os.path.getmtime(d) for d in deps):
+        return  # up to date with the test source AND every header it can include
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-std=c++17", "-O2", "-x", "hip",
                            "-Wno-unused-result", "-I" + os.path.join(ROOT, "include"), SRC, "-o", EXE])
 
