@@ -121,7 +121,13 @@ def main():
     layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
     blocked = None
     if layout == "blocked":
-        blocked = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds))
+        try:
+            blocked = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds))
+        except Exception as e:  # noqa: BLE001 -- a rank that cannot build the blocked copy keeps its CSR shard
+            if args.layout == "blocked":
+                raise
+            print(f"[rank {rank}] column-blocked plan unavailable ({type(e).__name__}: {e}); using the CSR shard",
+                  file=sys.stderr)
     torch.cuda.synchronize()
 
     gather_mode = {"mode": "p2p"}
