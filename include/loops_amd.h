@@ -187,6 +187,10 @@ int loops_colblock_plan_refresh_values_f64(loops_colblock_plan_t* plan, const do
 /* the value type must match the plan's (LOOPS_E_BADARG otherwise) */
 int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream);
 int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, double* y, void* stream);
+/* the same product with the tuned kernel of another schedule over the stacked CSR: LOOPS_MERGE_PATH_FLAT
+ * (= loops_spmv_colblock_f32), LOOPS_WORK_ORIENTED or LOOPS_GROUP_MAPPED; LOOPS_E_CONFIG otherwise */
+int loops_spmv_colblock_schedule_f32(const loops_colblock_plan_t* plan, int schedule, const float* x, float* y,
+                                     void* stream);
 /* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);

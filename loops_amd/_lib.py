@@ -37,7 +37,7 @@ SYMBOLS = [
     "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_row_gather_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_spmv_csc_f32", "loops_autotune_merge_path_f32",
     "loops_colblock_plan_create", "loops_colblock_plan_destroy", "loops_colblock_plan_info", "loops_colblock_plan_arrays",
     "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32",
-    "loops_colblock_plan_create_f64", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
+    "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
 ]
 
 
@@ -112,6 +112,7 @@ def lib() -> C.CDLL:
         L.loops_colblock_plan_create_f64.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
         L.loops_colblock_plan_refresh_values_f64.argtypes = [vp, vp, vp]
         L.loops_spmv_colblock_f64.argtypes = [vp, vp, vp, vp]
+        L.loops_spmv_colblock_schedule_f32.argtypes = [vp, ci, vp, vp, vp]
         L.loops_colblock_plan_destroy.argtypes = [vp]
         L.loops_colblock_plan_destroy.restype = None
         L.loops_colblock_plan_info.argtypes = [vp, C.POINTER(ci), vp]

@@ -313,11 +313,24 @@ int colblock_auto(int cols, int vbytes) {
 }
 
 template <typename T>
-int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hipStream_t stream) {
+int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hipStream_t stream,
+                  int schedule = LOOPS_MERGE_PATH_FLAT) {
   if (p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
   if (p->rows == 0) return 0;
   int err = 0;
   T* ys = static_cast<T*>(p->ys);
+  if (schedule != LOOPS_MERGE_PATH_FLAT) {  // the other two fused CSR kernels over the same stacked CSR
+    kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
+    const T* sval = static_cast<const T*>(p->sval);
+    if (schedule == LOOPS_WORK_ORIENTED)
+      err = kernels::launch_work_oriented_fused<256, 8, true>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);
+    else if (schedule == LOOPS_GROUP_MAPPED)
+      err = kernels::launch_group_mapped_fused<256, 8, true>(stream, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);
+    else
+      return LOOPS_E_CONFIG;
+    if (!err) err = kernels::launch_reduce_blocks<T>(stream, ys, p->rows, p->K, y);
+    return err;
+  }
   if (stages & 3) {
     kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
     err = kernels::launch_merge_path_fused<256, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
@@ -643,6 +656,11 @@ int loops_colblock_plan_refresh_values_f64(loops_colblock_plan_t* plan, const do
 int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream) {
   if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
   return colblock_spmv<float>(plan, 7, x, y, as_stream(stream));
+}
+int loops_spmv_colblock_schedule_f32(const loops_colblock_plan_t* plan, int schedule, const float* x, float* y,
+                                     void* stream) {
+  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  return colblock_spmv<float>(plan, 7, x, y, as_stream(stream), schedule);
 }
 int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, double* y, void* stream) {
   if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;

@@ -226,6 +226,16 @@ class ColumnBlockedPlan:
         L.check(fn(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock")
         return y
 
+    def spmv_schedule(self, schedule: str, x, y=None):
+        """y = A x with the tuned kernel of ``schedule`` (merge_path_flat / work_oriented / group_mapped) over
+        the stacked CSR (f32 plans)."""
+        assert self.dtype == torch.float32 and x.dtype == torch.float32 and x.numel() == self.cols
+        if y is None:
+            y = torch.empty(self.rows, dtype=torch.float32, device=x.device)
+        L.check(L.lib().loops_spmv_colblock_schedule_f32(self._h, L.SCHEDULES[schedule], _ptr(x), _ptr(y), _stream()),
+                "loops_spmv_colblock_schedule_f32(" + schedule + ")")
+        return y
+
     def spmv_stage(self, stage: int, x, y):
         L.check(L.lib().loops_spmv_colblock_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock_stage_f32")
         return y

@@ -35,10 +35,17 @@ for name, rows, cols, nnz in cases:
     cb = S.ColumnBlockedPlan(csr); y2 = torch.empty(rows, device="cuda")
     t1 = ev(lambda: cb.spmv(x, y2))
     st = [ev(lambda s=s: cb.spmv_stage(s, x, y2)) for s in (0, 1, 2)]
+    other = {}
+    for sch in ("work_oriented", "group_mapped"):
+        tp = ev(lambda: S.spmv(sch, csr, x, y), 10)
+        tb = ev(lambda: cb.spmv_schedule(sch, x, y2), 10)
+        other[sch] = {"plain_ms": round(tp, 4), "blocked_ms": round(tb, 4), "equal": bool(torch.equal(y, y2))}
+    S.merge_path_flat(csr, x, y, plan=plan)
     cb.spmv(x, y2); torch.cuda.synchronize()
     out[name] = {"rows": rows, "cols": cols, "nnz": nnz, "x_MB": cols * 4 >> 20, "plain_ms": round(t0, 4), "blocks": cb.num_blocks,
                  "blocked_ms": round(t1, 4), "stages_ms": [round(s, 4) for s in st], "equal": bool(torch.equal(y, y2)),
-                 "GFLOPs_plain": round(2 * nnz / t0 / 1e6, 1), "GFLOPs_blocked": round(2 * nnz / t1 / 1e6, 1)}
+                 "GFLOPs_plain": round(2 * nnz / t0 / 1e6, 1), "GFLOPs_blocked": round(2 * nnz / t1 / 1e6, 1),
+                 "other_schedules": other}
     print(name, out[name], file=sys.stderr, flush=True)
     del csr, cb, plan
 print(json.dumps(out))

@@ -51,7 +51,10 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
     for K in (0, 1, 3, 8):
         if K > cols:
             continue
-        assert np.array_equal(S.ColumnBlockedPlan(csr, K).spmv(x).cpu().numpy(), want), ("blocked", K) + tag
+        cb = S.ColumnBlockedPlan(csr, K)
+        assert np.array_equal(cb.spmv(x).cpu().numpy(), want), ("blocked", K) + tag
+        for sch in ("work_oriented", "group_mapped"):
+            assert np.array_equal(cb.spmv_schedule(sch, x).cpu().numpy(), want), ("blocked", K, sch) + tag
     # COO (sorted and shuffled) and ELL
     ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(off))
     for perm in (np.arange(idx.size), rng.permutation(idx.size)):
