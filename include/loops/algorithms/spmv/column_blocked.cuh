@@ -33,18 +33,22 @@ struct column_blocked_t {
   vector_t<type_t> partial;           ///< num_blocks * rows partial results
   plan_t plan;
 
-  /// Blocks of x of about 2 MB, at most 8 (one per XCD).
-  static int automatic_blocks(std::size_t cols) {
+  /// Blocks of x of about 2 MB, at most half the mean row length (each block adds `rows` row-end items
+  /// to the merge path) and at most 64.
+  static int automatic_blocks(std::size_t cols, std::size_t rows, std::size_t nnzs) {
     int k = 1;
-    while (k < 8 && cols * sizeof(type_t) / k > (std::size_t(2) << 20)) k *= 2;
-    return k;
+    while (k < 64 && cols * sizeof(type_t) / k > (std::size_t(2) << 20)) k *= 2;
+    const std::size_t mean = rows ? nnzs / rows : 0;
+    int cap = 2;
+    while (cap < 64 && std::size_t(cap) * 2 <= mean / 2) cap *= 2;
+    return k < cap ? k : cap;
   }
 
   /// @param blocks 0 = automatic; @param block_bounds optional explicit boundaries (blocks + 1 values).
   explicit column_blocked_t(csr_t<index_t, offset_t, type_t>& csr, int blocks = 0, const int* block_bounds = nullptr,
                             xpu::stream_t stream = 0)
       : rows(csr.rows), cols(csr.cols), nnzs(csr.nnzs),
-        num_blocks(blocks > 0 ? blocks : automatic_blocks(csr.cols)),
+        num_blocks(blocks > 0 ? blocks : automatic_blocks(csr.cols, csr.rows, csr.nnzs)),
         bounds(num_blocks + 1), offsets(std::size_t(num_blocks) * csr.rows + 1), indices(csr.nnzs), values(csr.nnzs),
         perm(csr.nnzs), partial(std::size_t(num_blocks) * csr.rows),
         plan(build(csr, block_bounds, stream), stream, plan_t::prepass_always) {}

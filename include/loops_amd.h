@@ -161,7 +161,7 @@ int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols
  * (k * rows + r) holds the part of row r inside block k -- an ordinary CSR of K * rows rows that the
  * fused merge_path_flat kernel runs unchanged, each XCD staying inside (about) one column block so its
  * L2 holds cols * 4 / K bytes of x; a K-way row reduce finishes y (include/loops/kernels/column_blocked.hxx).
- * num_blocks <= 0: automatic (x[block] ~ 2 MB, at most 8).  block_bounds: NULL for equal blocks, or
+ * num_blocks <= 0: automatic (x[block] ~ 2 MB, at most half the mean row length and at most 64 blocks).  block_bounds: NULL for equal blocks, or
  * num_blocks + 1 ascending HOST ints with [0] = 0 and [num_blocks] = cols (multi-GPU: the owners' row
  * ranges).  Creation is synchronous on `stream` (device radix sort + scan, O(nnz)).
  * y = A x is deterministic; it sums each row block by block, so it is bit-identical to the plain

@@ -304,12 +304,17 @@ void colblock_free(loops_colblock_plan* p) {
   delete p;
 }
 
-// K for a column count: x[block] of about 2 MB (half the per-XCD L2), at most 8 blocks (one per XCD)
-int colblock_auto(int cols, int vbytes) {
+// Automatic block count: x[block] of about 2 MB (half a per-XCD L2), but never more blocks than half the
+// mean row length -- every block adds `rows` row-end items to the merge path (measured: N=8 shard of C2,
+// 16 nnz/row: K = 8 beats 16; C5 shard, 32 nnz/row, x = 64 MB: K = 16 beats 8 and 32) -- and at most 64.
+int colblock_auto(int cols, int vbytes, int rows, int nnz) {
   const long long bytes = static_cast<long long>(cols) * vbytes;
   int k = 1;
-  while (k < 8 && bytes / k > (2ll << 20)) k *= 2;
-  return k;
+  while (k < 64 && bytes / k > (2ll << 20)) k *= 2;
+  const long long mean = rows > 0 ? nnz / rows : 0;
+  int cap = 2;
+  while (cap < 64 && cap * 2 <= mean / 2) cap *= 2;
+  return k < cap ? k : cap;
 }
 
 template <typename T>
@@ -345,7 +350,7 @@ template <typename T>
 int colblock_create(int rows, int cols, int nnz, const int* offsets, const int* indices, const T* values,
                     int num_blocks, const int* block_bounds, hipStream_t st, loops_colblock_plan** out) {
   if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
-  int K = num_blocks > 0 ? num_blocks : colblock_auto(cols, static_cast<int>(sizeof(T)));
+  int K = num_blocks > 0 ? num_blocks : colblock_auto(cols, static_cast<int>(sizeof(T)), rows, nnz);
   if (K > 64) return LOOPS_E_CONFIG;
   if (K > cols && cols > 0) K = cols;
   if (K < 1) K = 1;

@@ -285,12 +285,17 @@ def column_blocked(offsets, indices, values, bounds):
             perm.astype(np.int32))
 
 
-def auto_blocks(cols):
-    """K the library picks when asked for num_blocks = 0: x[block] about 2 MB of fp32, at most 8."""
+def auto_blocks(cols, rows, nnz, vbytes=4):
+    """K the library picks when asked for num_blocks = 0: x[block] about 2 MB, at most half the mean row
+    length (power of two, at least 2) and at most 64."""
     k = 1
-    while k < 8 and cols * 4 // k > (2 << 20):
+    while k < 64 and cols * vbytes // k > (2 << 20):
         k *= 2
-    return k
+    mean = nnz // rows if rows else 0
+    cap = 2
+    while cap < 64 and cap * 2 <= mean // 2:
+        cap *= 2
+    return min(k, cap)
 
 
 # --------------------------------------------------------------------------- reference (real)

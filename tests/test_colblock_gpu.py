@@ -50,7 +50,7 @@ def test_powerlaw_auto_blocks_bit_exact_and_refresh():
     off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, nnz, cap=1 << 12), cols, 1, 0, True, None)
     csr = _dev(off, idx, val, rows, cols)
     plan = S.ColumnBlockedPlan(csr)
-    assert plan.num_blocks == O.auto_blocks(cols) == 8
+    assert plan.num_blocks == O.auto_blocks(cols, rows, nnz) == 8
     assert np.array_equal(plan.block_bounds, _uniform_bounds(cols, 8))
     want = O.column_blocked(off, idx, val, plan.block_bounds)
     for a, b in zip(plan.arrays(), want):

@@ -53,4 +53,10 @@ def test_column_blocked_spec_is_a_row_permuted_split():
 
 def test_auto_blocks_rule():
     from oracle import oracle as O
-    assert [O.auto_blocks(c) for c in (1, 1 << 19, (1 << 19) + 1, 1 << 20, 1 << 21, 1 << 22, 1 << 26)] == [1, 1, 2, 2, 4, 8, 8]
+    # long rows: the x-size rule alone (2 MB slices, at most 64)
+    assert [O.auto_blocks(c, 1, 1 << 20) for c in (1, 1 << 19, (1 << 19) + 1, 1 << 20, 1 << 22, 1 << 26)] == [1, 1, 2, 2, 8, 64]
+    # the row-length cap: half the mean row length, power of two, at least 2
+    assert O.auto_blocks(1 << 23, 1 << 20, 1 << 24) == 8      # N = 8 shard of C2: 16 nnz/row
+    assert O.auto_blocks(1 << 24, 1 << 21, 1 << 26) == 16     # C5 shard: 32 nnz/row, x = 64 MB
+    assert O.auto_blocks(1 << 24, 1 << 20, 1 << 21) == 2      # 2 nnz/row: never more than 2 blocks
+    assert O.auto_blocks(1 << 20, 1 << 13, 1 << 17, vbytes=8) == 4
