@@ -78,7 +78,12 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  *   (algorithms/spmv/merge_path_flat.cuh:97-139, work_oriented.cuh:103-121,
  *    thread_mapped.cuh:70-91, group_mapped.cuh:72-105, original.cuh:58-75,
  *    flat_partitioned.cuh:70-110).
- * Unlike the reference wrappers these do NOT block on the stream. */
+ * Unlike the reference wrappers these do NOT block on the stream.
+ * Concurrency: the plan-less entry points (this one, loops_spmm_csr_*) keep their merge-path scratch
+ * (coordinates, carry-outs) in ONE buffer per host thread and tile shape, reused by every call.  Calls
+ * issued from one thread are therefore only safe back to back on the SAME stream (stream order protects
+ * the scratch); to overlap products on several streams give each its own plan (loops_merge_plan_create +
+ * loops_spmv_merge_path_*).  A plan, likewise, serves one product at a time. */
 int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
                        const float* values, const float* x, float* y, void* stream);
 int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
