@@ -58,6 +58,11 @@ for name, (deg, cols, window) in cases.items():
         ms = ev(fn, iters=10 if label == "thread_mapped" else 20)
         ok = bool(np.array_equal(y.cpu().numpy(), ref))
         row[label] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "bit_exact": ok}
+    cb = S.ColumnBlockedPlan(csr)   # automatic block count
+    ms = ev(lambda: cb.spmv(x, y))
+    row["column_blocked"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "blocks": cb.num_blocks,
+                             "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+    cb.close()
     if R is not None:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         for kind, label in ((2, "ref_hip_merge_path"), (1, "ref_hip_work_oriented"), (0, "ref_hip_thread_mapped")):
