@@ -37,33 +37,51 @@ namespace kernels {
 
 namespace colblock {
 
-/// key[i] = (stacked row of nonzero i) << 32 | i ; counts[stacked row + 1] += 1
+/// key[i] = (stacked row of nonzero i) << 32 | i ; counts[stacked row + 1] += (nonzeros in it).
+/// A lane owns IPT consecutive nonzeros: ONE search over the offsets for the row of the first, then a
+/// walk along the offsets; consecutive nonzeros of the same stacked row share one atomic.
 /// `bounds` (K + 1 ascending column boundaries, bounds[0] = 0, bounds[K] = cols) in global memory.
-template <typename index_t, typename offset_t>
+template <int IPT, typename index_t, typename offset_t>
 __global__ void __launch_bounds__(256)
 make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indices, const int rows, const int nnz,
           const int* __restrict__ bounds, const int K, unsigned long long* __restrict__ keys,
           int* __restrict__ counts) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nnz) return;
-  // row of nonzero i: last r with offsets[r] <= i  (upper_bound over offsets[1..rows])
-  int lo = 0, count = rows;
+  const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
+  if (base_ll >= nnz) return;
+  const int base = static_cast<int>(base_ll);
+  // row of nonzero `base`: last r with offsets[r] <= base  (upper_bound over offsets[1..rows])
+  int row = 0, count = rows;
   while (count > 0) {
     const int half = count >> 1;
-    const int mid = lo + half;
-    if (offsets[mid + 1] <= i) {
-      lo = mid + 1;
+    const int mid = row + half;
+    if (offsets[mid + 1] <= base) {
+      row = mid + 1;
       count -= half + 1;
     } else {
       count = half;
     }
   }
-  const int c = static_cast<int>(indices[i]);
-  int k = 0;
-  while (k + 1 < K && bounds[k + 1] <= c) ++k;
-  const unsigned int srow = static_cast<unsigned int>(k) * static_cast<unsigned int>(rows) + static_cast<unsigned int>(lo);
-  keys[i] = (static_cast<unsigned long long>(srow) << 32) | static_cast<unsigned int>(i);
-  atomicAdd(counts + srow + 1, 1);
+  offset_t row_end = offsets[row + 1];
+  unsigned int run_row = 0xffffffffu;
+  int run_len = 0;
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int i = base + j;
+    if (i >= nnz) break;
+    while (i >= row_end) row_end = offsets[++row + 1];  // skip empty rows
+    const int c = static_cast<int>(indices[i]);
+    int k = 0;
+    while (k + 1 < K && bounds[k + 1] <= c) ++k;
+    const unsigned int srow = static_cast<unsigned int>(k) * static_cast<unsigned int>(rows) + static_cast<unsigned int>(row);
+    keys[i] = (static_cast<unsigned long long>(srow) << 32) | static_cast<unsigned int>(i);
+    if (srow != run_row) {
+      if (run_len) atomicAdd(counts + run_row + 1, run_len);
+      run_row = srow;
+      run_len = 0;
+    }
+    ++run_len;
+  }
+  if (run_len) atomicAdd(counts + run_row + 1, run_len);
 }
 
 /// perm[j] = original position of the j-th nonzero of the stacked matrix; gathers col_idx.
@@ -148,7 +166,9 @@ int build_column_blocked(hipStream_t stream, const offset_t* offsets, const inde
   std::size_t cub_bytes = temp_bytes - 2 * key_bytes;
   const dim3 grid(math::ceil_div(nnz, 256)), block(256);
   static_assert(sizeof(offset_t) == sizeof(int), "stacked offsets are accumulated with 32-bit atomics");
-  hipLaunchKernelGGL((colblock::make_keys<index_t, offset_t>), grid, block, 0, stream, offsets, indices, out.rows, nnz,
+  constexpr int KEYS_PER_LANE = 8;
+  hipLaunchKernelGGL((colblock::make_keys<KEYS_PER_LANE, index_t, offset_t>),
+                     dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), block, 0, stream, offsets, indices, out.rows, nnz,
                      bounds_dev, out.K, keys_in, reinterpret_cast<int*>(out.soff));
   int end_bit = 33;
   while (end_bit < 64 && (static_cast<unsigned long long>(srows) >> (end_bit - 32)) != 0) ++end_bit;
