@@ -49,3 +49,36 @@ def test_product_never_imports_the_oracle():
         for f in files:
             src = open(os.path.join(base, f)).read()
             assert "liboracle" not in src and "loops_oracle" not in src, f
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """No CPU fallback: with the shared library absent every product call raises LoopsError."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from loops_amd import _lib\n"
+        "try:\n"
+        "    _lib.lib()\n"
+        "except _lib.LoopsError as e:\n"
+        "    assert 'no CPU fallback' in str(e), str(e); print('LOUD')\n"
+        "else:\n"
+        "    print('SILENT')\n" % ROOT)
+    env = dict(os.environ, LOOPS_AMD_LIB=str(tmp_path / "libloops_amd_missing.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("LOUD"), r.stdout + r.stderr
+
+
+def test_argument_errors_of_the_newer_entry_points():
+    L = _lib.lib()
+    assert L.loops_spmm_csr_f32(0, 4, 4, 4, None, None, None, None, 8, None, None) == -1
+    assert L.loops_spmm_csr_f32(0, 4, 4, 4, None, None, None, None, -1, None, None) == -1
+    assert L.loops_spmm_merge_path_f32(None, 4, 4, 4, None, None, None, None, 8, None, None) == -1
+    assert L.loops_colblock_plan_create(4, 4, 4, None, None, None, 2, None, None, None) == -1
+    assert L.loops_colblock_plan_info(None, None, None) == -1
+    assert L.loops_spmv_colblock_f32(None, None, None, None) == -1
+    assert L.loops_spmv_coo_f32(1, 4, 4, 4, None, None, None, None, None, None) == -1
+    assert L.loops_spmv_coo_f32(7, 4, 4, 0, None, None, None, None, 1, None) == -1       # unknown mode
+    assert L.loops_spmv_ell_f32(1, 4, 4, 2, None, None, None, None, None) == -1
+    assert L.loops_spmv_csc_f32(1, 4, 4, 4, None, None, None, None, None, None) == -1
+    assert L.loops_autotune_merge_path_f32(4, 4, 4, None, None, None, None, None, 1, None, None, None) == -1
