@@ -54,6 +54,7 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
                             int stages = 3, bool stacked = false) {
   const int m = plan.num_merge_tiles;
   if (m == 0) return 0;
+  if (m == 1) stages &= ~2;  // one tile holds every row completely: no carry-out to add (launch-bound sizes: 1 kernel)
   T* carry_val = static_cast<T*>(plan.carry_val);
   if (stages & 1) {
     const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;

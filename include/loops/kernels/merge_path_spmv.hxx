@@ -338,9 +338,11 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
 
   const int tid = threadIdx.x;
   const int b = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
-  // tile coordinates (wave-uniform: scalar loads)
-  const coord_t c0 = coords[b];
-  const coord_t c1 = coords[b + 1];
+  // tile coordinates (wave-uniform: scalar loads).  A matrix that fits ONE merge tile needs no
+  // coordinate table: its tile is the whole merge path (and no fix-up: nothing leaves the tile).
+  const bool single = gridDim.x == 1;
+  const coord_t c0 = single ? coord_t{0u, 0u} : coords[b];
+  const coord_t c1 = single ? coord_t{static_cast<unsigned int>(rows), static_cast<unsigned int>(nnz)} : coords[b + 1];
   const int row0 = static_cast<int>(c0.x);
   const int nz0 = static_cast<int>(c0.y);
   const int nrows = static_cast<int>(c1.x) - row0;

@@ -210,7 +210,7 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
     case LOOPS_MERGE_PATH_FLAT: {
       loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
       if (!p) return err;
-      err = plan_compute(p, off, stream);
+      if (p->num_tiles > 1) err = plan_compute(p, off, stream);  // a single-tile kernel derives its own coordinates
       if (!err) err = spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
       return err;
     }
