@@ -283,7 +283,11 @@ def main():
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(k_main_avg, 5),
                 "median_launch_ms": round(k_main_med, 5), "fixup_avg_launch_ms": round(k_fix_avg, 5),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 4),
-                "measured_gather_Gelem_per_s": round(gather_gps, 2)}
+                "measured_gather_Gelem_per_s": round(gather_gps, 2),
+                # time the x gathers of this shard alone need at the measured random-gather rate of this box
+                # (same indices, same x, no streams) over the kernel's time: how much of the kernel is the gather
+                "gather_only_ms": round(loc_nnz / gather_gps / 1e6, 5),
+                "gather_only_over_kernel": round(loc_nnz / gather_gps / 1e6 / k_main_avg, 4)}
     if k_reduce_avg is not None:
         roofline["block_reduce_avg_launch_ms"] = round(k_reduce_avg, 5)
 
