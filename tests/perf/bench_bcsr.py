@@ -1,7 +1,7 @@
 """BASELINE config C4: BCSR 4x4, 2^18 block-rows x 16 blocks, bcsr_thread_mapped register path vs the
 MFMA path, against the B_bcsr roofline of SURVEY 8(d)."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S
 from oracle import oracle as O

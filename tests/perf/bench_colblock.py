@@ -2,7 +2,7 @@
 (a) rank shards of an N-GPU weak-scaling run (2^20 rows x N*2^20 cols, 2^24 nnz), (b) a C3-sized
 scale-free stand-in (7.4 M rows, 194 M nnz, x = 30 MB).  Exactly-summable inputs: results must be equal."""
 import argparse, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S
 

@@ -2,7 +2,7 @@
 on the C2 workload and on a C3-sized scale-free stand-in; prints a table + JSON (stderr/stdout).
 Also times the reference's own HIP kernels on the same GPU when oracle/_ref is present."""
 import argparse, json, os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S, _lib
 
@@ -54,7 +54,7 @@ for sched in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped
     rec(f"tuned {sched}", lambda: S.spmv(sched, csr, x, y))
 for sched in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "flat_partitioned"):
     rec(f"schedule-API {sched} (incl. y zero-fill)", lambda: S.spmv_schedule_api(sched, csr, x, y))
-so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libloops_ref_gpu.so")
+so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "libloops_ref_gpu.so")
 if args.ref_gpu and os.path.exists(so):
     R = _lib.load_shared(so)
     p = lambda a: a.ctypes.data_as(C.c_void_p)

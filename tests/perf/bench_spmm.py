@@ -4,7 +4,7 @@ Tuned merge-path SpMM (with a held plan) vs the reference-shaped thread_mapped S
 the tuned SpMV with x = B[:, j] bit-exactly (exactly-summable inputs).
 Algorithmic bytes: nnz * 8 + (rows + 1) * 4 + cols * n * 4 (B once) + rows * n * 4 (C once)."""
 import argparse, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S
 
@@ -51,7 +51,7 @@ for n in [int(w) for w in a.widths.split(",")]:
         row["thread_mapped (reference-shaped)"] = {"avg_ms": round(avg2, 3), "GFLOPs": round(flops / avg2 / 1e6, 1),
                                                    "equal": bool(torch.equal(C2, Cd))}
         print(f"        thread_mapped   {avg2*1e3:9.1f} us  {flops/avg2/1e6:9.1f} GFLOP/s  equal={torch.equal(C2, Cd)}", file=sys.stderr)
-        so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libloops_ref_gpu.so")
+        so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "libloops_ref_gpu.so")
         if a.ref_gpu and os.path.exists(so):
             import ctypes as C
             from loops_amd import _lib

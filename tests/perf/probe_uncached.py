@@ -1,7 +1,7 @@
 """Experiment: put the matrix stream (col_idx / values) in uncached or fine-grained device memory
 (hipExtMallocWithFlags) so that it does not displace x from the XCD L2s; measure read rate and SpMV."""
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S, _lib
 

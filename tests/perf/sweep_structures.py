@@ -2,7 +2,7 @@
 matrices, plots/data/*.csv; none of them is available here): the tuned schedules + the reference's own
 HIP backend on synthetic matrices of very different row-length / column structure, all ~2^24 nnz."""
 import ctypes as C, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S, _lib
 from oracle import oracle as O
@@ -38,7 +38,7 @@ cases["extreme skew: 64 rows hold ~all nnz"] = (d, 1 << 18, None)
 d = np.where(np.arange(1 << 21) % 4 == 0, 32, 0).astype(np.int64)
 cases["75 % empty rows, degree 32 otherwise"] = (d, 1 << 21, None)
 
-so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libloops_ref_gpu.so")
+so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "libloops_ref_gpu.so")
 R = _lib.load_shared(so) if os.path.exists(so) else None
 out = {}
 for name, (deg, cols, window) in cases.items():
