@@ -49,6 +49,13 @@ def test_product_never_imports_the_oracle():
         for f in files:
             src = open(os.path.join(base, f)).read()
             assert "liboracle" not in src and "loops_oracle" not in src, f
+    # nor do the probes / drivers outside tests/ (only tests/, smoke() and bench.py may touch oracle/)
+    for top in ("scripts", "examples"):
+        for base, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cu", ".sh")) and f != "build_reference_examples.sh":
+                    src = open(os.path.join(base, f)).read()
+                    assert not re.search(r"(import\s+oracle|from\s+oracle|liboracle|oracle/_ref)", src), f
 
 
 def test_missing_extension_fails_loudly(tmp_path):
