@@ -131,6 +131,7 @@ def main():
     torch.cuda.synchronize()
 
     gather_mode = {"mode": "p2p"}
+    exchanges = {}
 
     def spmv_local():
         if blocked is not None:
@@ -141,21 +142,43 @@ def main():
     def step():
         spmv_local()
         if world > 1:
-            P.allgatherv_(y_full, shard, mode=gather_mode["mode"])
+            exchanges[gather_mode["mode"]].run()
 
-    if world > 1:  # grouped p2p is the design; fall back to the library collective if this build refuses it
-        try:
-            step()
+    comm_dev = "cuda" if args.backend == "nccl" else "cpu"
+    exchange_probe = None
+    if world > 1:
+        # The exchange is an allgatherv(y).  Two implementations (loops_amd/partition.py): "p2p" = one grouped
+        # batch of direct sends / receives (every xGMI link at once), "padded" = the library all_gather on
+        # max-count slots + local compaction.  Which one is faster depends on the RCCL build and on how much
+        # host time a grouped p2p launch costs, so both are timed here, outside the timed region, and every
+        # rank adopts the same winner (a mode that raises on any rank is excluded everywhere).
+        exchange_probe = {}
+        for mode in ("p2p", "padded"):
+            ok = 1.0
+            try:
+                exchanges[mode] = P.Allgatherv(y_full, shard, mode)
+                gather_mode["mode"] = mode
+                step()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] allgatherv mode {mode} unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], device=comm_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag) < 1.0:
+                exchanges.pop(mode, None)
+                continue
+            dist.barrier()
             torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            print(f"[rank {rank}] batched p2p allgatherv unavailable ({type(e).__name__}: {e}); using padded all_gather",
-                  file=sys.stderr)
-            gather_mode["mode"] = "padded"
-        flag = torch.tensor([1.0 if gather_mode["mode"] == "padded" else 0.0],
-                            device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if float(flag) > 0:
-            gather_mode["mode"] = "padded"
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exchange_probe[mode] = round(float(t), 5)
+        assert exchange_probe, "no allgatherv implementation works on this backend"
+        gather_mode["mode"] = min(exchange_probe, key=exchange_probe.get)
 
     def barrier():
         if world > 1:
@@ -355,6 +378,7 @@ def main():
                        "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}]" if world > 1 else ""),
                        "ms_per_step_with_prepass": None if ms_with_prepass is None else round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
+                       "allgatherv_probe_ms_per_step": exchange_probe,
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
                        "column_blocked_layout_same_matrix": blocked_info,
                        "reference_hip_backend_on_this_gpu": ref_gpu},

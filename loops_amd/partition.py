@@ -126,6 +126,56 @@ def allgatherv_(y_full: torch.Tensor, shard: Shard, group=None, mode: str = "p2p
     return y_full
 
 
+class Allgatherv:
+    """The per-step exchange of one (y_full, shard) pair with everything that does not change between
+    steps built once: the point-to-point op list (views of y_full) for mode "p2p", the padded scratch and
+    the slot views for mode "padded".  ``run()`` == ``allgatherv_(y_full, shard, mode=mode)`` with less
+    host work per call (at N = 8 a step is ~0.2 ms of GPU time; the host must not be the slower side)."""
+
+    def __init__(self, y_full: torch.Tensor, shard: Shard, mode: str = "p2p", group=None):
+        if mode not in ("p2p", "padded"):
+            raise ValueError(mode)
+        self.y_full, self.shard, self.mode, self.group = y_full, shard, mode, group
+        self.staged = shard.world > 1 and y_full.is_cuda and dist.get_backend(group) == "gloo"
+        if shard.world == 1 or self.staged:
+            return
+        b = shard.bounds
+        self.mine = y_full[int(b[shard.rank]):int(b[shard.rank + 1])]
+        self.ops = []
+        if mode == "p2p":
+            for peer in range(shard.world):
+                if peer == shard.rank:
+                    continue
+                if self.mine.numel():
+                    self.ops.append(dist.P2POp(dist.isend, self.mine, peer, group))
+                theirs = y_full[int(b[peer]):int(b[peer + 1])]
+                if theirs.numel():
+                    self.ops.append(dist.P2POp(dist.irecv, theirs, peer, group))
+        else:
+            slot = int(shard.counts.max())
+            self.scratch = torch.empty(slot * (shard.world + 1), dtype=y_full.dtype, device=y_full.device)
+            self.send = self.scratch[:slot]
+            self.recv = self.scratch[slot: slot * (shard.world + 1)]
+            self.copies = [(y_full[int(b[peer]):int(b[peer + 1])], self.recv[peer * slot: peer * slot + int(b[peer + 1] - b[peer])])
+                           for peer in range(shard.world) if peer != shard.rank and b[peer + 1] > b[peer]]
+
+    def run(self) -> torch.Tensor:
+        if self.shard.world == 1:
+            return self.y_full
+        if self.staged:  # functional-test path (ranks sharing one GPU over gloo): host staging, see allgatherv_
+            return allgatherv_(self.y_full, self.shard, self.group, self.mode)
+        if self.mode == "p2p":
+            if self.ops:
+                for req in dist.batch_isend_irecv(self.ops):
+                    req.wait()
+            return self.y_full
+        self.send[: self.mine.numel()].copy_(self.mine)
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        for dst, src in self.copies:
+            dst.copy_(src)
+        return self.y_full
+
+
 def column_block_bounds(owner_bounds, max_blocks: int = 8, target_bytes: int = 2 << 20, elem_bytes: int = 4):
     """Column boundaries for the column-blocked layout of a shard (spmv.ColumnBlockedPlan): the owners'
     row ranges (x[block k] = the y slice rank k produces), each cut into s equal pieces so that a block

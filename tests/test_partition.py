@@ -56,6 +56,14 @@ def _worker(rank, world, port, q):
             y[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1)
             P.allgatherv_(y, shard, mode=mode)
             ok = ok and bool(torch.equal(y, want))
+            # the prebuilt-exchange object, run twice (op lists / scratch are reused between steps)
+            y2 = torch.full((total,), -1.0)
+            ex = P.Allgatherv(y2, shard, mode)
+            for rep in (1.0, 3.0):
+                y2.fill_(-1.0)
+                y2[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1) * rep
+                ex.run()
+                ok = ok and bool(torch.equal(y2, want * rep))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
