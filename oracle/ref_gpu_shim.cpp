@@ -19,6 +19,8 @@
 //   schedule::setup<work_oriented>      include/loops/schedule/work_oriented.hxx:45-190
 //   merge_path::preprocess_t            include/loops/schedule/merge_path_flat.hxx:99-172
 //   algorithms::spmm::thread_mapped     include/loops/algorithms/spmm/thread_mapped.cuh:68-94
+//   algorithms::spmv::coo_/csc_/ell_thread_mapped, bcsr_thread_mapped<4,4>
+//                                       include/loops/algorithms/spmv/{coo,csc,ell,bcsr}_thread_mapped.cuh
 // (group_mapped is excluded from the reference's HIP build: schedule.hxx:69-74.)
 #include <loops/schedule.hxx>
 #include <loops/container/formats.hxx>
@@ -29,6 +31,10 @@
 #include <loops/algorithms/spmv/thread_mapped.cuh>
 #include <loops/algorithms/spmv/work_oriented.cuh>
 #include <loops/algorithms/spmm/thread_mapped.cuh>
+#include <loops/algorithms/spmv/coo_thread_mapped.cuh>
+#include <loops/algorithms/spmv/csc_thread_mapped.cuh>
+#include <loops/algorithms/spmv/ell_thread_mapped.cuh>
+#include <loops/algorithms/spmv/bcsr_thread_mapped.cuh>
 
 #include <algorithm>
 
@@ -174,6 +180,71 @@ int refgpu_spmm_f32(long rows, long cols, long nnz, const int* off, const int* i
     }
     if (ms) *ms = best;
     thrust::copy(dC.m_data.begin(), dC.m_data.end(), Cm);
+    return 0;
+  } catch (...) { return 1; }
+}
+
+// The reference's kernels for the other sparse formats on this GPU.  The container is built from the
+// CSR with the reference's OWN converting constructors (coo.hxx:88, csc.hxx:105, ell.hxx:114), on the
+// device.  format: 0 = COO, 1 = CSC, 2 = ELL.  y is zero-filled before every run (their contract).
+int refgpu_format_spmv_f32(int format, long rows, long cols, long nnz, const int* off, const int* idx,
+                           const float* val, const float* x, float* y, int iters, float* ms) {
+  try {
+    host_csr h = make_host(rows, cols, nnz, off, idx, val);
+    dev_csr csr(h);
+    vector_t<float> dx(x, x + cols);
+    vector_t<float> dy(rows);
+    float best = 1e30f;
+    auto run = [&](auto&& call) {
+      for (int it = 0; it < iters; ++it) {
+        thrust::fill(dy.begin(), dy.end(), 0.0f);
+        hipDeviceSynchronize();
+        util::timer_t timer;
+        timer.start();
+        call();
+        timer.stop();
+        best = std::min(best, timer.milliseconds());
+      }
+    };
+    if (format == 0) {
+      coo_t<int, float> coo(csr);
+      run([&] { algorithms::spmv::coo_thread_mapped(coo, dx, dy); });
+    } else if (format == 1) {
+      csc_t<int, int, float> csc(csr);
+      run([&] { algorithms::spmv::csc_thread_mapped(csc, dx, dy); });
+    } else if (format == 2) {
+      ell_t<int, float> ell(csr);
+      run([&] { algorithms::spmv::ell_thread_mapped(ell, dx, dy); });
+    } else {
+      return 2;
+    }
+    if (ms) *ms = best;
+    thrust::copy(dy.begin(), dy.end(), y);
+    return 0;
+  } catch (...) { return 1; }
+}
+
+// The reference's bcsr_thread_mapped<4, 4> on this GPU, from ready block arrays (its host-side
+// CSR -> BCSR builder is not what is being timed).  x_padded has num_block_cols * 4 entries.
+int refgpu_bcsr4x4_spmv_f32(long rows, long cols, long num_block_rows, long num_block_cols, long num_blocks,
+                            const int* block_offsets, const int* block_cols, const float* block_values,
+                            const float* x_padded, float* y, int iters, float* ms) {
+  try {
+    bcsr_t<4, 4, int, int, float> b;
+    b.rows = rows; b.cols = cols; b.nnzs = num_blocks * 16;
+    b.num_block_rows = num_block_rows; b.num_block_cols = num_block_cols; b.num_blocks = num_blocks;
+    b.block_offsets = vector_t<int>(block_offsets, block_offsets + num_block_rows + 1);
+    b.block_col_indices = vector_t<int>(block_cols, block_cols + num_blocks);
+    b.values = vector_t<float>(block_values, block_values + num_blocks * 16);
+    vector_t<float> dx(x_padded, x_padded + num_block_cols * 4);
+    vector_t<float> dy(rows);
+    float best = 1e30f;
+    for (int it = 0; it < iters; ++it) {
+      auto timer = algorithms::spmv::bcsr_thread_mapped(b, dx, dy);
+      best = std::min(best, timer.milliseconds());
+    }
+    if (ms) *ms = best;
+    thrust::copy(dy.begin(), dy.end(), y);
     return 0;
   } catch (...) { return 1; }
 }
