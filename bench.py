@@ -352,16 +352,9 @@ def main():
         for _ in range(reps1):
             O.spmv_f32(off, idx, val, x_h)
         t1 = (time.perf_counter() - t0) / reps1
-        # threads = the CPUs this process may really use: affinity mask, capped by the cgroup CPU quota (a box
-        # that shows 256 logical CPUs but grants 16 CPUs' worth of time throttles a 128-thread team to a crawl)
-        usable = len(os.sched_getaffinity(0))
-        try:
-            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-            if quota != "max":
-                usable = max(1, min(usable, int(int(quota) / int(period))))
-        except (OSError, ValueError):
-            pass
-        O.lib().oracle_set_num_threads(int(usable))
+        # OpenMP leg: the oracle sizes its team to the CPUs this process may really use (affinity mask capped by
+        # the cgroup quota, oracle.usable_cpus): a box that shows 256 logical CPUs but grants 16 CPUs' worth of
+        # time throttles a 128-thread team to a crawl
         threads = O.lib().oracle_num_threads()
         t0 = time.perf_counter()
         O.spmv_f32(off, idx, val, x_h, omp=True)

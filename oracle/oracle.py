@@ -51,7 +51,20 @@ def lib() -> C.CDLL:
         _LIB.oracle_hash.restype = C.c_uint
         _LIB.oracle_hash.argtypes = [C.c_uint]
         _LIB.oracle_default_ne_f32.argtypes = [C.c_float, C.c_float]
+        _LIB.oracle_set_num_threads(usable_cpus())  # OpenMP variants: never more threads than CPUs granted
     return _LIB
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def ref() -> C.CDLL | None:
