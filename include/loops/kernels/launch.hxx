@@ -34,7 +34,21 @@ struct merge_plan_view {
   int* carry_row;       ///< M carry-out rows
   void* carry_val;      ///< M carry-out partial sums (value type of the SpMV)
   int num_merge_tiles;  ///< M
+  bool self_complete = false;  ///< every tile head <= TPB (launch_merge_path_head_check): no carries, no fix-up
+  const int* head_start = nullptr;  ///< M first-nonzero-of-the-first-row entries (self-completing plans)
 };
+
+/// Sets *flag_dev (zeroed here) to 1 if some merge tile starts more than `limit` nonzeros inside a row.
+template <typename offset_t>
+int launch_merge_path_head_check(hipStream_t stream, const coord_t* coords, int num_merge_tiles, int rows,
+                                 const offset_t* offsets, int limit, int* flag_dev, int* head_start) {
+  hipError_t e = hipMemsetAsync(flag_dev, 0, sizeof(int), stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (num_merge_tiles == 0) return 0;
+  hipLaunchKernelGGL(merge_path_head_check<offset_t>, dim3(math::ceil_div(num_merge_tiles, 256)), dim3(256), 0, stream,
+                     coords, num_merge_tiles, rows, offsets, limit, flag_dev, head_start);
+  return launch_status();
+}
 
 /// coords[i] = merge-path split at diagonal i * tpb * ipt, i in [0, M].
 template <typename offset_t>
@@ -56,6 +70,20 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   if (m == 0) return 0;
   if (m == 1) stages &= ~2;  // one tile holds every row completely: no carry-out to add (launch-bound sizes: 1 kernel)
   T* carry_val = static_cast<T*>(plan.carry_val);
+  if (plan.self_complete && plan.head_start && !stacked && m > 1) {
+    // no row crosses more than one tile boundary with more than TPB nonzeros behind it: tiles complete their
+    // rows themselves -- one kernel, no carry-outs (the "fix-up" stage has nothing to do)
+    if (stages & 1) {
+      const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+      if (aligned)
+        hipLaunchKernelGGL((merge_path_spmv_fused_self<TPB, IPT, PAD, NT, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
+                           stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y);
+      else
+        hipLaunchKernelGGL((merge_path_spmv_fused_self<TPB, IPT, PAD, NT, false, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
+                           stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y);
+    }
+    return launch_status();
+  }
   if (stages & 1) {
     const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
     auto go = [&](auto kernel) {

@@ -135,6 +135,26 @@ __global__ void merge_path_coordinates(const offset_t* __restrict__ offsets, int
   coords[i] = coord_t{static_cast<unsigned int>(lo < rows ? lo : rows), static_cast<unsigned int>(d - lo)};
 }
 
+/// Largest "head" over all merge tiles: head(b) = nonzeros of the row a tile STARTS in that lie before the
+/// tile (coords[b].y - offsets[coords[b].x]).  If no head exceeds `limit`, every row crosses at most one tile
+/// boundary and the closing tile can re-read the <= limit nonzeros it is missing itself: the plan is
+/// "self-completing" -- no carry-outs, no fix-up kernel (merge_path_spmv_fused<..., SELF = true>).
+/// Also records head_start[b] = the first nonzero of that row (what the self-completing kernel starts from).
+template <typename offset_t>
+__global__ void merge_path_head_check(const coord_t* __restrict__ coords, const int num_merge_tiles, const int rows,
+                                      const offset_t* __restrict__ offsets, const int limit, int* __restrict__ flag,
+                                      int* __restrict__ head_start) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= num_merge_tiles) return;
+  const coord_t c = coords[b];
+  int start = static_cast<int>(c.y);
+  if (static_cast<int>(c.x) < rows) {
+    start = static_cast<int>(offsets[c.x]);
+    if (static_cast<int>(c.y) - start > limit) atomicOr(flag, 1);
+  }
+  head_start[b] = start;
+}
+
 /**
  * The merge-tile engine shared by the three tuned CSR SpMV kernels.  One call processes ONE
  * merge tile -- `nrows` row ends and `natoms` nonzeros starting at (row0, nz0) on the merge path,
@@ -326,15 +346,22 @@ struct merge_tile_engine {
  * @tparam NT   stream col_idx / values with non-temporal loads.
  * @tparam VEC  `indices` and `values` are 16-byte aligned (checked by the host launcher).
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, bool SELF, typename index_t, typename offset_t, typename type_t>
 __device__ __forceinline__ void
 merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const int nnz,
-                      const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
-                      const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
-                      int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t>;
+                     const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                     const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                     int* __restrict__ carry_row, type_t* __restrict__ carry_val,
+                     const int* __restrict__ head_start = nullptr) {
+  // SELF (self-completing plans, merge_path_head_check): the tile is EXTENDED backwards to the start of the row
+  // it begins in -- at most TPB extra nonzeros -- so that row is summed completely here and nothing has to be
+  // carried in from the previous tile (which sums the same nonzeros into an open tail it then discards).
+  // The extended tile has up to TPB * IPT + TPB merge items: one more item per thread.
+  constexpr int ITEMS = SELF ? IPT + 1 : IPT;
+  constexpr bool PADDED = SELF ? (ITEMS % 2 == 0) : PAD;
+  using engine_t = merge_tile_engine<TPB, ITEMS, PADDED, NT, VEC, index_t, offset_t, type_t>;
   __shared__ typename engine_t::storage_t s_engine;
-  __shared__ offset_t s_re[TPB * IPT + IPT + 1];
+  __shared__ offset_t s_re[TPB * ITEMS + ITEMS + 1];
 
   const int tid = threadIdx.x;
   const int b = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
@@ -344,20 +371,23 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   const coord_t c0 = single ? coord_t{0u, 0u} : coords[b];
   const coord_t c1 = single ? coord_t{static_cast<unsigned int>(rows), static_cast<unsigned int>(nnz)} : coords[b + 1];
   const int row0 = static_cast<int>(c0.x);
-  const int nz0 = static_cast<int>(c0.y);
+  int nz0 = static_cast<int>(c0.y);
   const int nrows = static_cast<int>(c1.x) - row0;
+  if constexpr (SELF) nz0 = head_start[b];  // back to the start of row `row0` (recorded by merge_path_head_check)
   const int natoms = static_cast<int>(c1.y) - nz0;
 
   // row ends of the tile -> LDS (visible after the engine's first barrier)
-  for (int i = tid; i < nrows + IPT; i += TPB) {
+  for (int i = tid; i < nrows + ITEMS; i += TPB) {
     int r = row0 + i;
     r = r < rows - 1 ? r : rows - 1;
     s_re[i] = offsets[r + 1];
   }
   const type_t carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, type_t(0));
-  if (tid == 0) {
-    carry_row[b] = row0 + nrows;  // == c1.x: the row still open when the tile ends
-    carry_val[b] = carry;
+  if constexpr (!SELF) {
+    if (tid == 0) {
+      carry_row[b] = row0 + nrows;  // == c1.x: the row still open when the tile ends
+      carry_val[b] = carry;
+    }
   }
 }
 
@@ -367,7 +397,18 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
                       const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                       const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
                       int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
+}
+
+/// Self-completing variant (plans whose heads are all <= TPB, merge_path_head_check): every tile finishes the
+/// rows it closes by itself, nothing is carried between tiles and no fix-up kernel follows.
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused_self(const coord_t* __restrict__ coords, const int* __restrict__ head_start, const int rows,
+                           const int nnz, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                           const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y) {
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, true>(coords, rows, nnz, offsets, indices, values, x, y, nullptr,
+                                                     static_cast<type_t*>(nullptr), head_start);
 }
 
 /// The same kernel under its own symbol for column-blocked ("stacked") CSRs (column_blocked.hxx), so
@@ -378,7 +419,7 @@ merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows
                               const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                               const type_t* __restrict__ values, const type_t* __restrict__ x,
                               type_t* __restrict__ y, int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
 }
 
 /**

@@ -63,6 +63,22 @@ __global__ void generate_search_coordinates(layout_t layout, tile_size_t num_til
   }
 }
 
+/// For every merge tile b: head_start[b] = first atom of the tile (row) the merge tile starts in, and
+/// *flag |= 1 if that is more than `limit` atoms before the merge tile (see preprocess_t::classify).
+template <typename layout_t>
+__global__ void classify_tile_heads(layout_t layout, const coord_t* coords, std::size_t num_merge_tiles,
+                                    unsigned int limit, int* flag, int* head_start) {
+  const std::size_t b = static_cast<std::size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= num_merge_tiles) return;
+  const coord_t c = coords[b];
+  unsigned int start = c.y;
+  if (c.x < static_cast<unsigned int>(layout.num_tiles())) {
+    start = static_cast<unsigned int>(layout.tile_begin(c.x));
+    if (c.y - start > limit) atomicOr(flag, 1);
+  }
+  head_start[b] = static_cast<int>(start);
+}
+
 /**
  * Host-side plan for a (layout, TPB, IPT) triple: the per-workgroup start coordinates, plus
  * the scratch the fused SpMV needs for rows that straddle workgroups (one {row, partial}
@@ -94,10 +110,14 @@ class preprocess_t {
         num_merge_tiles(math::ceil_div(total_work, items_per_tile)),
         d_tile_coordinates(nullptr),
         d_scratch(nullptr),
-        owner(true) {
-    // one allocation: [coords (M+1) x 8 B | carry values (M+2) x 8 B | carry rows (M+2) x 4 B]
+        owner(true),
+        self_complete_(false),
+        layout_copy(_layout) {
+    // one allocation: [coords (M+1) x 8 B | carry values (M+2) x 8 B | carry rows (M+2) x 4 B |
+    //                  head flag 4 B | head starts (M+1) x 4 B]
     const std::size_t coord_bytes = (num_merge_tiles + 1) * sizeof(coord_t);
-    const std::size_t bytes = coord_bytes + (num_merge_tiles + 2) * (sizeof(double) + sizeof(int));
+    const std::size_t bytes = coord_bytes + (num_merge_tiles + 2) * (sizeof(double) + sizeof(int)) +
+                              (num_merge_tiles + 2) * sizeof(int);
     error::throw_if_exception(xpu::malloc(&d_scratch, bytes), "merge_path::preprocess_t: allocation failed.");
     if (prepass == prepass_always || (prepass == prepass_auto && num_merge_tiles >= min_tiles_for_prepass)) {
       d_tile_coordinates = static_cast<coord_t*>(d_scratch);
@@ -116,7 +136,9 @@ class preprocess_t {
         num_merge_tiles(rhs.num_merge_tiles),
         d_tile_coordinates(rhs.d_tile_coordinates),
         d_scratch(rhs.d_scratch),
-        owner(false) {}
+        owner(false),
+        self_complete_(rhs.self_complete_),
+        layout_copy(rhs.layout_copy) {}
   preprocess_t& operator=(preprocess_t const&) = delete;
 
   __host__ __device__ ~preprocess_t() {
@@ -140,12 +162,39 @@ class preprocess_t {
                                   (num_merge_tiles + 2) * sizeof(double));
   }
 
+  /// Decides (one stream synchronisation) whether the fused SpMV over this plan can run as ONE kernel: true
+  /// when no merge tile starts more than THREADS_PER_BLOCK atoms inside a tile of the layout (row) -- every
+  /// merge tile can then re-read the short head of its first row itself and nothing is carried between
+  /// tiles (kernels::merge_path_spmv_fused_self).  Needs the coordinate table (prepass run).
+  bool classify(xpu::stream_t stream = 0) {
+    self_complete_ = false;
+    if (!d_tile_coordinates || num_merge_tiles <= 1) return false;
+    int* flag = head_flag();
+    if (hipMemsetAsync(flag, 0, sizeof(int), stream) != hipSuccess) return false;
+    constexpr std::size_t block = 256;
+    launch::non_cooperative(stream, classify_tile_heads<layout_t>,
+                            dim3(static_cast<unsigned int>(math::ceil_div(num_merge_tiles, block))), dim3(block),
+                            layout_copy, d_tile_coordinates, num_merge_tiles,
+                            static_cast<unsigned int>(THREADS_PER_BLOCK), flag, head_starts());
+    int host_flag = 1;
+    if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+    if (xpu::stream_synchronize(stream) != 0) return false;
+    self_complete_ = host_flag == 0;
+    return self_complete_;
+  }
+  __host__ __device__ bool self_complete() const { return self_complete_; }
+  __host__ __device__ int* head_starts() const { return head_flag() + 1; }
+
  private:
   std::size_t total_work;
   std::size_t num_merge_tiles;
+  __host__ __device__ int* head_flag() const { return carry_rows() + (num_merge_tiles + 2); }
+
   coord_t* d_tile_coordinates;
   void* d_scratch;
   bool owner;
+  bool self_complete_;
+  layout_t layout_copy;
 };
 
 }  // namespace merge_path

@@ -69,6 +69,11 @@ int loops_merge_plan_destroy(loops_merge_plan_t* plan);
 /* Recompute the coordinates on `stream` (what constructing a new preprocess_t does). */
 int loops_merge_plan_refresh(loops_merge_plan_t* plan, const int* offsets, void* stream);
 int loops_merge_plan_num_tiles(const loops_merge_plan_t* plan);
+/* 1 if no merge tile starts more than TPB nonzeros inside a row (checked when the plan is created or
+ * refreshed, one stream synchronisation): the planned merge_path_flat SpMV then runs as ONE kernel -- every
+ * tile re-reads the short head of its first row itself, nothing is carried between tiles, no fix-up launch.
+ * 0 otherwise (some row is long: tile kernel + carry-out fix-up, as in every plan-less call). */
+int loops_merge_plan_self_complete(const loops_merge_plan_t* plan);
 /* Synchronous copy of the 2 * (M + 1) unsigned coordinates {x0, y0, x1, y1, ...} to the host. */
 int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
 

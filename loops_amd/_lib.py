@@ -29,7 +29,7 @@ TILES = {"256x8": (0, 256, 8), "128x7": (1, 128, 7), "4x2": (2, 4, 2), "256x7": 
 SYMBOLS = [
     "loops_version", "loops_device_compute_units",
     "loops_merge_plan_create", "loops_merge_plan_destroy", "loops_merge_plan_refresh",
-    "loops_merge_plan_num_tiles", "loops_merge_plan_coords",
+    "loops_merge_plan_num_tiles", "loops_merge_plan_coords", "loops_merge_plan_self_complete",
     "loops_spmv_csr_f32", "loops_spmv_csr_f64", "loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64",
     "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
         L.loops_merge_plan_destroy.argtypes = [vp]
         L.loops_merge_plan_refresh.argtypes = [vp, vp, vp]
         L.loops_merge_plan_num_tiles.argtypes = [vp]
+        L.loops_merge_plan_self_complete.argtypes = [vp]
         L.loops_merge_plan_coords.argtypes = [vp, vp]
         for name in ("loops_spmv_csr_f32", "loops_spmv_csr_f64"):
             getattr(L, name).argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]

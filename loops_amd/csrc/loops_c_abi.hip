@@ -71,6 +71,9 @@ struct loops_merge_plan {
   void* base;
   mutable void* wide_carry;         // SpMM carry-outs, M x n values, grown on demand
   mutable size_t wide_carry_bytes;
+  int* head_flag;      // device word written by merge_path_head_check
+  int* head_start;     // M + 1: first nonzero of the row each tile starts in
+  int self_complete;   // 1: every tile head <= tpb -> one kernel, no carry-outs / fix-up (held plans only)
 };
 
 namespace {
@@ -78,6 +81,21 @@ namespace {
 int plan_compute(loops_merge_plan* p, const int* offsets, hipStream_t stream) {
   return kernels::launch_merge_path_coordinates(stream, offsets, p->rows, p->nnz, p->tpb * p->ipt, p->num_tiles,
                                                 p->coords);
+}
+
+// Held plans only (one synchronisation at creation / refresh): can every tile finish its rows by itself?
+int plan_classify(loops_merge_plan* p, const int* offsets, hipStream_t stream) {
+  p->self_complete = 0;
+  if (p->num_tiles <= 1) return 0;
+  int err = kernels::launch_merge_path_head_check(stream, p->coords, p->num_tiles, p->rows, offsets, p->tpb, p->head_flag,
+                                                  p->head_start);
+  if (err) return err;
+  int flag = 1;
+  hipError_t e = hipMemcpyAsync(&flag, p->head_flag, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  p->self_complete = flag == 0 ? 1 : 0;
+  return 0;
 }
 
 int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
@@ -91,12 +109,15 @@ int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
   p->num_tiles = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(s.tpb) * s.ipt));
   p->capacity = p->num_tiles;
   const size_t m = static_cast<size_t>(p->num_tiles);
-  const size_t bytes = (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int));
+  const size_t bytes = (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int)) + (m + 2) * sizeof(int);
   hipError_t e = hipMalloc(&p->base, bytes);
   if (e != hipSuccess) { delete p; return static_cast<int>(e); }
   p->coords = static_cast<coord_t*>(p->base);
   p->carry_val = reinterpret_cast<double*>(p->coords + (m + 1));
   p->carry_row = reinterpret_cast<int*>(p->carry_val + (m + 2));
+  p->head_flag = p->carry_row + (m + 2);
+  p->head_start = p->head_flag + 1;
+  p->self_complete = 0;
   *out = p;
   return 0;
 }
@@ -126,7 +147,7 @@ loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
 template <int TPB, int IPT, bool PAD, bool NT, typename T>
 int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, const int* off, const int* idx,
                  const T* val, const T* x, T* y, hipStream_t stream, int stages) {
-  kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles};
+  kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles, p->self_complete != 0, p->head_start};
   return kernels::launch_merge_path_fused<TPB, IPT, PAD, NT>(stream, view, rows, nnz, off, idx, val, x, y, stages);
 }
 
@@ -422,6 +443,7 @@ int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_conf
   int err = plan_alloc(rows, nnz, tile_config, &p);
   if (err) return err;
   err = plan_compute(p, offsets, as_stream(stream));
+  if (!err) err = plan_classify(p, offsets, as_stream(stream));
   if (err) { (void)hipFree(p->base); delete p; return err; }
   *out = p;
   return 0;
@@ -437,8 +459,12 @@ int loops_merge_plan_destroy(loops_merge_plan_t* plan) {
 
 int loops_merge_plan_refresh(loops_merge_plan_t* plan, const int* offsets, void* stream) {
   if (!plan || !offsets) return LOOPS_E_BADARG;
-  return plan_compute(plan, offsets, as_stream(stream));
+  int err = plan_compute(plan, offsets, as_stream(stream));
+  if (!err) err = plan_classify(plan, offsets, as_stream(stream));
+  return err;
 }
+
+int loops_merge_plan_self_complete(const loops_merge_plan_t* plan) { return plan ? plan->self_complete : LOOPS_E_BADARG; }
 
 int loops_merge_plan_num_tiles(const loops_merge_plan_t* plan) { return plan ? plan->num_tiles : LOOPS_E_BADARG; }
 

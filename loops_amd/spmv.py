@@ -73,6 +73,11 @@ class MergePathPlan:
     def num_tiles(self) -> int:
         return int(L.lib().loops_merge_plan_num_tiles(self._h))
 
+    @property
+    def self_complete(self) -> bool:
+        """True when the planned SpMV runs as one kernel (no row needs a carry-out; loops_merge_plan_self_complete)."""
+        return bool(L.lib().loops_merge_plan_self_complete(self._h))
+
     def coords(self) -> np.ndarray:
         out = np.zeros((self.num_tiles + 1, 2), np.uint32)
         L.check(L.lib().loops_merge_plan_coords(self._h, out.ctypes.data_as(C.c_void_p)), "loops_merge_plan_coords")

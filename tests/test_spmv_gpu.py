@@ -308,3 +308,37 @@ def test_launch_box_autotuner():
     assert all(t > 0 for t in times.values()) and times[best] == min(times.values())
     plan = S.MergePathPlan(csr, best)
     assert torch.equal(S.merge_path_flat(csr, x, plan=plan), S.spmv("merge_path_flat", csr, x))
+
+
+@pytest.mark.parametrize("tile", ["256x8", "128x7", "256x7", "512x8", "256x16"])
+def test_self_completing_plans(tile):
+    """Held plans whose tiles all start <= TPB nonzeros inside a row run as ONE kernel (tiles re-read the short
+    head of their first row, no carry-outs, no fix-up); plans over long rows keep the two-kernel path.  Both
+    must give the plain result; the classification must match its definition."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    tpb, ipt = int(tile.split("x")[0]), int(tile.split("x")[1])
+    rng = np.random.default_rng(tpb + ipt)
+    cases = {
+        "degree 16": np.full(40_000, 16, np.int64),
+        "degree 0..40": rng.integers(0, 41, size=30_000),
+        "rows up to 2*TPB": rng.integers(0, 2 * tpb, size=4_000),          # some heads > TPB: not self-completing
+        "one long row among short ones": np.concatenate([np.full(5_000, 8, np.int64), [5 * tpb * ipt], np.full(5_000, 8, np.int64)]),
+        "75 % empty": np.where(np.arange(60_000) % 4 == 0, 32, 0).astype(np.int64),
+    }
+    for name, deg in cases.items():
+        rows = deg.size
+        cols = 50_000
+        off, idx, val = G.csr_from_degrees(deg.astype(np.int64), cols, 1, 0, True, None)
+        csr = _dev(off, idx, val, rows, cols)
+        xh = G.uniform_distribution_int(cols)
+        x = torch.from_numpy(xh).cuda()
+        plan = S.MergePathPlan(csr, tile)
+        # definition: every tile's head (nonzeros of its first row that precede it) is <= TPB
+        coords = plan.coords().astype(np.int64)
+        heads = [int(c[1]) - int(off[c[0]]) for c in coords[:-1] if c[0] < rows]
+        assert plan.self_complete == (plan.num_tiles > 1 and max(heads) <= tpb), (name, tile, max(heads))
+        y = torch.full((rows,), 3.0, device="cuda")
+        S.merge_path_flat(csr, x, y, plan=plan)
+        assert np.array_equal(y.cpu().numpy(), O.spmv_f32(off, idx, val, xh)), (name, tile)
+    assert any(True for _ in cases)
