@@ -341,4 +341,9 @@ def test_self_completing_plans(tile):
         y = torch.full((rows,), 3.0, device="cuda")
         S.merge_path_flat(csr, x, y, plan=plan)
         assert np.array_equal(y.cpu().numpy(), O.spmv_f32(off, idx, val, xh)), (name, tile)
-    assert any(True for _ in cases)
+        # the same plan type in fp64 (the classification depends on the structure only)
+        csr64 = _dev(off, idx, val.astype(np.float64), rows, cols)
+        plan64 = S.MergePathPlan(csr64, tile)
+        assert plan64.self_complete == plan.self_complete
+        y64 = S.merge_path_flat(csr64, x.double(), plan=plan64).cpu().numpy()
+        assert np.array_equal(y64, O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64))), (name, tile, "f64")
