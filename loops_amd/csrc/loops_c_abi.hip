@@ -746,6 +746,7 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
     loops_merge_plan* p = nullptr;
     err = plan_alloc(rows, nnz, cfg, &p);
     if (!err) err = plan_compute(p, offsets, st);
+    if (!err) err = plan_classify(p, offsets, st);  // time what a held plan of this shape would run
     for (int it = 0; !err && it < 2; ++it) err = spmv_merge_path<float>(p, 0, rows, nnz, offsets, indices, values, x, y, st);
     float ms = 0.f;
     if (!err) {
