@@ -78,6 +78,11 @@ def main():
     ap.add_argument("--ref-gpu", action="store_true",
                     help="also time the reference's own HIP kernels on this GPU (oracle/_ref/libloops_ref_gpu.so)")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
+    ap.add_argument("--overlap-chunks", type=int, default=2,
+                    help="N > 1: also try the step with the SpMV cut into this many row chunks whose exchanges overlap "
+                         "the next chunk's kernel (0 = do not try); the fastest candidate of the start-up probe is used")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "padded", "p2p-chunked"],
+                    help="N > 1: allgatherv implementation; auto = the fastest of the start-up probe")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked"],
                     help="how a rank holds its row-range shard: 'csr' as sliced; 'blocked' = column-blocked by owner "
                          "(x of N x 4 MB does not fit the per-XCD L2: include/loops/kernels/column_blocked.hxx); "
@@ -139,10 +144,41 @@ def main():
         else:
             S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
 
+    chunked = {"plans": None, "exchange": None}
+
     def step():
+        if gather_mode["mode"] == "p2p-chunked":
+            for c, (sub_run, y_sub) in enumerate(chunked["plans"]):
+                sub_run(y_sub)
+                chunked["exchange"].post(c)
+            chunked["exchange"].finish()
+            return
         spmv_local()
         if world > 1:
             exchanges[gather_mode["mode"]].run()
+
+    def build_chunked(chunks):
+        """The shard cut into `chunks` row pieces (balanced by rows + nnz), each with its own plan in the shard's
+        layout, and the chunked exchange over the matching pieces of every rank's slice."""
+        cb = P.chunk_bounds_from_degrees(degrees, bounds, chunks)
+        mine = cb[rank] - shard.row_begin
+        plans = []
+        keep = []  # device CSRs / plans must outlive the closures
+        for c in range(chunks):
+            a, b = int(mine[c]), int(mine[c + 1])
+            so, si, sv = P.slice_csr(off, idx, val, a, b)
+            sub = S.CSR.from_numpy(b - a, cols, so, si, sv)
+            y_sub = y_loc[a:b]
+            if blocked is not None:
+                pl = S.ColumnBlockedPlan(sub, block_bounds=P.column_block_bounds(bounds))
+                run = (lambda pl: (lambda y_sub: pl.spmv(x, y_sub)))(pl)
+            else:
+                pl = S.MergePathPlan(sub, args.tile)
+                run = (lambda sub, pl: (lambda y_sub: S.merge_path_flat(sub, x, y_sub, plan=pl, variant=args.variant)))(sub, pl)
+            keep.append((sub, pl))
+            plans.append((run, y_sub))
+        chunked["plans"], chunked["keep"] = plans, keep
+        chunked["exchange"] = P.ChunkedAllgatherv(y_full, shard, cb)
 
     comm_dev = "cuda" if args.backend == "nccl" else "cpu"
     exchange_probe = None
@@ -178,7 +214,33 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             exchange_probe[mode] = round(float(t), 5)
         assert exchange_probe, "no allgatherv implementation works on this backend"
+        if args.overlap_chunks >= 2 and "p2p" in exchange_probe:
+            # third candidate: the same p2p exchange, posted per row chunk so that it overlaps the next chunk's kernel
+            ok = 1.0
+            try:
+                build_chunked(args.overlap_chunks)
+                gather_mode["mode"] = "p2p-chunked"
+                step()
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] chunked overlap unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], device=comm_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag) >= 1.0:
+                dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=comm_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exchange_probe["p2p-chunked"] = round(float(t), 5)
         gather_mode["mode"] = min(exchange_probe, key=exchange_probe.get)
+        if args.exchange != "auto":
+            assert args.exchange in exchange_probe, f"--exchange {args.exchange} is not available here: {exchange_probe}"
+            gather_mode["mode"] = args.exchange
 
     def barrier():
         if world > 1:
@@ -385,7 +447,7 @@ def main():
                        "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
                                        f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)",
-                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}]" if world > 1 else ""),
+                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (f", {args.overlap_chunks} chunks overlapping the SpMV" if gather_mode['mode'] == 'p2p-chunked' else "") + "]" if world > 1 else ""),
                        "ms_per_step_with_prepass": None if ms_with_prepass is None else round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
                        "allgatherv_probe_ms_per_step": exchange_probe,

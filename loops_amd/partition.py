@@ -176,6 +176,63 @@ class Allgatherv:
         return self.y_full
 
 
+class ChunkedAllgatherv:
+    """The allgatherv(y) of a step cut into C chunks that overlap with the SpMV: every rank's slice is split
+    into C contiguous row chunks (`chunk_bounds[r]` = the C + 1 GLOBAL row boundaries of rank r's slice); as
+    soon as a rank has computed its chunk c it posts the grouped point-to-point exchange of chunk c of EVERY
+    rank (`post(c)`, asynchronous: the transfer runs on the communication stream while chunk c + 1 is being
+    computed), and `finish()` waits for all of them at the end of the step.  Same direct pattern as mode
+    "p2p" of `Allgatherv`, C groups of smaller messages instead of one."""
+
+    def __init__(self, y_full: torch.Tensor, shard: Shard, chunk_bounds, group=None):
+        self.y_full, self.shard, self.group = y_full, shard, group
+        self.chunks = len(chunk_bounds[shard.rank]) - 1
+        self.staged = shard.world > 1 and y_full.is_cuda and dist.get_backend(group) == "gloo"
+        self.pending = []
+        self.ops = []
+        if shard.world == 1 or self.staged:
+            return
+        for c in range(self.chunks):
+            mine = y_full[int(chunk_bounds[shard.rank][c]):int(chunk_bounds[shard.rank][c + 1])]
+            ops = []
+            for peer in range(shard.world):
+                if peer == shard.rank:
+                    continue
+                if mine.numel():
+                    ops.append(dist.P2POp(dist.isend, mine, peer, group))
+                theirs = y_full[int(chunk_bounds[peer][c]):int(chunk_bounds[peer][c + 1])]
+                if theirs.numel():
+                    ops.append(dist.P2POp(dist.irecv, theirs, peer, group))
+            self.ops.append(ops)
+
+    def post(self, c: int) -> None:
+        if self.shard.world == 1 or self.staged:
+            return
+        if self.ops[c]:
+            self.pending.extend(dist.batch_isend_irecv(self.ops[c]))
+
+    def finish(self) -> torch.Tensor:
+        if self.shard.world == 1:
+            return self.y_full
+        if self.staged:  # functional-test path (ranks sharing one GPU over gloo): one staged exchange at the end
+            return allgatherv_(self.y_full, self.shard, self.group, "p2p")
+        for req in self.pending:
+            req.wait()
+        self.pending = []
+        return self.y_full
+
+
+def chunk_bounds_from_degrees(degrees: np.ndarray, bounds: np.ndarray, chunks: int):
+    """For every rank r: the chunks + 1 GLOBAL row boundaries that cut its slice [bounds[r], bounds[r + 1]) into
+    `chunks` pieces balanced by rows + nonzeros (same split rule as the ranks themselves).  Every rank computes
+    the same table from the same degrees: no communication."""
+    out = []
+    for r in range(bounds.size - 1):
+        a, b = int(bounds[r]), int(bounds[r + 1])
+        out.append(row_ranges_from_degrees(degrees[a:b], chunks) + a)
+    return out
+
+
 def column_block_bounds(owner_bounds, max_blocks: int = 8, target_bytes: int = 2 << 20, elem_bytes: int = 4):
     """Column boundaries for the column-blocked layout of a shard (spmv.ColumnBlockedPlan): the owners'
     row ranges (x[block k] = the y slice rank k produces), each cut into s equal pieces so that a block

@@ -64,6 +64,16 @@ def _worker(rank, world, port, q):
                 y2[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1) * rep
                 ex.run()
                 ok = ok and bool(torch.equal(y2, want * rep))
+        # chunked exchange: every rank's slice in 2 pieces, posted one after the other, waited at the end
+        cb = [np.array([bounds[r], (bounds[r] + bounds[r + 1]) // 2, bounds[r + 1]], np.int64) for r in range(world)]
+        y3 = torch.full((total,), -1.0)
+        y3[shard.row_begin:shard.row_end] = torch.arange(shard.row_begin, shard.row_end, dtype=torch.float32) * (rank + 1)
+        cx = P.ChunkedAllgatherv(y3, shard, cb)
+        for rep in range(2):
+            for c in range(cx.chunks):
+                cx.post(c)
+            cx.finish()
+            ok = ok and bool(torch.equal(y3, want))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -98,3 +108,13 @@ def test_column_block_bounds_follow_owner_ranges():
     assert P.column_block_bounds(np.array([0, 1 << 20])).size - 1 == 2            # N = 1: 4 MB -> 2 blocks
     assert P.column_block_bounds(np.arange(9) << 20).size - 1 == 8                # N = 8: one block per owner
     assert P.column_block_bounds(np.array([0, 1000, 2000])).tolist() == [0, 1000, 2000]   # small x: owners only
+
+
+def test_chunk_bounds_from_degrees_cover_each_slice():
+    from loops_amd import generate as G, partition as P
+    deg = G.powerlaw_degrees(1 << 13, 1 << 17, cap=1 << 11)
+    bounds = P.row_ranges_from_degrees(deg, 4)
+    cb = P.chunk_bounds_from_degrees(deg, bounds, 3)
+    assert len(cb) == 4
+    for r in range(4):
+        assert cb[r][0] == bounds[r] and cb[r][-1] == bounds[r + 1] and cb[r].size == 4 and (np.diff(cb[r]) >= 0).all()

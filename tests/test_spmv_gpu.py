@@ -294,6 +294,14 @@ def test_bench_two_ranks_functional():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["shard_layout"] == "csr" and d["config"]["parity_vs_oracle_bit_exact"] is True
+    assert set(d["config"]["allgatherv_probe_ms_per_step"]) == {"p2p", "padded", "p2p-chunked"}
+    # every exchange implementation, forced: same gathered vector (checked against the oracle inside bench.py)
+    for exchange in ("padded", "p2p-chunked"):
+        r = subprocess.run(cmd + ["--exchange", exchange, "--overlap-chunks", "3"], capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["config"]["parity_vs_oracle_bit_exact"] is True and exchange in d["config"]["step_includes"]
 
 
 def test_launch_box_autotuner():
