@@ -181,6 +181,21 @@ def main():
         chunked["exchange"] = P.ChunkedAllgatherv(y_full, shard, cb)
 
     comm_dev = "cuda" if args.backend == "nccl" else "cpu"
+
+    def probe_ms(warm=3, timed=20):
+        """ms per step of the current gather_mode: max over ranks, connections / caches warmed first."""
+        for _ in range(warm):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            step()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / timed * 1e3], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t), 5)
+
     exchange_probe = None
     if world > 1:
         # The exchange is an allgatherv(y).  Two implementations (loops_amd/partition.py): "p2p" = one grouped
@@ -204,15 +219,7 @@ def main():
             if float(flag) < 1.0:
                 exchanges.pop(mode, None)
                 continue
-            dist.barrier()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(10):
-                step()
-            torch.cuda.synchronize()
-            t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=comm_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            exchange_probe[mode] = round(float(t), 5)
+            exchange_probe[mode] = probe_ms()
         assert exchange_probe, "no allgatherv implementation works on this backend"
         if args.overlap_chunks >= 2 and "p2p" in exchange_probe:
             # third candidate: the same p2p exchange, posted per row chunk so that it overlaps the next chunk's kernel
@@ -228,15 +235,7 @@ def main():
             flag = torch.tensor([ok], device=comm_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag) >= 1.0:
-                dist.barrier()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    step()
-                torch.cuda.synchronize()
-                t = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], dtype=torch.float64, device=comm_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                exchange_probe["p2p-chunked"] = round(float(t), 5)
+                exchange_probe["p2p-chunked"] = probe_ms()
         gather_mode["mode"] = min(exchange_probe, key=exchange_probe.get)
         if args.exchange != "auto":
             assert args.exchange in exchange_probe, f"--exchange {args.exchange} is not available here: {exchange_probe}"
