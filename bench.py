@@ -300,6 +300,16 @@ def main():
         k_main_avg, k_main_med = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 0, args.variant), iters)
         k_fix_avg, _ = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 1, args.variant), iters)
 
+    # the SpMV of a step without the exchange (BASELINE C5: "kernel-only and kernel + allgatherv")
+    for _ in range(5):
+        spmv_local()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        spmv_local()
+    torch.cuda.synchronize()
+    spmv_only_ms = (time.perf_counter() - t0) / iters * 1e3
+
     ms_with_prepass = None
     if blocked is None:  # the plan-less entry point: coordinates rebuilt every call, as the reference wrapper does
         def with_prepass():
@@ -449,6 +459,7 @@ def main():
                        "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (f", {args.overlap_chunks} chunks overlapping the SpMV" if gather_mode['mode'] == 'p2p-chunked' else "") + "]" if world > 1 else ""),
                        "ms_per_step_with_prepass": None if ms_with_prepass is None else round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
+                       "spmv_only_ms_per_step": round(spmv_only_ms, 5),
                        "allgatherv_probe_ms_per_step": exchange_probe,
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
                        "column_blocked_layout_same_matrix": blocked_info,
