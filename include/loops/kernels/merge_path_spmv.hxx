@@ -23,7 +23,13 @@
  *              through 4 LDS words, and the one partial row leaving the workgroup goes to a
  *              {row, value} carry-out slot.
  *  5. FIX-UP   a tiny second kernel adds the carry-outs to y (rows longer than a merge tile
- *              span several workgroups: max degree 2^14 vs 2048-item tiles).
+ *              span several workgroups: max degree 2^14 vs 2048-item tiles).  Plans in which no
+ *              tile starts more than TPB nonzeros inside a row skip 5 altogether: the tile is
+ *              extended backwards to the start of its first row (merge_path_spmv_fused_self).
+ *
+ * Workgroup -> tile mapping is XCD-contiguous (detail::xcd_contiguous): the hardware deals
+ * workgroups round-robin to the 8 XCDs, the kernels renumber them so that each XCD walks ONE
+ * contiguous run of tiles and its private L2 sees one neighbourhood of x.
  *
  * Steps 1-4 are the `merge_tile_engine`; the three tuned CSR kernels differ only in how they
  * cut the merge path into tiles: merge_path_flat (one plan tile per workgroup), work_oriented
