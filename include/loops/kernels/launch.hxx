@@ -62,7 +62,9 @@ int launch_merge_path_coordinates(hipStream_t stream, const offset_t* offsets, i
 
 /// Fused merge-path SpMV (+ fix-up).  stages: bit 0 = tile kernel, bit 1 = fix-up.
 /// `stacked`: the matrix is a column-blocked CSR -- same code under its own kernel symbol.
-template <int TPB, int IPT, bool PAD, bool NT, typename index_t, typename offset_t, typename T>
+/// MASK (default): bit-mask split instead of the per-thread search (merge_tile_engine<..., MASK = true>):
+/// 1-2 % faster on every input measured (C2 103.3 -> 102.5 us, band-8192 50.4 -> 49.5, runs 43.7 -> 42.7).
+template <int TPB, int IPT, bool PAD, bool NT, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
                             const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
                             int stages = 3, bool stacked = false) {
@@ -70,32 +72,31 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   if (m == 0) return 0;
   if (m == 1) stages &= ~2;  // one tile holds every row completely: no carry-out to add (launch-bound sizes: 1 kernel)
   T* carry_val = static_cast<T*>(plan.carry_val);
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
   if (plan.self_complete && plan.head_start && !stacked && m > 1) {
     // no row crosses more than one tile boundary with more than TPB nonzeros behind it: tiles complete their
     // rows themselves -- one kernel, no carry-outs (the "fix-up" stage has nothing to do)
     if (stages & 1) {
-      const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
       if (aligned)
-        hipLaunchKernelGGL((merge_path_spmv_fused_self<TPB, IPT, PAD, NT, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
-                           stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y);
+        hipLaunchKernelGGL((merge_path_spmv_fused_self<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>), dim3(m),
+                           dim3(TPB), 0, stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y);
       else
-        hipLaunchKernelGGL((merge_path_spmv_fused_self<TPB, IPT, PAD, NT, false, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
-                           stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y);
+        hipLaunchKernelGGL((merge_path_spmv_fused_self<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>), dim3(m),
+                           dim3(TPB), 0, stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y);
     }
     return launch_status();
   }
   if (stages & 1) {
-    const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
     auto go = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
                          plan.carry_row, carry_val);
     };
     if (stacked) {
-      if (aligned) go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, true, index_t, offset_t, T>);
-      else go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, false, index_t, offset_t, T>);
+      if (aligned) go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
+      else go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);
     } else {
-      if (aligned) go(merge_path_spmv_fused<TPB, IPT, PAD, NT, true, index_t, offset_t, T>);
-      else go(merge_path_spmv_fused<TPB, IPT, PAD, NT, false, index_t, offset_t, T>);
+      if (aligned) go(merge_path_spmv_fused<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
+      else go(merge_path_spmv_fused<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);
     }
   }
   if (stages & 2)

@@ -179,7 +179,8 @@ __global__ void merge_path_head_check(const coord_t* __restrict__ coords, const 
  * ends (row0 + nrows), uniform across the workgroup.  Collective: every thread of the workgroup
  * must call it; contains 3 workgroup barriers.
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+          bool MASK = false>
 struct merge_tile_engine {
   static constexpr int TILE = TPB * IPT;
   static constexpr int WAVES = TPB / wave::size;
@@ -191,7 +192,20 @@ struct merge_tile_engine {
     type_t wave_val[WAVES];
     int wave_head[WAVES];
     type_t carry;
+    // MASK split: bit p of `mask` = 1 iff merged position p of the tile is a row end
+    unsigned int mask[MASK ? TILE / 32 + 2 : 1];
+    int wave_ends[MASK ? WAVES : 1];
   };
+
+  /// MASK engines: zero the row-end marks (whole workgroup; follow with a barrier before marking).
+  static __device__ __forceinline__ void clear_marks(storage_t& s) {
+    for (int i = threadIdx.x; i < TILE / 32 + 2; i += TPB) s.mask[i] = 0u;
+  }
+  /// MASK engines: row (row0 + i) of the tile ends at nonzero offset `end` (tile starts at nonzero nz0).
+  static __device__ __forceinline__ void mark_row_end(storage_t& s, int i, int end, int nz0) {
+    const int p = (end - nz0) + i;
+    atomicOr(&s.mask[p >> 5], 1u << (p & 31));
+  }
 
   static __device__ __forceinline__ type_t run(storage_t& s, const offset_t* re, const int row0, const int nz0,
                                                const int nrows, const int natoms, const int nnz,
@@ -200,7 +214,6 @@ struct merge_tile_engine {
                                                type_t* __restrict__ y, const type_t carry_in) {
     const int tid = threadIdx.x;
     const int nz1 = nz0 + natoms;
-
     // ---- 1. STREAM ------------------------------------------------------------------------
     const int abase = VEC ? (nz0 & ~3) : nz0;  // 16-byte aligned element base of the tile
     const int shift = nz0 - abase;             // 0..3 leading elements owned by the previous tile
@@ -261,50 +274,91 @@ struct merge_tile_engine {
     if (s.prod[detail::slot<PAD>(tid)] == type_t(-12345.678)) y[tid] = type_t(1);
     return type_t(0);
 #endif
-    // ---- 2. SPLIT: this thread's start on the merge path (search.hxx semantics, in LDS) ------
+    // ---- 2. SPLIT: this thread's start on the merge path -------------------------------------
     const int total = nrows + natoms;  // == TILE except in a last / short tile
     const int diag = tid * IPT;
     int tx, ty;
-    {
-      int lo = diag - natoms > 0 ? diag - natoms : 0;
-      int count = (diag < nrows ? diag : nrows) - lo;
-      while (count > 0) {
-        const int half = count >> 1;
-        const int mid = lo + half;
-        if (re[mid] <= nz0 + (diag - mid - 1)) {
-          lo = mid + 1;
-          count -= half + 1;
-        } else {
-          count = half;
-        }
-      }
-      tx = lo < nrows ? lo : nrows;
-      ty = diag - lo;
-    }
-
-    // ---- 3. WALK: IPT merge steps out of LDS ------------------------------------------------
     type_t sum = type_t(0);
     type_t first_sum = type_t(0);
     int first_row = 0;
     bool closed = false;
-    int row_end = re[tx];
+    if constexpr (MASK) {
+      // Row end i sits at merged position (end offset - nz0) + i.  The CALLER has cleared the mask
+      // (clear_marks + barrier) and marked every row end of the tile (mark_row_end) before calling; the marks
+      // are visible after the STREAM barrier above.  A thread's start is the number of marks before its first
+      // item (prefix popcount: one wavefront scan + WAVES LDS words) instead of a dependent halving search, and
+      // the walk reads its IPT bits instead of comparing against row ends (`re` is not used).  Same split as
+      // the search (search.hxx semantics: a nonzero precedes the row end it belongs to).
+      const unsigned long long window =
+          (static_cast<unsigned long long>(s.mask[(diag >> 5) + 1]) << 32) | s.mask[diag >> 5];
+      const unsigned int bits = static_cast<unsigned int>(window >> (diag & 31)) & ((1u << IPT) - 1u);
+      const int ends = __popc(bits);
+      const int before = wave::exclusive_sum(ends);
+      if (wave::lane() == wave::size - 1) s.wave_ends[tid / wave::size] = before + ends;
+      __syncthreads();
+      tx = before;
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-      if (diag + j < total) {
-        if (nz0 + ty < row_end) {  // merge step consumes a nonzero
-          sum += s.prod[detail::slot<PAD>(ty + shift)];
-          ++ty;
-        } else {  // merge step consumes a row end: row (row0 + tx) is complete
-          if (!closed) {
-            first_sum = sum;
-            first_row = tx;
-            closed = true;
+      for (int w = 0; w < WAVES; ++w)
+        if (w < tid / wave::size) tx += s.wave_ends[w];
+      ty = diag - tx;
+      // ---- 3. WALK: IPT merge steps, row end or nonzero by the mask bit ----------------------
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        if (diag + j < total) {
+          if ((bits >> j) & 1u) {  // row (row0 + tx) is complete
+            if (!closed) {
+              first_sum = sum;
+              first_row = tx;
+              closed = true;
+            } else {
+              y[row0 + tx] = sum;
+            }
+            sum = type_t(0);
+            ++tx;
           } else {
-            y[row0 + tx] = sum;
+            sum += s.prod[detail::slot<PAD>(ty + shift)];
+            ++ty;
           }
-          sum = type_t(0);
-          ++tx;
-          row_end = re[tx];
+        }
+      }
+    } else {
+      {
+        int lo = diag - natoms > 0 ? diag - natoms : 0;
+        int count = (diag < nrows ? diag : nrows) - lo;
+        while (count > 0) {
+          const int half = count >> 1;
+          const int mid = lo + half;
+          if (re[mid] <= nz0 + (diag - mid - 1)) {
+            lo = mid + 1;
+            count -= half + 1;
+          } else {
+            count = half;
+          }
+        }
+        tx = lo < nrows ? lo : nrows;
+        ty = diag - lo;
+      }
+
+      // ---- 3. WALK: IPT merge steps out of LDS ------------------------------------------------
+      int row_end = re[tx];
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        if (diag + j < total) {
+          if (nz0 + ty < row_end) {  // merge step consumes a nonzero
+            sum += s.prod[detail::slot<PAD>(ty + shift)];
+            ++ty;
+          } else {  // merge step consumes a row end: row (row0 + tx) is complete
+            if (!closed) {
+              first_sum = sum;
+              first_row = tx;
+              closed = true;
+            } else {
+              y[row0 + tx] = sum;
+            }
+            sum = type_t(0);
+            ++tx;
+            row_end = re[tx];
+          }
         }
       }
     }
@@ -352,7 +406,8 @@ struct merge_tile_engine {
  * @tparam NT   stream col_idx / values with non-temporal loads.
  * @tparam VEC  `indices` and `values` are 16-byte aligned (checked by the host launcher).
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, bool SELF, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, bool SELF, bool MASK, typename index_t, typename offset_t,
+          typename type_t>
 __device__ __forceinline__ void
 merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const int nnz,
                      const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
@@ -365,9 +420,9 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   // The extended tile has up to TPB * IPT + TPB merge items: one more item per thread.
   constexpr int ITEMS = SELF ? IPT + 1 : IPT;
   constexpr bool PADDED = SELF ? (ITEMS % 2 == 0) : PAD;
-  using engine_t = merge_tile_engine<TPB, ITEMS, PADDED, NT, VEC, index_t, offset_t, type_t>;
+  using engine_t = merge_tile_engine<TPB, ITEMS, PADDED, NT, VEC, index_t, offset_t, type_t, MASK>;
   __shared__ typename engine_t::storage_t s_engine;
-  __shared__ offset_t s_re[TPB * ITEMS + ITEMS + 1];
+  __shared__ offset_t s_re[MASK ? 1 : TPB * ITEMS + ITEMS + 1];
 
   const int tid = threadIdx.x;
   const int b = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
@@ -382,11 +437,18 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   if constexpr (SELF) nz0 = head_start[b];  // back to the start of row `row0` (recorded by merge_path_head_check)
   const int natoms = static_cast<int>(c1.y) - nz0;
 
-  // row ends of the tile -> LDS (visible after the engine's first barrier)
-  for (int i = tid; i < nrows + ITEMS; i += TPB) {
-    int r = row0 + i;
-    r = r < rows - 1 ? r : rows - 1;
-    s_re[i] = offsets[r + 1];
+  if constexpr (MASK) {
+    // row ends of the tile -> marks in the engine's bit mask, straight from the registers that loaded them
+    engine_t::clear_marks(s_engine);
+    __syncthreads();
+    for (int i = tid; i < nrows; i += TPB) engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
+  } else {
+    // row ends of the tile -> LDS (visible after the engine's first barrier)
+    for (int i = tid; i < nrows + ITEMS; i += TPB) {
+      int r = row0 + i;
+      r = r < rows - 1 ? r : rows - 1;
+      s_re[i] = offsets[r + 1];
+    }
   }
   const type_t carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, type_t(0));
   if constexpr (!SELF) {
@@ -397,35 +459,40 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   }
 }
 
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+          bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const int nnz,
                       const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                       const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
                       int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, offsets, indices, values, x, y, carry_row,
+                                                            carry_val);
 }
 
 /// Self-completing variant (plans whose heads are all <= TPB, merge_path_head_check): every tile finishes the
 /// rows it closes by itself, nothing is carried between tiles and no fix-up kernel follows.
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+          bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_self(const coord_t* __restrict__ coords, const int* __restrict__ head_start, const int rows,
                            const int nnz, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                            const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, true>(coords, rows, nnz, offsets, indices, values, x, y, nullptr,
-                                                     static_cast<type_t*>(nullptr), head_start);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, true, MASK>(coords, rows, nnz, offsets, indices, values, x, y, nullptr,
+                                                           static_cast<type_t*>(nullptr), head_start);
 }
 
 /// The same kernel under its own symbol for column-blocked ("stacked") CSRs (column_blocked.hxx), so
 /// that profiles attribute those launches separately from the plain-CSR SpMV.
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+          bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows, const int nnz,
                               const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                               const type_t* __restrict__ values, const type_t* __restrict__ x,
                               type_t* __restrict__ y, int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false>(coords, rows, nnz, offsets, indices, values, x, y, carry_row, carry_val);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, offsets, indices, values, x, y, carry_row,
+                                                            carry_val);
 }
 
 /**

@@ -96,7 +96,9 @@ int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* off
 
 /* merge_path_flat with a prebuilt plan: exactly the region the reference times
  * (merge_path_flat.cuh:121-136 starts its timer after the pre-pass).  `variant` selects a
- * compiled code variant of the fused kernel (0 = default). */
+ * compiled code variant of the fused kernel: 0 = default (bit-mask split of the tile among the threads);
+ * tuning aids with the per-thread halving search instead: 4 (otherwise as 0), 1 = non-temporal streaming
+ * loads, 2 = unpadded LDS product array, 3 = both. */
 int loops_spmv_merge_path_f32(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
                               const int* offsets, const int* indices, const float* values, const float* x,
                               float* y, void* stream);

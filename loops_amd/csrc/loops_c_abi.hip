@@ -144,11 +144,12 @@ loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
 
 // ------------------------------------------------------------------------- fused merge path
 // stages: bit 0 = fused tile kernel, bit 1 = fix-up (3 = the whole SpMV)
-template <int TPB, int IPT, bool PAD, bool NT, typename T>
+template <int TPB, int IPT, bool PAD, bool NT, typename T, bool MASK = false>  // false: the search-based tuning variants
 int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, const int* off, const int* idx,
                  const T* val, const T* x, T* y, hipStream_t stream, int stages) {
   kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles, p->self_complete != 0, p->head_start};
-  return kernels::launch_merge_path_fused<TPB, IPT, PAD, NT>(stream, view, rows, nnz, off, idx, val, x, y, stages);
+  return kernels::launch_merge_path_fused<TPB, IPT, PAD, NT, int, int, T, MASK>(stream, view, rows, nnz, off, idx, val, x, y,
+                                                                                  stages);
 }
 
 template <typename T>
@@ -156,9 +157,12 @@ int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, c
                     const T* val, const T* x, T* y, hipStream_t stream, int stages = 3) {
   const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(p->tpb) * p->ipt));
   if (rows != p->rows || nnz != p->nnz) return LOOPS_E_BADARG;
-  // variant: bit 0 = non-temporal streaming loads, bit 1 = unpadded LDS product array
-  const bool nt = variant & 1, nopad = variant & 2;
+  // variant 0 = the default kernel (bit-mask split, padded LDS products, temporal loads).  Tuning aids, all with
+  // the per-thread halving search of the first implementation: 4 = otherwise as 0; bit 0 = non-temporal
+  // streaming loads, bit 1 = unpadded LDS product array (1, 2, 3)
+  const bool nt = variant & 1, nopad = variant & 2, mask = variant == 0;
 #define LOOPS_FUSED(TPB, IPT)                                                                                    \
+  if (mask) return launch_fused<TPB, IPT, true, false, T, true>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
   if (!nopad && !nt) return launch_fused<TPB, IPT, true, false, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
   if (!nopad && nt) return launch_fused<TPB, IPT, true, true, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages);   \
   if (nopad && !nt) return launch_fused<TPB, IPT, false, false, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \

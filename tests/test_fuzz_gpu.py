@@ -49,9 +49,10 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         assert np.array_equal(S.spmv(sch, csr, x, y).cpu().numpy(), want), (sch,) + tag
     # held plan (self-completing single-kernel path when every tile head is short, two kernels otherwise)
     for tile in ("256x8", "128x7"):
-        y = torch.full((rows,), 5.0, device="cuda")
-        S.merge_path_flat(csr, x, y, plan=S.MergePathPlan(csr, tile))
-        assert np.array_equal(y.cpu().numpy(), want), ("planned", tile) + tag
+        for variant in (0, 4):   # 4 = bit-mask split
+            y = torch.full((rows,), 5.0, device="cuda")
+            S.merge_path_flat(csr, x, y, plan=S.MergePathPlan(csr, tile), variant=variant)
+            assert np.array_equal(y.cpu().numpy(), want), ("planned", tile, variant) + tag
     # column-blocked plans
     for K in (0, 1, 3, 8):
         if K > cols:

@@ -62,7 +62,7 @@ def test_battery_tuned_paths(schedule):
 
 
 @pytest.mark.parametrize("tile", ["256x8", "128x7", "256x7", "512x8", "256x16"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_merge_path_fused_variants(tile, variant):
     """Every compiled tile shape / code variant of the fused kernel, with a prebuilt plan."""
     from loops_amd import spmv as S, generate as G
