@@ -13,8 +13,9 @@
  *              (global_load_dwordx4 from a 16-byte aligned base), x is gathered through L2 /
  *              Infinity Cache, and the products land in LDS (2048 x 4 B per workgroup).
  *              Row-end offsets of the tile are staged in LDS next to them.
- *  2. SPLIT    each thread finds its start on the merge path with a halving search over the
- *              LDS-resident row ends (<= 11 LDS probes).
+ *  2. SPLIT    each thread finds its start on the merge path: row ends mark their merged position in
+ *              an LDS bit mask and the start is a prefix popcount (MASK engines, merge_path_flat), or
+ *              a halving search over the LDS-resident row ends (<= 11 LDS probes).
  *  3. WALK     IPT merge steps per thread out of LDS: accumulate in a register, store y[row]
  *              directly for every row that both starts and ends inside the thread.
  *  4. STITCH   partial rows crossing thread boundaries are combined with a 6-step 64-lane
