@@ -229,8 +229,8 @@ struct merge_tile_engine {
         live[k] = e < nz1;
         if (live[k]) {
           if (interior || e + 3 < nnz) {
-            detail::load4<index_t, NT>(indices + e, col[k]);
-            detail::load4<type_t, NT>(values + e, val[k]);
+            detail::load4<index_t, NT>(indices + static_cast<unsigned int>(e), col[k]);
+            detail::load4<type_t, NT>(values + static_cast<unsigned int>(e), val[k]);
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -250,7 +250,7 @@ struct merge_tile_engine {
 #ifdef LOOPS_PROBE_NO_GATHER  // measurement aid (never defined in a product build): cost with x[col] free
             xv[j] = static_cast<type_t>(col[k][j] & 1);
 #else
-            xv[j] = x[col[k][j]];
+            xv[j] = x[static_cast<unsigned int>(col[k][j])];  // column ids are non-negative: zero-extend (saddr + voffset)
 #endif
           }
           const int i = (k * TPB + tid) * 4;
@@ -303,24 +303,22 @@ struct merge_tile_engine {
         if (w < tid / wave::size) tx += s.wave_ends[w];
       ty = diag - tx;
       // ---- 3. WALK: IPT merge steps, row end or nonzero by the mask bit ----------------------
+      // select-based: the only control flow left is the predicated store of a completed row
+      const unsigned int live = (diag + IPT <= total) ? ((1u << IPT) - 1u)
+                                                      : (diag < total ? ((1u << (total - diag)) - 1u) : 0u);
 #pragma unroll
       for (int j = 0; j < IPT; ++j) {
-        if (diag + j < total) {
-          if ((bits >> j) & 1u) {  // row (row0 + tx) is complete
-            if (!closed) {
-              first_sum = sum;
-              first_row = tx;
-              closed = true;
-            } else {
-              y[row0 + tx] = sum;
-            }
-            sum = type_t(0);
-            ++tx;
-          } else {
-            sum += s.prod[detail::slot<PAD>(ty + shift)];
-            ++ty;
-          }
-        }
+        const bool on = (live >> j) & 1u;
+        const bool end = on && ((bits >> j) & 1u);  // row (row0 + tx) is complete
+        const bool atom = on && !end;
+        const type_t p = s.prod[detail::slot<PAD>(ty + shift)];  // read even on a row end (in bounds, unused)
+        if (end && closed) y[row0 + tx] = sum;
+        first_sum = (end && !closed) ? sum : first_sum;
+        first_row = (end && !closed) ? tx : first_row;
+        closed = closed || end;
+        sum = end ? type_t(0) : (atom ? sum + p : sum);
+        tx += end ? 1 : 0;
+        ty += atom ? 1 : 0;
       }
     } else {
       {
