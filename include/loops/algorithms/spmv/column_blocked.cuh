@@ -51,14 +51,16 @@ struct column_blocked_t {
         num_blocks(blocks > 0 ? blocks : automatic_blocks(csr.cols, csr.rows, csr.nnzs)),
         bounds(num_blocks + 1), offsets(std::size_t(num_blocks) * csr.rows + 1), indices(csr.nnzs), values(csr.nnzs),
         perm(csr.nnzs), partial(std::size_t(num_blocks) * csr.rows),
-        plan(build(csr, block_bounds, stream), stream, plan_t::prepass_always) {}
+        plan(build(csr, block_bounds, stream), stream, plan_t::prepass_always) {
+    plan.classify(stream);  // short stacked rows only -> one SpMV kernel, no carry-outs
+  }
 
   /// y = A x; asynchronous on `stream`.
   void spmv_async(vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
     constexpr int block_size = launch_t<type_t>::block_size;
     constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
     kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
-                                  static_cast<int>(plan.merge_tiles())};
+                                  static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
     kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
         stream, view, static_cast<int>(num_blocks * rows), static_cast<int>(nnzs), offsets.data().get(),
         indices.data().get(), values.data().get(), x.data().get(), partial.data().get(), 3, true);

@@ -73,7 +73,7 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   if (m == 1) stages &= ~2;  // one tile holds every row completely: no carry-out to add (launch-bound sizes: 1 kernel)
   T* carry_val = static_cast<T*>(plan.carry_val);
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-  if (plan.self_complete && plan.head_start && !stacked && m > 1) {
+  if (plan.self_complete && plan.head_start && m > 1) {  // (plain and column-blocked CSRs alike)
     // no row crosses more than one tile boundary with more than TPB nonzeros behind it: tiles complete their
     // rows themselves -- one kernel, no carry-outs (the "fix-up" stage has nothing to do)
     if (stages & 1) {
