@@ -313,8 +313,7 @@ def main():
     ms_with_prepass = None
     if blocked is None:  # the plan-less entry point: coordinates rebuilt every call, as the reference wrapper does
         def with_prepass():
-            plan.refresh(csr)
-            S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
+            S.spmv("merge_path_flat", csr, x, y_loc)  # loops_spmv_csr_f32: coordinates + tile kernel + fix-up, no held plan
 
         for _ in range(5):
             with_prepass()
