@@ -196,7 +196,10 @@ struct merge_tile_engine {
     // MASK split: bit p of `mask` = 1 iff merged position p of the tile is a row end
     unsigned int mask[MASK ? TILE / 32 + 2 : 1];
     int wave_ends[MASK ? WAVES : 1];
+    // MASK engines: the first YT rows a tile completes are staged here and leave as coalesced stores
+    type_t ytile[MASK ? TILE / 4 : 1];
   };
+  static constexpr int YT = MASK ? TILE / 4 : 0;
 
   /// MASK engines: zero the row-end marks (whole workgroup; follow with a barrier before marking).
   static __device__ __forceinline__ void clear_marks(storage_t& s) {
@@ -312,7 +315,10 @@ struct merge_tile_engine {
         const bool end = on && ((bits >> j) & 1u);  // row (row0 + tx) is complete
         const bool atom = on && !end;
         const type_t p = s.prod[detail::slot<PAD>(ty + shift)];  // read even on a row end (in bounds, unused)
-        if (end && closed) y[row0 + tx] = sum;
+        if (end && closed) {  // a row completed inside this thread: stage it (coalesced copy-out below)
+          if (tx < YT) s.ytile[tx] = sum;
+          else y[row0 + tx] = sum;
+        }
         first_sum = (end && !closed) ? sum : first_sum;
         first_row = (end && !closed) ? tx : first_row;
         closed = closed || end;
@@ -391,9 +397,18 @@ struct merge_tile_engine {
       }
     }
     if (reaches_tile_start) wave_in += carry_in;
-    if (closed) y[row0 + first_row] = first_sum + prev_run + (prev_head ? type_t(0) : wave_in);
+    if (closed) {
+      const type_t v = first_sum + prev_run + (prev_head ? type_t(0) : wave_in);
+      if (MASK && first_row < YT) s.ytile[first_row] = v;
+      else y[row0 + first_row] = v;
+    }
     if (tid == TPB - 1) s.carry = run_sum + (head ? type_t(0) : wave_in);
     __syncthreads();
+    if constexpr (MASK) {
+      // rows row0 .. row0 + min(nrows, YT) - 1 were all completed in this tile: one coalesced store each
+      const int staged = nrows < YT ? nrows : YT;
+      for (int i = tid; i < staged; i += TPB) y[row0 + i] = s.ytile[i];
+    }
     return s.carry;
   }
 };
