@@ -46,9 +46,10 @@ def pmc_traffic(args):
     (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE counts the 128-B requests of this kernel at
     64 B on gfx950 (MI355X_MICROARCH.md, HBM section; checked here against TCC_MISS * 128 B).
     None when the configuration differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json" if args.tile == "256x8"
+                        else f"r01_c2_pmc_summary_{args.tile}.json")
     if not os.path.exists(path) or args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 \
-            or args.tile != "256x8" or args.variant != 0 or args.layout == "blocked":
+            or args.variant != 0 or args.layout == "blocked":
         return None
     d = json.load(open(path))
     for k, v in d.items():
@@ -64,7 +65,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-rows", type=int, default=20, help="rows per GPU = 2^this (C2: 20)")
     ap.add_argument("--log2-nnz", type=int, default=24, help="nnz per GPU = 2^this (C2: 24)")
-    ap.add_argument("--tile", default="256x8")
+    ap.add_argument("--tile", default="auto",
+                    help="merge-tile shape TPBxIPT of the held plan; auto = the launch-box autotuner picks it on this "
+                         "matrix before the timed region (loops_autotune_merge_path_f32)")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
@@ -122,6 +125,16 @@ def main():
     y_full = torch.zeros(rows, dtype=torch.float32, device="cuda")
     y_loc = y_full[shard.row_begin:shard.row_end]
     gen_s = time.time() - t0
+    tile_probe = None
+    if args.tile == "auto":  # measured launch box: every compiled tile shape timed on this shard, outside the timed region
+        best, tile_probe = S.autotune_merge_path(csr, x, repeats=30)
+        if world > 1:  # one shape for the whole job: the one with the smallest worst-rank time
+            names = sorted(tile_probe)
+            t = torch.tensor([tile_probe[n] for n in names], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            best = names[int(torch.argmin(t))]
+        args.tile = best
+        tile_probe = {k: round(v, 5) for k, v in tile_probe.items()}
     plan = S.MergePathPlan(csr, args.tile)
     layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
     blocked = None
@@ -452,7 +465,8 @@ def main():
                                    "fp32, merge_path_flat" + (f", columns banded (window {args.window})" if args.window else ", columns uniform")
                                    + (f", row-range sharded + allgatherv(y) over {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'}" if world > 1 else ""),
                        "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
-                       "tile": args.tile, "variant": args.variant, "merge_tiles_per_gpu": plan.num_tiles,
+                       "tile": args.tile, "tile_autotune_ms": tile_probe, "variant": args.variant,
+                       "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
                                        f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)",
                        "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (f", {args.overlap_chunks} chunks overlapping the SpMV" if gather_mode['mode'] == 'p2p-chunked' else "") + "]" if world > 1 else ""),
