@@ -364,7 +364,7 @@ int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hi
   if (stages & 3) {
     kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles,
                                   p->merge->self_complete != 0, p->merge->head_start};
-    err = kernels::launch_merge_path_fused<256, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
+    err = kernels::launch_merge_path_fused<512, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
                                                                 static_cast<const T*>(p->sval), x, ys, stages & 3,
                                                                 /*stacked=*/true);
   }
@@ -408,7 +408,7 @@ int colblock_create(int rows, int cols, int nnz, const int* offsets, const int* 
     kernels::column_blocked_view<int, int, T> view{rows, cols, nnz, K, p->soff, p->sidx, static_cast<T*>(p->sval), p->perm};
     err = kernels::build_column_blocked(st, offsets, indices, values, p->bounds_dev, view, temp, temp_bytes);
   }
-  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, LOOPS_TILE_DEFAULT, &p->merge);
+  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, LOOPS_TILE_512x8, &p->merge);
   if (!err) err = plan_compute(p->merge, p->soff, st);
   if (!err) err = plan_classify(p->merge, p->soff, st);  // short stacked rows only: no carry-outs, no fix-up launch
   if (!err) err = static_cast<int>(hipStreamSynchronize(st));  // the temporaries go away below
