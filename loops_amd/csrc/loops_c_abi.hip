@@ -353,7 +353,7 @@ int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hi
     kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
     const T* sval = static_cast<const T*>(p->sval);
     if (schedule == LOOPS_WORK_ORIENTED)
-      err = kernels::launch_work_oriented_fused<256, 8, true>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);
+      err = kernels::launch_work_oriented_fused<512, 8, true>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);  // the plan's tile shape
     else if (schedule == LOOPS_GROUP_MAPPED)
       err = kernels::launch_group_mapped_fused<256, 8, true>(stream, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);
     else
