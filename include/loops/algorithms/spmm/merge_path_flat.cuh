@@ -16,10 +16,17 @@ namespace loops {
 namespace algorithms {
 namespace spmm {
 
+/// Plan of the SpMM kernel: merge tiles of spmv::launch_t (256 x 8 / 256 x 4) -- the SpMM stages the tile's
+/// row ends and {B-row offset, value} pairs in LDS, so it keeps the smaller tile.
+template <typename index_t, typename offset_t, typename type_t>
+using merge_path_plan_t =
+    schedule::merge_path::preprocess_t<spmv::launch_t<type_t>::block_size, spmv::launch_t<type_t>::items_per_thread,
+                                       index_t, offset_t, std::size_t, std::size_t>;
+
 /// SpMM with a prebuilt plan and caller-held carry-out scratch (plan.merge_tiles() * B.cols values);
 /// asynchronous on `stream`.
 template <typename index_t, typename offset_t, typename type_t>
-void merge_path_flat_async(const spmv::merge_path_plan_t<index_t, offset_t, type_t>& plan,
+void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,
                            csr_t<index_t, offset_t, type_t>& csr, matrix_t<type_t>& B, matrix_t<type_t>& C,
                            vector_t<type_t>& carry, xpu::stream_t stream = 0) {
   constexpr int block_size = spmv::launch_t<type_t>::block_size;
@@ -35,7 +42,7 @@ void merge_path_flat_async(const spmv::merge_path_plan_t<index_t, offset_t, type
 template <typename index_t, typename offset_t, typename type_t>
 util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, matrix_t<type_t>& B, matrix_t<type_t>& C,
                               xpu::stream_t stream = 0) {
-  using plan_t = spmv::merge_path_plan_t<index_t, offset_t, type_t>;
+  using plan_t = merge_path_plan_t<index_t, offset_t, type_t>;
   plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows),
                                         static_cast<offset_t>(csr.nnzs)),
               stream, plan_t::prepass_always);

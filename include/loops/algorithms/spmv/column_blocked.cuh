@@ -57,8 +57,8 @@ struct column_blocked_t {
 
   /// y = A x; asynchronous on `stream`.
   void spmv_async(vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
-    constexpr int block_size = launch_t<type_t>::block_size;
-    constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
+    constexpr int block_size = merge_path_launch_t<type_t>::block_size;
+    constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
     kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
                                   static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
     kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(

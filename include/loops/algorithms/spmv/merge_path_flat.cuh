@@ -29,7 +29,8 @@ namespace spmv {
 
 template <typename index_t, typename offset_t, typename type_t>
 using merge_path_plan_t =
-    schedule::merge_path::preprocess_t<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread, index_t,
+    schedule::merge_path::preprocess_t<merge_path_launch_t<type_t>::block_size,
+                                       merge_path_launch_t<type_t>::items_per_thread, index_t,
                                        offset_t, std::size_t, std::size_t>;
 
 /// SpMV with a prebuilt plan; asynchronous on `stream`.
@@ -37,8 +38,8 @@ template <typename index_t, typename offset_t, typename type_t>
 void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,
                            csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                            xpu::stream_t stream = 0) {
-  constexpr int block_size = launch_t<type_t>::block_size;
-  constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
+  constexpr int block_size = merge_path_launch_t<type_t>::block_size;
+  constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
   kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
                                 static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
   kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
