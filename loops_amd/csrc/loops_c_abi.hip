@@ -233,7 +233,8 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
   if (rows == 0) return 0;
   switch (schedule) {
     case LOOPS_MERGE_PATH_FLAT: {
-      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
+      // 512 x 8 merge tiles: the measured best shape of this kernel on MI355X (see launch_box.hxx)
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_512x8, &err);
       if (!p) return err;
       if (p->num_tiles > 1) err = plan_compute(p, off, stream);  // a single-tile kernel derives its own coordinates
       if (!err) err = spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
