@@ -50,7 +50,9 @@ for name, (deg, cols, window) in cases.items():
     x = torch.from_numpy(xh).cuda(); y = torch.empty(rows, device="cuda")
     abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
     row = {"rows": rows, "cols": cols, "nnz": nnz, "max_degree": int(deg.max())}
-    plan = S.MergePathPlan(csr)
+    tile, _ = S.autotune_merge_path(csr, x, 10)   # launch-box autotuner: the tile shape of the held plan
+    row["tile"] = tile
+    plan = S.MergePathPlan(csr, tile)
     for label, fn in (("merge_path_flat", lambda: S.merge_path_flat(csr, x, y, plan=plan)),
                       ("work_oriented", lambda: S.spmv("work_oriented", csr, x, y)),
                       ("group_mapped", lambda: S.spmv("group_mapped", csr, x, y)),
@@ -70,6 +72,6 @@ for name, (deg, cols, window) in cases.items():
             R.refgpu_spmv_f32(kind, C.c_long(rows), C.c_long(cols), C.c_long(nnz), p(off), p(idx), p(val), p(xh), p(yr), 3, C.byref(ms))
             row[label] = {"us": round(ms.value * 1e3, 1)}
     out[name] = row
-    print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict)), file=sys.stderr, flush=True)
+    print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} tile {tile} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict)), file=sys.stderr, flush=True)
     del csr, x, y, plan
 print(json.dumps(out))
