@@ -164,15 +164,15 @@ int launch_thread_mapped_spmm(hipStream_t stream, int rows, const offset_t* offs
 }
 
 /// Tuned work_oriented: fixed occupancy-sized grid, even share of plan tiles per workgroup.
-template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T>
+template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_work_oriented_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
                                const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
   const int m = plan.num_merge_tiles;
   if (m == 0) return 0;
   T* carry_val = static_cast<T*>(plan.carry_val);
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-  auto k_vec = work_oriented_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T>;
-  auto k_scl = work_oriented_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T>;
+  auto k_vec = work_oriented_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T, MASK>;
+  auto k_scl = work_oriented_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T, MASK>;
   static const int resident = static_cast<int>(launch_box::occupancy_grid(k_vec, TPB));  // blocks per CU x CUs
   const int tiles_per_group = math::ceil_div(m, resident < 1 ? 1 : resident);
   const int groups = math::ceil_div(m, tiles_per_group);

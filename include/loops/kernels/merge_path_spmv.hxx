@@ -516,16 +516,17 @@ merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows
  * (Even-share semantics of schedule::setup<work_oriented>, reference work_oriented.hxx:79-91,
  * at merge-tile granularity.)
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+          bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge_tiles, const int tiles_per_group,
                          const int rows, const int nnz, const offset_t* __restrict__ offsets,
                          const index_t* __restrict__ indices, const type_t* __restrict__ values,
                          const type_t* __restrict__ x, type_t* __restrict__ y, int* __restrict__ carry_row,
                          type_t* __restrict__ carry_val) {
-  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t>;
+  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t, MASK>;
   __shared__ typename engine_t::storage_t s_engine;
-  __shared__ offset_t s_re[TPB * IPT + IPT + 1];
+  __shared__ offset_t s_re[MASK ? 1 : TPB * IPT + IPT + 1];
 
   const int tid = threadIdx.x;
   const int g = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
@@ -541,10 +542,16 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
     const int nz0 = static_cast<int>(c0.y);
     const int nrows = static_cast<int>(c1.x) - row0;
     const int natoms = static_cast<int>(c1.y) - nz0;
-    for (int i = tid; i < nrows + IPT; i += TPB) {
-      int r = row0 + i;
-      r = r < rows - 1 ? r : rows - 1;
-      s_re[i] = offsets[r + 1];
+    if constexpr (MASK) {  // row ends -> marks of the engine's bit mask (the barrier also fences the previous tile)
+      engine_t::clear_marks(s_engine);
+      __syncthreads();
+      for (int i = tid; i < nrows; i += TPB) engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
+    } else {
+      for (int i = tid; i < nrows + IPT; i += TPB) {
+        int r = row0 + i;
+        r = r < rows - 1 ? r : rows - 1;
+        s_re[i] = offsets[r + 1];
+      }
     }
     // carry-in of the share's FIRST tile belongs to an earlier workgroup: it goes through the fix-up
     carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, carry);
