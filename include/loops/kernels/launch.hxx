@@ -188,17 +188,17 @@ int launch_work_oriented_fused(hipStream_t stream, const merge_plan_view& plan, 
 }
 
 /// Tuned group_mapped: one workgroup per TPB consecutive rows, no plan, no atomics.
-template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T>
+template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_group_mapped_fused(hipStream_t stream, int rows, int nnz, const offset_t* offsets, const index_t* indices,
                               const T* values, const T* x, T* y) {
   if (rows == 0) return 0;
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
   const dim3 grid(math::ceil_div(rows, TPB)), block(TPB);
   if (aligned)
-    hipLaunchKernelGGL((group_mapped_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T>), grid, block, 0,
+    hipLaunchKernelGGL((group_mapped_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T, MASK>), grid, block, 0,
                        stream, rows, nnz, offsets, indices, values, x, y);
   else
-    hipLaunchKernelGGL((group_mapped_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T>), grid, block, 0,
+    hipLaunchKernelGGL((group_mapped_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T, MASK>), grid, block, 0,
                        stream, rows, nnz, offsets, indices, values, x, y);
   return launch_status();
 }

@@ -570,12 +570,13 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
  * row offsets, which sit in LDS once: no global search, no plan, no cross-workgroup carry (a
  * workgroup owns whole rows), no atomics, no zero-fill of y.
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t>
+template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+          bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restrict__ offsets,
                         const index_t* __restrict__ indices, const type_t* __restrict__ values,
                         const type_t* __restrict__ x, type_t* __restrict__ y) {
-  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t>;
+  using engine_t = merge_tile_engine<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t, MASK>;
   constexpr int TILE = TPB * IPT;
   __shared__ typename engine_t::storage_t s_engine;
   __shared__ offset_t s_off[TPB + 1 + IPT];  // offsets of the group's rows (+ clamped slack)
@@ -615,6 +616,12 @@ group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restric
     }
     const int tx1 = lo < group_rows ? lo : group_rows;
     const int ty1 = d1 - lo;
+    if constexpr (MASK) {  // row ends of the tile (already in LDS) -> marks of the engine's bit mask
+      engine_t::clear_marks(s_engine);
+      __syncthreads();
+      for (int i = tid; i < tx1 - tx0; i += TPB)
+        engine_t::mark_row_end(s_engine, i, static_cast<int>(row_end[tx0 + i]), nz_begin + ty0);
+    }
     carry = engine_t::run(s_engine, row_end + tx0, group_row0 + tx0, nz_begin + ty0, tx1 - tx0, ty1 - ty0, nnz,
                           indices, values, x, y, carry);
     tx0 = tx1;

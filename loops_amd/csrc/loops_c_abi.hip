@@ -252,7 +252,11 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
       return kernels::launch_work_oriented_fused<256, 8, true>(stream, view, rows, nnz, off, idx, val, x, y);
     }
     case LOOPS_GROUP_MAPPED:
+#ifdef LOOPS_GROUP_MAPPED_SEARCH  // A/B aid (never defined in a product build): the search-based split
+      return kernels::launch_group_mapped_fused<256, 8, true, int, int, T, false>(stream, rows, nnz, off, idx, val, x, y);
+#else
       return kernels::launch_group_mapped_fused<256, 8, true>(stream, rows, nnz, off, idx, val, x, y);
+#endif
     case LOOPS_FLAT_PARTITIONED: {
       // atomic kernel accumulates into y: zero it on the stream first
       hipError_t e = hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), stream);
