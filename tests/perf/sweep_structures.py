@@ -24,12 +24,28 @@ def chunked(deg, cols, window):
     off = np.concatenate([[0]] + [p[0][1:].astype(np.int64) + sum(int(q[0][-1]) for q in parts[:i]) for i, p in enumerate(parts)]).astype(np.int32)
     return off, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
 
+def scale_free(deg, cols, skew=3.0, seed=11):
+    """Graph-like adjacency: power-law row lengths AND power-law column popularity (hub vertices): column id =
+    perm[floor(cols * u^skew)], u uniform -- half of all nonzeros fall on cols / 2^skew columns.  Columns sorted
+    inside a row, repeats kept (a multigraph; SpMV semantics do not care)."""
+    r = np.random.default_rng(seed)
+    rows, nnz = deg.size, int(deg.sum())
+    off = np.zeros(rows + 1, np.int64); np.cumsum(deg, out=off[1:])
+    hub = r.permutation(cols).astype(np.int64)
+    col = hub[np.minimum((cols * r.random(nnz) ** skew).astype(np.int64), cols - 1)]
+    key = (np.repeat(np.arange(rows, dtype=np.int64), deg) << 32) | col
+    key.sort()
+    idx = (key & 0xFFFFFFFF).astype(np.int32)
+    val = ((r.integers(1, 9, nnz)).astype(np.float32) / np.float32(8))
+    return off.astype(np.int32), idx, val
+
 N = 1 << 24
 rng = np.random.default_rng(1)
 cases = {}
 cases["power-law rows, uniform cols (C2)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, None)
 cases["power-law rows, banded cols (w=8192)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, 8192)
 cases["power-law rows, consecutive cols (runs)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, -1)
+cases["power-law rows, power-law cols (scale-free graph)"] = (G.powerlaw_degrees(1 << 20, N), 1 << 20, "scale_free")
 cases["uniform degree 16, uniform cols"] = (np.full(1 << 20, 16, np.int64), 1 << 20, None)
 cases["uniform degree 16, banded (FEM-like, w=64)"] = (np.full(1 << 20, 16, np.int64), 1 << 20, 64)
 cases["short rows: degree 1-3, 8M rows"] = (rng.integers(1, 4, 1 << 23).astype(np.int64), 1 << 23, None)
@@ -40,9 +56,12 @@ cases["75 % empty rows, degree 32 otherwise"] = (d, 1 << 21, None)
 
 so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "libloops_ref_gpu.so")
 R = _lib.load_shared(so) if os.path.exists(so) else None
+only = [a for a in sys.argv[1:] if not a.startswith("-")]   # optional: substrings of the case names to run
 out = {}
 for name, (deg, cols, window) in cases.items():
-    off, idx, val = chunked(deg, cols, window)
+    if only and not any(o in name for o in only):
+        continue
+    off, idx, val = scale_free(deg, cols) if isinstance(window, str) else chunked(deg, cols, window)
     rows, nnz = deg.size, int(off[-1])
     xh = G.uniform_distribution_int(cols)
     ref = O.spmv_f32(off, idx, val, xh, omp=True)
@@ -74,4 +93,4 @@ for name, (deg, cols, window) in cases.items():
     out[name] = row
     print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} tile {tile} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict)), file=sys.stderr, flush=True)
     del csr, x, y, plan
-print(json.dumps(out))
+    print(json.dumps({name: row}), flush=True)   # one JSON object per case: a run cut short keeps what it measured
