@@ -211,58 +211,118 @@ struct merge_tile_engine {
     atomicOr(&s.mask[p >> 5], 1u << (p & 31));
   }
 
+  /// STREAM of a 16-byte aligned tile in three straight-line phases, so that every load of a phase is in flight
+  /// before the first one is waited for: (1) col_idx / values vectors, (2) the x gathers, (3) products -> LDS.
+  /// `mark` runs between (1) and (2).  INTERIOR: no load of the tile can pass the end of the arrays.
+  template <bool INTERIOR, typename mark_t>
+  static __device__ __forceinline__ void stream_vectors(storage_t& s, const int abase, const int nz1, const int nnz,
+                                                        const index_t* __restrict__ indices,
+                                                        const type_t* __restrict__ values,
+                                                        const type_t* __restrict__ x, mark_t& mark) {
+    const int tid = threadIdx.x;
+    index_t col[KV][4];
+    type_t val[KV][4];
+    type_t xv[KV][4];
+    if constexpr (INTERIOR) {
+      // Branch-free: a lane whose vector lies behind the tile's last nonzero loads the tile's LAST vector instead
+      // (same line for all of them) and its products land in slots the walk never reads.
+      int emax = (nz1 - 1) & ~3;
+      emax = emax > abase ? emax : abase;
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        int e = abase + (k * TPB + tid) * 4;
+        e = e < emax ? e : emax;
+        detail::load4<index_t, NT>(indices + static_cast<unsigned int>(e), col[k]);
+        detail::load4<type_t, NT>(values + static_cast<unsigned int>(e), val[k]);
+      }
+      mark();
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#ifdef LOOPS_PROBE_NO_GATHER  // measurement aid (never defined in a product build): cost with x[col] free
+          xv[k][j] = static_cast<type_t>(col[k][j] & 1);
+#else
+          xv[k][j] = x[static_cast<unsigned int>(col[k][j])];  // column ids are non-negative: zero-extend
+#endif
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KV; ++k) {
+        const int i = (k * TPB + tid) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // the round that overhangs the array: surplus lanes all write slot NPROD - 1, which is never read
+          // (no branch: a predicated store would pull this round's gathers behind the other rounds' wait)
+          const int slot = ((k + 1) * TPB * 4 <= NPROD || i + j < NPROD) ? i + j : NPROD - 1;
+          s.prod[detail::slot<PAD>(slot)] = val[k][j] * xv[k][j];
+        }
+      }
+      return;
+    }
+    bool live[KV];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const int e = abase + (k * TPB + tid) * 4;
+      live[k] = e < nz1;
+      if (live[k]) {
+        if (e + 3 < nnz) {
+          detail::load4<index_t, NT>(indices + static_cast<unsigned int>(e), col[k]);
+          detail::load4<type_t, NT>(values + static_cast<unsigned int>(e), val[k]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = e + j < nnz;
+            col[k][j] = ok ? indices[e + j] : index_t(0);
+            val[k][j] = ok ? values[e + j] : type_t(0);
+          }
+        }
+      }
+    }
+    mark();
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      if (live[k]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[k][j] = x[static_cast<unsigned int>(col[k][j])];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      if (live[k]) {
+        const int i = (k * TPB + tid) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[k][j];
+      }
+    }
+  }
+
+  struct no_marks {
+    __device__ __forceinline__ void operator()() const {}
+  };
+
+  /// `mark` (MASK engines): called once, after the tile's col_idx / values loads have been ISSUED and before the
+  /// x gathers wait for them -- the caller's row-offset loads + mark_row_end() go there, so that their latency
+  /// overlaps the stream's instead of preceding it.  The mask must have been cleared (clear_marks + barrier).
+  template <typename mark_t = no_marks>
   static __device__ __forceinline__ type_t run(storage_t& s, const offset_t* re, const int row0, const int nz0,
                                                const int nrows, const int natoms, const int nnz,
                                                const index_t* __restrict__ indices,
                                                const type_t* __restrict__ values, const type_t* __restrict__ x,
-                                               type_t* __restrict__ y, const type_t carry_in) {
+                                               type_t* __restrict__ y, const type_t carry_in,
+                                               mark_t mark = mark_t{}) {
     const int tid = threadIdx.x;
     const int nz1 = nz0 + natoms;
     // ---- 1. STREAM ------------------------------------------------------------------------
     const int abase = VEC ? (nz0 & ~3) : nz0;  // 16-byte aligned element base of the tile
     const int shift = nz0 - abase;             // 0..3 leading elements owned by the previous tile
     if constexpr (VEC) {
-      const bool interior = abase + KV * 4 * TPB <= nnz;  // every vector load in-bounds (uniform)
-      index_t col[KV][4];
-      type_t val[KV][4];
-      bool live[KV];
-#pragma unroll
-      for (int k = 0; k < KV; ++k) {
-        const int e = abase + (k * TPB + tid) * 4;
-        live[k] = e < nz1;
-        if (live[k]) {
-          if (interior || e + 3 < nnz) {
-            detail::load4<index_t, NT>(indices + static_cast<unsigned int>(e), col[k]);
-            detail::load4<type_t, NT>(values + static_cast<unsigned int>(e), val[k]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const bool ok = e + j < nnz;
-              col[k][j] = ok ? indices[e + j] : index_t(0);
-              val[k][j] = ok ? values[e + j] : type_t(0);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KV; ++k) {
-        if (live[k]) {
-          type_t xv[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-#ifdef LOOPS_PROBE_NO_GATHER  // measurement aid (never defined in a product build): cost with x[col] free
-            xv[j] = static_cast<type_t>(col[k][j] & 1);
-#else
-            xv[j] = x[static_cast<unsigned int>(col[k][j])];  // column ids are non-negative: zero-extend (saddr + voffset)
-#endif
-          }
-          const int i = (k * TPB + tid) * 4;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[j];
-        }
-      }
+      // every vector load of the tile in-bounds?  (uniform; false only for the last tile(s) of the matrix)
+      if (abase + KV * 4 * TPB <= nnz) stream_vectors<true>(s, abase, nz1, nnz, indices, values, x, mark);
+      else stream_vectors<false>(s, abase, nz1, nnz, indices, values, x, mark);
     } else {
       // Unaligned arrays: coalesced 4-byte loads, one element per lane per round.
+      mark();
 #pragma unroll
       for (int k = 0; k < IPT; ++k) {
         const int i = k * TPB + tid;
@@ -455,7 +515,6 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
     // row ends of the tile -> marks in the engine's bit mask, straight from the registers that loaded them
     engine_t::clear_marks(s_engine);
     __syncthreads();
-    for (int i = tid; i < nrows; i += TPB) engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
   } else {
     // row ends of the tile -> LDS (visible after the engine's first barrier)
     for (int i = tid; i < nrows + ITEMS; i += TPB) {
@@ -464,7 +523,12 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
       s_re[i] = offsets[r + 1];
     }
   }
-  const type_t carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, type_t(0));
+  const type_t carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, type_t(0), [&]() {
+    if constexpr (MASK) {
+      for (int i = tid; i < nrows; i += TPB)
+        engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
+    }
+  });
   if constexpr (!SELF) {
     if (tid == 0) {
       carry_row[b] = row0 + nrows;  // == c1.x: the row still open when the tile ends
@@ -545,7 +609,6 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
     if constexpr (MASK) {  // row ends -> marks of the engine's bit mask (the barrier also fences the previous tile)
       engine_t::clear_marks(s_engine);
       __syncthreads();
-      for (int i = tid; i < nrows; i += TPB) engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
     } else {
       for (int i = tid; i < nrows + IPT; i += TPB) {
         int r = row0 + i;
@@ -554,7 +617,12 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
       }
     }
     // carry-in of the share's FIRST tile belongs to an earlier workgroup: it goes through the fix-up
-    carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, carry);
+    carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, carry, [&]() {
+      if constexpr (MASK) {
+        for (int i = tid; i < nrows; i += TPB)
+          engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
+      }
+    });
     open_row = row0 + nrows;
   }
   if (tid == 0 && t_begin < t_end) {
