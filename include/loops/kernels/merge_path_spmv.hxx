@@ -369,12 +369,20 @@ struct merge_tile_engine {
       // select-based: the only control flow left is the predicated store of a completed row
       const unsigned int live = (diag + IPT <= total) ? ((1u << IPT) - 1u)
                                                       : (diag < total ? ((1u << (total - diag)) - 1u) : 0u);
+      const unsigned int end_bits = bits & live;    // bit j: merge step j completes row (row0 + tx)
+      const unsigned int atom_bits = ~bits & live;  // bit j: merge step j consumes a nonzero
+      // the product under every step, all IPT LDS reads in flight together (their addresses depend on the mask
+      // bits only): the walk itself then runs out of registers
+      type_t p[IPT];
 #pragma unroll
       for (int j = 0; j < IPT; ++j) {
-        const bool on = (live >> j) & 1u;
-        const bool end = on && ((bits >> j) & 1u);  // row (row0 + tx) is complete
-        const bool atom = on && !end;
-        const type_t p = s.prod[detail::slot<PAD>(ty + shift)];  // read even on a row end (in bounds, unused)
+        p[j] = s.prod[detail::slot<PAD>(ty + shift)];  // read even on a row end (in bounds, unused)
+        ty += (atom_bits >> j) & 1u;
+      }
+#pragma unroll
+      for (int j = 0; j < IPT; ++j) {
+        const bool end = (end_bits >> j) & 1u;
+        const bool atom = (atom_bits >> j) & 1u;
         if (end && closed) {  // a row completed inside this thread: stage it (coalesced copy-out below)
           if (tx < YT) s.ytile[tx] = sum;
           else y[row0 + tx] = sum;
@@ -382,9 +390,8 @@ struct merge_tile_engine {
         first_sum = (end && !closed) ? sum : first_sum;
         first_row = (end && !closed) ? tx : first_row;
         closed = closed || end;
-        sum = end ? type_t(0) : (atom ? sum + p : sum);
+        sum = end ? type_t(0) : (atom ? sum + p[j] : sum);
         tx += end ? 1 : 0;
-        ty += atom ? 1 : 0;
       }
     } else {
       {
