@@ -509,14 +509,19 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   const int b = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
   // tile coordinates (wave-uniform: scalar loads).  A matrix that fits ONE merge tile needs no
   // coordinate table: its tile is the whole merge path (and no fix-up: nothing leaves the tile).
+  // All three scalar loads are issued UNCONDITIONALLY and together (one wait instead of three dependent ones at the
+  // head of every workgroup): `coords` holds gridDim.x + 1 entries also for a single-tile launch, where their
+  // contents are ignored.
   const bool single = gridDim.x == 1;
-  const coord_t c0 = single ? coord_t{0u, 0u} : coords[b];
-  const coord_t c1 = single ? coord_t{static_cast<unsigned int>(rows), static_cast<unsigned int>(nnz)} : coords[b + 1];
-  const int row0 = static_cast<int>(c0.x);
-  int nz0 = static_cast<int>(c0.y);
-  const int nrows = static_cast<int>(c1.x) - row0;
-  if constexpr (SELF) nz0 = head_start[b];  // back to the start of row `row0` (recorded by merge_path_head_check)
-  const int natoms = static_cast<int>(c1.y) - nz0;
+  const coord_t m0 = coords[b];
+  const coord_t m1 = coords[b + 1];
+  int head = 0;
+  if constexpr (SELF) head = head_start[b];  // start of row `row0` (recorded by merge_path_head_check)
+  const int row0 = single ? 0 : static_cast<int>(m0.x);
+  int nz0 = single ? 0 : static_cast<int>(m0.y);
+  const int nrows = (single ? rows : static_cast<int>(m1.x)) - row0;
+  if constexpr (SELF) nz0 = head;
+  const int natoms = (single ? nnz : static_cast<int>(m1.y)) - nz0;
 
   if constexpr (MASK) {
     // row ends of the tile -> marks in the engine's bit mask, straight from the registers that loaded them

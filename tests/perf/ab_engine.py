@@ -1,7 +1,7 @@
 """A/B aid: held-plan merge_path_flat on a gather-bound (C2) and two L1-local (FEM-like band, fp32 / fp64)
 matrices; run once per library (LOOPS_AMD_LIB) and compare.  Prints us per SpMV (median of 50) + bit-exactness."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S
 from oracle import oracle as O
