@@ -27,7 +27,7 @@ for name, (deg, window) in cases.items():
         csr = S.CSR.from_numpy(rows, cols, off, idx, v)
         x = torch.from_numpy(xx).cuda(); y = torch.empty(rows, device="cuda", dtype=x.dtype)
         out = []
-        for tile in ("256x8", "512x8", "256x16"):
+        for tile in ("256x8", "128x7", "256x7", "512x8", "256x16"):
             plan = S.MergePathPlan(csr, tile)
             us = ev(lambda: S.merge_path_flat(csr, x, y, plan=plan))
             out.append(f"{tile} {us:7.1f}us self={int(plan.self_complete)} ok={bool(np.array_equal(y.cpu().numpy(), ref))}")
