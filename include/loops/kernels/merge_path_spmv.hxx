@@ -710,17 +710,27 @@ group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restric
 }
 
 /// y[row] += sum of the carry-outs of the run of merge tiles that ended inside `row`.
+/// Latency-bound (a few thousand lanes, each a chain of dependent loads): the neighbours' rows, the two first
+/// values of the run and y[row] are requested together, so the common case (runs of one or two tiles) costs two
+/// dependent memory round trips instead of four or five.
 template <typename type_t>
 __global__ void merge_path_spmv_fixup(const int* __restrict__ carry_row, const type_t* __restrict__ carry_val,
                                       int num_merge_tiles, int rows, type_t* __restrict__ y) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= num_merge_tiles) return;
+  const bool has_next = i + 1 < num_merge_tiles;
   const int r = carry_row[i];
-  if (r >= rows) return;
-  if (i > 0 && carry_row[i - 1] == r) return;  // not the first tile of the run
+  const int before = i > 0 ? carry_row[i - 1] : -1;
+  const int after = has_next ? carry_row[i + 1] : -1;
   type_t s = carry_val[i];
-  for (int j = i + 1; j < num_merge_tiles && carry_row[j] == r; ++j) s += carry_val[j];
-  y[r] += s;
+  const type_t second = has_next ? carry_val[i + 1] : type_t(0);
+  if (r >= rows || before == r) return;  // nothing open / not the first tile of the run
+  const type_t old = y[r];
+  if (after == r) {
+    s += second;
+    for (int j = i + 2; j < num_merge_tiles && carry_row[j] == r; ++j) s += carry_val[j];
+  }
+  y[r] = old + s;
 }
 
 }  // namespace kernels
