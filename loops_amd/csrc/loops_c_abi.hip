@@ -62,6 +62,14 @@ inline int check_csr(int rows, int cols, int nnz, const void* off, const void* i
 }  // namespace
 
 // ------------------------------------------------------------------------------------ plan
+// merge-tile shape of column-blocked plans (both schedules): 512 x 8 measured best on shards whose x exceeds an L2
+#ifndef LOOPS_COLBLOCK_TPB
+#define LOOPS_COLBLOCK_TPB 512
+#endif
+constexpr int COLBLOCK_TPB = LOOPS_COLBLOCK_TPB;
+constexpr int COLBLOCK_TILE = COLBLOCK_TPB == 512 ? LOOPS_TILE_512x8 : LOOPS_TILE_256x8;
+static_assert(COLBLOCK_TPB == 512 || COLBLOCK_TPB == 256, "column-blocked plans: 512 x 8 or 256 x 8 tiles");
+
 struct loops_merge_plan {
   int rows, nnz, cfg, tpb, ipt, num_tiles;
   int capacity;        // merge tiles the allocation can hold (>= num_tiles)
@@ -358,7 +366,7 @@ int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hi
     kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
     const T* sval = static_cast<const T*>(p->sval);
     if (schedule == LOOPS_WORK_ORIENTED)
-      err = kernels::launch_work_oriented_fused<512, 8, true>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);  // the plan's tile shape
+      err = kernels::launch_work_oriented_fused<COLBLOCK_TPB, 8, true>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);  // the plan's tile shape
     else if (schedule == LOOPS_GROUP_MAPPED)
       err = kernels::launch_group_mapped_fused<256, 8, true>(stream, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);
     else
@@ -369,7 +377,7 @@ int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hi
   if (stages & 3) {
     kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles,
                                   p->merge->self_complete != 0, p->merge->head_start};
-    err = kernels::launch_merge_path_fused<512, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
+    err = kernels::launch_merge_path_fused<COLBLOCK_TPB, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
                                                                 static_cast<const T*>(p->sval), x, ys, stages & 3,
                                                                 /*stacked=*/true);
   }
@@ -413,7 +421,7 @@ int colblock_create(int rows, int cols, int nnz, const int* offsets, const int* 
     kernels::column_blocked_view<int, int, T> view{rows, cols, nnz, K, p->soff, p->sidx, static_cast<T*>(p->sval), p->perm};
     err = kernels::build_column_blocked(st, offsets, indices, values, p->bounds_dev, view, temp, temp_bytes);
   }
-  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, LOOPS_TILE_512x8, &p->merge);
+  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, COLBLOCK_TILE, &p->merge);
   if (!err) err = plan_compute(p->merge, p->soff, st);
   if (!err) err = plan_classify(p->merge, p->soff, st);  // short stacked rows only: no carry-outs, no fix-up launch
   if (!err) err = static_cast<int>(hipStreamSynchronize(st));  // the temporaries go away below
