@@ -133,6 +133,11 @@ def main():
             t = torch.tensor([tile_probe[n] for n in names], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             best = names[int(torch.argmin(t))]
+            tile_probe = {n: float(v) for n, v in zip(names, t.tolist())}
+        # the library's default shape unless another one is measurably (> 1 %) faster: shapes within the run-to-run
+        # noise of the probe must not flip the kernel (and its profile) between runs
+        if "512x8" in tile_probe and tile_probe["512x8"] <= 1.01 * tile_probe[best]:
+            best = "512x8"
         args.tile = best
         tile_probe = {k: round(v, 5) for k, v in tile_probe.items()}
     plan = S.MergePathPlan(csr, args.tile)
