@@ -16,7 +16,11 @@ def ev(fn, iters=50, warm=5):
 
 rows = cols = 1 << 20
 cases = {"c2": (G.powerlaw_degrees(rows, 1 << 24), None), "band64": (np.full(rows, 16, np.int64), 64),
-         "pl_runs": (G.powerlaw_degrees(rows, 1 << 24), -1)}
+         "pl_runs": (G.powerlaw_degrees(rows, 1 << 24), -1), "pl_band64": (G.powerlaw_degrees(rows, 1 << 24), 64),
+         "u16_runs": (np.full(rows, 16, np.int64), -1)}
+only = sys.argv[1:]
+if only:
+    cases = {k: v for k, v in cases.items() if k in only}
 for name, (deg, window) in cases.items():
     off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
     xh = G.uniform_distribution_int(cols)
