@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-local-context", action="store_true",
+                    help="skip the N = 1 context measurement of the same kernel on a banded matrix of the same size")
     ap.add_argument("--window", type=int, default=0,
                     help="0: uniform hashed columns (SURVEY 8d, the headline); W > 0: columns in a band of W around "
                          "the diagonal (locality variant, reported for context)")
@@ -374,6 +376,30 @@ def main():
                                 "same fused kernel + K-way row reduce; not the headline"}
         cb.close()
 
+    # for context at N = 1: the SAME kernel on a matrix of the same size whose columns are local (16 per row inside a
+    # 64-column band): what the kernel does when the x gather is served by L1 -- its roofline fraction as a kernel,
+    # next to the headline's, which is set by the random gather (never `value`)
+    local_info = None
+    if world == 1 and rank == 0 and not args.window and not args.no_local_context:
+        l_off, l_idx, l_val = G.csr_from_degrees(np.full(csr.rows, csr.nnzs // csr.rows, np.int64), cols, seed=1, window=64)
+        l_csr = S.CSR.from_numpy(csr.rows, cols, l_off, l_idx, l_val)
+        l_plan = S.MergePathPlan(l_csr, "256x8")
+        yl = torch.empty_like(y_loc)
+        for _ in range(5):
+            S.merge_path_flat(l_csr, x, yl, plan=l_plan)
+        l_avg, _ = event_time(lambda: S.merge_path_flat(l_csr, x, yl, plan=l_plan), 100)
+        y_tm = torch.empty_like(yl)  # cross-check against the row-sequential thread_mapped kernel (exact inputs: equal)
+        S.spmv("thread_mapped", l_csr, x, y_tm)
+        l_ok = bool(torch.equal(yl, y_tm))
+        lb = algorithmic_bytes(l_csr.rows, cols, l_csr.nnzs)
+        local_info = {"workload": f"{l_csr.rows} rows x {l_csr.nnzs // l_csr.rows} nnz, columns in a 64-wide band, fp32, held plan 256x8"
+                                  + (" (self-completing: one kernel)" if l_plan.self_complete else ""),
+                      "avg_launch_ms": round(l_avg, 5), "GFLOPs": round(2.0 * l_csr.nnzs / (l_avg * 1e-3) / 1e9, 1),
+                      "roofline": {"bound": "hbm", "achieved": round(lb / (l_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                   "unit": "GB/s", "frac": round(lb / (l_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                      "equal_to_thread_mapped_result": l_ok, "note": "context, not the headline workload"}
+        del l_csr, l_plan, yl, y_tm
+
     # calibration probes: achievable streaming rate and gather rate on this box
     n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
     src = torch.empty(n_copy, dtype=torch.float32, device="cuda").normal_()
@@ -481,6 +507,7 @@ def main():
                        "allgatherv_probe_ms_per_step": exchange_probe,
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
                        "column_blocked_layout_same_matrix": blocked_info,
+                       "same_kernel_local_columns": local_info,
                        "reference_hip_backend_on_this_gpu": ref_gpu},
             "roofline": roofline, "cpu_baseline": cpu,
         }
