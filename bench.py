@@ -96,7 +96,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from loops_amd import generate as G, partition as P, spmv as S
+    from loops_amd import generate as G, partition as P, probes as PR, spmv as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -420,12 +420,12 @@ def main():
     n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
     src = torch.empty(n_copy, dtype=torch.float32, device="cuda").normal_()
     dst = torch.empty_like(src)
-    copy_avg = batch_event_time(lambda: S.stream_copy(src, dst), 20)
+    copy_avg = batch_event_time(lambda: PR.stream_copy(src, dst), 20)
     copy_gbps = 2 * n_copy * 4 / (copy_avg * 1e-3) / 1e9
     del src, dst
     gidx = torch.from_numpy(idx[: 1 << 24]).cuda() if idx.size >= 1 << 24 else csr.indices
     gout = torch.empty(gidx.numel(), dtype=torch.float32, device="cuda")
-    gat_avg = batch_event_time(lambda: S.gather(x, gidx, gout), 20)
+    gat_avg = batch_event_time(lambda: PR.gather(x, gidx, gout), 20)
     gather_gps = gidx.numel() / (gat_avg * 1e-3) / 1e9
 
     loc_rows, loc_nnz = csr.rows, csr.nnzs

@@ -134,16 +134,7 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       a[u] = a_next[u];
-#if defined(LOOPS_PROBE_NO_GATHER)  // measurement aid (never defined in a product build): x free
-      const float f = static_cast<float>(bc_next[u] & 3);
-      xv[u] = f32x4{f, f, f, f};
-#elif defined(LOOPS_PROBE_SMALL_GATHER)  // measurement aid: the gather confined to 4 KB of x
-      xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u] & 255) * 4);
-#elif defined(LOOPS_PROBE_NT_GATHER)  // measurement aid: non-temporal x gather
-      xv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4));
-#else
       xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4);
-#endif
     }
     if (k0 + UNROLL < steps) fetch(k0 + UNROLL);
 #pragma unroll

@@ -64,7 +64,7 @@ int launch_merge_path_coordinates(hipStream_t stream, const offset_t* offsets, i
 /// `stacked`: the matrix is a column-blocked CSR -- same code under its own kernel symbol.
 /// MASK (default): bit-mask split instead of the per-thread search (merge_tile_engine<..., MASK = true>):
 /// 1-2 % faster on every input measured (C2 103.3 -> 102.5 us, band-8192 50.4 -> 49.5, runs 43.7 -> 42.7).
-template <int TPB, int IPT, bool PAD, bool NT, typename index_t, typename offset_t, typename T, bool MASK = true>
+template <int TPB, int IPT, bool PAD, int NT, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
                             const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
                             int stages = 3, bool stacked = false) {

@@ -195,12 +195,7 @@ merge_path_spmm(const coord_t* __restrict__ coords, const int rows, const int nn
     row_end = s_re[row];
   };
   auto fetch = [&](const entry_t& e, type_t (&out)[V]) {
-#ifdef LOOPS_PROBE_NO_GATHER  // measurement aid (never defined in a product build): cost with B rows free
-#pragma unroll
-    for (int k = 0; k < V; ++k) out[k] = static_cast<type_t>(e.brow & 7);
-#else
     detail::load_row<V>(Bc + static_cast<std::size_t>(e.brow) * V, out);
-#endif
   };
   int a = ty0;
   for (; a + U <= ty1; a += U) {  // full batches: U rows of B in flight, no bounds checks

@@ -62,6 +62,59 @@ using coord_t = coordinate_t<unsigned int>;
 
 namespace detail {
 
+/// Cache policy of a tile's memory accesses -- the `NT` template parameter of the engine and its kernels:
+///   0 (false)                 plain global loads
+///   1 (true)                  non-temporal global loads of col_idx / values
+///   policy::make(i, v, x)     buffer loads carrying explicit gfx950 cache-policy bits (the `aux` operand of
+///                             raw.buffer.load: SC0 = 1, NT = 2, SC1 = 16) for the col_idx stream, the values stream
+///                             and the x gather; x_aux = 0 keeps the gather a plain global load (no 4 GB limit on x)
+namespace policy {
+constexpr int sc0 = 1, nt = 2, sc1 = 16;
+constexpr int make(int idx_aux, int val_aux, int x_aux = 0) { return 0x10000 | idx_aux | (val_aux << 5) | (x_aux << 10); }
+constexpr bool buffered(int p) { return (p & 0x10000) != 0; }
+constexpr int idx_aux(int p) { return p & 31; }
+constexpr int val_aux(int p) { return (p >> 5) & 31; }
+constexpr int x_aux(int p) { return (p >> 10) & 31; }
+constexpr unsigned int rsrc_flags = 0x00020000u;  // gfx9 raw buffer: DATA_FORMAT = 32 bit, no swizzle, no TID
+}  // namespace policy
+
+/// 4 consecutive elements at byte offset `byte_off` of buffer `r` with cache-policy bits AUX (see policy).
+template <typename T, int AUX>
+__device__ __forceinline__ void buffer_load4(const __amdgpu_buffer_rsrc_t r, const int byte_off, T (&out)[4]) {
+  using w4 = unsigned int __attribute__((ext_vector_type(4)));
+  if constexpr (sizeof(T) == 4) {
+    using v4 = T __attribute__((ext_vector_type(4)));
+    const w4 raw = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX);
+    const v4 v = __builtin_bit_cast(v4, raw);
+    out[0] = v.x;
+    out[1] = v.y;
+    out[2] = v.z;
+    out[3] = v.w;
+  } else {
+    static_assert(sizeof(T) == 8, "buffer_load4: 4- or 8-byte elements");
+    using v2 = T __attribute__((ext_vector_type(2)));
+    const w4 ra = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX);
+    const w4 rb = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off + 16, 0, AUX);
+    const v2 a = __builtin_bit_cast(v2, ra), b = __builtin_bit_cast(v2, rb);
+    out[0] = a.x;
+    out[1] = a.y;
+    out[2] = b.x;
+    out[3] = b.y;
+  }
+}
+
+/// One element at byte offset `byte_off` of buffer `r` with cache-policy bits AUX.
+template <typename T, int AUX>
+__device__ __forceinline__ T buffer_load1(const __amdgpu_buffer_rsrc_t r, const unsigned int byte_off) {
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, static_cast<int>(byte_off), 0, AUX));
+  } else {
+    using w2 = unsigned int __attribute__((ext_vector_type(2)));
+    const w2 raw = __builtin_amdgcn_raw_buffer_load_b64(r, static_cast<int>(byte_off), 0, AUX);
+    return __builtin_bit_cast(T, raw);
+  }
+}
+
 /// 4 consecutive elements with the widest loads the element size allows: one 16-byte
 /// global_load_dwordx4 for 32-bit elements, two for 64-bit ones.  (Written against the native
 /// ext-vector types: element-wise bit_cast of a __vector_size__ vector miscompiles on ROCm 7.2
@@ -98,14 +151,10 @@ __device__ __forceinline__ void load4(const T* __restrict__ p, T (&out)[4]) {
 /// per XCD keeps the x / B rows that neighbouring tiles share (banded, clustered, web-graph
 /// matrices) in ONE L2 instead of all eight.
 __device__ __forceinline__ int xcd_contiguous(int i, int m) {
-#ifdef LOOPS_PROBE_NO_XCD_SWIZZLE  // measurement aid (never defined in a product build): round-robin tiles
-  return i;
-#else
   constexpr int XCDS = 8;
   const int k = i % XCDS, j = i / XCDS;
   const int base = m / XCDS, rem = m % XCDS;
   return k * base + (k < rem ? k : rem) + j;
-#endif
 }
 
 /// LDS index of product slot i.  With PAD one word of padding every 32 slots turns the
@@ -180,7 +229,7 @@ __global__ void merge_path_head_check(const coord_t* __restrict__ coords, const 
  * ends (row0 + nrows), uniform across the workgroup.  Collective: every thread of the workgroup
  * must call it; contains 3 workgroup barriers.
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 struct merge_tile_engine {
   static constexpr int TILE = TPB * IPT;
@@ -228,23 +277,47 @@ struct merge_tile_engine {
       // (same line for all of them) and its products land in slots the walk never reads.
       int emax = (nz1 - 1) & ~3;
       emax = emax > abase ? emax : abase;
+      if constexpr (detail::policy::buffered(NT)) {
+        // explicit cache-policy bits: the tile's streams as buffer loads relative to the tile's (scalar) base
+        namespace pol = detail::policy;
+        const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<index_t*>(indices + abase), 0, KV * TPB * 4 * static_cast<int>(sizeof(index_t)), pol::rsrc_flags);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<type_t*>(values + abase), 0, KV * TPB * 4 * static_cast<int>(sizeof(type_t)), pol::rsrc_flags);
 #pragma unroll
-      for (int k = 0; k < KV; ++k) {
-        int e = abase + (k * TPB + tid) * 4;
-        e = e < emax ? e : emax;
-        detail::load4<index_t, NT>(indices + static_cast<unsigned int>(e), col[k]);
-        detail::load4<type_t, NT>(values + static_cast<unsigned int>(e), val[k]);
+        for (int k = 0; k < KV; ++k) {
+          int e = (k * TPB + tid) * 4;
+          e = e < emax - abase ? e : emax - abase;
+          detail::buffer_load4<index_t, pol::idx_aux(NT)>(ri, e * static_cast<int>(sizeof(index_t)), col[k]);
+          detail::buffer_load4<type_t, pol::val_aux(NT)>(rv, e * static_cast<int>(sizeof(type_t)), val[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+          int e = abase + (k * TPB + tid) * 4;
+          e = e < emax ? e : emax;
+          detail::load4<index_t, NT == 1>(indices + static_cast<unsigned int>(e), col[k]);
+          detail::load4<type_t, NT == 1>(values + static_cast<unsigned int>(e), val[k]);
+        }
       }
       mark();
+      if constexpr (detail::policy::buffered(NT) && detail::policy::x_aux(NT) != 0) {
+        // (measurement shapes only: 32-bit byte offsets limit x to 4 GB)
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<type_t*>(x), 0, -1, detail::policy::rsrc_flags);
 #pragma unroll
-      for (int k = 0; k < KV; ++k) {
+        for (int k = 0; k < KV; ++k) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#ifdef LOOPS_PROBE_NO_GATHER  // measurement aid (never defined in a product build): cost with x[col] free
-          xv[k][j] = static_cast<type_t>(col[k][j] & 1);
-#else
-          xv[k][j] = x[static_cast<unsigned int>(col[k][j])];  // column ids are non-negative: zero-extend
-#endif
+          for (int j = 0; j < 4; ++j)
+            xv[k][j] = detail::buffer_load1<type_t, detail::policy::x_aux(NT)>(
+                rx, static_cast<unsigned int>(col[k][j]) * static_cast<unsigned int>(sizeof(type_t)));
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xv[k][j] = x[static_cast<unsigned int>(col[k][j])];  // column ids are non-negative: zero-extend
         }
       }
 #pragma unroll
@@ -267,8 +340,8 @@ struct merge_tile_engine {
       live[k] = e < nz1;
       if (live[k]) {
         if (e + 3 < nnz) {
-          detail::load4<index_t, NT>(indices + static_cast<unsigned int>(e), col[k]);
-          detail::load4<type_t, NT>(values + static_cast<unsigned int>(e), val[k]);
+          detail::load4<index_t, NT == 1>(indices + static_cast<unsigned int>(e), col[k]);
+          detail::load4<type_t, NT == 1>(values + static_cast<unsigned int>(e), val[k]);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -334,10 +407,6 @@ struct merge_tile_engine {
     }
     __syncthreads();
 
-#ifdef LOOPS_PROBE_STREAM_ONLY  // measurement aid: stop after the products are in LDS
-    if (s.prod[detail::slot<PAD>(tid)] == type_t(-12345.678)) y[tid] = type_t(1);
-    return type_t(0);
-#endif
     // ---- 2. SPLIT: this thread's start on the merge path -------------------------------------
     const int total = nrows + natoms;  // == TILE except in a last / short tile
     const int diag = tid * IPT;
@@ -435,10 +504,6 @@ struct merge_tile_engine {
       }
     }
 
-#ifdef LOOPS_PROBE_NO_STITCH  // measurement aid: skip the cross-thread combination
-    if (closed) y[row0 + first_row] = first_sum + sum;
-    return type_t(0);
-#endif
     // ---- 4. STITCH: partial rows across threads / wavefronts ----------------------------------
     const int lane = wave::lane();
     const int w = tid / wave::size;
@@ -487,7 +552,7 @@ struct merge_tile_engine {
  * @tparam NT   stream col_idx / values with non-temporal loads.
  * @tparam VEC  `indices` and `values` are 16-byte aligned (checked by the host launcher).
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, bool SELF, bool MASK, typename index_t, typename offset_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, bool SELF, bool MASK, typename index_t, typename offset_t,
           typename type_t>
 __device__ __forceinline__ void
 merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const int nnz,
@@ -549,7 +614,7 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   }
 }
 
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const int nnz,
@@ -562,7 +627,7 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
 
 /// Self-completing variant (plans whose heads are all <= TPB, merge_path_head_check): every tile finishes the
 /// rows it closes by itself, nothing is carried between tiles and no fix-up kernel follows.
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_self(const coord_t* __restrict__ coords, const int* __restrict__ head_start, const int rows,
@@ -574,7 +639,7 @@ merge_path_spmv_fused_self(const coord_t* __restrict__ coords, const int* __rest
 
 /// The same kernel under its own symbol for column-blocked ("stacked") CSRs (column_blocked.hxx), so
 /// that profiles attribute those launches separately from the plain-CSR SpMV.
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows, const int nnz,
@@ -592,7 +657,7 @@ merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows
  * (Even-share semantics of schedule::setup<work_oriented>, reference work_oriented.hxx:79-91,
  * at merge-tile granularity.)
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge_tiles, const int tiles_per_group,
@@ -650,7 +715,7 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
  * row offsets, which sit in LDS once: no global search, no plan, no cross-workgroup carry (a
  * workgroup owns whole rows), no atomics, no zero-fill of y.
  */
-template <int TPB, int IPT, bool PAD, bool NT, bool VEC, typename index_t, typename offset_t, typename type_t,
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 __global__ void __launch_bounds__(TPB)
 group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restrict__ offsets,

@@ -242,26 +242,6 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
 int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
                        const float* values, const float* x, float* y, void* stream);
 
-/* ---- device-side measurement helpers ---------------------------------------------------------- */
-/* Streaming copy dst[i] = src[i] (16 B per lane) -- measures the achievable HBM rate the
- * roofline fraction is also quoted against.  dst == src selects a READ-ONLY stream
- * (per-lane sums, nothing written): the achievable read rate. */
-int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
-/* out[i] = table[idx[i]] -- measures the L2 / Infinity-Cache gather rate that bounds x reads.
- * mode: 0 plain loads, 1 non-temporal, 2 agent-scope (sc1: bypass the CU's L1), 3 system-scope. */
-int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream);
-
-/* `blocks` x 256 lanes each issue `reps` 4-byte loads from a power-of-two table (pattern 0
- * consecutive, 1 hashed, 2 broadcast): the address rate of the CU's vector-memory path. */
-int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
-                           void* stream);
-
-/* Row-gather probe (the SpMM's B access pattern in isolation): sub-groups of row_floats / 4 lanes
- * read `count` rows of row_floats floats (8..256, power of two) of `table` selected by `idx`, 16 B
- * per lane, 8 rows in flight; `out` needs blocks * 256 floats. */
-int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
-                         void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("LOOPS_AMD_LIB", os.path.join(_HERE, "libloops_amd.so"))
 SRC_PATH = os.path.join(_HERE, "csrc", "loops_c_abi.hip")
+PROBES_LIB_PATH = os.environ.get("LOOPS_PROBES_LIB", os.path.join(_HERE, "libloops_probes.so"))
+PROBES_SRC_PATH = os.path.join(_HERE, "csrc", "loops_probes.hip")
 INCLUDE_DIR = os.path.join(_ROOT, "include")
 
 # enum loops_schedule (include/loops_amd.h)
@@ -34,10 +36,10 @@ SYMBOLS = [
     "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
     "loops_work_oriented_grid", "loops_spmv_bcsr_f32",
-    "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_row_gather_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_spmv_csc_f32", "loops_autotune_merge_path_f32",
+    "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_spmv_csc_f32", "loops_autotune_merge_path_f32",
     "loops_colblock_plan_create", "loops_colblock_plan_destroy", "loops_colblock_plan_info", "loops_colblock_plan_arrays",
     "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32",
-    "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64", "loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32",
+    "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64",
 ]
 
 
@@ -45,20 +47,32 @@ class LoopsError(RuntimeError):
     pass
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libloops_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    deps = [SRC_PATH]
+def _compile(src: str, out: str, extra_deps=(), force: bool = False, verbose: bool = False, defines=()) -> str:
+    deps = [src, *extra_deps]
     for base, _, files in os.walk(INCLUDE_DIR):
         deps += [os.path.join(base, f) for f in files]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DLOOPS_TARGET_GFX=0x950",
-           "-I" + INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+           *["-D" + d for d in defines], "-I" + INCLUDE_DIR, src, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libloops_amd.so -- the product -- for gfx950 with hipcc (cross-compiles without a GPU)."""
+    return _compile(SRC_PATH, LIB_PATH, force=force, verbose=verbose)
+
+
+def build_probes(force: bool = False, verbose: bool = False) -> str:
+    """Compile libloops_probes.so: calibration kernels and experimental instantiations, measurement only
+    (loops_amd/csrc/loops_probes.h).  The product library neither links nor loads it."""
+    csrc = os.path.dirname(PROBES_SRC_PATH)
+    return _compile(PROBES_SRC_PATH, PROBES_LIB_PATH, [os.path.join(csrc, "probes.hxx"), os.path.join(csrc, "loops_probes.h")],
+                    force=force, verbose=verbose)
 
 
 _lib = None
@@ -108,7 +122,6 @@ def lib() -> C.CDLL:
         L.loops_spmm_csr_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmm_csr_f64.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmm_merge_path_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
-        L.loops_row_gather_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, vp, vp]
         L.loops_colblock_plan_create.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
         L.loops_colblock_plan_create_f64.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
         L.loops_colblock_plan_refresh_values_f64.argtypes = [vp, vp, vp]
@@ -125,9 +138,6 @@ def lib() -> C.CDLL:
         L.loops_spmv_ell_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]
         L.loops_autotune_merge_path_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]
         L.loops_spmv_csc_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
-        L.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
-        L.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
-        L.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         _lib = L
     return _lib
 

@@ -24,7 +24,6 @@
 #include <loops/kernels/ell_spmv.hxx>
 #include <loops/kernels/csc_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
-#include <loops/kernels/probes.hxx>
 
 using namespace loops;
 using kernels::coord_t;
@@ -152,7 +151,7 @@ loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
 
 // ------------------------------------------------------------------------- fused merge path
 // stages: bit 0 = fused tile kernel, bit 1 = fix-up (3 = the whole SpMV)
-template <int TPB, int IPT, bool PAD, bool NT, typename T, bool MASK = false>  // false: the search-based tuning variants
+template <int TPB, int IPT, bool PAD, int NT, typename T, bool MASK = false>  // false: the search-based tuning variants
 int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, const int* off, const int* idx,
                  const T* val, const T* x, T* y, hipStream_t stream, int stages) {
   kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles, p->self_complete != 0, p->head_start};
@@ -617,30 +616,6 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
   if (R == 3 && C == 3) return kernels::launch_bcsr_thread_mapped<3, 3>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
   if (R == 4 && C == 4) return kernels::launch_bcsr_thread_mapped<4, 4>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
   return LOOPS_E_CONFIG;
-}
-
-int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) {
-  if (!src || !dst) return LOOPS_E_BADARG;
-  return kernels::launch_stream_copy(as_stream(stream), src, dst, n);
-}
-
-int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream) {
-  if (!table || !idx || !out) return LOOPS_E_BADARG;
-  return kernels::launch_gather(as_stream(stream), table, idx, out, n, mode);
-}
-
-int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
-                           void* stream) {
-  if (!table || !out || table_words <= 0 || (table_words & (table_words - 1)) || reps < 0 || blocks <= 0)
-    return LOOPS_E_BADARG;
-  return kernels::launch_address_rate(as_stream(stream), table, table_words, reps, pattern, blocks, out);
-}
-
-int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
-                         void* stream) {
-  if (!table || !idx || !out || blocks <= 0) return LOOPS_E_BADARG;
-  const int rc = kernels::launch_row_gather(as_stream(stream), table, idx, count, row_floats, blocks, out);
-  return rc == -1 ? LOOPS_E_CONFIG : rc;
 }
 
 int loops_spmm_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,

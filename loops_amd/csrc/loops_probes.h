@@ -1,0 +1,51 @@
+/*
+ * loops_probes.h -- C ABI of libloops_probes.so: MEASUREMENT code only (calibration kernels and
+ * experimental instantiations of the product kernels).  Nothing here is part of the drop-in
+ * boundary (include/loops_amd.h); only bench.py, scripts/ and tests/perf/ load this library.
+ *
+ * Conventions as in loops_amd.h: device pointers, `stream` = hipStream_t as void*, asynchronous,
+ * 0 on success / hipError_t / negative LOOPS_E_*.
+ */
+#ifndef LOOPS_PROBES_H_
+#define LOOPS_PROBES_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Streaming copy dst[i] = src[i] (16 B per lane) -- the achievable HBM rate the roofline fraction is
+ * also quoted against.  dst == src selects a READ-ONLY stream (per-lane sums, nothing
+ * written): the achievable read rate. */
+int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
+/* out[i] = table[idx[i]] -- the L2 / Infinity-Cache gather rate that bounds x reads.
+ * mode: 0 plain loads, 1 non-temporal, 2 agent-scope (sc1: bypass the CU's L1), 3 system-scope,
+ * 4 plain gather with non-temporal index / output streams. */
+int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream);
+/* `blocks` x 256 lanes each issue `reps` 4-byte loads from a power-of-two table (pattern 0
+ * consecutive, 1 hashed, 2 broadcast): the address rate of the CU's vector-memory path. */
+int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
+                           void* stream);
+/* Row-gather probe (the SpMM's B access pattern in isolation): sub-groups of row_floats / 4 lanes
+ * read `count` rows of row_floats floats (8..256, power of two) of `table` selected by `idx`, 16 B
+ * per lane, 8 rows in flight; `out` needs blocks * 256 floats. */
+int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
+                         void* stream);
+
+/* Cache-policy experiment: the product's fused merge_path_flat kernel (merge_path_spmv_fused<512, 8>,
+ * bit-mask split, 16-byte aligned arrays required) instantiated with explicit gfx950 cache-policy bits on
+ * its col_idx stream / values stream / x gather.  `policy` indexes the table returned by
+ * loops_probe_policy_name(); stages: bit 0 = tile kernel, bit 1 = fix-up, bit 2 = build the coordinates
+ * into `scratch` first (needed once per matrix).  `scratch`: loops_probe_merge_path_scratch_bytes() bytes. */
+size_t loops_probe_merge_path_scratch_bytes(int rows, int nnz);
+int loops_probe_policy_count(void);
+const char* loops_probe_policy_name(int policy);
+int loops_probe_merge_path_f32(int policy, int stages, int rows, int cols, int nnz, const int* offsets,
+                               const int* indices, const float* values, const float* x, float* y, void* scratch,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOOPS_PROBES_H_ */

@@ -1,0 +1,148 @@
+// loops_probes.hip -- libloops_probes.so: measurement code only (see loops_probes.h).  Built next to the product
+// library by loops_amd/_lib.py; never linked into, loaded by, or required by libloops_amd.so.
+#include "loops_probes.h"
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+#include <loops/kernels/launch.hxx>
+#include <loops/util/math.hxx>
+
+#include "probes.hxx"
+
+using namespace loops;
+using kernels::coord_t;
+
+namespace {
+
+constexpr int E_BADARG = -1, E_CONFIG = -3;
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+constexpr int TPB = 512, IPT = 8;
+
+namespace pol = kernels::detail::policy;
+
+struct policy_entry {
+  const char* name;
+};
+
+// policy id -> (engine NT parameter); keep the two tables in step
+constexpr int kPolicies[] = {
+    0,                                               // 0 plain global loads (the product kernel)
+    1,                                               // 1 __builtin_nontemporal_load on both streams
+    pol::make(0, 0),                                 // 2 buffer loads, no bits
+    pol::make(pol::sc0, pol::sc0),                   // 3
+    pol::make(pol::nt, pol::nt),                     // 4
+    pol::make(pol::sc1, pol::sc1),                   // 5
+    pol::make(pol::sc0 | pol::sc1, pol::sc0 | pol::sc1),  // 6
+    pol::make(pol::nt | pol::sc1, pol::nt | pol::sc1),    // 7
+    pol::make(pol::nt | pol::sc0, pol::nt | pol::sc0),    // 8
+    pol::make(19, 19),                               // 9 sc0 sc1 nt
+    pol::make(pol::nt, 0),                           // 10
+    pol::make(0, pol::nt),                           // 11
+    pol::make(0, 0, pol::sc0),                       // 12
+    pol::make(0, 0, pol::sc1),                       // 13
+    pol::make(0, 0, pol::nt),                        // 14
+    pol::make(0, 0, pol::sc0 | pol::sc1),            // 15
+    pol::make(pol::nt, pol::nt, pol::sc1),           // 16
+    pol::make(pol::nt | pol::sc1, pol::nt | pol::sc1, pol::sc1),  // 17
+};
+const char* const kPolicyNames[] = {
+    "global plain", "global nontemporal", "buffer plain", "stream sc0", "stream nt", "stream sc1", "stream sc0+sc1",
+    "stream nt+sc1", "stream nt+sc0", "stream sc0+sc1+nt", "idx nt / val plain", "idx plain / val nt", "gather sc0",
+    "gather sc1", "gather nt", "gather sc0+sc1", "stream nt, gather sc1", "stream nt+sc1, gather sc1",
+};
+constexpr int kNumPolicies = sizeof(kPolicies) / sizeof(kPolicies[0]);
+static_assert(kNumPolicies == sizeof(kPolicyNames) / sizeof(kPolicyNames[0]), "policy tables out of step");
+
+struct scratch_view {
+  coord_t* coords;
+  float* carry_val;
+  int* carry_row;
+  int m;
+};
+
+scratch_view carve(void* scratch, int rows, int nnz) {
+  const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(TPB) * IPT));
+  auto* coords = static_cast<coord_t*>(scratch);
+  auto* carry_val = reinterpret_cast<double*>(coords + (m + 1));
+  auto* carry_row = reinterpret_cast<int*>(carry_val + (m + 2));
+  return {coords, reinterpret_cast<float*>(carry_val), carry_row, m};
+}
+
+template <int P>
+void launch_policy(const scratch_view& v, int rows, int nnz, const int* off, const int* idx, const float* val,
+                   const float* x, float* y, hipStream_t stream) {
+  hipLaunchKernelGGL((kernels::merge_path_spmv_fused<TPB, IPT, true, kPolicies[P], true, int, int, float, true>), dim3(v.m),
+                     dim3(TPB), 0, stream, v.coords, rows, nnz, off, idx, val, x, y, v.carry_row, v.carry_val);
+}
+
+template <int... Ps>
+bool dispatch(int policy, std::integer_sequence<int, Ps...>, const scratch_view& v, int rows, int nnz, const int* off,
+              const int* idx, const float* val, const float* x, float* y, hipStream_t stream) {
+  return ((policy == Ps ? (launch_policy<Ps>(v, rows, nnz, off, idx, val, x, y, stream), true) : false) || ...);
+}
+
+}  // namespace
+
+extern "C" {
+
+int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) {
+  if (!src || !dst) return E_BADARG;
+  return kernels::launch_stream_copy(as_stream(stream), src, dst, n);
+}
+
+int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream) {
+  if (!table || !idx || !out) return E_BADARG;
+  return kernels::launch_gather(as_stream(stream), table, idx, out, n, mode);
+}
+
+int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
+                           void* stream) {
+  if (!table || !out || table_words <= 0 || (table_words & (table_words - 1)) || reps < 0 || blocks <= 0) return E_BADARG;
+  return kernels::launch_address_rate(as_stream(stream), table, table_words, reps, pattern, blocks, out);
+}
+
+int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
+                         void* stream) {
+  if (!table || !idx || !out || blocks <= 0) return E_BADARG;
+  const int rc = kernels::launch_row_gather(as_stream(stream), table, idx, count, row_floats, blocks, out);
+  return rc == -1 ? E_CONFIG : rc;
+}
+
+size_t loops_probe_merge_path_scratch_bytes(int rows, int nnz) {
+  const size_t m = static_cast<size_t>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(TPB) * IPT));
+  return (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int)) + 64;
+}
+
+int loops_probe_policy_count(void) { return kNumPolicies; }
+const char* loops_probe_policy_name(int policy) {
+  return policy >= 0 && policy < kNumPolicies ? kPolicyNames[policy] : nullptr;
+}
+
+int loops_probe_merge_path_f32(int policy, int stages, int rows, int cols, int nnz, const int* offsets,
+                               const int* indices, const float* values, const float* x, float* y, void* scratch,
+                               void* stream) {
+  (void)cols;
+  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz <= 0) return E_BADARG;
+  if (policy < 0 || policy >= kNumPolicies) return E_CONFIG;
+  if ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) return E_BADARG;
+  hipStream_t st = as_stream(stream);
+  const scratch_view v = carve(scratch, rows, nnz);
+  if (v.m < 2) return E_CONFIG;  // single-tile matrices take another path in the product
+  if (stages & 4) {
+    const int err = kernels::launch_merge_path_coordinates(st, offsets, rows, nnz, TPB * IPT, v.m, v.coords);
+    if (err) return err;
+  }
+  if (stages & 1) {
+    if (!dispatch(policy, std::make_integer_sequence<int, kNumPolicies>{}, v, rows, nnz, offsets, indices, values, x, y, st))
+      return E_CONFIG;
+  }
+  if (stages & 2)
+    hipLaunchKernelGGL(kernels::merge_path_spmv_fixup<float>, dim3(math::ceil_div(v.m, 256)), dim3(256), 0, st, v.carry_row,
+                       v.carry_val, v.m, rows, y);
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // extern "C"

@@ -14,9 +14,77 @@ reference's examples and the power-law CSR / uniform BCSR workloads named by BAS
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import subprocess
+
 import numpy as np
 
 _M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+# ------------------------------------------------------------------------------ native builder
+# The numpy functions below are the SPECIFICATION of the workloads; libloops_gen.so (csrc/loops_gen.cpp, host C++ +
+# OpenMP) computes the same arrays bit for bit and is what the big configurations use (C3 stand-in: 194 M nonzeros,
+# C5: 537 M) -- numpy needs minutes there.  tests/test_generate.py compares the two.  Every generator takes
+# ``native=None`` (use the library when it is built), ``True`` (require it) or ``False`` (numpy).
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GEN_LIB_PATH = os.path.join(_HERE, "libloops_gen.so")
+GEN_SRC_PATH = os.path.join(_HERE, "csrc", "loops_gen.cpp")
+_gen = None
+_UNIFORM = -(1 << 63)
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (an OpenMP team larger
+    than the quota is throttled to a crawl on the GPU boxes: 256 logical CPUs, 16 CPUs' worth of time)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def build_native(force: bool = False) -> str:
+    """g++ -O3 -fopenmp build of the native workload builder (host code only)."""
+    if not force and os.path.exists(GEN_LIB_PATH) and os.path.getmtime(GEN_LIB_PATH) >= os.path.getmtime(GEN_SRC_PATH):
+        return GEN_LIB_PATH
+    subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-fopenmp", "-shared", "-fPIC", GEN_SRC_PATH, "-o", GEN_LIB_PATH])
+    return GEN_LIB_PATH
+
+
+def native(required: bool = False):
+    """The loaded libloops_gen.so, or None when it has not been built (``required``: raise instead)."""
+    global _gen
+    if _gen is None and os.path.exists(GEN_LIB_PATH):
+        L = C.CDLL(GEN_LIB_PATH)
+        ll, vp = C.c_longlong, C.c_void_p
+        L.loops_gen_degree_total.argtypes = [vp, ll, C.c_double, ll]
+        L.loops_gen_degree_total.restype = ll
+        L.loops_gen_degrees.argtypes = [vp, ll, C.c_double, ll, vp]
+        L.loops_gen_degrees.restype = None
+        L.loops_gen_perm_keys.argtypes = [C.c_ulonglong, ll, vp]
+        L.loops_gen_perm_keys.restype = None
+        L.loops_gen_csr_rows.argtypes = [vp, vp, ll, ll, C.c_ulonglong, ll, C.c_int, ll, vp, vp]
+        L.loops_gen_x_int.argtypes = [ll, ll, C.c_int, C.c_int, C.c_uint, vp]
+        L.loops_gen_x_int.restype = None
+        L.loops_gen_set_threads.argtypes = [C.c_int]
+        L.loops_gen_set_threads.restype = None
+        L.loops_gen_set_threads(usable_cpus())
+        _gen = L
+    if _gen is None and required:
+        raise RuntimeError(f"{GEN_LIB_PATH} not built (loops_amd.generate.build_native())")
+    return _gen
+
+
+def _use_native(flag):
+    return native(required=True) if flag else (None if flag is False else native())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
 
 
 def splitmix64(z):
@@ -42,9 +110,14 @@ def hash32(a):
     return a
 
 
-def uniform_distribution_int(n, lo=1, hi=10, seed=42, dtype=np.float32, start=0):
+def uniform_distribution_int(n, lo=1, hi=10, seed=42, dtype=np.float32, start=0, native=None):
     """x[i] for i in [start, start + n): minstd_rand seeded with hash(i) * seed, one draw, mapped
     through uniform_int_distribution<int>(lo, hi) (rocThrust semantics)."""
+    L = _use_native(native) if n >= (1 << 16) or native else None
+    if L is not None:
+        x = np.empty(n, np.float32)
+        L.loops_gen_x_int(int(start), int(n), int(lo), int(hi), int(seed) & 0xFFFFFFFF, _p(x))
+        return x if dtype == np.float32 else x.astype(dtype)
     m = np.uint64(2147483647)
     i = np.arange(start, start + n, dtype=np.uint64)
     s = (hash32(i & np.uint64(0xFFFFFFFF)) * np.uint64(seed & 0xFFFFFFFF)) & np.uint64(0xFFFFFFFF)
@@ -57,12 +130,15 @@ def uniform_distribution_int(n, lo=1, hi=10, seed=42, dtype=np.float32, start=0)
 
 
 # ------------------------------------------------------------------------------ power-law CSR
-def powerlaw_degrees(rows, nnz, alpha=0.8, cap=1 << 14, perm_seed=0x5EED):
+def powerlaw_degrees(rows, nnz, alpha=0.8, cap=1 << 14, perm_seed=0x5EED, native=None):
     """Row degrees d = clamp(floor(c / (rank + 1)^alpha), 1, cap) with c bisected so sum(d) == nnz,
     assigned to rows through the fixed permutation argsort(splitmix64(perm_seed ^ r))."""
     rank = np.arange(1, rows + 1, dtype=np.float64) ** (-alpha)
+    L = _use_native(native)
 
     def total(c):
+        if L is not None:
+            return int(L.loops_gen_degree_total(_p(rank), rows, float(c), int(cap)))
         return int(np.clip(np.floor(c * rank), 1, cap).sum())
 
     lo, hi = 0.0, float(cap) * rows
@@ -72,14 +148,23 @@ def powerlaw_degrees(rows, nnz, alpha=0.8, cap=1 << 14, perm_seed=0x5EED):
             lo = mid
         else:
             hi = mid
-    d = np.clip(np.floor(hi * rank), 1, cap).astype(np.int64)
+    if L is not None:
+        d = np.empty(rows, np.int64)
+        L.loops_gen_degrees(_p(rank), rows, float(hi), int(cap), _p(d))
+    else:
+        d = np.clip(np.floor(hi * rank), 1, cap).astype(np.int64)
     diff = int(d.sum()) - nnz  # hi gives total >= nnz: shave the residual off the largest uncapped rows
     if diff:
         idx = np.flatnonzero((d < cap) & (d > 1)) if diff > 0 else np.flatnonzero(d < cap)
         assert idx.size >= abs(diff), "cannot fix degree residual"
         d[idx[: abs(diff)]] -= np.sign(diff)
     assert int(d.sum()) == nnz
-    perm = np.argsort(splitmix64(np.uint64(perm_seed) ^ np.arange(rows, dtype=np.uint64)), kind="stable")
+    if L is not None:
+        keys = np.empty(rows, np.uint64)
+        L.loops_gen_perm_keys(int(perm_seed), rows, _p(keys))
+    else:
+        keys = splitmix64(np.uint64(perm_seed) ^ np.arange(rows, dtype=np.uint64))
+    perm = np.argsort(keys, kind="stable")
     out = np.empty(rows, np.int64)
     out[perm] = d  # rank k's degree lands on row perm[k]
     return out
@@ -108,7 +193,7 @@ def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None):
     return (rows_abs + off) % np.int64(cols)
 
 
-def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None):
+def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None, native=None):
     """Rows [row_begin, row_begin + len(degrees)) of the hashed matrix: per-row distinct columns
     sorted ascending; values k/8 (exact) or U[0.5, 1.5) (realistic).  `window` = None draws
     columns uniformly over [0, cols); an integer draws them from a band of that many
@@ -118,6 +203,16 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None
     np.cumsum(degrees, out=offsets[1:])
     nnz = int(offsets[-1])
     assert int(degrees.max(initial=0)) <= cols
+    assert nnz < (1 << 31), "int32 offsets"
+    L = _use_native(native) if (window is None or window == -1 or window > 0) else None
+    if L is not None:
+        deg64 = np.ascontiguousarray(degrees, np.int64)
+        indices = np.empty(nnz, np.int32)
+        values = np.empty(nnz, np.float32)
+        rc = L.loops_gen_csr_rows(_p(deg64), _p(offsets), nrows, int(cols), int(seed), int(row_begin), int(bool(exact)),
+                                  _UNIFORM if window is None else int(window), _p(indices), _p(values))
+        assert rc == 0, "a row cannot hold that many distinct columns"
+        return offsets.astype(np.int32), indices, values
     rloc = np.repeat(np.arange(nrows, dtype=np.int64), degrees)
     k = np.arange(nnz, dtype=np.int64) - np.repeat(offsets[:-1], degrees)
     rabs = rloc + row_begin

@@ -368,27 +368,6 @@ def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None =
     return y
 
 
-# ------------------------------------------------------------------------------- probes
-def stream_copy(src, dst):
-    L.check(L.lib().loops_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "loops_stream_copy_f32")
-
-
-def gather(table, idx, out, mode: int = 0):
-    L.check(L.lib().loops_gather_f32(_ptr(table), _ptr(idx), _ptr(out), idx.numel(), mode, _stream()),
-            "loops_gather_f32")
-
-
-def address_rate(table, reps: int, pattern: int, blocks: int, out):
-    L.check(L.lib().loops_address_rate_f32(_ptr(table), table.numel(), reps, pattern, blocks, _ptr(out), _stream()),
-            "loops_address_rate_f32")
-
-
-def row_gather(table, idx, row_floats: int, blocks: int, out):
-    """Row-gather probe: see loops_row_gather_f32."""
-    L.check(L.lib().loops_row_gather_f32(_ptr(table), _ptr(idx), idx.numel(), row_floats, blocks, _ptr(out), _stream()),
-            "loops_row_gather_f32")
-
-
 def coo_spmv(rows: int, cols: int, row_indices, col_indices, values, x, y=None, tuned: bool = True):
     """COO SpMV (loops_spmv_coo_f32): ``tuned`` = one atomic per run of equal row indices (y zero-filled
     inside); otherwise the reference shape, one atomic per nonzero into a y zero-filled here."""

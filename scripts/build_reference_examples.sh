@@ -14,12 +14,15 @@ fail=0
 build() {  # src out extra-flags
   if /opt/rocm/bin/hipcc $FLAGS $3 "$1" -o "$2" > "$2.log" 2>&1; then echo "ok   $(basename $2)"; else echo "FAIL $(basename $2) (see $2.log)"; fail=1; fi
 }
+JOBS=${JOBS:-$(nproc)}
+n=0
 for src in $REF/examples/spmv/*.cu; do
   name=$(basename "$src" .cu)
   build "$src" "$OUT/loops.spmv.$name.f32" "-DLOOPS_VALUE_T=float -I$REF/examples/spmv" &
   build "$src" "$OUT/loops.spmv.$name.f64" "-DLOOPS_VALUE_T=double -I$REF/examples/spmv" &
-  wait
+  n=$((n+2)); if [ $n -ge $JOBS ]; then wait; n=0; fi
 done
+wait
 build "$REF/examples/spmm/thread_mapped.cu" "$OUT/loops.spmm.thread_mapped" "-I$REF/examples/spmm" &
 build "$REF/examples/saxpy/saxpy.cu" "$OUT/loops.saxpy" "" &
 build "$REF/examples/range/range.cu" "$OUT/loops.range" "" &
@@ -27,4 +30,6 @@ build "$REF/examples/range/range.cu" "$OUT/loops.range" "" &
 build "$ROOT/examples/spmm/merge_path_flat.cu" "$OUT/loops.spmm.merge_path_flat" "" &
 build "$ROOT/examples/spmv/column_blocked.cu" "$OUT/loops.spmv.column_blocked" "" &
 wait
+# which headers these binaries were built from: tests/test_examples_gpu.py refuses stale binaries
+if [ $fail -eq 0 ]; then python3 "$ROOT/scripts/headers_digest.py" > "$OUT/HEADERS.sha256"; fi
 exit $fail

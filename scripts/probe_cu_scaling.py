@@ -1,7 +1,7 @@
 import sys, os
 sys.path.insert(0, "/root/repo" if os.path.exists("/root/repo/loops_amd") else os.getcwd())
 import numpy as np, torch
-from loops_amd import spmv as S
+from loops_amd import probes as S
 def ev(fn, iters=10):
     for _ in range(2): fn()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]

@@ -3,7 +3,7 @@ bounds the x[col] reads of SpMV on this box)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from loops_amd import spmv as S
+from loops_amd import probes as S
 
 def ev(fn, iters=20):
     for _ in range(3): fn()

@@ -3,7 +3,7 @@ random rows of 32..1024 bytes from tables of 1 MB (L2-resident) .. 1 GB (HBM), 2
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from loops_amd import spmv as S
+from loops_amd import probes as S
 
 def ev(fn, iters=10, warm=2):
     for _ in range(warm): fn()

@@ -82,8 +82,9 @@ def _built_extension():
     """The HIP extension is built in-tree before any test runs (hipcc cross-compiles without a GPU;
     a no-op when libloops_amd.so is newer than its sources).  There is no fallback path to test:
     if this fails, every product call would raise LoopsError."""
-    from loops_amd import _lib
+    from loops_amd import _lib, generate
     _lib.build()
+    generate.build_native()
 
 
 def load_golden(name):

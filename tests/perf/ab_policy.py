@@ -1,0 +1,53 @@
+"""Cache-policy A/B of the fused merge_path_flat kernel on C2 (and optionally a banded C2): every compiled policy
+of libloops_probes.so (loops_probe_merge_path_f32: explicit sc0 / sc1 / nt bits on the col_idx stream, the values
+stream and the x gather), tile kernel only, back-to-back launches between one pair of events; bit-exactness of
+kernel + fix-up against policy 0.
+
+    python tests/perf/ab_policy.py [--iters 50] [--window W] [--only 0,4,13] [--json out.json]
+
+Run it under `rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum ... --kernel-trace` to get the L2 hit rate per policy: the
+kernels differ in one template argument (the engine's NT parameter), printed here as `nt_param`."""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from loops_amd import generate as G, probes as PR, spmv as S
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--window", type=int, default=0)
+ap.add_argument("--only", default="")
+ap.add_argument("--json", default="")
+ap.add_argument("--log2-rows", type=int, default=20)
+ap.add_argument("--log2-nnz", type=int, default=24)
+args = ap.parse_args()
+
+rows = cols = 1 << args.log2_rows
+deg = G.powerlaw_degrees(rows, 1 << args.log2_nnz)
+off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, args.window or None)
+csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
+y = torch.empty(rows, device="cuda")
+run = PR.PolicyRunner(csr)
+names = PR.policies()
+only = [int(t) for t in args.only.split(",") if t] or list(range(len(names)))
+run.run(0, x, y)
+torch.cuda.synchronize()
+ref = y.clone()
+out = {}
+for p in only:
+    y.zero_()
+    run.run(p, x, y)
+    ok = bool(torch.equal(y, ref))
+    for _ in range(3):
+        run.run(p, x, y, stages=1)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.iters):
+        run.run(p, x, y, stages=1)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / args.iters * 1e3
+    out[p] = {"name": names[p], "us": round(us, 2), "exact": ok}
+    print(f"policy {p:2d} {names[p]:28s} {us:8.2f} us  exact={ok}", flush=True)
+if args.json:
+    json.dump(out, open(args.json, "w"), indent=1)

@@ -3,7 +3,7 @@
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
-from loops_amd import generate as G, spmv as S, _lib
+from loops_amd import generate as G, spmv as S, probes as PR, _lib
 
 hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
 hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
@@ -50,7 +50,7 @@ for name, flags in (("coarse (hipMalloc default)", None), ("fine-grained", 1), (
     S.merge_path_flat(csr, x, y, plan=plan); torch.cuda.synchronize()
     ok = np.array_equal(y.cpu().numpy(), ref)
     # read-only stream rate over the values array
-    L = _lib.lib()
+    L = PR.lib()
     def rd():
         _lib.check(L.loops_stream_copy_f32(C.c_void_p(cv.data_ptr()), C.c_void_p(cv.data_ptr()), cv.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "read")
     msr = ev(rd)

@@ -89,3 +89,23 @@ def test_argument_errors_of_the_newer_entry_points():
     assert L.loops_spmv_ell_f32(1, 4, 4, 2, None, None, None, None, None) == -1
     assert L.loops_spmv_csc_f32(1, 4, 4, 4, None, None, None, None, None, None) == -1
     assert L.loops_autotune_merge_path_f32(4, 4, 4, None, None, None, None, None, 1, None, None, None) == -1
+
+
+def test_measurement_code_lives_outside_the_product_library():
+    """Calibration kernels / experimental instantiations are libloops_probes.so (loops_amd/csrc/loops_probes.h),
+    loaded only by loops_amd/probes.py for bench.py, scripts/ and tests/perf/: the product library exports none of
+    them, the product header declares none, the product modules never import the probes module, and no
+    measurement macro is left in the shipped kernels."""
+    L = _lib.load_shared(_lib.build())
+    P = _lib.load_shared(_lib.build_probes())
+    for name in ("loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32", "loops_row_gather_f32",
+                 "loops_probe_merge_path_f32"):
+        assert hasattr(P, name), name
+        assert not hasattr(L, name), name
+        assert name not in open(os.path.join(ROOT, "include", "loops_amd.h")).read()
+    for mod in ("spmv.py", "_lib.py", "partition.py", "generate.py", "__init__.py"):
+        src = open(os.path.join(ROOT, "loops_amd", mod)).read()
+        assert "probes" not in src.replace("build_probes", "").replace("PROBES_", "").replace("libloops_probes", "").replace("loops_probes", ""), mod
+    for base, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            assert "LOOPS_PROBE" not in open(os.path.join(base, f)).read(), f

@@ -20,10 +20,23 @@ SPMV = ["merge_path", "thread_mapped", "work_oriented", "group_mapped", "origina
 
 
 def _run(exe, *args):
+    # On a GPU box a missing or stale binary is a FAILURE, not a skip: a snapshot without the prebuilt artefacts
+    # must not go green with the drop-in boundary untested.
     path = os.path.join(BIN, exe)
-    if not os.path.exists(path):
-        pytest.skip(f"{exe} not built (scripts/build_reference_examples.sh needs /root/reference)")
+    assert os.path.exists(path), f"{exe} not built: run scripts/build_reference_examples.sh in the dev container (needs /root/reference)"
     return subprocess.run([path, *args], capture_output=True, text=True, timeout=300)
+
+
+def test_example_binaries_were_built_from_these_headers():
+    """The binaries travel prebuilt (their sources live in /root/reference): they must come from the CURRENT
+    include/ tree, otherwise this suite would exercise stale kernels (scripts/build_reference_examples.sh records
+    the digest of the headers it compiled against)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from headers_digest import digest
+    manifest = os.path.join(BIN, "HEADERS.sha256")
+    assert os.path.exists(manifest), "build/examples/HEADERS.sha256 missing: rebuild with scripts/build_reference_examples.sh"
+    assert open(manifest).read().strip() == digest(), "example binaries are stale: include/ changed since scripts/build_reference_examples.sh ran"
 
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])

@@ -42,3 +42,28 @@ def test_uniform_bcsr():
     for br in range(64):
         c = bcols[boff[br]:boff[br + 1]]
         assert (np.diff(c) > 0).all()
+
+
+def test_native_builder_equals_the_numpy_specification():
+    """libloops_gen.so (host C++ / OpenMP, used for the 194 M- and 537 M-nonzero configurations) against the numpy
+    functions that define the workloads: degrees, CSR rows (uniform / runs / band columns, exact and realistic
+    values, a row range generated alone) and the x generator -- bit for bit."""
+    G.build_native()
+    for rows, nnz, cap in ((1 << 12, 1 << 16, 1 << 10), (100003, 1500007, 1 << 14)):
+        d0 = G.powerlaw_degrees(rows, nnz, cap=cap, native=False)
+        d1 = G.powerlaw_degrees(rows, nnz, cap=cap, native=True)
+        assert np.array_equal(d0, d1) and d1.dtype == d0.dtype
+        for window in (None, -1, 64, 4096):
+            for exact in (True, False):
+                a = G.csr_from_degrees(d0[100:3000], rows, 3, 100, exact, window, native=False)
+                b = G.csr_from_degrees(d0[100:3000], rows, 3, 100, exact, window, native=True)
+                assert all(np.array_equal(u, v) and u.dtype == v.dtype for u, v in zip(a, b)), (rows, window, exact)
+        assert np.array_equal(G.uniform_distribution_int(rows + 70000, native=False),
+                              G.uniform_distribution_int(rows + 70000, native=True))
+        assert np.array_equal(G.uniform_distribution_int(70000, -5, 5, 12345, start=999, native=False),
+                              G.uniform_distribution_int(70000, -5, 5, 12345, start=999, native=True))
+    # heavy duplicate pressure: 60 distinct columns wanted out of 64 (many redraw rounds)
+    deg = np.full(50, 60, np.int64)
+    a = G.csr_from_degrees(deg, 64, 5, 0, True, None, native=False)
+    b = G.csr_from_degrees(deg, 64, 5, 0, True, None, native=True)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))

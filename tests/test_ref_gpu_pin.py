@@ -12,7 +12,18 @@ from loops_amd import _lib
 
 pytestmark = pytest.mark.gpu
 SO = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
-needs_ref = pytest.mark.skipif(not os.path.exists(SO), reason="oracle/_ref/libloops_ref_gpu.so not shipped")
+
+
+def needs_ref(fn):
+    """On a GPU box the reference build MUST be there (oracle/Makefile, dev container): a snapshot without it fails
+    instead of skipping, or the device-side pin would silently go untested."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        assert os.path.exists(SO), "oracle/_ref/libloops_ref_gpu.so not shipped: run `make -C oracle ref` in the dev container"
+        return fn(*a, **k)
+    return wrapper
 
 
 def _p(a):

@@ -206,9 +206,35 @@ def test_full_size_c2_bit_exact_and_properties():
     yr = S.merge_path_flat(csr_r, torch.from_numpy(xr).cuda(), plan=plan).cpu().numpy()
     rep = O.rigorous_validate_f32(off_r, idx_r, val_r, xr, yr)
     assert rep.gpu_overruns == 0 and rep.naive_mismatches == 0
-    y64 = O.spmv_f64acc_f32(off_r, idx_r, val_r, xr)
-    rel = np.abs(yr - y64) / np.maximum(np.abs(y64), 1.0)
-    assert rel.max() < 1e-6 * 16, rel.max()
+    # north star: fp32 y within 1e-6 RELATIVE.  Reference = f64 accumulation (not rounded to f32).  Measured, not
+    # assumed: every row with <= 64 nonzeros must meet 1e-6 outright (all terms positive here: no cancellation to
+    # hide behind); longer rows are held to the a-priori bound of ANY summation order, n * 2^-24 relative to the
+    # row's L1 mass (= |y| here), and the measured maxima are recorded next to the sequential-f32 figures of the
+    # reference's own CPU path (reference::spmv, util/reference.hxx:61-76) for DESIGN.md section 4.
+    yd = O.spmv_f64(off_r, idx_r, val_r.astype(np.float64), xr.astype(np.float64))
+    yseq = O.spmv_f32(off_r, idx_r, val_r, xr, omp=True)
+    n = np.diff(off_r.astype(np.int64))
+    rel_gpu = np.abs(yr.astype(np.float64) - yd) / np.abs(yd)
+    rel_seq = np.abs(yseq.astype(np.float64) - yd) / np.abs(yd)
+    short = n <= 64
+    assert rel_gpu[short].max() <= 1e-6, rel_gpu[short].max()
+    assert np.all(rel_gpu[~short] <= n[~short] * 2.0 ** -24), (rel_gpu[~short] / (n[~short] * 2.0 ** -24)).max()
+    record = {"workload": "C2 realistic values (U[0.5,1.5) values and x), 2^20 rows / 2^24 nnz",
+              "rows_le_64_nnz": int(short.sum()), "rows_gt_64_nnz": int((~short).sum()),
+              "gpu_max_rel_err_rows_le_64": float(rel_gpu[short].max()), "gpu_max_rel_err_rows_gt_64": float(rel_gpu[~short].max()),
+              "sequential_f32_max_rel_err_rows_le_64": float(rel_seq[short].max()),
+              "sequential_f32_max_rel_err_rows_gt_64": float(rel_seq[~short].max()),
+              "gpu_rows_over_1e-6": int((rel_gpu > 1e-6).sum()), "sequential_f32_rows_over_1e-6": int((rel_seq > 1e-6).sum())}
+    print("fp32 tolerance record:", record)
+    try:
+        import json
+        os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+        json.dump(record, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                                            "parity_c2_fp32_tolerance.json"), "w"), indent=1)
+    except OSError:
+        pass
+    # the GPU's blocked summation must not be worse than the reference's sequential one on the long rows
+    assert rel_gpu[~short].max() <= max(rel_seq[~short].max(), 1e-6)
 
 
 def test_row_range_shards_reassemble_on_one_gpu():
@@ -237,6 +263,31 @@ def test_row_range_shards_reassemble_on_one_gpu():
                 S.spmv(sched, csr, xd, y_full[a:b])
                 assert np.array_equal(y_full[a:b].cpu().numpy(), ref[a:b]), (world, rank, sched)
         assert np.array_equal(y_full.cpu().numpy(), ref), world
+
+
+@pytest.mark.parametrize("window", [None, 65536], ids=["uniform", "band65536"])
+def test_c3_standin_group_mapped_vs_work_oriented(window):
+    """BASELINE config C3 (indochina-2004: 7 414 866 rows / 194 109 311 nnz, group_mapped vs work_oriented): the
+    SuiteSparse file is not shipped (datasets/suitesparse.txt:2052), so the two schedules -- and merge_path_flat --
+    run on generated stand-ins of exactly that shape: scale-free degrees with uniformly random columns (no
+    locality: lower bound) and with columns in a 65 536-wide band (crawl-order locality of a web graph).
+    Bit-exact against the oracle.  tests/perf/bench_schedules.py --mtx PATH runs the real file when supplied."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows = cols = 7_414_866
+    nnz = 194_109_311
+    deg = G.powerlaw_degrees(rows, nnz, native=True)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, native=True)
+    assert off[-1] == nnz and off.size == rows + 1
+    x = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, x, omp=True)
+    csr = _dev(off, idx, val, rows, cols)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty(rows, device="cuda")
+    for sched in ("group_mapped", "work_oriented", "merge_path_flat"):
+        y.fill_(-1.0)
+        S.spmv(sched, csr, xd, y)
+        assert np.array_equal(y.cpu().numpy(), ref), (sched, window)
 
 
 def test_c5_shard_size_properties():
