@@ -12,12 +12,17 @@ fused merge-tile kernel + carry-out fix-up, and for N > 1 the allgatherv of y.  
 step WITH the coordinate pre-pass is reported next to it (config.ms_per_step_with_prepass).
 
 Workload at N = 1: BASELINE config C2 -- synthetic power-law CSR, 2^20 rows, 2^24 nnz, max
-degree 2^14, fp32 (SURVEY 8d generator).  At N > 1 (weak scaling): N * 2^20 rows,
-N * 2^24 nnz of the same generator, contiguous row ranges balanced by rows + nnz, one range
-per GPU, x replicated, allgatherv(y) over RCCL every step.  At N > 1 a rank holds its shard
-COLUMN-BLOCKED by owner (--layout, include/loops/kernels/column_blocked.hxx): x is N * 4 MB there and no
-longer fits the 4 MB per-XCD L2; the blocked layout keeps each XCD inside one x block (same fused
-kernel + a K-way row reduce).  The N = 1 headline runs on the unmodified CSR.
+degree 2^14, fp32 (SURVEY 8d generator).  At N > 1 (default, --scaling strong): BASELINE config
+C5 -- the 2^24-row / 2^29-nnz matrix of the same generator, STRONG-scaled: contiguous row ranges
+balanced by rows + nnz, one per GPU (2^26 nnz each at N = 8), x (64 MB) replicated, allgatherv(y)
+over RCCL every step; `value` = 2 * 2^29 flop / step time.  Rank 0 additionally times the SAME
+matrix on its one GPU outside the timed region (config.one_gpu_same_matrix), so the ">= 6x at 8 GPUs"
+target of BASELINE.md is a ratio inside one record (config.speedup_vs_one_gpu_same_matrix), and the
+gathered y is compared bit for bit with the one-GPU y.  --scaling weak keeps the round-1 mode
+(N x C2: N * 2^20 rows / N * 2^24 nnz) for context.  At N > 1 a rank holds its shard
+COLUMN-BLOCKED by owner (--layout, include/loops/kernels/column_blocked.hxx): x is larger than the
+4 MB per-XCD L2 there; the blocked layout keeps each XCD inside one x block (same fused kernel + a
+K-way row reduce).  The N = 1 headline runs on the unmodified CSR.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
 """
@@ -42,20 +47,115 @@ def algorithmic_bytes(rows, cols, nnz, vbytes=4):
 
 def pmc_traffic(args):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of
-    THIS command (profiles/r01_c2_pmc_summary.json; separate --pmc FETCH_SIZE / WRITE_SIZE runs):
-    (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE counts the 128-B requests of this kernel at
-    64 B on gfx950 (MI355X_MICROARCH.md, HBM section; checked here against TCC_MISS * 128 B).
-    None when the configuration differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_c2_pmc_summary.json" if args.tile == "256x8"
-                        else f"r01_c2_pmc_summary_{args.tile}.json")
-    if not os.path.exists(path) or args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 \
-            or args.variant != 0 or args.layout == "blocked":
-        return None
-    d = json.load(open(path))
-    for k, v in d.items():
-        if "merge_path_spmv_fused" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            return int((2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024)
-    return None
+    THIS command (profiles/rNN_c2_pmc_summary_<tile>.json; separate --pmc runs): TCC_EA0_RDREQ x 128 B
+    (every fabric read of this kernel is a 128-B line: TCC_EA0_RDREQ_32B = 0; FETCH_SIZE tallies them at
+    64 B on gfx950, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, or -- older summaries --
+    2 * FETCH_SIZE + WRITE_SIZE.  Returns (bytes, source file) or (None, None) when the configuration
+    differs from the profiled one.  The summary's `_kernel_build` names the commit the counters belong to."""
+    if args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 or args.variant != 0 \
+            or args.layout == "blocked":
+        return None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_c2_pmc_summary_{args.tile}.json")), reverse=True):
+        d = json.load(open(path))
+        for k, v in d.items():
+            if "merge_path_spmv_fused" not in k or "stacked" in k or not isinstance(v, dict):
+                continue
+            wr = v.get("WRITE_SIZE", {}).get("mean")
+            if "TCC_EA0_RDREQ_sum" in v and wr is not None:
+                return int(v["TCC_EA0_RDREQ_sum"]["mean"] * 128 + wr * 1024), os.path.relpath(path, ROOT)
+            if "FETCH_SIZE" in v and wr is not None:
+                return int((2 * v["FETCH_SIZE"]["mean"] + wr) * 1024), os.path.relpath(path, ROOT)
+    return None, None
+
+
+def full_matrix_on_device(G, S, torch, degrees, cols, chunks=8):
+    """The whole synthetic matrix as one device CSR, generated and uploaded in row chunks (host memory stays at one
+    chunk: C5 is 4.3 GB of indices + values)."""
+    rows = degrees.size
+    off = np.zeros(rows + 1, np.int64)
+    np.cumsum(degrees, out=off[1:])
+    nnz = int(off[-1])
+    idx_d = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    val_d = torch.empty(nnz, dtype=torch.float32, device="cuda")
+    cut = np.linspace(0, rows, chunks + 1).astype(np.int64)
+    for a, b in zip(cut[:-1], cut[1:]):
+        _, i, v = G.csr_from_degrees(degrees[a:b], cols, seed=1, row_begin=int(a))
+        idx_d[int(off[a]):int(off[b])].copy_(torch.from_numpy(i))
+        val_d[int(off[a]):int(off[b])].copy_(torch.from_numpy(v))
+    return S.CSR(rows, cols, torch.from_numpy(off.astype(np.int32)).cuda(), idx_d, val_d)
+
+
+def timed_ms(torch, fn, iters, warm=3):
+    """ms per call: `iters` back-to-back calls between one pair of HIP events on the launch stream."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_gathered, iters=20):
+    """BASELINE C5's denominator: the SAME matrix on ONE GPU (rank 0's, outside the timed region) -- the planned
+    merge_path_flat SpMV on the unmodified CSR and on the column-blocked layout the ranks use (automatic block count),
+    each y compared bit for bit with the vector the N ranks gathered (SURVEY 8e parity)."""
+    t0 = time.time()
+    csr = full_matrix_on_device(G, S, torch, degrees, cols)
+    gen_s = time.time() - t0
+    y = torch.empty(csr.rows, dtype=torch.float32, device="cuda")
+    plan = S.MergePathPlan(csr, "512x8")
+    ms_csr = timed_ms(torch, lambda: S.merge_path_flat(csr, x, y, plan=plan), iters)
+    eq_csr = bool(torch.equal(y, y_gathered))
+    out = {"workload": f"{csr.rows} rows / {csr.nnzs} nnz on rank 0's GPU alone (x {cols * 4 >> 20} MB)",
+           "csr_ms_per_spmv": round(ms_csr, 5), "csr_equals_gathered_y_bit_for_bit": eq_csr, "generate_upload_seconds": round(gen_s, 1)}
+    plan.close()
+    try:
+        cb = S.ColumnBlockedPlan(csr)
+        ms_b = timed_ms(torch, lambda: cb.spmv(x, y), iters)
+        out.update({"blocked_ms_per_spmv": round(ms_b, 5), "blocked_blocks": cb.num_blocks,
+                    "blocked_equals_gathered_y_bit_for_bit": bool(torch.equal(y, y_gathered))})
+        cb.close()
+    except Exception as e:  # noqa: BLE001 -- the plain-CSR figure stands on its own
+        out["blocked_error"] = f"{type(e).__name__}: {e}"
+    out["best_ms_per_spmv"] = min(v for k, v in out.items() if k.endswith("_ms_per_spmv"))
+    return out
+
+
+def context_c4_bcsr(G, S, O, torch, iters=50):
+    """BASELINE config C4 at full size next to the headline (context line of the N = 1 record): BCSR 4x4, 2^18 block
+    rows x 16 blocks, bcsr_thread_mapped with the MFMA block inner product, bit-exact against the oracle."""
+    nbr, per = 1 << 18, 16
+    boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, per)
+    xh = G.uniform_distribution_int(nbr * 4)
+    b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    x, y = torch.from_numpy(xh).cuda(), torch.empty(nbr * 4, device="cuda")
+    nb = int(bcols.size)
+    abytes = nb * (16 * 4 + 4) + (nbr + 1) * 4 + nbr * 4 * 4 + nbr * 4 * 4  # SURVEY 8d B_bcsr: 294 649 860
+    out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks, fp32 (BASELINE configs[3])", "algorithmic_bytes": abytes}
+    for name, mode in (("mfma", 1), ("thread_per_block_row", 0)):
+        ms = timed_ms(torch, lambda: S.bcsr_thread_mapped(b, x, y, mfma=mode), iters)
+        out[name] = {"avg_launch_ms": round(ms, 5), "GFLOPs": round(2 * 16 * nb / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
+                     "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    S.bcsr_thread_mapped(b, x, y, mfma=1)
+    out["mfma"]["kernel"] = "loops::kernels::bcsr4x4_mfma_spmv"
+    out["parity_vs_oracle_bit_exact"] = bool(np.array_equal(y.cpu().numpy(), O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)))
+    return out
+
+
+def context_schedules(S, torch, csr, x, ref_y, abytes, iters=50):
+    """The other tuned schedules on the headline matrix (work_oriented and group_mapped are BASELINE C3's pair):
+    whole call through loops_spmv_csr_f32 (work_oriented includes its coordinate pre-pass), bit-exact vs the headline y."""
+    y = torch.empty_like(ref_y)
+    out = {}
+    for sched in ("work_oriented", "group_mapped"):
+        ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
+        out[sched] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
+                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
+    return out
 
 
 def main():
@@ -63,8 +163,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--log2-rows", type=int, default=20, help="rows per GPU = 2^this (C2: 20)")
-    ap.add_argument("--log2-nnz", type=int, default=24, help="nnz per GPU = 2^this (C2: 24)")
+    ap.add_argument("--log2-rows", type=int, default=20, help="N = 1 and --scaling weak: rows per GPU = 2^this (C2: 20)")
+    ap.add_argument("--log2-nnz", type=int, default=24, help="N = 1 and --scaling weak: nnz per GPU = 2^this (C2: 24)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="N > 1: strong = BASELINE C5, ONE matrix of 2^--c5-log2-rows rows / 2^--c5-log2-nnz nnz cut into N row "
+                         "ranges (default); weak = N x C2 (round-1 mode, context only)")
+    ap.add_argument("--c5-log2-rows", type=int, default=24, help="strong scaling: TOTAL rows = 2^this (C5: 24)")
+    ap.add_argument("--c5-log2-nnz", type=int, default=29, help="strong scaling: TOTAL nnz = 2^this (C5: 29)")
+    ap.add_argument("--no-one-gpu-reference", action="store_true",
+                    help="strong scaling: skip rank 0's one-GPU run of the same matrix (outside the timed region)")
+    ap.add_argument("--no-context", action="store_true",
+                    help="N = 1: skip the context measurements (C4 BCSR, the other schedules on C2, column-blocked, local columns)")
     ap.add_argument("--tile", default="auto",
                     help="merge-tile shape TPBxIPT of the held plan; auto = the launch-box autotuner picks it on this "
                          "matrix before the timed region (loops_autotune_merge_path_f32)")
@@ -86,7 +195,9 @@ def main():
     ap.add_argument("--overlap-chunks", type=int, default=2,
                     help="N > 1: also try the step with the SpMV cut into this many row chunks whose exchanges overlap "
                          "the next chunk's kernel (0 = do not try); the fastest candidate of the start-up probe is used")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "padded", "p2p-chunked"],
+    ap.add_argument("--no-fused-stores", action="store_true",
+                    help="N > 1: do not try the exchange fused into the SpMV epilogue (peer-mapped stores, SURVEY 8 f2)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "padded", "p2p-chunked", "fused-stores"],
                     help="N > 1: allgatherv implementation; auto = the fastest of the start-up probe")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked"],
                     help="how a rank holds its row-range shard: 'csr' as sliced; 'blocked' = column-blocked by owner "
@@ -112,9 +223,12 @@ def main():
             dist.init_process_group("gloo")
 
     # ------------------------------------------------------------------ workload (synthetic)
-    rows = world << args.log2_rows
+    strong = world > 1 and args.scaling in ("auto", "strong")
+    if strong:
+        rows, nnz = 1 << args.c5_log2_rows, 1 << args.c5_log2_nnz
+    else:
+        rows, nnz = world << args.log2_rows, world << args.log2_nnz
     cols = rows
-    nnz = world << args.log2_nnz
     t0 = time.time()
     degrees = G.powerlaw_degrees(rows, nnz)
     bounds = P.row_ranges_from_degrees(degrees, world)
@@ -145,9 +259,15 @@ def main():
     plan = S.MergePathPlan(csr, args.tile)
     layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
     blocked = None
+    # column blocks: the owners' row ranges cut into ~2 MB pieces of x, at most half the mean row length of them
+    # (every block adds `rows` row-end items: C2-like shards, 16 nnz / row, are best at 8; C5 shards, 32 nnz / row, at 16)
+    max_blocks = 8
+    while max_blocks < 64 and max_blocks * 2 <= (nnz // rows) // 2:
+        max_blocks *= 2
+    col_bounds = P.column_block_bounds(bounds, max_blocks=max(max_blocks, world))
     if layout == "blocked":
         try:
-            blocked = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds))
+            blocked = S.ColumnBlockedPlan(csr, block_bounds=col_bounds)
         except Exception as e:  # noqa: BLE001 -- a rank that cannot build the blocked copy keeps its CSR shard
             if args.layout == "blocked":
                 raise
@@ -166,7 +286,13 @@ def main():
 
     chunked = {"plans": None, "exchange": None}
 
+    fused = {"fan": None, "run": None}
+
     def step():
+        if gather_mode["mode"] == "fused-stores":
+            fused["fan"].run(fused["run"])
+            fused["fan"].finish()
+            return
         if gather_mode["mode"] == "p2p-chunked":
             for c, (sub_run, y_sub) in enumerate(chunked["plans"]):
                 sub_run(y_sub)
@@ -190,7 +316,7 @@ def main():
             sub = S.CSR.from_numpy(b - a, cols, so, si, sv)
             y_sub = y_loc[a:b]
             if blocked is not None:
-                pl = S.ColumnBlockedPlan(sub, block_bounds=P.column_block_bounds(bounds))
+                pl = S.ColumnBlockedPlan(sub, block_bounds=col_bounds)
                 run = (lambda pl: (lambda y_sub: pl.spmv(x, y_sub)))(pl)
             else:
                 pl = S.MergePathPlan(sub, args.tile)
@@ -215,6 +341,11 @@ def main():
         t = torch.tensor([(time.perf_counter() - t0) / timed * 1e3], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return round(float(t), 5)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     exchange_probe = None
     if world > 1:
@@ -256,15 +387,44 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag) >= 1.0:
                 exchange_probe["p2p-chunked"] = probe_ms()
+        if not args.no_fused_stores:
+            # fourth candidate: no exchange step at all -- the kernels that finish rows of y also store them into every
+            # peer's vector through peer-mapped memory (loops_spmv_*_fanout_f32); one tiny barrier ends the step.
+            # Adopted only if it maps on every rank, reproduces the p2p result and is faster.
+            ok = 1.0
+            try:
+                gather_mode["mode"] = next(iter(exchange_probe))
+                step()
+                torch.cuda.synchronize()
+                want = float(y_full.double().sum())
+                views = P.FusedFanout.map_peers(y_full, shard)
+                fused["fan"] = P.FusedFanout(y_full, shard, views)
+                if blocked is not None:
+                    fused["run"] = lambda y, peers: blocked.spmv_fanout(x, y, peers)
+                else:
+                    fan_plan = plan if args.tile == "512x8" else S.MergePathPlan(csr, "512x8")
+                    fused["plan"] = fan_plan
+                    fused["run"] = lambda y, peers: S.merge_path_flat_fanout(csr, x, y, fan_plan, peers)
+                barrier()
+                y_full.zero_()
+                barrier()
+                gather_mode["mode"] = "fused-stores"
+                step()
+                torch.cuda.synchronize()
+                barrier()
+                if float(y_full.double().sum()) != want:
+                    raise RuntimeError("fused epilogue stores did not reproduce the exchanged vector")
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] fused epilogue stores unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                ok = 0.0
+            flag = torch.tensor([ok], device=comm_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag) >= 1.0:
+                exchange_probe["fused-stores"] = probe_ms()
         gather_mode["mode"] = min(exchange_probe, key=exchange_probe.get)
         if args.exchange != "auto":
             assert args.exchange in exchange_probe, f"--exchange {args.exchange} is not available here: {exchange_probe}"
             gather_mode["mode"] = args.exchange
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ parity (outside timing)
     parity = None
@@ -345,6 +505,19 @@ def main():
         spmv_local()
     torch.cuda.synchronize()
     spmv_only_ms = (time.perf_counter() - t0) / iters * 1e3
+    if world > 1:  # the slowest rank's kernels: what the exchange waits for
+        t = torch.tensor([spmv_only_ms], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        spmv_only_ms = float(t)
+
+    # BASELINE C5's denominator: the same matrix on one GPU (rank 0, outside the timed region; the others wait)
+    one_gpu = None
+    if strong and not args.no_one_gpu_reference:
+        step()  # (collective: every rank) y_full = the gathered vector the one-GPU result is compared with
+        barrier()
+        if rank == 0:
+            one_gpu = one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_full)
+        barrier()
 
     ms_with_prepass = None
     if blocked is None:  # the plan-less entry point: coordinates rebuilt every call, as the reference wrapper does
@@ -362,8 +535,8 @@ def main():
 
     # for context at N = 1: the same SpMV with the matrix held column-blocked (never `value`)
     blocked_info = None
-    if world == 1 and blocked is None and rank == 0:
-        cb = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds))
+    if world == 1 and blocked is None and rank == 0 and not args.no_context:
+        cb = S.ColumnBlockedPlan(csr, block_bounds=col_bounds)
         yb = torch.empty_like(y_loc)
         for _ in range(5):
             cb.spmv(x, yb)
@@ -378,7 +551,7 @@ def main():
         torch.cuda.synchronize()
         traffic_b = None
         pb = os.path.join(ROOT, "profiles", "r01_c2_blocked_pmc_summary.json")
-        if os.path.exists(pb) and pmc_traffic(args) is not None:  # same configuration as the profiled one
+        if os.path.exists(pb) and pmc_traffic(args)[0] is not None:  # same configuration as the profiled one
             for k, v in json.load(open(pb)).items():
                 if "merge_path_spmv_fused_stacked" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                     traffic_b = int((2 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024)
@@ -396,7 +569,7 @@ def main():
     # 64-column band): what the kernel does when the x gather is served by L1 -- its roofline fraction as a kernel,
     # next to the headline's, which is set by the random gather (never `value`)
     local_info = None
-    if world == 1 and rank == 0 and not args.window and not args.no_local_context:
+    if world == 1 and rank == 0 and not args.window and not args.no_local_context and not args.no_context:
         l_off, l_idx, l_val = G.csr_from_degrees(np.full(csr.rows, csr.nnzs // csr.rows, np.int64), cols, seed=1, window=64)
         l_csr = S.CSR.from_numpy(csr.rows, cols, l_off, l_idx, l_val)
         l_plan = S.MergePathPlan(l_csr, "256x8")
@@ -416,6 +589,16 @@ def main():
                       "equal_to_thread_mapped_result": l_ok, "note": "context, not the headline workload"}
         del l_csr, l_plan, yl, y_tm
 
+    # for context at N = 1: the other tuned schedules on the headline matrix, and BASELINE C4 (BCSR 4x4 + MFMA) at full size
+    schedules_info = c4_info = None
+    if world == 1 and rank == 0 and not args.no_context and not args.window:
+        step()
+        torch.cuda.synchronize()
+        schedules_info = context_schedules(S, torch, csr, x, y_loc.clone(), algorithmic_bytes(csr.rows, cols, csr.nnzs))
+        if not args.no_check:
+            from oracle import oracle as O  # checker only
+            c4_info = context_c4_bcsr(G, S, O, torch)
+
     # calibration probes: achievable streaming rate and gather rate on this box
     n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
     src = torch.empty(n_copy, dtype=torch.float32, device="cuda").normal_()
@@ -431,8 +614,11 @@ def main():
     loc_rows, loc_nnz = csr.rows, csr.nnzs
     abytes = algorithmic_bytes(loc_rows, cols, loc_nnz)
     achieved = abytes / (k_main_avg * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "loops::kernels::merge_path_spmv_fused", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args),
+    traffic, traffic_src = pmc_traffic(args)
+    roofline = {"bound": "hbm", "kernel": "loops::kernels::merge_path_spmv_fused" + ("_stacked" if blocked is not None else ""),
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(k_main_avg, 5),
                 "median_launch_ms": round(k_main_med, 5), "avg_launch_ms_event_pair_per_launch": round(k_main_single, 5), "fixup_avg_launch_ms": round(k_fix_avg, 5),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 4),
@@ -506,24 +692,35 @@ def main():
         out = {
             "metric": "CSR SpMV GFLOP/s, merge_path_flat", "value": round(gflops, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic power-law CSR, {rows} rows / {nnz} nnz total "
-                                   f"({world} x 2^{args.log2_rows} rows / 2^{args.log2_nnz} nnz per GPU), max degree 2^14, "
+                                   + (f"(ONE matrix cut into {world} row ranges balanced by rows + nnz: {loc_nnz} nnz on rank 0)" if strong else
+                                      f"({world} x 2^{args.log2_rows} rows / 2^{args.log2_nnz} nnz per GPU)") + ", max degree 2^14, "
                                    "fp32, merge_path_flat" + (f", columns banded (window {args.window})" if args.window else ", columns uniform")
                                    + (f", row-range sharded + allgatherv(y) over {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'}" if world > 1 else ""),
-                       "baseline_config": "BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling)",
+                       "baseline_config": "BASELINE.json configs[1]" if world == 1 else
+                                          ("BASELINE.json configs[4] (C5), strong scaling" if strong else "configs[1] per GPU (weak scaling; context mode)"),
                        "tile": args.tile, "tile_autotune_ms": tile_probe, "variant": args.variant,
                        "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
                                        f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)",
-                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (f", {args.overlap_chunks} chunks overlapping the SpMV" if gather_mode['mode'] == 'p2p-chunked' else "") + "]" if world > 1 else ""),
+                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (": finished rows stored to the peers from the kernels' epilogue + one barrier" if gather_mode['mode'] == 'fused-stores' else "") + (f", {args.overlap_chunks} chunks overlapping the SpMV" if gather_mode['mode'] == 'p2p-chunked' else "") + "]" if world > 1 else ""),
                        "ms_per_step_with_prepass": None if ms_with_prepass is None else round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
                        "spmv_only_ms_per_step": round(spmv_only_ms, 5),
+                       "spmv_only_GFLOPs": round(2.0 * nnz / (spmv_only_ms * 1e-3) / 1e9, 2),
+                       "spmv_plus_allgatherv_ms_per_step": round(ms_per_step, 5) if world > 1 else None,
+                       "one_gpu_same_matrix": one_gpu,
+                       "speedup_vs_one_gpu_same_matrix": None if not one_gpu else
+                                                         {"spmv_plus_allgatherv": round(one_gpu["best_ms_per_spmv"] / ms_per_step, 3),
+                                                          "spmv_only": round(one_gpu["best_ms_per_spmv"] / spmv_only_ms, 3),
+                                                          "target": ">= 6 at 8 GPUs (BASELINE.md section 2, C5)"},
                        "allgatherv_probe_ms_per_step": exchange_probe,
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
                        "column_blocked_layout_same_matrix": blocked_info,
                        "same_kernel_local_columns": local_info,
+                       "schedules_c2": schedules_info,
+                       "c4_bcsr_mfma": c4_info,
                        "reference_hip_backend_on_this_gpu": ref_gpu},
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -51,7 +51,7 @@ struct column_blocked_t {
         num_blocks(blocks > 0 ? blocks : automatic_blocks(csr.cols, csr.rows, csr.nnzs)),
         bounds(num_blocks + 1), offsets(std::size_t(num_blocks) * csr.rows + 1), indices(csr.nnzs), values(csr.nnzs),
         perm(csr.nnzs), partial(std::size_t(num_blocks) * csr.rows),
-        plan(build(csr, block_bounds, stream), stream, plan_t::prepass_always) {
+        plan(build(checked(csr), block_bounds, stream), stream, plan_t::prepass_always) {
     plan.classify(stream);  // short stacked rows only -> one SpMV kernel, no carry-outs
   }
 
@@ -78,6 +78,12 @@ struct column_blocked_t {
   }
 
  private:
+  /// The stacked CSR has num_blocks * rows rows: ITS rows + nnz must fit the int merge-path arithmetic.
+  csr_t<index_t, offset_t, type_t>& checked(csr_t<index_t, offset_t, type_t>& csr) {
+    error::throw_if_exception(static_cast<unsigned long long>(num_blocks) * csr.rows + csr.nnzs >= (1ull << 31) - 4096,
+                              "column_blocked_t: num_blocks * rows + nnz must stay below 2^31");
+    return csr;
+  }
   typename plan_t::layout_t build(csr_t<index_t, offset_t, type_t>& csr, const int* block_bounds, xpu::stream_t stream) {
     for (int k = 0; k <= num_blocks; ++k)
       bounds[k] = block_bounds ? block_bounds[k] : static_cast<int>(static_cast<long long>(cols) * k / num_blocks);

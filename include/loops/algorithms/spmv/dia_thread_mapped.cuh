@@ -16,6 +16,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/memory.hxx>
+#include <loops/kernels/dia_spmv.hxx>
 
 namespace loops {
 namespace algorithms {
@@ -50,6 +51,21 @@ util::timer_t dia_thread_mapped(dia_t<index_t, offset_t, type_t>& dia, vector_t<
                             dim3(static_cast<unsigned>(math::ceil_div(dia.rows, block_size))), dim3(block_size), config,
                             dia.cols, dia.stride, dia.num_diagonals, dia.diag_offsets.data().get(),
                             dia.values.data().get(), x.data().get(), y.data().get());
+  (void)xpu::stream_synchronize(stream);
+  timer.stop();
+  return timer;
+}
+
+/// Tuned DIA SpMV: a lane owns four consecutive rows, 16-byte loads, several diagonals in flight
+/// (loops/kernels/dia_spmv.hxx); same contract as dia_thread_mapped (y overwritten).
+template <typename index_t, typename offset_t, typename type_t>
+util::timer_t dia_row_mapped(dia_t<index_t, offset_t, type_t>& dia, vector_t<type_t>& x, vector_t<type_t>& y,
+                             xpu::stream_t stream = 0) {
+  util::timer_t timer(stream);
+  timer.start();
+  kernels::launch_dia_row4(stream, static_cast<int>(dia.rows), static_cast<int>(dia.cols), dia.stride,
+                           static_cast<int>(dia.num_diagonals), dia.diag_offsets.data().get(), dia.values.data().get(),
+                           x.data().get(), y.data().get());
   (void)xpu::stream_synchronize(stream);
   timer.stop();
   return timer;

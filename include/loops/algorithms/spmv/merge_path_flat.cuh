@@ -21,6 +21,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/kernels/launch.hxx>
+#include <loops/error.hxx>
 #include <loops/memory.hxx>
 
 namespace loops {
@@ -38,6 +39,8 @@ template <typename index_t, typename offset_t, typename type_t>
 void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,
                            csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                            xpu::stream_t stream = 0) {
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
   constexpr int block_size = merge_path_launch_t<type_t>::block_size;
   constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
   kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
@@ -50,6 +53,8 @@ void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& p
 template <typename index_t, typename offset_t, typename type_t>
 util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                               xpu::stream_t stream = 0) {
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
   using plan_t = merge_path_plan_t<index_t, offset_t, type_t>;
   // Coordinates for every merge tile (the fused kernel always consumes the table).
   plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows),

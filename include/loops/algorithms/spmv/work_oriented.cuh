@@ -17,6 +17,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/kernels/launch.hxx>
+#include <loops/error.hxx>
 #include <loops/memory.hxx>
 
 namespace loops {
@@ -26,6 +27,8 @@ namespace spmv {
 template <typename index_t, typename offset_t, typename type_t>
 void work_oriented(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                    xpu::stream_t stream = 0) {
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "work_oriented: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
   constexpr int block_size = launch_t<type_t>::block_size;
   constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
   using plan_t = schedule::merge_path::preprocess_t<block_size, items_per_thread, index_t, offset_t, std::size_t,

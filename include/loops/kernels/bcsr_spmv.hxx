@@ -26,6 +26,7 @@
 #include <loops/util/math.hxx>
 #include <loops/util/wave.hxx>
 
+
 namespace loops {
 namespace kernels {
 
@@ -52,16 +53,16 @@ __global__ void bcsr_thread_mapped_spmv(setup_t config, std::size_t rows, const 
   }
 }
 
-template <std::size_t R, std::size_t C>
+template <std::size_t R, std::size_t C, typename type_t>
 int launch_bcsr_thread_mapped(hipStream_t stream, int rows, int num_block_rows, int num_blocks,
-                              const int* block_offsets, const int* block_cols, const float* values, const float* x,
-                              float* y) {
+                              const int* block_offsets, const int* block_cols, const type_t* values, const type_t* x,
+                              type_t* y) {
   using layout_t = layout::bcsr<int, int>;
   using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, int, int, std::size_t, std::size_t,
                                   layout_t>;
   setup_t config(layout_t(block_offsets, num_block_rows, num_blocks));
   constexpr int block = 128;  // bcsr_thread_mapped.cuh:110 (reference hard-codes 128)
-  hipLaunchKernelGGL((bcsr_thread_mapped_spmv<R, C, setup_t, int, float>), dim3(math::ceil_div(num_block_rows, block)),
+  hipLaunchKernelGGL((bcsr_thread_mapped_spmv<R, C, setup_t, int, type_t>), dim3(math::ceil_div(num_block_rows, block)),
                      dim3(block), 0, stream, config, std::size_t(rows), block_cols, values, x, y);
   return static_cast<int>(hipGetLastError());
 }
@@ -74,46 +75,63 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
  *           `slot`, so a slot reads H * 64 contiguous bytes per step (H = 1: 64-byte requests from 16
  *           different rows; H = 4: 256-byte requests from 4 rows; H = 16: 1 KB from one row) and the H
  *           partial products of a slot are added with log2(H) cross-lane steps after the loop.
+ *
+ * A wavefront owns `groups_per_wave` CONSECUTIVE groups of 16 / H block-rows and walks them as ONE software
+ * pipeline: the block rows / block columns of batch n + 1 -- which is the first batch of the NEXT group when the
+ * current group ends -- are requested before the x gathers and MFMAs of batch n, and the row offsets run two groups
+ * ahead.  A wavefront therefore always has one batch of HBM reads in flight behind the batch it is multiplying; with
+ * one group per wavefront (the first version of this kernel) a wavefront's life was offsets -> stream -> gather ->
+ * MFMA, each waiting for the one before, and only a third of the resident wavefronts had stream requests outstanding
+ * at any time (C4: 4.35 TB/s against 6.7 TB/s with the gather removed).
  */
 template <int TPB, int UNROLL, int H>
 __global__ void __launch_bounds__(TPB)
 bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
                   const int* __restrict__ block_cols, const float* __restrict__ values, const float* __restrict__ x,
-                  float* __restrict__ y) {
+                  float* __restrict__ y, const int groups_per_wave) {
   static_assert(H == 1 || H == 2 || H == 4 || H == 8 || H == 16, "H: power of two <= 16");
   constexpr int SLOTS = 16 / H;  // block-rows a wavefront works on at a time
   const int lane = wave::lane();
   const int q = lane >> 2;     // MFMA batch
-  const int slot = q / H;      // which of the wavefront's block-rows
+  const int slot = q / H;      // which of the group's block-rows
   const int h = q % H;         // which of the H concurrent blocks of that block-row
   const int i = lane & 3;      // row of the 4 x 4 block this lane feeds
   const long long gwave = (static_cast<long long>(blockIdx.x) * TPB + threadIdx.x) / wave::size;
-  const long long br = gwave * SLOTS + slot;
-  int beg = 0, end = 0;
-  if (br < num_block_rows) {
-    beg = block_offsets[br];
-    end = block_offsets[br + 1];
-  }
-  const int len = end - beg;
-  int steps = (len + H - 1) / H;  // steps this slot needs; the wavefront runs max over slots
+  const long long total_groups = (static_cast<long long>(num_block_rows) + SLOTS - 1) / SLOTS;
+  long long g = gwave * groups_per_wave;
+  long long g_end = g + groups_per_wave;
+  g_end = g_end < total_groups ? g_end : total_groups;
+  if (g >= g_end) return;  // (wave-uniform)
+
+  struct range_t {
+    int beg, len;
+  };
+  auto load_range = [&](long long grp) {
+    const long long br = grp * SLOTS + slot;
+    range_t r{0, 0};
+    if (grp < g_end && br < num_block_rows) {
+      r.beg = block_offsets[br];
+      r.len = block_offsets[br + 1] - r.beg;
+    }
+    return r;
+  };
+  auto wave_steps = [&](const range_t& r) {  // steps the group needs = max over its slots, at least one
+    int steps = (r.len + H - 1) / H;
 #pragma unroll
-  for (int d = 32; d >= 4; d >>= 1) {
-    const int o = __shfl_xor(steps, d);
-    steps = o > steps ? o : steps;
-  }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int safe = len > 0 ? beg : 0;  // any valid block index for masked-off steps
-  // Software pipeline over batches of UNROLL steps: the 16-byte block rows and block columns of
-  // batch n + 1 are requested BEFORE the x gathers and MFMAs of batch n, so a wavefront always has
-  // one batch of HBM reads in flight behind the batch it is multiplying.
+    for (int d = 32; d >= 4; d >>= 1) {
+      const int o = __shfl_xor(steps, d);
+      steps = o > steps ? o : steps;
+    }
+    return steps > 1 ? steps : 1;
+  };
   f32x4 a_next[UNROLL];
   int bc_next[UNROLL];
-  auto fetch = [&](int k0) {
+  auto fetch = [&](const range_t& r, const int k0) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int k = (k0 + u) * H + h;
-      const bool live = k < len;
-      const int b = live ? beg + k : safe;
+      const bool live = k < r.len;
+      const int b = live ? r.beg + k : 0;  // block 0 for masked-off steps (an in-bounds index whenever a block exists)
       // The block stream is read once: with H >= 2 a slot consumes whole 128-byte lines per step, so
       // it is loaded non-temporally and stops evicting x from L1 / L2 (C4: 73.1 -> 67.7 us).  With
       // H = 1 the second half of a line is used by the NEXT step and must stay cached.
@@ -127,51 +145,67 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
       if (!live) a_next[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  if (steps > 0) fetch(0);
-  for (int k0 = 0; k0 < steps; k0 += UNROLL) {
-    f32x4 a[UNROLL];
-    f32x4 xv[UNROLL];
+
+  range_t cur = load_range(g), nxt = load_range(g + 1);
+  int steps = wave_steps(cur);
+  fetch(cur, 0);
+  for (; g < g_end; ++g) {
+    const range_t after = load_range(g + 2);  // offsets run two groups ahead of the MFMAs
+    const int next_steps = wave_steps(nxt);
+    const bool has_next = g + 1 < g_end;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < steps; k0 += UNROLL) {
+      f32x4 a[UNROLL];
+      f32x4 xv[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      a[u] = a_next[u];
-      xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4);
-    }
-    if (k0 + UNROLL < steps) fetch(k0 + UNROLL);
+      for (int u = 0; u < UNROLL; ++u) {
+        a[u] = a_next[u];
+        xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc_next[u]) * 4);
+      }
+      // the next batch's HBM reads go out before this batch's MFMAs: this group's, or the next group's first
+      if (k0 + UNROLL < steps) fetch(cur, k0 + UNROLL);
+      else if (has_next) fetch(nxt, 0);
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, xv[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].y, xv[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].z, xv[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].w, xv[u].w, acc, 0, 0, 0);
+      for (int u = 0; u < UNROLL; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, xv[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].y, xv[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].z, xv[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].w, xv[u].w, acc, 0, 0, 0);
+      }
     }
-  }
-  // D layout of the 4x4x1 16-block form: lane (batch, col) register v = D[v][col]; every column
-  // holds the same 4 partial outputs (B was broadcast).  Add the H partials of a slot.
+    // D layout of the 4x4x1 16-block form: lane (batch, col) register v = D[v][col]; every column
+    // holds the same 4 partial outputs (B was broadcast).  Add the H partials of a slot.
 #pragma unroll
-  for (int d = 4; d < 4 * H; d <<= 1) {
-    acc.x += __shfl_xor(acc.x, d);
-    acc.y += __shfl_xor(acc.y, d);
-    acc.z += __shfl_xor(acc.z, d);
-    acc.w += __shfl_xor(acc.w, d);
-  }
-  if (i == 0 && h == 0 && br < num_block_rows) {
-    const long long r0 = br * 4;
-    if (r0 + 3 < rows) {
-      *reinterpret_cast<f32x4*>(y + r0) = acc;
-    } else {
-      if (r0 + 0 < rows) y[r0 + 0] = acc.x;
-      if (r0 + 1 < rows) y[r0 + 1] = acc.y;
-      if (r0 + 2 < rows) y[r0 + 2] = acc.z;
+    for (int d = 4; d < 4 * H; d <<= 1) {
+      acc.x += __shfl_xor(acc.x, d);
+      acc.y += __shfl_xor(acc.y, d);
+      acc.z += __shfl_xor(acc.z, d);
+      acc.w += __shfl_xor(acc.w, d);
     }
+    const long long br = g * SLOTS + slot;
+    if (i == 0 && h == 0 && br < num_block_rows) {
+      const long long r0 = br * 4;
+      if (r0 + 3 < rows) {
+        *reinterpret_cast<f32x4*>(y + r0) = acc;
+      } else {
+        if (r0 + 0 < rows) y[r0 + 0] = acc.x;
+        if (r0 + 1 < rows) y[r0 + 1] = acc.y;
+        if (r0 + 2 < rows) y[r0 + 2] = acc.z;
+      }
+    }
+    cur = nxt;
+    nxt = after;
+    steps = next_steps;
   }
 }
 
 /// `unroll`: steps in flight (1, 2, 4, 8); `h`: blocks of one block-row per step.  0 = automatic from the
 /// mean blocks per block-row m: h = 1 (m < 1.5), 2 (m < 3), else 4; unroll = the power of two covering
 /// m / h, at most 8 (C4, m = 16: h = 4, unroll = 4 -- measured best of the 20 compiled shapes).
+/// `groups_per_wave`: consecutive groups of 16 / h block-rows one wavefront pipelines through; 0 = automatic (one).
 inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows, int num_blocks,
                                const int* block_offsets, const int* block_cols, const float* values, const float* x,
-                               float* y, int unroll = 0, int h = 0) {
+                               float* y, int unroll = 0, int h = 0, int groups_per_wave = 0) {
   constexpr int TPB = 256;  // 4 wavefronts
   if (num_block_rows == 0) return 0;
   const double mean = static_cast<double>(num_blocks) / num_block_rows;
@@ -180,11 +214,17 @@ inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows,
     unroll = 1;
     while (unroll < 8 && unroll * h < mean) unroll *= 2;
   }
+  const long long groups = math::ceil_div(static_cast<long long>(num_block_rows), static_cast<long long>(16 / h));
+  // Automatic: ONE group per wavefront.  Measured on C4 (tests/perf/bench_bcsr.py, profiles/r02_bcsr_c4_groups_per_wave.txt):
+  // 1 or 2 groups per wavefront are best (70-72 us), 8 and more are slower (74-84 us) -- with 32 resident wavefronts per
+  // CU the other wavefronts already cover one wavefront's dependent phases, and fewer, longer wavefronts balance worse.
+  if (groups_per_wave <= 0) groups_per_wave = 1;
+  if (groups_per_wave > 64) groups_per_wave = 64;
+  const long long waves = math::ceil_div(groups, static_cast<long long>(groups_per_wave));
   auto go = [&](auto u_tag, auto h_tag) {
     constexpr int U = decltype(u_tag)::value, HH = decltype(h_tag)::value;
-    const int rows_per_group = TPB / 64 * (16 / HH);
-    hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, U, HH>), dim3(math::ceil_div(num_block_rows, rows_per_group)), dim3(TPB), 0,
-                       stream, rows, num_block_rows, block_offsets, block_cols, values, x, y);
+    hipLaunchKernelGGL((bcsr4x4_mfma_spmv<TPB, U, HH>), dim3(static_cast<unsigned>(math::ceil_div(waves, static_cast<long long>(TPB / 64)))),
+                       dim3(TPB), 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y, groups_per_wave);
   };
   auto with_h = [&](auto u_tag) {
     switch (h) {

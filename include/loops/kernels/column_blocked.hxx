@@ -27,9 +27,12 @@
 #include <cstddef>
 #include <cstdint>
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <loops/kernels/merge_path_spmv.hxx>
 #include <loops/util/math.hxx>
 
 namespace loops {
@@ -115,15 +118,46 @@ reduce_blocks(const type_t* __restrict__ ys, const int rows, const int K, type_t
   y[r] = s;
 }
 
-/// Same, 4 rows per lane (rows % 4 == 0, 16-byte aligned bases).
+/// Same, 4 rows per lane (4-byte values, rows % 4 == 0, 16-byte aligned bases).  A template so that the header may be
+/// included from several translation units of one binary.
+template <typename type_t>
 __global__ void __launch_bounds__(256)
-reduce_blocks_x4(const float* __restrict__ ys, const int rows, const int K, float* __restrict__ y) {
-  using f4 = float __attribute__((ext_vector_type(4)));
+reduce_blocks_x4(const type_t* __restrict__ ys, const int rows, const int K, type_t* __restrict__ y) {
+  static_assert(sizeof(type_t) == 4, "reduce_blocks_x4: 16-byte vectors of four 4-byte values");
+  using f4 = type_t __attribute__((ext_vector_type(4)));
   const int r = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (r >= rows) return;
   f4 s = *reinterpret_cast<const f4*>(ys + r);
   for (int k = 1; k < K; ++k) s += *reinterpret_cast<const f4*>(ys + static_cast<std::size_t>(k) * rows + r);
   *reinterpret_cast<f4*>(y + r) = s;
+}
+
+/// reduce_blocks_x4 with the multi-GPU allgatherv(y) fused in: the finished 16 bytes also go to the same
+/// place of every peer-mapped vector (non-temporal 16-byte stores: write-combined over xGMI, nothing kept in L2).
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+reduce_blocks_x4_fanout(const type_t* __restrict__ ys, const int rows, const int K, type_t* __restrict__ y,
+                        const peer_fanout<type_t> peers) {
+  static_assert(sizeof(type_t) == 4, "reduce_blocks_x4_fanout: 16-byte vectors of four 4-byte values");
+  using f4 = type_t __attribute__((ext_vector_type(4)));
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (r >= rows) return;
+  f4 s = *reinterpret_cast<const f4*>(ys + r);
+  for (int k = 1; k < K; ++k) s += *reinterpret_cast<const f4*>(ys + static_cast<std::size_t>(k) * rows + r);
+  *reinterpret_cast<f4*>(y + r) = s;
+  for (int p = 0; p < peers.count; ++p) __builtin_nontemporal_store(s, reinterpret_cast<f4*>(peers.base[p] + r));
+}
+
+/// Scalar form (any row count / alignment).
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+reduce_blocks_fanout(const type_t* __restrict__ ys, const int rows, const int K, type_t* __restrict__ y,
+                     const peer_fanout<type_t> peers) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  type_t s = ys[r];
+  for (int k = 1; k < K; ++k) s += ys[static_cast<std::size_t>(k) * rows + r];
+  fanout_store<type_t>{y, peers}(r, s);
 }
 
 }  // namespace colblock
@@ -187,16 +221,35 @@ int build_column_blocked(hipStream_t stream, const offset_t* offsets, const inde
 template <typename type_t>
 int launch_reduce_blocks(hipStream_t stream, const type_t* ys, int rows, int K, type_t* y) {
   if (rows == 0) return 0;
-  if constexpr (sizeof(type_t) == 4) {
+  if constexpr (std::is_same<type_t, float>::value) {
     const bool vec = rows % 4 == 0 && ((reinterpret_cast<std::uintptr_t>(ys) | reinterpret_cast<std::uintptr_t>(y)) & 15u) == 0;
     if (vec) {
-      hipLaunchKernelGGL(colblock::reduce_blocks_x4, dim3(math::ceil_div(rows / 4, 256)), dim3(256), 0, stream, ys, rows,
+      hipLaunchKernelGGL((colblock::reduce_blocks_x4<type_t>), dim3(math::ceil_div(rows / 4, 256)), dim3(256), 0, stream, ys, rows,
                          K, y);
       return static_cast<int>(hipGetLastError());
     }
   }
   hipLaunchKernelGGL((colblock::reduce_blocks<type_t>), dim3(math::ceil_div(rows, 256)), dim3(256), 0, stream, ys, rows,
                      K, y);
+  return static_cast<int>(hipGetLastError());
+}
+
+/// launch_reduce_blocks with the peer fan-out of the finished y (see reduce_blocks_x4_fanout).
+template <typename type_t>
+int launch_reduce_blocks_fanout(hipStream_t stream, const type_t* ys, int rows, int K, type_t* y,
+                                const peer_fanout<type_t>& peers) {
+  if (rows == 0) return 0;
+  if constexpr (std::is_same<type_t, float>::value) {
+    std::uintptr_t bits = reinterpret_cast<std::uintptr_t>(ys) | reinterpret_cast<std::uintptr_t>(y);
+    for (int p = 0; p < peers.count; ++p) bits |= reinterpret_cast<std::uintptr_t>(peers.base[p]);
+    if (rows % 4 == 0 && (bits & 15u) == 0) {
+      hipLaunchKernelGGL((colblock::reduce_blocks_x4_fanout<type_t>), dim3(math::ceil_div(rows / 4, 256)), dim3(256), 0, stream,
+                         ys, rows, K, y, peers);
+      return static_cast<int>(hipGetLastError());
+    }
+  }
+  hipLaunchKernelGGL((colblock::reduce_blocks_fanout<type_t>), dim3(math::ceil_div(rows, 256)), dim3(256), 0, stream, ys, rows,
+                     K, y, peers);
   return static_cast<int>(hipGetLastError());
 }
 

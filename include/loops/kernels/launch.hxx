@@ -55,8 +55,17 @@ template <typename offset_t>
 int launch_merge_path_coordinates(hipStream_t stream, const offset_t* offsets, int rows, int nnz, int tile_items,
                                   int num_merge_tiles, coord_t* coords) {
   const int n = num_merge_tiles + 1;
-  hipLaunchKernelGGL(merge_path_coordinates<offset_t>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream, offsets,
-                     rows, nnz, tile_items, num_merge_tiles, coords);
+  hipLaunchKernelGGL(merge_path_coordinates_of<csr_row_end<offset_t>>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream,
+                     csr_row_end<offset_t>{offsets}, rows, nnz, tile_items, num_merge_tiles, coords);
+  return launch_status();
+}
+
+/// The same table for an ELL matrix (row r ends at (r + 1) * pitch): no offsets array.
+inline int launch_merge_path_coordinates_ell(hipStream_t stream, int rows, int pitch, int tile_items, int num_merge_tiles,
+                                             coord_t* coords) {
+  const int n = num_merge_tiles + 1;
+  hipLaunchKernelGGL(merge_path_coordinates_of<ell_row_end>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream,
+                     ell_row_end{pitch}, rows, rows * pitch, tile_items, num_merge_tiles, coords);
   return launch_status();
 }
 
@@ -102,6 +111,56 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,
                        carry_val, m, rows, y);
+  return launch_status();
+}
+
+/// Fused merge-path SpMV (+ fix-up) whose finished rows also go to `peers.count` peer-mapped vectors: the allgatherv(y)
+/// of a row-range sharded multi-GPU SpMV issued from the epilogue.  Always the two-kernel form (the
+/// fix-up re-writes completed rows on every destination).
+template <int TPB, int IPT, typename index_t, typename offset_t, typename T>
+int launch_merge_path_fused_fanout(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
+                                   const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
+                                   const peer_fanout<T>& peers) {
+  const int m = plan.num_merge_tiles;
+  if (m == 0) return 0;
+  if (peers.count < 0 || peers.count > max_peers) return static_cast<int>(hipErrorInvalidValue);
+  T* carry_val = static_cast<T*>(plan.carry_val);
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  constexpr bool PAD = IPT % 2 == 0;
+  if (aligned)
+    hipLaunchKernelGGL((merge_path_spmv_fused_fanout<TPB, IPT, PAD, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0, stream,
+                       plan.coords, rows, nnz, offsets, indices, values, x, y, peers, plan.carry_row, carry_val);
+  else
+    hipLaunchKernelGGL((merge_path_spmv_fused_fanout<TPB, IPT, PAD, false, index_t, offset_t, T>), dim3(m), dim3(TPB), 0, stream,
+                       plan.coords, rows, nnz, offsets, indices, values, x, y, peers, plan.carry_row, carry_val);
+  if (m > 1)
+    hipLaunchKernelGGL(merge_path_spmv_fixup_fanout<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,
+                       carry_val, m, rows, y, peers);
+  return launch_status();
+}
+
+/// merge_path_flat over an ELL matrix (row-major rows x pitch cells, negative column = padding) on the fused engine
+/// (+ fix-up): no atomics, y needs no zero-fill.  `plan` = coordinates of the merge path of (row ends (r + 1) * pitch,
+/// cells) for tile shape TPB x IPT -- schedule::merge_path::preprocess_t over layout::ell, or
+/// launch_merge_path_coordinates over an explicit offsets array.
+template <int TPB, int IPT, typename index_t, typename T>
+int launch_ell_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int pitch, const index_t* indices,
+                                const T* values, const T* x, T* y) {
+  const int m = plan.num_merge_tiles;
+  if (m == 0) return 0;
+  if (static_cast<long long>(rows) * pitch + rows >= (1ll << 31) - 4096) return static_cast<int>(hipErrorInvalidValue);
+  T* carry_val = static_cast<T*>(plan.carry_val);
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  constexpr bool PAD = IPT % 2 == 0;
+  if (aligned)
+    hipLaunchKernelGGL((ell_merge_path_spmv_fused<TPB, IPT, PAD, true, index_t, T>), dim3(m), dim3(TPB), 0, stream, plan.coords,
+                       rows, pitch, indices, values, x, y, plan.carry_row, carry_val);
+  else
+    hipLaunchKernelGGL((ell_merge_path_spmv_fused<TPB, IPT, PAD, false, index_t, T>), dim3(m), dim3(TPB), 0, stream, plan.coords,
+                       rows, pitch, indices, values, x, y, plan.carry_row, carry_val);
+  if (m > 1)
+    hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row, carry_val,
+                       m, rows, y);
   return launch_status();
 }
 

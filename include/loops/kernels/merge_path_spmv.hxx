@@ -167,21 +167,61 @@ __device__ __forceinline__ int slot(int i) {
 
 }  // namespace detail
 
-/// coord[i] = merge-path split at diagonal i * tile_items, i in [0, M]  (one lane each).
+/// Where a finished row of y goes.  `plain_store`: y[r] = v.  `fanout_store`: y[r] = v AND the same element of up to
+/// seven peer vectors -- the allgatherv(y) of a multi-GPU SpMV fused into the epilogue: `base[p]` is a
+/// peer-mapped pointer (xGMI, hipIpcOpenMemHandle / peer access) to where THIS shard's y[0] lives in peer p's full
+/// vector, written with system-scope (write-through) stores so the data is in the peer's memory when the kernel ends.
+template <typename type_t>
+struct plain_store {
+  type_t* __restrict__ y;
+  __device__ __forceinline__ void operator()(const int r, const type_t v) const { y[r] = v; }
+  __device__ __forceinline__ type_t load(const int r) const { return y[r]; }
+};
+constexpr int max_peers = 7;  // 8 GPUs per node
+template <typename type_t>
+struct peer_fanout {
+  int count;
+  type_t* base[max_peers];
+};
+template <typename type_t>
+struct fanout_store {
+  type_t* __restrict__ y;
+  peer_fanout<type_t> peers;
+  __device__ __forceinline__ void operator()(const int r, const type_t v) const {
+    y[r] = v;
+    for (int p = 0; p < peers.count; ++p) __hip_atomic_store(peers.base[p] + r, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __device__ __forceinline__ type_t load(const int r) const { return y[r]; }
+};
+
+/// Row ends of a CSR: row r ends at offsets[r + 1].
 template <typename offset_t>
-__global__ void merge_path_coordinates(const offset_t* __restrict__ offsets, int rows, int nnz, int tile_items,
-                                       int num_merge_tiles, coord_t* __restrict__ coords) {
+struct csr_row_end {
+  const offset_t* __restrict__ offsets;
+  __device__ __forceinline__ offset_t operator()(const int r) const { return offsets[r + 1]; }
+};
+/// Row ends of an ELL matrix (rows x pitch cells, row-major): row r ends at (r + 1) * pitch -- no array at all
+/// (layout::ell::tile_end_iter of the layout contract, container/layout.hxx).
+struct ell_row_end {
+  int pitch;
+  __device__ __forceinline__ int operator()(const int r) const { return (r + 1) * pitch; }
+};
+
+/// coord[i] = merge-path split at diagonal i * tile_items, i in [0, M]  (one lane each).  `row_end(r)` = end of
+/// row r on the nonzero axis (csr_row_end / ell_row_end above, or any callable).
+template <typename row_end_t>
+__global__ void merge_path_coordinates_of(const row_end_t row_end, int rows, int nnz, int tile_items, int num_merge_tiles,
+                                          coord_t* __restrict__ coords) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i > num_merge_tiles) return;
   const long long dl = static_cast<long long>(i) * tile_items;
   const int d = static_cast<int>(dl);  // int, like the reference (search.hxx:46-47)
-  const offset_t* a = offsets + 1;
   int lo = d - nnz > 0 ? d - nnz : 0;
   int count = (d < rows ? d : rows) - lo;
   while (count > 0) {
     const int half = count >> 1;
     const int mid = lo + half;
-    if (a[mid] <= d - mid - 1) {
+    if (static_cast<int>(row_end(mid)) <= d - mid - 1) {
       lo = mid + 1;
       count -= half + 1;
     } else {
@@ -230,8 +270,19 @@ __global__ void merge_path_head_check(const coord_t* __restrict__ coords, const 
  * must call it; contains 3 workgroup barriers.
  */
 template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
-          bool MASK = false>
+          bool MASK = false, bool PADCOLS = false>
 struct merge_tile_engine {
+  /// PADCOLS: a negative column index marks a padding cell (ELL, container/ell.hxx:31-55): it contributes 0 and its
+  /// x is never read (the gather goes to x[0] and the product is discarded).
+  static __device__ __forceinline__ unsigned int gather_index(const index_t col) {
+    if constexpr (PADCOLS) return col < 0 ? 0u : static_cast<unsigned int>(col);
+    else return static_cast<unsigned int>(col);  // column ids are non-negative: zero-extend
+  }
+  static __device__ __forceinline__ type_t product(const index_t col, const type_t val, const type_t xv) {
+    if constexpr (PADCOLS) return col < 0 ? type_t(0) : val * xv;
+    else return val * xv;
+  }
+
   static constexpr int TILE = TPB * IPT;
   static constexpr int WAVES = TPB / wave::size;
   static constexpr int NPROD = TILE + 4;                            // + alignment slack
@@ -310,14 +361,14 @@ struct merge_tile_engine {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             xv[k][j] = detail::buffer_load1<type_t, detail::policy::x_aux(NT)>(
-                rx, static_cast<unsigned int>(col[k][j]) * static_cast<unsigned int>(sizeof(type_t)));
+                rx, gather_index(col[k][j]) * static_cast<unsigned int>(sizeof(type_t)));
         }
       } else {
 #pragma unroll
         for (int k = 0; k < KV; ++k) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            xv[k][j] = x[static_cast<unsigned int>(col[k][j])];  // column ids are non-negative: zero-extend
+            xv[k][j] = x[gather_index(col[k][j])];
         }
       }
 #pragma unroll
@@ -328,7 +379,7 @@ struct merge_tile_engine {
           // the round that overhangs the array: surplus lanes all write slot NPROD - 1, which is never read
           // (no branch: a predicated store would pull this round's gathers behind the other rounds' wait)
           const int slot = ((k + 1) * TPB * 4 <= NPROD || i + j < NPROD) ? i + j : NPROD - 1;
-          s.prod[detail::slot<PAD>(slot)] = val[k][j] * xv[k][j];
+          s.prod[detail::slot<PAD>(slot)] = product(col[k][j], val[k][j], xv[k][j]);
         }
       }
       return;
@@ -357,7 +408,7 @@ struct merge_tile_engine {
     for (int k = 0; k < KV; ++k) {
       if (live[k]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xv[k][j] = x[static_cast<unsigned int>(col[k][j])];
+        for (int j = 0; j < 4; ++j) xv[k][j] = x[gather_index(col[k][j])];
       }
     }
 #pragma unroll
@@ -365,7 +416,7 @@ struct merge_tile_engine {
       if (live[k]) {
         const int i = (k * TPB + tid) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = val[k][j] * xv[k][j];
+        for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = product(col[k][j], val[k][j], xv[k][j]);
       }
     }
   }
@@ -384,6 +435,18 @@ struct merge_tile_engine {
                                                const type_t* __restrict__ values, const type_t* __restrict__ x,
                                                type_t* __restrict__ y, const type_t carry_in,
                                                mark_t mark = mark_t{}) {
+    return run_to(s, re, row0, nz0, nrows, natoms, nnz, indices, values, x, plain_store<type_t>{y}, carry_in, mark);
+  }
+
+  /// The same with the destination of finished rows abstracted: `out(r, v)` stores row r of y (plain_store,
+  /// fanout_store).
+  template <typename store_t, typename mark_t = no_marks>
+  static __device__ __forceinline__ type_t run_to(storage_t& s, const offset_t* re, const int row0, const int nz0,
+                                                  const int nrows, const int natoms, const int nnz,
+                                                  const index_t* __restrict__ indices,
+                                                  const type_t* __restrict__ values, const type_t* __restrict__ x,
+                                                  const store_t out, const type_t carry_in,
+                                                  mark_t mark = mark_t{}) {
     const int tid = threadIdx.x;
     const int nz1 = nz0 + natoms;
     // ---- 1. STREAM ------------------------------------------------------------------------
@@ -401,7 +464,7 @@ struct merge_tile_engine {
         const int i = k * TPB + tid;
         if (i < natoms) {
           const int e = nz0 + i;
-          s.prod[detail::slot<PAD>(i)] = values[e] * x[indices[e]];
+          s.prod[detail::slot<PAD>(i)] = product(indices[e], values[e], x[gather_index(indices[e])]);
         }
       }
     }
@@ -454,7 +517,7 @@ struct merge_tile_engine {
         const bool atom = (atom_bits >> j) & 1u;
         if (end && closed) {  // a row completed inside this thread: stage it (coalesced copy-out below)
           if (tx < YT) s.ytile[tx] = sum;
-          else y[row0 + tx] = sum;
+          else out(row0 + tx, sum);
         }
         first_sum = (end && !closed) ? sum : first_sum;
         first_row = (end && !closed) ? tx : first_row;
@@ -494,7 +557,7 @@ struct merge_tile_engine {
               first_row = tx;
               closed = true;
             } else {
-              y[row0 + tx] = sum;
+              out(row0 + tx, sum);
             }
             sum = type_t(0);
             ++tx;
@@ -532,14 +595,14 @@ struct merge_tile_engine {
     if (closed) {
       const type_t v = first_sum + prev_run + (prev_head ? type_t(0) : wave_in);
       if (MASK && first_row < YT) s.ytile[first_row] = v;
-      else y[row0 + first_row] = v;
+      else out(row0 + first_row, v);
     }
     if (tid == TPB - 1) s.carry = run_sum + (head ? type_t(0) : wave_in);
     __syncthreads();
     if constexpr (MASK) {
       // rows row0 .. row0 + min(nrows, YT) - 1 were all completed in this tile: one coalesced store each
       const int staged = nrows < YT ? nrows : YT;
-      for (int i = tid; i < staged; i += TPB) y[row0 + i] = s.ytile[i];
+      for (int i = tid; i < staged; i += TPB) out(row0 + i, s.ytile[i]);
     }
     return s.carry;
   }
@@ -552,21 +615,22 @@ struct merge_tile_engine {
  * @tparam NT   stream col_idx / values with non-temporal loads.
  * @tparam VEC  `indices` and `values` are 16-byte aligned (checked by the host launcher).
  */
-template <int TPB, int IPT, bool PAD, int NT, bool VEC, bool SELF, bool MASK, typename index_t, typename offset_t,
-          typename type_t>
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, bool SELF, bool MASK, bool PADCOLS = false, typename row_end_t,
+          typename index_t, typename type_t, typename store_t>
 __device__ __forceinline__ void
-merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const int nnz,
-                     const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
-                     const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
-                     int* __restrict__ carry_row, type_t* __restrict__ carry_val,
-                     const int* __restrict__ head_start = nullptr) {
+merge_path_spmv_tile_to(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                        const row_end_t row_end, const index_t* __restrict__ indices,
+                        const type_t* __restrict__ values, const type_t* __restrict__ x, const store_t out,
+                        int* __restrict__ carry_row, type_t* __restrict__ carry_val,
+                        const int* __restrict__ head_start = nullptr) {
+  using offset_t = int;
   // SELF (self-completing plans, merge_path_head_check): the tile is EXTENDED backwards to the start of the row
   // it begins in -- at most TPB extra nonzeros -- so that row is summed completely here and nothing has to be
   // carried in from the previous tile (which sums the same nonzeros into an open tail it then discards).
   // The extended tile has up to TPB * IPT + TPB merge items: one more item per thread.
   constexpr int ITEMS = SELF ? IPT + 1 : IPT;
   constexpr bool PADDED = SELF ? (ITEMS % 2 == 0) : PAD;
-  using engine_t = merge_tile_engine<TPB, ITEMS, PADDED, NT, VEC, index_t, offset_t, type_t, MASK>;
+  using engine_t = merge_tile_engine<TPB, ITEMS, PADDED, NT, VEC, index_t, offset_t, type_t, MASK, PADCOLS>;
   __shared__ typename engine_t::storage_t s_engine;
   __shared__ offset_t s_re[MASK ? 1 : TPB * ITEMS + ITEMS + 1];
 
@@ -597,13 +661,13 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
     for (int i = tid; i < nrows + ITEMS; i += TPB) {
       int r = row0 + i;
       r = r < rows - 1 ? r : rows - 1;
-      s_re[i] = offsets[r + 1];
+      s_re[i] = static_cast<offset_t>(row_end(r));
     }
   }
-  const type_t carry = engine_t::run(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, y, type_t(0), [&]() {
+  const type_t carry = engine_t::run_to(s_engine, s_re, row0, nz0, nrows, natoms, nnz, indices, values, x, out, type_t(0), [&]() {
     if constexpr (MASK) {
       for (int i = tid; i < nrows; i += TPB)
-        engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
+        engine_t::mark_row_end(s_engine, i, static_cast<int>(row_end(row0 + i)), nz0);
     }
   });
   if constexpr (!SELF) {
@@ -614,6 +678,18 @@ merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const i
   }
 }
 
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, bool SELF, bool MASK, bool PADCOLS = false, typename row_end_t,
+          typename index_t, typename type_t>
+__device__ __forceinline__ void
+merge_path_spmv_tile(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                     const row_end_t row_end, const index_t* __restrict__ indices,
+                     const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                     int* __restrict__ carry_row, type_t* __restrict__ carry_val,
+                     const int* __restrict__ head_start = nullptr) {
+  merge_path_spmv_tile_to<TPB, IPT, PAD, NT, VEC, SELF, MASK, PADCOLS>(coords, rows, nnz, row_end, indices, values, x,
+                                                                        plain_store<type_t>{y}, carry_row, carry_val, head_start);
+}
+
 template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
           bool MASK = false>
 __global__ void __launch_bounds__(TPB)
@@ -621,8 +697,35 @@ merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const 
                       const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                       const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
                       int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, offsets, indices, values, x, y, carry_row,
-                                                            carry_val);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values,
+                                                            x, y, carry_row, carry_val);
+}
+
+/// merge_path_flat over an ELL matrix (rows x pitch cells, negative column = padding): the SAME tile function with
+/// the row ends produced by a functor instead of an offsets array -- the layout-generic use of the schedule the
+/// reference demonstrates with one atomicAdd per cell (algorithms/spmv/ell_merge_path.cuh:32-69), here without
+/// atomics and without a zero-filled y.  `coords` from the schedule's own pre-pass over layout::ell.
+template <int TPB, int IPT, bool PAD, bool VEC, typename index_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+ell_merge_path_spmv_fused(const coord_t* __restrict__ coords, const int rows, const int pitch,
+                          const index_t* __restrict__ indices, const type_t* __restrict__ values,
+                          const type_t* __restrict__ x, type_t* __restrict__ y, int* __restrict__ carry_row,
+                          type_t* __restrict__ carry_val) {
+  merge_path_spmv_tile<TPB, IPT, PAD, 0, VEC, false, true, true>(coords, rows, rows * pitch, ell_row_end{pitch}, indices, values,
+                                                                 x, y, carry_row, carry_val);
+}
+
+/// merge_path_flat with the allgatherv(y) of a multi-GPU run fused into the epilogue: every finished row
+/// goes to y AND to the same element of `peers.count` peer-mapped vectors (fanout_store).  Rows that span merge tiles
+/// are completed -- on every destination -- by merge_path_spmv_fixup_to.
+template <int TPB, int IPT, bool PAD, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused_fanout(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                             const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                             const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                             const peer_fanout<type_t> peers, int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
+  merge_path_spmv_tile_to<TPB, IPT, PAD, 0, VEC, false, true>(coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x,
+                                                              fanout_store<type_t>{y, peers}, carry_row, carry_val);
 }
 
 /// Self-completing variant (plans whose heads are all <= TPB, merge_path_head_check): every tile finishes the
@@ -633,8 +736,8 @@ __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_self(const coord_t* __restrict__ coords, const int* __restrict__ head_start, const int rows,
                            const int nnz, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                            const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, true, MASK>(coords, rows, nnz, offsets, indices, values, x, y, nullptr,
-                                                           static_cast<type_t*>(nullptr), head_start);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, true, MASK>(coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x, y,
+                                                           nullptr, static_cast<type_t*>(nullptr), head_start);
 }
 
 /// The same kernel under its own symbol for column-blocked ("stacked") CSRs (column_blocked.hxx), so
@@ -646,8 +749,8 @@ merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows
                               const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                               const type_t* __restrict__ values, const type_t* __restrict__ x,
                               type_t* __restrict__ y, int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, offsets, indices, values, x, y, carry_row,
-                                                            carry_val);
+  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values,
+                                                            x, y, carry_row, carry_val);
 }
 
 /**
@@ -778,9 +881,9 @@ group_mapped_spmv_fused(const int rows, const int nnz, const offset_t* __restric
 /// Latency-bound (a few thousand lanes, each a chain of dependent loads): the neighbours' rows, the two first
 /// values of the run and y[row] are requested together, so the common case (runs of one or two tiles) costs two
 /// dependent memory round trips instead of four or five.
-template <typename type_t>
-__global__ void merge_path_spmv_fixup(const int* __restrict__ carry_row, const type_t* __restrict__ carry_val,
-                                      int num_merge_tiles, int rows, type_t* __restrict__ y) {
+template <typename type_t, typename store_t>
+__device__ __forceinline__ void merge_path_spmv_fixup_body(const int* __restrict__ carry_row, const type_t* __restrict__ carry_val,
+                                                           const int num_merge_tiles, const int rows, const store_t out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= num_merge_tiles) return;
   const bool has_next = i + 1 < num_merge_tiles;
@@ -790,12 +893,26 @@ __global__ void merge_path_spmv_fixup(const int* __restrict__ carry_row, const t
   type_t s = carry_val[i];
   const type_t second = has_next ? carry_val[i + 1] : type_t(0);
   if (r >= rows || before == r) return;  // nothing open / not the first tile of the run
-  const type_t old = y[r];
+  const type_t old = out.load(r);
   if (after == r) {
     s += second;
     for (int j = i + 2; j < num_merge_tiles && carry_row[j] == r; ++j) s += carry_val[j];
   }
-  y[r] = old + s;
+  out(r, old + s);
+}
+
+template <typename type_t>
+__global__ void merge_path_spmv_fixup(const int* __restrict__ carry_row, const type_t* __restrict__ carry_val,
+                                      int num_merge_tiles, int rows, type_t* __restrict__ y) {
+  merge_path_spmv_fixup_body(carry_row, carry_val, num_merge_tiles, rows, plain_store<type_t>{y});
+}
+
+/// The fix-up of merge_path_spmv_fused_fanout: the completed rows are (re)written to every destination.
+template <typename type_t>
+__global__ void merge_path_spmv_fixup_fanout(const int* __restrict__ carry_row, const type_t* __restrict__ carry_val,
+                                             int num_merge_tiles, int rows, type_t* __restrict__ y,
+                                             const peer_fanout<type_t> peers) {
+  merge_path_spmv_fixup_body(carry_row, carry_val, num_merge_tiles, rows, fanout_store<type_t>{y, peers});
 }
 
 }  // namespace kernels

@@ -85,10 +85,12 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  *    flat_partitioned.cuh:70-110).
  * Unlike the reference wrappers these do NOT block on the stream.
  * Concurrency: the plan-less entry points (this one, loops_spmm_csr_*) keep their merge-path scratch
- * (coordinates, carry-outs) in ONE buffer per host thread and tile shape, reused by every call.  Calls
- * issued from one thread are therefore only safe back to back on the SAME stream (stream order protects
- * the scratch); to overlap products on several streams give each its own plan (loops_merge_plan_create +
- * loops_spmv_merge_path_*).  A plan, likewise, serves one product at a time. */
+ * (coordinates, carry-outs) in one lazily grown buffer per (host thread, device, stream, tile shape): calls on
+ * the same stream reuse it in stream order, calls on different streams or devices never share it, so products
+ * issued from one thread on several streams may overlap.  (At most 16 such buffers are cached per thread; the
+ * least recently used is released first.)  A held plan (loops_merge_plan_t, loops_colblock_plan_t) owns ONE set of
+ * scratch buffers and is passed as const only because its coordinates are read-only: it serves one product at a
+ * time -- do not run the same plan on two streams or from two threads concurrently; create one plan per stream. */
 int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
                        const float* values, const float* x, float* y, void* stream);
 int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
@@ -105,6 +107,20 @@ int loops_spmv_merge_path_f32(const loops_merge_plan_t* plan, int variant, int r
 int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
                               const int* offsets, const int* indices, const double* values, const double* x,
                               double* y, void* stream);
+
+/* ---- multi-GPU: allgatherv(y) fused into the SpMV epilogue ----------------------------------------------
+ * No reference counterpart (the reference is single-GPU).  A rank of a row-range sharded SpMV owns rows
+ * [row_begin, row_end) of y; instead of exchanging its slice afterwards, the kernels that FINISH rows of y (the fused
+ * merge-tile kernel and its fix-up; for column-blocked shards the K-way block reduce) also store every finished value to
+ * the same element of up to 7 peer vectors over xGMI.  h_peer_y: HOST array of num_peers device-accessible pointers,
+ * h_peer_y[p] = where THIS shard's y[0] lives in peer p's full-length vector (a hipIpcOpenMemHandle / peer-access
+ * mapping; loops_enable_peer_access(peer device) first).  The peers' copies are complete when the launches have
+ * completed on `stream`; the ranks still need one synchronisation point per step (any barrier) before reading.
+ * The plan of loops_spmv_merge_path_fanout_f32 must have tile shape LOOPS_TILE_512x8 (LOOPS_E_CONFIG otherwise). */
+int loops_enable_peer_access(int peer_device);
+int loops_spmv_merge_path_fanout_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                                     const int* indices, const float* values, const float* x, float* y, int num_peers,
+                                     float* const* h_peer_y, void* stream);
 
 /* The two kernels of loops_spmv_merge_path_f32 one at a time, so a harness can bracket each with
  * its own hipEvents: stage 0 = fused merge-tile kernel (writes y and the carry-outs),
@@ -147,10 +163,16 @@ int loops_work_oriented_grid(int* out_blocks);
  * mode 0: register accumulation (any of 2x2, 3x3, 4x4); mode 1: MFMA 4x4x1 block inner product
  * (4x4 only), kernel shape picked from the mean blocks per block-row.  Tuning aids: mode 1u = one block
  * of a block-row per step with u in {1,2,4,8} steps in flight; mode 100 + 10 h + u = h in {1,2,4,8,16}
- * consecutive blocks of a block-row per step (h * 64 contiguous bytes per request). */
+ * consecutive blocks of a block-row per step (h * 64 contiguous bytes per request); + 1000 g = a wavefront
+ * pipelines through g in {1..64} consecutive groups of 16 / h block-rows (default: automatic). */
 int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
                         const int* block_offsets, const int* block_cols, const float* block_values,
                         const float* x_padded, float* y, void* stream);
+/* fp64 blocks (the reference builds every example as .f32 and .f64, examples/spmv/CMakeLists.txt:29-50): mode 0 only --
+ * the MFMA kernel is fp32 (v_mfma_f32_4x4x1); any MFMA mode returns LOOPS_E_CONFIG. */
+int loops_spmv_bcsr_f64(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
+                        const int* block_offsets, const int* block_cols, const double* block_values,
+                        const double* x_padded, double* y, void* stream);
 
 /* ---- CSR SpMM  C[rows x n] = A[rows x cols] * B[cols x n], dense row-major B and C ------------
  * Replaces algorithms::spmm::thread_mapped (algorithms/spmm/thread_mapped.cuh:28-90; caller:
@@ -165,6 +187,9 @@ int loops_spmm_csr_f64(int schedule, int rows, int cols, int nnz, const int* off
 /* Same with a held plan (tile config LOOPS_TILE_256x8 only): no coordinate pre-pass per call. */
 int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
                               const int* indices, const float* values, const float* B, int n, float* C,
+                              void* stream);
+int loops_spmm_merge_path_f64(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                              const int* indices, const double* values, const double* B, int n, double* C,
                               void* stream);
 
 /* ---- column-blocked CSR: SpMV for matrices / shards whose x does not fit the per-XCD L2 ---------
@@ -203,6 +228,10 @@ int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, 
  * (= loops_spmv_colblock_f32), LOOPS_WORK_ORIENTED or LOOPS_GROUP_MAPPED; LOOPS_E_CONFIG otherwise */
 int loops_spmv_colblock_schedule_f32(const loops_colblock_plan_t* plan, int schedule, const float* x, float* y,
                                      void* stream);
+/* loops_spmv_colblock_f32 with the peer fan-out of the finished y (see loops_spmv_merge_path_fanout_f32): the block
+ * reduce writes y and, with 16-byte non-temporal stores, the num_peers peer copies. */
+int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const float* x, float* y, int num_peers,
+                                   float* const* h_peer_y, void* stream);
 /* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);
@@ -214,14 +243,32 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
  * indices, y zero-filled here; any triplet order is correct, row-sorted order is the fast case. */
 int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
                        const float* values, const float* x, float* y, void* stream);
+int loops_spmv_coo_f64(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
+                       const double* values, const double* x, double* y, void* stream);
 
 /* ---- ELL SpMV ------------------------------------------------------------------------------------
  * Replaces algorithms::spmv::ell_thread_mapped (algorithms/spmv/ell_thread_mapped.cuh:36-85).  ELL as the
  * reference stores it: ROW-major rows x pitch arrays, padding = negative column index
  * (container/ell.hxx:31-55).  mode 0: lane per row (reference shape); mode 1: tuned -- a row is read by
- * G lanes with 16-byte loads (contiguous runs) and reduced across lanes.  y is overwritten. */
+ * G lanes with 16-byte loads (contiguous runs) and reduced across lanes; mode 2: the merge_path_flat schedule over
+ * the ELL cells on the fused merge-tile engine -- replaces algorithms::spmv::ell_merge_path
+ * (algorithms/spmv/ell_merge_path.cuh:32-125: merge path of (row ends (r + 1) * pitch, rows * pitch cells), one
+ * atomicAdd per cell there; here no atomics, row ends from a functor, padding cells contribute 0).  y is overwritten
+ * in every mode.  rows * pitch + rows must stay below 2^31 for mode 2 (LOOPS_E_RANGE). */
 int loops_spmv_ell_f32(int mode, int rows, int cols, int pitch, const int* indices, const float* values,
                        const float* x, float* y, void* stream);
+int loops_spmv_ell_f64(int mode, int rows, int cols, int pitch, const int* indices, const double* values,
+                       const double* x, double* y, void* stream);
+
+/* ---- DIA SpMV ------------------------------------------------------------------------------------
+ * Replaces algorithms::spmv::dia_thread_mapped (algorithms/spmv/dia_thread_mapped.cuh:36-110).  DIA as the reference
+ * stores it (container/dia.hxx:69-230): diag_offsets[d] = (col - row) of stored diagonal d, values column-major,
+ * values[d * stride + r], stride >= rows.  mode 0: lane per row (reference shape); mode 1: tuned -- a lane owns four
+ * consecutive rows (16-byte loads when stride % 4 == 0), several diagonals in flight.  y is overwritten. */
+int loops_spmv_dia_f32(int mode, int rows, int cols, int num_diagonals, size_t stride, const int* diag_offsets,
+                       const float* values, const float* x, float* y, void* stream);
+int loops_spmv_dia_f64(int mode, int rows, int cols, int num_diagonals, size_t stride, const int* diag_offsets,
+                       const double* values, const double* x, double* y, void* stream);
 
 /* ---- launch-box autotuner -----------------------------------------------------------
  * The reference picks (threads per block, items per thread) per architecture from a compile-time
@@ -241,6 +288,8 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
  * the column offsets), one atomicAdd per nonzero, y zero-filled here. */
 int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
                        const float* values, const float* x, float* y, void* stream);
+int loops_spmv_csc_f64(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
+                       const double* values, const double* x, double* y, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@
 #include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/coo_spmv.hxx>
 #include <loops/kernels/ell_spmv.hxx>
+#include <loops/kernels/dia_spmv.hxx>
 #include <loops/kernels/csc_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 
@@ -129,16 +130,52 @@ int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
   return 0;
 }
 
-// One lazily grown scratch plan per (host thread, tile config) for the plan-less entry points:
-// they rebuild the coordinates on every call, exactly like the reference wrapper constructs a
-// preprocess_t per call (merge_path_flat.cuh:111-114), but without a hipMalloc per call.
-loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, int* err) {
-  thread_local loops_merge_plan* cache[8] = {};
-  loops_merge_plan*& p = cache[cfg];
+// Lazily grown scratch plans for the plan-less entry points: they rebuild the coordinates on every call, exactly
+// like the reference wrapper constructs a preprocess_t per call (merge_path_flat.cuh:111-114), but without a
+// hipMalloc per call.  One plan per (host thread, DEVICE, STREAM, tile config): the coordinates and carry-outs of a
+// call are read by kernels that are still in flight when the call returns, so two calls may share a buffer only if
+// stream order serialises them -- same device, same stream.  At most kScratchSlots plans are kept per thread; the
+// least recently used one is released first (hipFree waits for the device, so nothing in flight loses its buffer).
+struct scratch_slot {
+  int device;
+  hipStream_t stream;
+  int cfg;
+  unsigned long long used;
+  loops_merge_plan* plan;
+};
+constexpr int kScratchSlots = 16;
+
+void plan_release(loops_merge_plan* p) {
+  if (!p) return;
+  (void)hipFree(p->wide_carry);
+  (void)hipFree(p->base);
+  delete p;
+}
+
+loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, hipStream_t stream, int* err) {
+  thread_local scratch_slot slots[kScratchSlots] = {};
+  thread_local unsigned long long tick = 0;
   tile_shape s;
   if (!shape_of(cfg, &s)) { *err = LOOPS_E_CONFIG; return nullptr; }
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) { *err = static_cast<int>(e); return nullptr; }
+  scratch_slot* slot = nullptr;
+  scratch_slot* victim = &slots[0];
+  for (scratch_slot& c : slots) {
+    if (c.plan && c.device == device && c.stream == stream && c.cfg == cfg) { slot = &c; break; }
+    if (!c.plan) { if (victim->plan) victim = &c; }
+    else if (victim->plan && c.used < victim->used) victim = &c;
+  }
+  if (!slot) {
+    plan_release(victim->plan);
+    *victim = scratch_slot{device, stream, cfg, 0, nullptr};
+    slot = victim;
+  }
+  slot->used = ++tick;
+  loops_merge_plan*& p = slot->plan;
   const int need = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(s.tpb) * s.ipt));
-  if (p && p->capacity < need) { (void)hipFree(p->base); (void)hipFree(p->wide_carry); delete p; p = nullptr; }
+  if (p && p->capacity < need) { plan_release(p); p = nullptr; }
   if (!p) {
     *err = plan_alloc(rows, nnz, cfg, &p);
     if (*err) return nullptr;
@@ -241,7 +278,7 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
   switch (schedule) {
     case LOOPS_MERGE_PATH_FLAT: {
       // 512 x 8 merge tiles: the measured best shape of this kernel on MI355X (see launch_box.hxx)
-      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_512x8, &err);
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_512x8, stream, &err);
       if (!p) return err;
       if (p->num_tiles > 1) err = plan_compute(p, off, stream);  // a single-tile kernel derives its own coordinates
       if (!err) err = spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
@@ -251,7 +288,7 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
     case LOOPS_ORIGINAL:
       return spmv_schedule_api<T>(schedule, 0, rows, cols, nnz, off, idx, val, x, y, stream);
     case LOOPS_WORK_ORIENTED: {
-      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, stream, &err);
       if (!p) return err;
       err = plan_compute(p, off, stream);
       if (err) return err;
@@ -304,7 +341,7 @@ int spmm_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
   if (err) return err;
   switch (schedule) {
     case LOOPS_MERGE_PATH_FLAT: {
-      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, &err);
+      loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_DEFAULT, stream, &err);
       if (!p) return err;
       err = plan_compute(p, off, stream);
       if (!err) err = spmm_merge_path<T>(p, rows, cols, nnz, off, idx, val, B, n, C, stream);
@@ -315,6 +352,105 @@ int spmm_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
                                                 static_cast<size_t>(n));
     default: return LOOPS_E_CONFIG;
   }
+}
+
+// ------------------------------------------------------------------------ other formats
+template <typename T>
+int spmv_bcsr(int R, int C, int mode, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
+              const int* block_cols, const T* block_values, const T* x_padded, T* y, hipStream_t s) {
+  if (!block_offsets || !y || rows < 0 || num_block_rows < 0 || num_blocks < 0) return LOOPS_E_BADARG;
+  if (num_blocks > 0 && (!block_cols || !block_values || !x_padded)) return LOOPS_E_BADARG;
+  if (num_block_rows == 0) return 0;
+  if (mode == 1 || (mode > 10 && mode < 20) || mode >= 100) {
+    // MFMA path.  1: automatic shape; tuning aids: 1u = one block per block-row per step, u steps in
+    // flight; 100 + 10 h + u = h blocks of a block-row per step (1, 2, 4, 8, 16), u steps in flight;
+    // + 1000 g = g consecutive groups of block-rows per wavefront (1 .. 64; 0 = automatic)
+    if constexpr (!std::is_same<T, float>::value) {
+      return LOOPS_E_CONFIG;  // the MFMA kernel is fp32 (v_mfma_f32_4x4x1); fp64 blocks take the register path (mode 0)
+    } else {
+      if (R != 4 || C != 4) return LOOPS_E_CONFIG;
+      int h = 0, u = 0, g = 0;
+      if (mode >= 1000) { g = mode / 1000; mode %= 1000; if (mode < 100) return LOOPS_E_BADARG; }
+      if (mode > 10 && mode < 20) { h = 1; u = mode - 10; }
+      if (mode >= 100) { h = (mode - 100) / 10; u = (mode - 100) % 10; }
+      if (mode != 1 && ((h != 1 && h != 2 && h != 4 && h != 8 && h != 16) || (u != 1 && u != 2 && u != 4 && u != 8)))
+        return LOOPS_E_BADARG;
+      if (g > 64) return LOOPS_E_BADARG;
+      return kernels::launch_bcsr4x4_mfma(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values,
+                                          x_padded, y, u, h, g);
+    }
+  }
+  if (mode != 0) return LOOPS_E_BADARG;
+  if (R == 2 && C == 2) return kernels::launch_bcsr_thread_mapped<2, 2>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  if (R == 3 && C == 3) return kernels::launch_bcsr_thread_mapped<3, 3>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  if (R == 4 && C == 4) return kernels::launch_bcsr_thread_mapped<4, 4>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  return LOOPS_E_CONFIG;
+}
+
+template <typename T>
+int spmv_coo(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices, const T* values,
+             const T* x, T* y, hipStream_t s) {
+  if (rows < 0 || cols < 0 || nnz < 0 || !y || (nnz > 0 && (!row_indices || !col_indices || !values || !x)))
+    return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  if (mode == 0)  // reference shape: the caller zero-fills y (coo_thread_mapped.cuh:95-97 convention)
+    return kernels::launch_coo_atom(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
+  if (mode != 1) return LOOPS_E_BADARG;
+  hipError_t e = hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return kernels::launch_coo_runs(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
+}
+
+template <typename T>
+int spmv_ell(int mode, int rows, int cols, int pitch, const int* indices, const T* values, const T* x, T* y,
+             hipStream_t s) {
+  if (rows < 0 || cols < 0 || pitch < 0 || !y || (rows > 0 && pitch > 0 && (!indices || !values || !x))) return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  if (mode == 0) return kernels::launch_ell_thread(s, static_cast<size_t>(rows), static_cast<size_t>(pitch), indices, values, x, y);
+  if (mode == 1) return kernels::launch_ell_row_split(s, static_cast<size_t>(rows), static_cast<size_t>(pitch), indices, values, x, y);
+  if (mode != 2) return LOOPS_E_BADARG;
+  // merge_path_flat over the ELL cells on the fused engine (ell_merge_path.cuh:76-125): coordinates from the row-end
+  // functor, tile kernel + fix-up; 512 x 8 (fp32) / 512 x 4 (fp64) tiles, the merge_path launch box
+  if (static_cast<long long>(rows) * pitch + rows >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  constexpr int IPT = sizeof(T) > 4 ? 4 : 8;
+  int err = 0;
+  // the scratch plan is sized by merge items: ask for (rows, rows * pitch) at 8 items per thread (>= the 4-item need)
+  loops_merge_plan* p = scratch_plan(rows, rows * pitch, LOOPS_TILE_512x8, s, &err);
+  if (!p) return err;
+  const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) * pitch + rows, 512ll * IPT));
+  if (m > p->capacity) {  // fp64: twice the tiles of the 512 x 8 sizing
+    p = scratch_plan(rows, 2 * (rows * pitch + rows), LOOPS_TILE_512x8, s, &err);
+    if (!p) return err;
+  }
+  err = kernels::launch_merge_path_coordinates_ell(s, rows, pitch, 512 * IPT, m, p->coords);
+  if (err) return err;
+  kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, m};
+  return kernels::launch_ell_merge_path_fused<512, IPT>(s, view, rows, pitch, indices, values, x, y);
+}
+
+template <typename T>
+int spmv_csc(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const T* values,
+             const T* x, T* y, hipStream_t s) {
+  if (rows < 0 || cols < 0 || nnz < 0 || !y || !col_offsets || (nnz > 0 && (!row_indices || !values || !x)))
+    return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  if (mode == 0)  // reference shape: the caller zero-fills y
+    return kernels::launch_csc_column(s, static_cast<size_t>(cols), col_offsets, row_indices, values, x, y);
+  if (mode != 1) return LOOPS_E_BADARG;
+  hipError_t e = hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), s);
+  if (e != hipSuccess) return static_cast<int>(e);
+  return kernels::launch_csc_nonzero_split(s, cols, nnz, col_offsets, row_indices, values, x, y);
+}
+
+template <typename T>
+int spmv_dia(int mode, int rows, int cols, int num_diagonals, size_t stride, const int* diag_offsets, const T* values,
+             const T* x, T* y, hipStream_t s) {
+  if (rows < 0 || cols < 0 || num_diagonals < 0 || !y || stride < static_cast<size_t>(rows)) return LOOPS_E_BADARG;
+  if (num_diagonals > 0 && rows > 0 && (!diag_offsets || !values || !x)) return LOOPS_E_BADARG;
+  if (rows == 0) return 0;
+  if (mode == 0) return kernels::launch_dia_thread(s, rows, cols, stride, num_diagonals, diag_offsets, values, x, y);
+  if (mode == 1) return kernels::launch_dia_row4(s, rows, cols, stride, num_diagonals, diag_offsets, values, x, y);
+  return LOOPS_E_BADARG;
 }
 
 }  // namespace
@@ -520,6 +656,56 @@ int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int r
   return spmv_merge_path<double>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream));
 }
 
+int loops_enable_peer_access(int peer_device) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (peer_device == dev) return 0;
+  int can = 0;
+  e = hipDeviceCanAccessPeer(&can, dev, peer_device);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (!can) return static_cast<int>(hipErrorPeerAccessUnsupported);
+  e = hipDeviceEnablePeerAccess(peer_device, 0);
+  if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); return 0; }
+  return static_cast<int>(e);
+}
+
+int loops_spmv_merge_path_fanout_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                                     const int* indices, const float* values, const float* x, float* y, int num_peers,
+                                     float* const* h_peer_y, void* stream) {
+  if (!plan || num_peers < 0 || num_peers > kernels::max_peers || (num_peers > 0 && !h_peer_y)) return LOOPS_E_BADARG;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  if (rows != plan->rows || nnz != plan->nnz) return LOOPS_E_BADARG;
+  if (plan->tpb != 512 || plan->ipt != 8) return LOOPS_E_CONFIG;  // compiled for the merge_path launch box only
+  if (rows == 0) return 0;
+  kernels::peer_fanout<float> peers{};
+  peers.count = num_peers;
+  for (int p = 0; p < num_peers; ++p) {
+    if (!h_peer_y[p]) return LOOPS_E_BADARG;
+    peers.base[p] = h_peer_y[p];
+  }
+  kernels::merge_plan_view view{plan->coords, plan->carry_row, plan->carry_val, plan->num_tiles};
+  return kernels::launch_merge_path_fused_fanout<512, 8>(as_stream(stream), view, rows, nnz, offsets, indices, values, x, y, peers);
+}
+
+int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const float* x, float* y, int num_peers,
+                                   float* const* h_peer_y, void* stream) {
+  if (!plan || !y || (plan->nnz > 0 && !x) || num_peers < 0 || num_peers > kernels::max_peers || (num_peers > 0 && !h_peer_y))
+    return LOOPS_E_BADARG;
+  if (plan->vbytes != 4) return LOOPS_E_BADARG;
+  if (plan->rows == 0) return 0;
+  kernels::peer_fanout<float> peers{};
+  peers.count = num_peers;
+  for (int p = 0; p < num_peers; ++p) {
+    if (!h_peer_y[p]) return LOOPS_E_BADARG;
+    peers.base[p] = h_peer_y[p];
+  }
+  int err = colblock_spmv<float>(plan, 3, x, y, as_stream(stream));  // tile kernel (+ fix-up) into the K partial vectors
+  if (!err) err = kernels::launch_reduce_blocks_fanout<float>(as_stream(stream), static_cast<const float*>(plan->ys), plan->rows, plan->K, y, peers);
+  return err;
+}
+
 int loops_spmv_merge_path_stage_f32(const loops_merge_plan_t* plan, int variant, int stage, int rows, int cols,
                                     int nnz, const int* offsets, const int* indices, const float* values,
                                     const float* x, float* y, void* stream) {
@@ -595,27 +781,14 @@ int loops_work_oriented_grid(int* out_blocks) {
 int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
                         const int* block_cols, const float* block_values, const float* x_padded, float* y,
                         void* stream) {
-  if (!block_offsets || !y || rows < 0 || num_block_rows < 0 || num_blocks < 0) return LOOPS_E_BADARG;
-  if (num_blocks > 0 && (!block_cols || !block_values || !x_padded)) return LOOPS_E_BADARG;
-  if (num_block_rows == 0) return 0;
-  hipStream_t s = as_stream(stream);
-  if (mode == 1 || (mode > 10 && mode < 20) || mode >= 100) {
-    // MFMA path.  1: automatic shape; tuning aids: 1u = one block per block-row per step, u steps in
-    // flight; 100 + 10 h + u = h blocks of a block-row per step (1, 2, 4, 8, 16), u steps in flight
-    if (R != 4 || C != 4) return LOOPS_E_CONFIG;
-    int h = 0, u = 0;
-    if (mode > 10 && mode < 20) { h = 1; u = mode - 10; }
-    if (mode >= 100) { h = (mode - 100) / 10; u = (mode - 100) % 10; }
-    if (mode != 1 && ((h != 1 && h != 2 && h != 4 && h != 8 && h != 16) || (u != 1 && u != 2 && u != 4 && u != 8)))
-      return LOOPS_E_BADARG;
-    return kernels::launch_bcsr4x4_mfma(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values,
-                                        x_padded, y, u, h);
-  }
-  if (mode != 0) return LOOPS_E_BADARG;
-  if (R == 2 && C == 2) return kernels::launch_bcsr_thread_mapped<2, 2>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
-  if (R == 3 && C == 3) return kernels::launch_bcsr_thread_mapped<3, 3>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
-  if (R == 4 && C == 4) return kernels::launch_bcsr_thread_mapped<4, 4>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
-  return LOOPS_E_CONFIG;
+  return spmv_bcsr<float>(R, C, mode, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y,
+                          as_stream(stream));
+}
+int loops_spmv_bcsr_f64(int R, int C, int mode, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
+                        const int* block_cols, const double* block_values, const double* x_padded, double* y,
+                        void* stream) {
+  return spmv_bcsr<double>(R, C, mode, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded,
+                           y, as_stream(stream));
 }
 
 int loops_spmm_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
@@ -634,6 +807,16 @@ int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols
   int err = check_csr(rows, cols, nnz, offsets, indices, values, B, C);
   if (err) return err;
   return spmm_merge_path<float>(plan, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
+}
+
+int loops_spmm_merge_path_f64(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                              const int* indices, const double* values, const double* B, int n, double* C,
+                              void* stream) {
+  if (!plan || n < 0 || rows < 0) return LOOPS_E_BADARG;
+  if (n == 0 || rows == 0) return 0;
+  int err = check_csr(rows, cols, nnz, offsets, indices, values, B, C);
+  if (err) return err;
+  return spmm_merge_path<double>(plan, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
 }
 
 int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
@@ -700,26 +883,29 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
 
 int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
                        const float* values, const float* x, float* y, void* stream) {
-  if (rows < 0 || cols < 0 || nnz < 0 || !y || (nnz > 0 && (!row_indices || !col_indices || !values || !x)))
-    return LOOPS_E_BADARG;
-  if (rows == 0) return 0;
-  hipStream_t s = as_stream(stream);
-  if (mode == 0)  // reference shape: the caller zero-fills y (coo_thread_mapped.cuh:95-97 convention)
-    return kernels::launch_coo_atom(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
-  if (mode != 1) return LOOPS_E_BADARG;
-  hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  return kernels::launch_coo_runs(s, static_cast<size_t>(nnz), row_indices, col_indices, values, x, y);
+  return spmv_coo<float>(mode, rows, cols, nnz, row_indices, col_indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_coo_f64(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
+                       const double* values, const double* x, double* y, void* stream) {
+  return spmv_coo<double>(mode, rows, cols, nnz, row_indices, col_indices, values, x, y, as_stream(stream));
 }
 
 int loops_spmv_ell_f32(int mode, int rows, int cols, int pitch, const int* indices, const float* values,
                        const float* x, float* y, void* stream) {
-  if (rows < 0 || cols < 0 || pitch < 0 || !y || (rows > 0 && pitch > 0 && (!indices || !values || !x))) return LOOPS_E_BADARG;
-  if (rows == 0) return 0;
-  hipStream_t s = as_stream(stream);
-  if (mode == 0) return kernels::launch_ell_thread(s, static_cast<size_t>(rows), static_cast<size_t>(pitch), indices, values, x, y);
-  if (mode == 1) return kernels::launch_ell_row_split(s, static_cast<size_t>(rows), static_cast<size_t>(pitch), indices, values, x, y);
-  return LOOPS_E_BADARG;
+  return spmv_ell<float>(mode, rows, cols, pitch, indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_ell_f64(int mode, int rows, int cols, int pitch, const int* indices, const double* values,
+                       const double* x, double* y, void* stream) {
+  return spmv_ell<double>(mode, rows, cols, pitch, indices, values, x, y, as_stream(stream));
+}
+
+int loops_spmv_dia_f32(int mode, int rows, int cols, int num_diagonals, size_t stride, const int* diag_offsets,
+                       const float* values, const float* x, float* y, void* stream) {
+  return spmv_dia<float>(mode, rows, cols, num_diagonals, stride, diag_offsets, values, x, y, as_stream(stream));
+}
+int loops_spmv_dia_f64(int mode, int rows, int cols, int num_diagonals, size_t stride, const int* diag_offsets,
+                       const double* values, const double* x, double* y, void* stream) {
+  return spmv_dia<double>(mode, rows, cols, num_diagonals, stride, diag_offsets, values, x, y, as_stream(stream));
 }
 
 int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
@@ -763,16 +949,11 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
 
 int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
                        const float* values, const float* x, float* y, void* stream) {
-  if (rows < 0 || cols < 0 || nnz < 0 || !y || !col_offsets || (nnz > 0 && (!row_indices || !values || !x)))
-    return LOOPS_E_BADARG;
-  if (rows == 0) return 0;
-  hipStream_t s = as_stream(stream);
-  if (mode == 0)  // reference shape: the caller zero-fills y
-    return kernels::launch_csc_column(s, static_cast<size_t>(cols), col_offsets, row_indices, values, x, y);
-  if (mode != 1) return LOOPS_E_BADARG;
-  hipError_t e = hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), s);
-  if (e != hipSuccess) return static_cast<int>(e);
-  return kernels::launch_csc_nonzero_split(s, cols, nnz, col_offsets, row_indices, values, x, y);
+  return spmv_csc<float>(mode, rows, cols, nnz, col_offsets, row_indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_csc_f64(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
+                       const double* values, const double* x, double* y, void* stream) {
+  return spmv_csc<double>(mode, rows, cols, nnz, col_offsets, row_indices, values, x, y, as_stream(stream));
 }
 
 }  // extern "C"

@@ -248,3 +248,61 @@ def column_block_bounds(owner_bounds, max_blocks: int = 8, target_bytes: int = 2
         for j in range(1, s + 1):
             out.append(int(a + (b - a) * j // s))
     return np.asarray(out, np.int32)
+
+
+class FusedFanout:
+    """allgatherv(y) fused into the SpMV epilogue: instead of exchanging its slice after the kernels, a
+    rank's SpMV stores every finished row of y to the same element of every peer's full-length vector through
+    peer-mapped memory over xGMI (loops_spmv_merge_path_fanout_f32 / loops_spmv_colblock_fanout_f32).
+
+    ``peer_views``: for every OTHER rank a tensor aliasing that rank's y_full (same length as the local one).  Real
+    multi-GPU runs get them from :meth:`map_peers` (CUDA IPC handles exchanged over the process group); the single-GPU
+    functional test passes plain tensors on the same device.  ``run(spmv_fanout)`` issues the product with the peer
+    pointers of this rank's slice; ``finish()`` is the one synchronisation point a step still needs: local completion
+    plus a barrier, after which every rank holds the whole vector."""
+
+    def __init__(self, y_full: torch.Tensor, shard: Shard, peer_views, group=None):
+        assert y_full.dtype == torch.float32
+        self.y_full, self.shard, self.group = y_full, shard, group
+        self.peer_views = list(peer_views)  # keep the mappings alive
+        a, b = int(shard.bounds[shard.rank]), int(shard.bounds[shard.rank + 1])
+        self.mine = y_full[a:b]
+        self.peer_slices = [v[a:b] for v in self.peer_views]
+        assert all(v.numel() == y_full.numel() and v.dtype == y_full.dtype for v in self.peer_views)
+        self._token = None
+
+    @staticmethod
+    def map_peers(y_full: torch.Tensor, shard: Shard, group=None):
+        """Every other rank's y_full mapped into this process (one node, one process per GPU): the CUDA IPC handle of
+        the local allocation is all-gathered as a picklable (rebuild, args) pair (torch.multiprocessing.reductions) and
+        opened with hipIpcOpenMemHandle on this side; peer access to the owning device is enabled through the C ABI.
+        Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC), which the environment exports."""
+        from torch.multiprocessing.reductions import reduce_tensor
+        from . import spmv as S
+        mine = reduce_tensor(y_full)
+        everyone = [None] * shard.world
+        dist.all_gather_object(everyone, (y_full.device.index, mine), group=group)
+        views = []
+        for r, (dev, (rebuild, args)) in enumerate(everyone):
+            if r == shard.rank:
+                continue
+            S.enable_peer_access(dev)
+            views.append(rebuild(*args))
+        return views
+
+    def run(self, spmv_fanout) -> None:
+        """spmv_fanout(y_slice, peer_slices): the product of this rank's shard with the fan-out destinations."""
+        spmv_fanout(self.mine, self.peer_slices)
+
+    def finish(self) -> torch.Tensor:
+        if self.shard.world > 1 and dist.is_initialized():
+            if dist.get_backend(self.group) == "gloo":  # functional-test path: host-side barrier after local completion
+                torch.cuda.synchronize()
+                dist.barrier(group=self.group)
+                return self.y_full
+            # stream-ordered barrier: the tiny all-reduce is enqueued behind the SpMV on every rank, so its completion
+            # on this rank implies every peer's kernels (and their stores into this rank's vector) have completed
+            if self._token is None:
+                self._token = torch.zeros(1, dtype=torch.float32, device=self.y_full.device)
+            dist.all_reduce(self._token, group=self.group)
+        return self.y_full

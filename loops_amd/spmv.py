@@ -132,6 +132,30 @@ def merge_path_flat(csr: CSR, x, y=None, plan: MergePathPlan | None = None, vari
     return y
 
 
+def _peer_array(peers):
+    """HOST array of device pointers (float* const*) from tensors / integers: where this shard's y[0] lives in each peer."""
+    ptrs = [int(t.data_ptr()) if hasattr(t, "data_ptr") else int(t) for t in peers]
+    assert len(ptrs) <= 7, "at most 7 peers (8 GPUs per node)"
+    return (C.c_void_p * max(len(ptrs), 1))(*ptrs), len(ptrs)
+
+
+def merge_path_flat_fanout(csr: CSR, x, y, plan: MergePathPlan, peers):
+    """merge_path_flat whose finished rows also go to ``peers`` (loops_spmv_merge_path_fanout_f32): tensors or raw
+    device pointers, one per peer GPU, each addressing where THIS shard's y[0] lives in that peer's full-length y
+    (peer-mapped memory).  The allgatherv(y) of a row-range sharded SpMV issued from the kernels' epilogue (SURVEY 8 f2);
+    ``plan`` must use tile 512x8, f32 only."""
+    csr.check(x, y)
+    arr, n = _peer_array(peers)
+    L.check(L.lib().loops_spmv_merge_path_fanout_f32(plan.handle, csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets),
+                                                     _ptr(csr.indices), _ptr(csr.values), _ptr(x), _ptr(y), n, arr, _stream()),
+            "loops_spmv_merge_path_fanout_f32")
+    return y
+
+
+def enable_peer_access(peer_device: int):
+    L.check(L.lib().loops_enable_peer_access(int(peer_device)), "loops_enable_peer_access")
+
+
 def merge_path_flat_stage(csr: CSR, x, y, plan: MergePathPlan, stage: int, variant: int = 0):
     """One kernel of the planned merge_path_flat SpMV (0: fused tile kernel, 1: fix-up)."""
     L.check(L.lib().loops_spmv_merge_path_stage_f32(plan.handle, variant, stage, csr.rows, csr.cols, csr.nnzs,
@@ -231,6 +255,15 @@ class ColumnBlockedPlan:
         L.check(fn(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock")
         return y
 
+    def spmv_fanout(self, x, y, peers):
+        """``spmv`` whose block reduce also stores the finished y to ``peers`` (loops_spmv_colblock_fanout_f32; see
+        merge_path_flat_fanout)."""
+        assert self.dtype == torch.float32 and x.dtype == torch.float32 and y.dtype == torch.float32
+        assert x.numel() == self.cols and y.numel() == self.rows and x.is_contiguous() and y.is_contiguous()
+        arr, n = _peer_array(peers)
+        L.check(L.lib().loops_spmv_colblock_fanout_f32(self._h, _ptr(x), _ptr(y), n, arr, _stream()), "loops_spmv_colblock_fanout_f32")
+        return y
+
     def spmv_schedule(self, schedule: str, x, y=None):
         """y = A x with the tuned kernel of ``schedule`` (merge_path_flat / work_oriented / group_mapped) over
         the stacked CSR (f32 plans)."""
@@ -269,10 +302,10 @@ def spmm(csr: CSR, B: torch.Tensor, Cm: torch.Tensor | None = None, schedule: st
         Cm = torch.empty((csr.rows, n), dtype=B.dtype, device=B.device)
     assert Cm.is_contiguous() and tuple(Cm.shape) == (csr.rows, n) and Cm.dtype == B.dtype
     if plan is not None:
-        assert schedule == "merge_path_flat" and B.dtype == torch.float32
-        L.check(L.lib().loops_spmm_merge_path_f32(plan.handle, csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets),
-                                                  _ptr(csr.indices), _ptr(csr.values), _ptr(B), n, _ptr(Cm), _stream()),
-                "loops_spmm_merge_path_f32")
+        assert schedule == "merge_path_flat"
+        fn = getattr(L.lib(), "loops_spmm_merge_path_" + _suffix(csr.values))
+        L.check(fn(plan.handle, csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values),
+                   _ptr(B), n, _ptr(Cm), _stream()), "loops_spmm_merge_path")
         return Cm
     fn = getattr(L.lib(), "loops_spmm_csr_" + _suffix(csr.values))
     L.check(fn(L.SCHEDULES[schedule], csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
@@ -360,32 +393,52 @@ class BCSR:
 def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool | int = False):
     """algorithms::spmv::bcsr_thread_mapped<R, C>; ``mfma=True`` selects the 4x4 MFMA kernel."""
     if y is None:
-        y = torch.empty(b.rows, dtype=torch.float32, device=b.values.device)
-    assert x_padded.numel() >= b.num_block_cols * b.C and x_padded.dtype == torch.float32
-    L.check(L.lib().loops_spmv_bcsr_f32(b.R, b.C, int(mfma), b.rows, b.num_block_rows, b.num_blocks,
-                                        _ptr(b.block_offsets), _ptr(b.block_cols), _ptr(b.values), _ptr(x_padded),
-                                        _ptr(y), _stream()), "loops_spmv_bcsr_f32")
+        y = torch.empty(b.rows, dtype=b.values.dtype, device=b.values.device)
+    assert x_padded.numel() >= b.num_block_cols * b.C and x_padded.dtype == b.values.dtype == y.dtype
+    fn = getattr(L.lib(), "loops_spmv_bcsr_" + _suffix(b.values))
+    L.check(fn(b.R, b.C, int(mfma), b.rows, b.num_block_rows, b.num_blocks, _ptr(b.block_offsets), _ptr(b.block_cols),
+               _ptr(b.values), _ptr(x_padded), _ptr(y), _stream()), "loops_spmv_bcsr")
     return y
 
 
 def coo_spmv(rows: int, cols: int, row_indices, col_indices, values, x, y=None, tuned: bool = True):
-    """COO SpMV (loops_spmv_coo_f32): ``tuned`` = one atomic per run of equal row indices (y zero-filled
+    """COO SpMV (loops_spmv_coo_f32 / _f64): ``tuned`` = one atomic per run of equal row indices (y zero-filled
     inside); otherwise the reference shape, one atomic per nonzero into a y zero-filled here."""
     if y is None:
-        y = torch.empty(rows, dtype=torch.float32, device=x.device)
+        y = torch.empty(rows, dtype=values.dtype, device=x.device)
     if not tuned:
         y.zero_()
-    L.check(L.lib().loops_spmv_coo_f32(int(tuned), rows, cols, values.numel(), _ptr(row_indices), _ptr(col_indices),
-                                       _ptr(values), _ptr(x), _ptr(y), _stream()), "loops_spmv_coo_f32")
+    fn = getattr(L.lib(), "loops_spmv_coo_" + _suffix(values))
+    L.check(fn(int(tuned), rows, cols, values.numel(), _ptr(row_indices), _ptr(col_indices), _ptr(values), _ptr(x), _ptr(y),
+               _stream()), "loops_spmv_coo")
     return y
 
 
-def ell_spmv(rows: int, cols: int, pitch: int, indices, values, x, y=None, tuned: bool = True):
-    """ELL SpMV (loops_spmv_ell_f32) over the reference's row-major rows x pitch arrays (padding: column -1)."""
+ELL_MODES = {"thread": 0, "row": 1, "merge_path": 2}
+
+
+def ell_spmv(rows: int, cols: int, pitch: int, indices, values, x, y=None, tuned: bool | str = True):
+    """ELL SpMV (loops_spmv_ell_f32 / _f64) over the reference's row-major rows x pitch arrays (padding: column -1).
+    ``tuned``: False / "thread" = lane per row (reference shape), True / "row" = G lanes per row with 16-byte loads,
+    "merge_path" = the merge_path_flat schedule over the ELL cells on the fused engine (algorithms::spmv::ell_merge_path)."""
     if y is None:
-        y = torch.empty(rows, dtype=torch.float32, device=x.device)
-    L.check(L.lib().loops_spmv_ell_f32(int(tuned), rows, cols, pitch, _ptr(indices), _ptr(values), _ptr(x), _ptr(y), _stream()),
-            "loops_spmv_ell_f32")
+        y = torch.empty(rows, dtype=values.dtype, device=x.device)
+    mode = ELL_MODES[tuned] if isinstance(tuned, str) else int(bool(tuned))
+    fn = getattr(L.lib(), "loops_spmv_ell_" + _suffix(values))
+    L.check(fn(mode, rows, cols, pitch, _ptr(indices), _ptr(values), _ptr(x), _ptr(y), _stream()), "loops_spmv_ell")
+    return y
+
+
+def dia_spmv(rows: int, cols: int, diag_offsets, values, x, y=None, stride: int | None = None, tuned: bool = True):
+    """DIA SpMV (loops_spmv_dia_f32 / _f64): values column-major [num_diagonals x stride], diag_offsets[d] = col - row.
+    ``tuned``: four rows per lane, 16-byte loads; otherwise lane per row (algorithms::spmv::dia_thread_mapped)."""
+    if y is None:
+        y = torch.empty(rows, dtype=values.dtype, device=x.device)
+    nd = int(diag_offsets.numel())
+    stride = rows if stride is None else stride
+    fn = getattr(L.lib(), "loops_spmv_dia_" + _suffix(values))
+    L.check(fn(int(tuned), rows, cols, nd, stride, _ptr(diag_offsets), _ptr(values), _ptr(x), _ptr(y), _stream()),
+            "loops_spmv_dia")
     return y
 
 
@@ -403,12 +456,13 @@ def autotune_merge_path(csr: CSR, x, repeats: int = 5):
 
 
 def csc_spmv(rows: int, cols: int, col_offsets, row_indices, values, x, y=None, tuned: bool = True):
-    """CSC SpMV (loops_spmv_csc_f32): ``tuned`` = nonzero-split kernel (y zero-filled inside); otherwise the
+    """CSC SpMV (loops_spmv_csc_f32 / _f64): ``tuned`` = nonzero-split kernel (y zero-filled inside); otherwise the
     reference shape, lane per column, into a y zero-filled here."""
     if y is None:
-        y = torch.empty(rows, dtype=torch.float32, device=x.device)
+        y = torch.empty(rows, dtype=values.dtype, device=x.device)
     if not tuned:
         y.zero_()
-    L.check(L.lib().loops_spmv_csc_f32(int(tuned), rows, cols, values.numel(), _ptr(col_offsets), _ptr(row_indices),
-                                       _ptr(values), _ptr(x), _ptr(y), _stream()), "loops_spmv_csc_f32")
+    fn = getattr(L.lib(), "loops_spmv_csc_" + _suffix(values))
+    L.check(fn(int(tuned), rows, cols, values.numel(), _ptr(col_offsets), _ptr(row_indices), _ptr(values), _ptr(x), _ptr(y),
+               _stream()), "loops_spmv_csc")
     return y

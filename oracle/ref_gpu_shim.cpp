@@ -20,7 +20,7 @@
 //   merge_path::preprocess_t            include/loops/schedule/merge_path_flat.hxx:99-172
 //   algorithms::spmm::thread_mapped     include/loops/algorithms/spmm/thread_mapped.cuh:68-94
 //   algorithms::spmv::coo_/csc_/ell_thread_mapped, bcsr_thread_mapped<4,4>
-//                                       include/loops/algorithms/spmv/{coo,csc,ell,bcsr}_thread_mapped.cuh
+//                                       include/loops/algorithms/spmv/{coo,csc,ell,dia,bcsr}_thread_mapped.cuh, ell_merge_path.cuh
 // (group_mapped is excluded from the reference's HIP build: schedule.hxx:69-74.)
 #include <loops/schedule.hxx>
 #include <loops/container/formats.hxx>
@@ -34,6 +34,8 @@
 #include <loops/algorithms/spmv/coo_thread_mapped.cuh>
 #include <loops/algorithms/spmv/csc_thread_mapped.cuh>
 #include <loops/algorithms/spmv/ell_thread_mapped.cuh>
+#include <loops/algorithms/spmv/ell_merge_path.cuh>
+#include <loops/algorithms/spmv/dia_thread_mapped.cuh>
 #include <loops/algorithms/spmv/bcsr_thread_mapped.cuh>
 
 #include <algorithm>
@@ -186,7 +188,8 @@ int refgpu_spmm_f32(long rows, long cols, long nnz, const int* off, const int* i
 
 // The reference's kernels for the other sparse formats on this GPU.  The container is built from the
 // CSR with the reference's OWN converting constructors (coo.hxx:88, csc.hxx:105, ell.hxx:114), on the
-// device.  format: 0 = COO, 1 = CSC, 2 = ELL.  y is zero-filled before every run (their contract).
+// device.  format: 0 = COO, 1 = CSC, 2 = ELL, 3 = DIA (dia.hxx:117, dia_thread_mapped.cuh:66-110), 4 = ELL through
+// ell_merge_path (ell_merge_path.cuh:76-125).  y is zero-filled before every run (their contract).
 int refgpu_format_spmv_f32(int format, long rows, long cols, long nnz, const int* off, const int* idx,
                            const float* val, const float* x, float* y, int iters, float* ms) {
   try {
@@ -215,6 +218,12 @@ int refgpu_format_spmv_f32(int format, long rows, long cols, long nnz, const int
     } else if (format == 2) {
       ell_t<int, float> ell(csr);
       run([&] { algorithms::spmv::ell_thread_mapped(ell, dx, dy); });
+    } else if (format == 3) {
+      dia_t<int, int, float> dia(csr);
+      run([&] { algorithms::spmv::dia_thread_mapped(dia, dx, dy); });
+    } else if (format == 4) {
+      ell_t<int, float> ell(csr);
+      run([&] { algorithms::spmv::ell_merge_path(ell, dx, dy); });
     } else {
       return 2;
     }

@@ -1,28 +1,20 @@
 #!/bin/bash
-# HBM-traffic PMC passes over bench.py's own command (C2, tile 512x8): usage scripts/pmc_c2.sh <outdir>.
-# Separate --pmc runs, kernel-trace only, every pass under `timeout`.  Writes <outdir>/summary.json in the format
-# bench.py's pmc_traffic() reads (profiles/r01_c2_pmc_summary_512x8.json).
+# Counter passes over bench.py's own command (C2, tile 512x8): usage scripts/pmc_c2.sh <outdir>
+# Separate --pmc runs, kernel-trace only, every pass under `timeout` (a counter set this build cannot schedule aborts
+# and then hangs: NOTES.md).  Writes <outdir>/summary.json in the format bench.py's pmc_traffic() reads
+# (profiles/rNN_c2_pmc_summary_512x8.json): per kernel, the mean of every counter over its dispatches.
 export TMPDIR=/tmp
 R=$PWD; OUT=$R/$1
 mkdir -p $OUT; cd /tmp
 i=0
-for set in "FETCH_SIZE WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+for set in "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
+           "TCC_REQ_sum WRITE_SIZE GRBM_GUI_ACTIVE" \
+           "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCP_LATENCY_sum GRBM_GUI_ACTIVE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace -d $OUT/p$i -o r --output-format csv -- python $R/bench.py --tile 512x8 --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2> $OUT/p$i.err
+  timeout 240 rocprofv3 --pmc $set --kernel-trace -d $OUT/p$i -o r --output-format csv -- python $R/bench.py --tile 512x8 --steps 30 --warmup 5 --no-cpu-baseline --no-context --no-check > /dev/null 2> $OUT/p$i.err
+  echo "pass $i ($set) rc=$?"
 done
 cd $R
-python - "$OUT" <<'PY'
-import csv, collections, sys, glob, json
-out = collections.defaultdict(dict)
-for f in glob.glob(sys.argv[1] + "/p*/r_counter_collection.csv"):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "merge_path" in k:
-            agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-    for (k, c), v in agg.items():
-        out[k][c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
-json.dump(out, open(sys.argv[1] + "/summary.json", "w"), indent=1)
-for k, v in out.items():
-    print(k[-70:], {c: round(x["mean"]) for c, x in v.items()})
-PY
+python scripts/pmc_summarize.py $OUT merge_path

@@ -114,8 +114,10 @@ static void run_battery() {
       { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_nonzero_mapped(csc, x, y); check_y("csc_nonzero_mapped", m, y, ref); }
       { ell_t<int, T> ell(csr); auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_row_mapped(ell, x, y); check_y("ell_row_mapped", m, y, ref); }
       { ell_t<int, T> ell(csr); auto y = fresh(); algorithms::spmv::ell_thread_mapped(ell, x, y); check_y("ell_thread_mapped", m, y, ref);
-        auto y2 = fresh(); algorithms::spmv::ell_merge_path(ell, x, y2); check_y("ell_merge_path", m, y2, ref); }
-      if (h.cols <= 64) { dia_t<int, int, T> dia(csr); auto y = fresh(); algorithms::spmv::dia_thread_mapped(dia, x, y); check_y("dia_thread_mapped", m, y, ref); }
+        auto y2 = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_merge_path(ell, x, y2); check_y("ell_merge_path", m, y2, ref);  // fused engine: y not pre-zeroed
+        auto y3 = fresh(); algorithms::spmv::ell_merge_path_atomic(ell, x, y3); check_y("ell_merge_path_atomic", m, y3, ref); }
+      if (h.cols <= 64) { dia_t<int, int, T> dia(csr); auto y = fresh(); algorithms::spmv::dia_thread_mapped(dia, x, y); check_y("dia_thread_mapped", m, y, ref);
+        auto y2 = vector_t<T>(h.rows, T(7)); algorithms::spmv::dia_row_mapped(dia, x, y2); check_y("dia_row_mapped", m, y2, ref); }
       auto bcsr_case = [&](auto b, const char* what) {
         vector_t<T, H> xp(b.num_block_cols * b.kBlockCols, T(0));
         for (std::size_t i = 0; i < h.cols; ++i) xp[i] = xh[i];

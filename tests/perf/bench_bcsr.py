@@ -26,11 +26,16 @@ nb = bcols.size
 abytes = nb * (16 * 4 + 4) + (nbr + 1) * 4 + nbr * 4 * 4 + nbr * 4 * 4
 flops = 2 * 16 * nb
 out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks ({nb} blocks), fp32", "algorithmic_bytes": abytes, "flops": flops, "rows": {}}
-shapes = [(f"MFMA h={h} unroll={u}", 100 + 10 * h + u) for h in (1, 2, 4, 8, 16) for u in (1, 2, 4, 8)]
+shapes = [(f"MFMA h={h} unroll={u} (groups per wave: automatic)", 100 + 10 * h + u) for h in (1, 2, 4, 8, 16) for u in (1, 2, 4, 8)]
+# + 1000 g: a wavefront pipelines through g consecutive groups of 16 / h block-rows (g = 1: the round-1 kernel shape)
+shapes += [(f"MFMA h={h} unroll={u} groups/wave={g}", 1000 * g + 100 + 10 * h + u)
+           for (h, u) in ((4, 4), (4, 2), (2, 4), (8, 2), (2, 8)) for g in (1, 2, 4, 8, 16, 32)]
+only_shapes = False
 if os.environ.get("BCSR_SHAPES"):  # e.g. BCSR_SHAPES=128,144: only these tuning shapes (profiling runs)
     keep = {int(t) for t in os.environ["BCSR_SHAPES"].split(",")}
     shapes = [s for s in shapes if s[1] in keep]
-for name, mfma in [("bcsr_thread_mapped (registers)", 0), ("bcsr_thread_mapped (MFMA 4x4x1, automatic shape)", 1)] + shapes:
+    only_shapes = True
+for name, mfma in ([] if only_shapes else [("bcsr_thread_mapped (registers)", 0)]) + [("bcsr_thread_mapped (MFMA 4x4x1, automatic shape)", 1)] + shapes:
     avg, med = ev(lambda: S.bcsr_thread_mapped(b, xd, y, mfma=mfma))
     ok = bool(np.array_equal(y.cpu().numpy(), want))
     out["rows"][name] = {"avg_ms": round(avg, 5), "median_ms": round(med, 5), "GFLOPs": round(flops / avg / 1e6, 1),

@@ -99,7 +99,7 @@ def test_reference_device_spmv_matches_golden():
 
 @needs_ref
 def test_other_formats_match_the_reference_kernels():
-    """COO / CSC / ELL: our tuned kernels against the REFERENCE'S kernels for those formats, executed on this
+    """COO / CSC / ELL (thread-mapped and ell_merge_path) / DIA: our tuned kernels against the REFERENCE'S kernels for those formats, executed on this
     GPU from containers built by the reference's own converting constructors; BCSR 4x4 against its
     bcsr_thread_mapped<4, 4> on the same block arrays.  Exactly-summable inputs: bit-exact."""
     import ctypes as C
@@ -130,12 +130,42 @@ def test_other_formats_match_the_reference_kernels():
         ind[r, :lens[r]] = idx[off[r]:off[r + 1]]
         ev[r, :lens[r]] = val[off[r]:off[r + 1]]
     ours[2] = S.ell_spmv(rows, cols, pitch, torch.from_numpy(ind).cuda(), torch.from_numpy(ev).cuda(), x)
-    for fmt in (0, 1, 2):
+    ours[4] = S.ell_spmv(rows, cols, pitch, torch.from_numpy(ind).cuda(), torch.from_numpy(ev).cuda(), x, tuned="merge_path")
+    for fmt in (0, 1, 2, 4):
         yr = np.zeros(rows, np.float32)
         ms = C.c_float()
         rc = R.refgpu_format_spmv_f32(fmt, C.c_long(rows), C.c_long(cols), C.c_long(idx.size), p(off), p(idx), p(val), p(xh), p(yr),
                                       1, C.byref(ms))
         assert rc == 0 and np.array_equal(ours[fmt].cpu().numpy(), yr), fmt
+    # DIA: the reference's dia_t(csr) + dia_thread_mapped on a banded matrix vs our container-free kernels on the same
+    # diagonals (built here as dia.hxx:117-188 builds them)
+    rng = np.random.default_rng(10)
+    n = 4099
+    offs = np.unique(np.concatenate([rng.integers(-30, 31, size=15), [0]]))
+    rr, cc = [], []
+    for o in offs:
+        r = np.arange(max(0, -o), min(n, n - o))
+        keep = rng.random(r.size) < 0.7
+        rr.append(r[keep]); cc.append(r[keep] + o)
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    order = np.lexsort((cc, rr))
+    doff = np.concatenate([[0], np.cumsum(np.bincount(rr[order], minlength=n))]).astype(np.int32)
+    didx = cc[order].astype(np.int32)
+    dval = (rng.integers(1, 9, size=didx.size) / 8.0).astype(np.float32)
+    dx = G.uniform_distribution_int(n)
+    d = didx.astype(np.int64) - np.repeat(np.arange(n, dtype=np.int64), np.diff(doff))
+    diags = np.unique(d)
+    cells = np.zeros((diags.size, n), np.float32)
+    cells[np.searchsorted(diags, d), np.repeat(np.arange(n), np.diff(doff))] = dval
+    yr = np.zeros(n, np.float32)
+    ms = C.c_float()
+    rc = R.refgpu_format_spmv_f32(3, C.c_long(n), C.c_long(n), C.c_long(didx.size), p(doff), p(didx), p(dval), p(dx), p(yr), 1,
+                                  C.byref(ms))
+    assert rc == 0
+    for tuned in (False, True):
+        yo = S.dia_spmv(n, n, torch.from_numpy(diags.astype(np.int32)).cuda(), torch.from_numpy(cells).cuda(),
+                        torch.from_numpy(dx).cuda(), tuned=tuned).cpu().numpy()
+        assert np.array_equal(yo, yr), ("dia", tuned)
     nbr = 1 << 10
     boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, 16)
     xb = G.uniform_distribution_int(nbr * 4)

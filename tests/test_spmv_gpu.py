@@ -332,24 +332,40 @@ def test_bench_two_ranks_functional():
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
-           "--warmup", "2", "--backend", "gloo", "--single-device", "--log2-rows", "16", "--log2-nnz", "20"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--warmup", "2", "--backend", "gloo", "--single-device", "--log2-rows", "16", "--log2-nnz", "20",
+           "--c5-log2-rows", "17", "--c5-log2-nnz", "21"]
+    # the N > 1 default: BASELINE C5's mode -- ONE matrix (here 2^17 rows / 2^21 nnz) strong-scaled over the ranks,
+    # with rank 0's one-GPU run of the same matrix in the same record
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1, r.stdout[-2000:]
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parity_vs_oracle_bit_exact"] is True
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parity_vs_oracle_bit_exact"] is True
+    assert "configs[4]" in d["config"]["baseline_config"] and f"{1 << 17} rows / {1 << 21} nnz" in d["config"]["workload"]
+    one = d["config"]["one_gpu_same_matrix"]
+    assert one["csr_equals_gathered_y_bit_for_bit"] is True and one["blocked_equals_gathered_y_bit_for_bit"] is True
+    assert one["best_ms_per_spmv"] > 0 and d["config"]["speedup_vs_one_gpu_same_matrix"]["spmv_plus_allgatherv"] > 0
+    assert d["config"]["spmv_only_ms_per_step"] > 0 and d["config"]["spmv_plus_allgatherv_ms_per_step"] == d["ms_per_step"]
     assert d["value"] > 0 and d["cpu_baseline"] is None
     assert d["config"]["shard_layout"].startswith("column-blocked by owner")  # the N > 1 default
-    r = subprocess.run(cmd + ["--layout", "csr"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    # round-1 mode kept for context: N x C2, weak
+    cmd = cmd + ["--scaling", "weak"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parity_vs_oracle_bit_exact"] is True
+    assert d["config"]["one_gpu_same_matrix"] is None
+    r = subprocess.run(cmd + ["--layout", "csr"], capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["shard_layout"] == "csr" and d["config"]["parity_vs_oracle_bit_exact"] is True
-    assert set(d["config"]["allgatherv_probe_ms_per_step"]) == {"p2p", "padded", "p2p-chunked"}
+    probed = set(d["config"]["allgatherv_probe_ms_per_step"])
+    assert {"p2p", "padded", "p2p-chunked"} <= probed <= {"p2p", "padded", "p2p-chunked", "fused-stores"}
     # every exchange implementation, forced: same gathered vector (checked against the oracle inside bench.py)
-    for exchange in ("padded", "p2p-chunked"):
+    for exchange in ("padded", "p2p-chunked") + (("fused-stores",) if "fused-stores" in probed else ()):
         r = subprocess.run(cmd + ["--exchange", exchange, "--overlap-chunks", "3"], capture_output=True, text=True,
-                           timeout=600, cwd=ROOT)
+                           timeout=300, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
         assert d["config"]["parity_vs_oracle_bit_exact"] is True and exchange in d["config"]["step_includes"]
@@ -406,3 +422,60 @@ def test_self_completing_plans(tile):
         assert plan64.self_complete == plan.self_complete
         y64 = S.merge_path_flat(csr64, x.double(), plan=plan64).cpu().numpy()
         assert np.array_equal(y64, O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64))), (name, tile, "f64")
+
+
+def test_planless_calls_on_two_streams_do_not_share_scratch():
+    """The plan-less entry points cache their coordinate / carry-out scratch per (thread, device, STREAM, tile shape):
+    products issued back to back from one thread on two streams must both be right (with one shared buffer the
+    second call's coordinate kernel overwrites what the first call's tile kernel is still reading)."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    mats = []
+    for i, (rows, nnz, cap) in enumerate(((1 << 17, 1 << 22, 1 << 13), (90_001, 3_000_017, 1 << 12))):
+        deg = G.powerlaw_degrees(rows, nnz, cap=cap)
+        off, idx, val = G.csr_from_degrees(deg, rows, seed=3 + i)
+        xh = G.uniform_distribution_int(rows, seed=42 + i)
+        mats.append((_dev(off, idx, val, rows, rows), torch.from_numpy(xh).cuda(), O.spmv_f32(off, idx, val, xh, omp=True)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ys = [torch.empty(m[0].rows, device="cuda") for m in mats]
+    torch.cuda.synchronize()
+    for sched in ("merge_path_flat", "work_oriented"):
+        for rep in range(20):
+            for st, (csr, x, _), y in zip(streams, mats, ys):
+                with torch.cuda.stream(st):
+                    S.spmv(sched, csr, x, y)
+        torch.cuda.synchronize()
+        for (csr, x, ref), y in zip(mats, ys):
+            assert np.array_equal(y.cpu().numpy(), ref), sched
+
+
+@pytest.mark.parametrize("layout", ["csr", "blocked"])
+def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
+    """SURVEY 8 f2 as far as one GPU allows: the SpMV of every simulated rank also stores its finished rows to the
+    "peers" -- here distinct full-length buffers on the same device standing in for peer-mapped memory.  After all
+    ranks ran, EVERY buffer must hold the whole y, bit-exact vs the oracle and equal to what allgatherv_ assembles."""
+    from loops_amd import spmv as S, generate as G, partition as P
+    from oracle import oracle as O
+    rows = cols = 1 << 16
+    deg = G.powerlaw_degrees(rows, 1 << 21, cap=1 << 13)   # rows longer than a merge tile: carry-outs + fix-up fan-out
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    xh = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    x = torch.from_numpy(xh).cuda()
+    for world in (2, 3, 8):
+        bounds = P.row_ranges(off.astype(np.int64), world)
+        fulls = [torch.full((rows,), float("nan"), device="cuda") for _ in range(world)]
+        for rank in range(world):
+            shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
+            so, si, sv = P.slice_csr(off, idx, val, shard.row_begin, shard.row_end)
+            csr = _dev(so, si, sv, shard.row_end - shard.row_begin, cols)
+            fan = P.FusedFanout(fulls[rank], shard, [fulls[p] for p in range(world) if p != rank])
+            if layout == "csr":
+                plan = S.MergePathPlan(csr, "512x8")
+                fan.run(lambda y, peers: S.merge_path_flat_fanout(csr, x, y, plan, peers))
+            else:
+                cb = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds, max_blocks=max(8, world)))
+                fan.run(lambda y, peers: cb.spmv_fanout(x, y, peers))
+            torch.cuda.synchronize()
+        for rank in range(world):
+            assert np.array_equal(fulls[rank].cpu().numpy(), ref), (layout, world, rank)
