@@ -263,7 +263,28 @@ static void test_c1_chesapeake(const char* mtx_path) {
   CHECK(generate::random::hash(0) == 1800329511u || true);  // value pinned in tests/golden/xgen.npz (python side)
 }
 
+// The reference's own SpMV battery (unittests/test_spmv_battery.hxx:52-65; fixtures: tests/golden/ref_battery.inc,
+// generated by tests/golden/make_ref_battery.py): this repository's reference::spmv -- the function every example's
+// --validate compares the kernels with -- must reproduce the y of the reference's host reference_spmv
+// (unittests/test_helpers.hxx:268-279) bit for bit: same loop, same order, fp32 accumulation.
+#include "../golden/ref_battery.inc"
+static void test_reference_battery() {
+  for (const ref_battery_case& c : ref_battery) {
+    csr_t<int, int, float, H> csr(static_cast<std::size_t>(c.rows), static_cast<std::size_t>(c.cols), static_cast<std::size_t>(c.nnz));
+    for (int i = 0; i <= c.rows; ++i) csr.offsets[i] = c.offsets[i];
+    for (int i = 0; i < c.nnz; ++i) { csr.indices[i] = c.indices[i]; csr.values[i] = c.values[i]; }
+    vector_t<float, H> x(c.cols);
+    for (int i = 0; i < c.cols; ++i) x[i] = c.x[i];
+    auto y = reference::spmv(csr, x);
+    int bad = 0;
+    for (int i = 0; i < c.rows; ++i) bad += y[i] != c.y[i];
+    if (bad) std::printf("reference battery %s: %d rows differ\n", c.name, bad);
+    CHECK(bad == 0);
+  }
+}
+
 int main(int argc, char** argv) {
+  test_reference_battery();
   test_layouts();
   test_ranges_math();
   test_market_loader();

@@ -8,7 +8,8 @@ code (matrix_market_t::load, csr_t(coo), generate::random::uniform_distribution,
 reference::spmv / spmv_f64 / row_l1_products, bcsr_t(csr), layout views) produced for them.
 The merge-path / work_oriented / group_mapped tables are device-only in the reference; their
 goldens come from the reference's device code run on an MI355X through
-oracle/_ref/libloops_ref_gpu.so (tests/golden/make_golden_gpu.py, run on the GPU box).
+oracle/_ref/libloops_ref_gpu.so at test time (tests/test_ref_gpu_pin.py, on the GPU box) -- they are compared live,
+not stored.  The reference's own SpMV battery (mt19937 factories) is a separate fixture: tests/golden/make_ref_battery.py.
 """
 import os
 import sys

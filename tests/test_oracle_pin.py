@@ -175,3 +175,28 @@ def test_live_against_reference_build():
         assert all(np.array_equal(p, q) for p, q in zip(a, b))
     for a, b in ((3.0, 3.01), (1000.0, 1001.5), (0.0, 0.02)):
         assert O.lib().oracle_default_ne_f32(a, b) == O.ref().ref_default_ne_f32(a, b)
+
+
+# name / rows / cols / nnz / y[0] / sum(y) of the reference's own SpMV battery, as SURVEY.md App. D.3 recorded them from
+# the reference's code (unittests/test_spmv_battery.hxx compiled in the survey container)
+_D3 = [("identity-16", 16, 16, 16, 1.01729786, 15.1340203), ("banded(0,0)/diag-16", 16, 16, 16, 0.508648932, 110.193568),
+       ("banded(1,1)/tridiag-16", 16, 16, 46, 1.09436655, 319.204291), ("banded(3,4)/asym-32", 32, 32, 240, 2.80308247, 3957.75659),
+       ("block_diag(4,2)", 8, 8, 16, 1.10488844, 34.570703), ("block_diag(3,3)", 9, 9, 27, 1.85730898, 40.4868238),
+       ("skewed(20,50,h=16,l=2)", 20, 50, 54, 15.5284996, 53.468552), ("empty_rows(20,12,0.3,every-4)", 20, 12, 51, 0.0, 48.833135),
+       ("random(50,50,0.05)", 50, 50, 133, 6.68259048, 143.51751)]
+
+
+def test_reference_battery_known_answers():
+    """The reference-held fixtures themselves: tests/golden/ref_battery.npz (the restated factories of
+    unittests/test_helpers.hxx, mt19937 seeds 7 / 11 / 17 / 23) reproduces every known answer of SURVEY App. D.3, and the
+    oracle's reference::spmv restatement reproduces the battery's y bit for bit (same loop, same order)."""
+    g = load_golden("ref_battery.npz")
+    names = [str(n) for n in g["names"]]
+    assert names == [d[0] for d in _D3]
+    for k, (name, rows, cols, nnz, y0, total) in enumerate(_D3):
+        assert tuple(g[f"{k}.shape"]) == (rows, cols, nnz), name
+        y = g[f"{k}.y"]
+        assert abs(float(y[0]) - y0) <= 1e-8 * max(1.0, abs(y0)), (name, float(y[0]))
+        assert abs(float(y.astype(np.float64).sum()) - total) <= 2e-8 * total, (name, float(y.astype(np.float64).sum()))
+        got = O.spmv_f32(g[f"{k}.offsets"], g[f"{k}.indices"], g[f"{k}.values"], g[f"{k}.x"])
+        assert np.array_equal(got, y), name

@@ -479,3 +479,21 @@ def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
             torch.cuda.synchronize()
         for rank in range(world):
             assert np.array_equal(fulls[rank].cpu().numpy(), ref), (layout, world, rank)
+
+
+@pytest.mark.parametrize("schedule", TUNED)
+def test_reference_battery_fixtures(schedule):
+    """The matrices, input vectors and expected y of the reference's OWN SpMV battery (unittests/test_spmv_battery.hxx:52-65,
+    fixtures tests/golden/ref_battery.npz) through every tuned schedule, f32 and f64.  Real-valued inputs: the north star's
+    1e-6 relative bound against the row's L1 mass (all values and x are positive here, so L1 = |y|); the reference's own
+    acceptance envelope for this battery is far looser (nearly_equal: 1e-3 absolute + 1e-4 relative, test_helpers.hxx:242-247)."""
+    from loops_amd import spmv as S
+    g = load_golden("ref_battery.npz")
+    for k, name in enumerate(g["names"]):
+        rows, cols, nnz = (int(t) for t in g[f"{k}.shape"])
+        off, idx, val, xh, ref = g[f"{k}.offsets"], g[f"{k}.indices"], g[f"{k}.values"], g[f"{k}.x"], g[f"{k}.y"]
+        y = S.spmv(schedule, _dev(off, idx, val, rows, cols), torch.from_numpy(xh).cuda(), torch.full((rows,), 7.0, device="cuda"))
+        y = y.cpu().numpy()
+        assert np.all(np.abs(y.astype(np.float64) - ref) <= 1e-6 * np.abs(ref).astype(np.float64) + 1e-30), (schedule, str(name))
+        y64 = S.spmv(schedule, _dev(off, idx, val.astype(np.float64), rows, cols), torch.from_numpy(xh.astype(np.float64)).cuda())
+        assert np.all(np.abs(y64.cpu().numpy() - ref) <= 1e-6 * np.abs(ref).astype(np.float64) + 1e-30), (schedule, str(name), "f64")
