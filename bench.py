@@ -146,6 +146,35 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
     return out
 
 
+def context_c3_standins(G, S, O, torch, iters=10):
+    """BASELINE config C3 next to the headline (context): `group_mapped` vs `work_oriented` (+ merge_path_flat) on generated
+    stand-ins of indochina-2004's exact shape -- 7 414 866 rows / 194 109 311 nnz; the SuiteSparse file is not shipped
+    (datasets/suitesparse.txt:2052 in the reference): scale-free degrees with uniformly random columns (no locality: a lower
+    bound for a crawl-ordered web graph) and with columns in a 65 536-wide band.  Whole calls through loops_spmv_csr_f32,
+    bit-exact against the oracle."""
+    rows = cols = 7_414_866
+    nnz = 194_109_311
+    deg = G.powerlaw_degrees(rows, nnz)
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    abytes = algorithmic_bytes(rows, cols, nnz)
+    out = {"shape": f"{rows} rows / {nnz} nnz (LAW/indochina-2004's), fp32", "algorithmic_bytes": abytes,
+           "note": "generated stand-ins: the SuiteSparse file is not available offline; tests/perf/bench_schedules.py --mtx PATH runs the real one"}
+    for tag, window in (("uniform_columns", None), ("band_65536", 65536)):
+        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
+        csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+        ref = O.spmv_f32(off, idx, val, xh, omp=True)
+        y = torch.empty(rows, device="cuda")
+        res = {}
+        for sched in ("group_mapped", "work_oriented", "merge_path_flat"):
+            ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
+            res[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
+                          "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+        out[tag] = res
+        del csr, off, idx, val, y
+    return out
+
+
 def context_schedules(S, torch, csr, x, ref_y, abytes, iters=50):
     """The other tuned schedules on the headline matrix (work_oriented and group_mapped are BASELINE C3's pair):
     whole call through loops_spmv_csr_f32 (work_oriented includes its coordinate pre-pass), bit-exact vs the headline y."""
@@ -242,6 +271,9 @@ def main():
     y_loc = y_full[shard.row_begin:shard.row_end]
     gen_s = time.time() - t0
     tile_probe = None
+    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
+    if args.tile == "auto" and layout == "blocked":
+        args.tile = "512x8"  # column-blocked plans are built for 512 x 8 tiles (COLBLOCK_TILE): nothing to tune on the CSR shard
     if args.tile == "auto":  # measured launch box: every compiled tile shape timed on this shard, outside the timed region
         best, tile_probe = S.autotune_merge_path(csr, x, repeats=30)
         if world > 1:  # one shape for the whole job: the one with the smallest worst-rank time
@@ -257,7 +289,6 @@ def main():
         args.tile = best
         tile_probe = {k: round(v, 5) for k, v in tile_probe.items()}
     plan = S.MergePathPlan(csr, args.tile)
-    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
     blocked = None
     # column blocks: the owners' row ranges cut into ~2 MB pieces of x, at most half the mean row length of them
     # (every block adds `rows` row-end items: C2-like shards, 16 nnz / row, are best at 8; C5 shards, 32 nnz / row, at 16)
@@ -390,37 +421,55 @@ def main():
         if not args.no_fused_stores:
             # fourth candidate: no exchange step at all -- the kernels that finish rows of y also store them into every
             # peer's vector through peer-mapped memory (loops_spmv_*_fanout_f32); one tiny barrier ends the step.
-            # Adopted only if it maps on every rank, reproduces the p2p result and is faster.
-            ok = 1.0
+            # Adopted only if it maps on every rank, reproduces the exchanged vector and is faster.  Every collective
+            # below is reached by every rank whatever fails locally (failures are agreed on with an all-reduce).
+            def agreed(ok):
+                flag = torch.tensor([1.0 if ok else 0.0], device=comm_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return float(flag) >= 1.0
+
+            gather_mode["mode"] = next(iter(exchange_probe))
+            step()
+            barrier()
+            want = float(y_full.double().sum())
+            handles = [None] * world
             try:
-                gather_mode["mode"] = next(iter(exchange_probe))
-                step()
-                torch.cuda.synchronize()
-                want = float(y_full.double().sum())
-                views = P.FusedFanout.map_peers(y_full, shard)
-                fused["fan"] = P.FusedFanout(y_full, shard, views)
-                if blocked is not None:
-                    fused["run"] = lambda y, peers: blocked.spmv_fanout(x, y, peers)
-                else:
-                    fan_plan = plan if args.tile == "512x8" else S.MergePathPlan(csr, "512x8")
-                    fused["plan"] = fan_plan
-                    fused["run"] = lambda y, peers: S.merge_path_flat_fanout(csr, x, y, fan_plan, peers)
-                barrier()
+                from torch.multiprocessing.reductions import reduce_tensor
+                mine = (y_full.device.index, reduce_tensor(y_full))
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] cannot export y for peer mapping ({type(e).__name__}: {e})", file=sys.stderr)
+                mine = None
+            dist.all_gather_object(handles, mine)
+            ok = all(h is not None for h in handles)
+            if ok:
+                try:
+                    views = P.FusedFanout.open_peers(handles, rank)
+                    fused["fan"] = P.FusedFanout(y_full, shard, views)
+                    if blocked is not None:
+                        fused["run"] = lambda y, peers: blocked.spmv_fanout(x, y, peers)
+                    else:
+                        fan_plan = plan if args.tile == "512x8" else S.MergePathPlan(csr, "512x8")
+                        fused["plan"] = fan_plan
+                        fused["run"] = lambda y, peers: S.merge_path_flat_fanout(csr, x, y, fan_plan, peers)
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] peer mapping unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                    ok = False
+            if agreed(ok):
                 y_full.zero_()
                 barrier()
-                gather_mode["mode"] = "fused-stores"
-                step()
-                torch.cuda.synchronize()
+                launched = True
+                try:
+                    fused["fan"].run(fused["run"])
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] fused epilogue stores failed to launch ({type(e).__name__}: {e})", file=sys.stderr)
+                    launched = False
                 barrier()
-                if float(y_full.double().sum()) != want:
-                    raise RuntimeError("fused epilogue stores did not reproduce the exchanged vector")
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] fused epilogue stores unavailable ({type(e).__name__}: {e})", file=sys.stderr)
-                ok = 0.0
-            flag = torch.tensor([ok], device=comm_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag) >= 1.0:
-                exchange_probe["fused-stores"] = probe_ms()
+                good = launched and float(y_full.double().sum()) == want
+                if not good and launched:
+                    print(f"[rank {rank}] fused epilogue stores did not reproduce the exchanged vector", file=sys.stderr)
+                if agreed(good):
+                    gather_mode["mode"] = "fused-stores"
+                    exchange_probe["fused-stores"] = probe_ms()
         gather_mode["mode"] = min(exchange_probe, key=exchange_probe.get)
         if args.exchange != "auto":
             assert args.exchange in exchange_probe, f"--exchange {args.exchange} is not available here: {exchange_probe}"
@@ -590,7 +639,7 @@ def main():
         del l_csr, l_plan, yl, y_tm
 
     # for context at N = 1: the other tuned schedules on the headline matrix, and BASELINE C4 (BCSR 4x4 + MFMA) at full size
-    schedules_info = c4_info = None
+    schedules_info = c4_info = c3_info = None
     if world == 1 and rank == 0 and not args.no_context and not args.window:
         step()
         torch.cuda.synchronize()
@@ -598,6 +647,7 @@ def main():
         if not args.no_check:
             from oracle import oracle as O  # checker only
             c4_info = context_c4_bcsr(G, S, O, torch)
+            c3_info = context_c3_standins(G, S, O, torch)
 
     # calibration probes: achievable streaming rate and gather rate on this box
     n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
@@ -721,11 +771,14 @@ def main():
                        "same_kernel_local_columns": local_info,
                        "schedules_c2": schedules_info,
                        "c4_bcsr_mfma": c4_info,
+                       "c3_standin_schedules": c3_info,
                        "reference_hip_backend_on_this_gpu": ref_gpu},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
+        fused.clear()  # peer mappings go before the processes that own the memory do
+        barrier()
         dist.destroy_process_group()
 
 

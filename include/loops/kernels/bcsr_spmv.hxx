@@ -201,7 +201,8 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
 
 /// `unroll`: steps in flight (1, 2, 4, 8); `h`: blocks of one block-row per step.  0 = automatic from the
 /// mean blocks per block-row m: h = 1 (m < 1.5), 2 (m < 3), else 4; unroll = the power of two covering
-/// m / h, at most 8 (C4, m = 16: h = 4, unroll = 4 -- measured best of the 20 compiled shapes).
+/// m / (2 h), at most 8 (C4, m = 16: h = 4, unroll = 2 -- 69.0 us against 72.1 us for unroll = 4 by rocprofv3's kernel
+/// duration, profiles/r02_bcsr_c4_kernel_stats.csv).
 /// `groups_per_wave`: consecutive groups of 16 / h block-rows one wavefront pipelines through; 0 = automatic (one).
 inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows, int num_blocks,
                                const int* block_offsets, const int* block_cols, const float* values, const float* x,
@@ -210,9 +211,9 @@ inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows,
   if (num_block_rows == 0) return 0;
   const double mean = static_cast<double>(num_blocks) / num_block_rows;
   if (h == 0) h = mean < 1.5 ? 1 : mean < 3 ? 2 : 4;
-  if (unroll == 0) {
+  if (unroll == 0) {  // two batches per block-row: the second batch's HBM reads fly behind the first one's gathers + MFMAs
     unroll = 1;
-    while (unroll < 8 && unroll * h < mean) unroll *= 2;
+    while (unroll < 8 && 2 * unroll * h < mean) unroll *= 2;
   }
   const long long groups = math::ceil_div(static_cast<long long>(num_block_rows), static_cast<long long>(16 / h));
   // Automatic: ONE group per wavefront.  Measured on C4 (tests/perf/bench_bcsr.py, profiles/r02_bcsr_c4_groups_per_wave.txt):

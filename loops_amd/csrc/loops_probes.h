@@ -45,6 +45,12 @@ int loops_probe_merge_path_f32(int policy, int stages, int rows, int cols, int n
                                const int* indices, const float* values, const float* x, float* y, void* scratch,
                                void* stream);
 
+/* Tile-shape experiment: the same kernel with merge-tile shapes the product does not ship.  shape: 0 = 512 x 8 (the
+ * product's), 1 = 512 x 16, 2 = 1024 x 8, 3 = 1024 x 4, 4 = 256 x 8.  `scratch`: 4 x loops_probe_merge_path_scratch_bytes(). */
+int loops_probe_merge_path_shape_f32(int shape, int stages, int rows, int cols, int nnz, const int* offsets,
+                                     const int* indices, const float* values, const float* x, float* y, void* scratch,
+                                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

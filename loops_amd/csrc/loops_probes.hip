@@ -84,9 +84,51 @@ bool dispatch(int policy, std::integer_sequence<int, Ps...>, const scratch_view&
   return ((policy == Ps ? (launch_policy<Ps>(v, rows, nnz, off, idx, val, x, y, stream), true) : false) || ...);
 }
 
+// Tile-shape experiment: shapes the product does not ship (a 512 x 16 tile halves the number of resident workgroups and
+// of concurrently streamed lines per XCD; 1024 x 8 synchronises 16 wavefronts per workgroup barrier).
+template <int T, int I>
+int run_shape(int stages, int rows, int nnz, const int* off, const int* idx, const float* val, const float* x, float* y,
+              void* scratch, hipStream_t st) {
+  const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(T) * I));
+  if (m < 2) return E_CONFIG;
+  auto* coords = static_cast<coord_t*>(scratch);
+  auto* carry_val = reinterpret_cast<float*>(coords + (m + 1));
+  auto* carry_row = reinterpret_cast<int*>(reinterpret_cast<double*>(coords + (m + 1)) + (m + 2));
+  if (stages & 4) {
+    const int err = kernels::launch_merge_path_coordinates(st, off, rows, nnz, T * I, m, coords);
+    if (err) return err;
+  }
+  if (stages & 1)
+    hipLaunchKernelGGL((kernels::merge_path_spmv_fused<T, I, true, 0, true, int, int, float, true>), dim3(m), dim3(T), 0, st, coords,
+                       rows, nnz, off, idx, val, x, y, carry_row, carry_val);
+  if (stages & 2)
+    hipLaunchKernelGGL(kernels::merge_path_spmv_fixup<float>, dim3(math::ceil_div(m, 256)), dim3(256), 0, st, carry_row, carry_val, m,
+                       rows, y);
+  return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace
 
 extern "C" {
+
+/* shape: 0 = 512 x 8 (the product's), 1 = 512 x 16, 2 = 1024 x 8, 3 = 1024 x 4, 4 = 256 x 8; scratch sized for 256 x 4 tiles
+ * (loops_probe_merge_path_scratch_bytes() * 4 is enough for every shape here) */
+int loops_probe_merge_path_shape_f32(int shape, int stages, int rows, int cols, int nnz, const int* offsets,
+                                     const int* indices, const float* values, const float* x, float* y, void* scratch,
+                                     void* stream) {
+  (void)cols;
+  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz <= 0) return E_BADARG;
+  if ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) return E_BADARG;
+  hipStream_t st = as_stream(stream);
+  switch (shape) {
+    case 0: return run_shape<512, 8>(stages, rows, nnz, offsets, indices, values, x, y, scratch, st);
+    case 1: return run_shape<512, 16>(stages, rows, nnz, offsets, indices, values, x, y, scratch, st);
+    case 2: return run_shape<1024, 8>(stages, rows, nnz, offsets, indices, values, x, y, scratch, st);
+    case 3: return run_shape<1024, 4>(stages, rows, nnz, offsets, indices, values, x, y, scratch, st);
+    case 4: return run_shape<256, 8>(stages, rows, nnz, offsets, indices, values, x, y, scratch, st);
+    default: return E_CONFIG;
+  }
+}
 
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) {
   if (!src || !dst) return E_BADARG;

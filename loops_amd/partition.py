@@ -259,7 +259,9 @@ class FusedFanout:
     multi-GPU runs get them from :meth:`map_peers` (CUDA IPC handles exchanged over the process group); the single-GPU
     functional test passes plain tensors on the same device.  ``run(spmv_fanout)`` issues the product with the peer
     pointers of this rank's slice; ``finish()`` is the one synchronisation point a step still needs: local completion
-    plus a barrier, after which every rank holds the whole vector."""
+    plus a barrier, after which every rank holds the whole vector.  A caller that READS y_full between two products
+    (an iterative solver) must also keep a fast rank's next product from overwriting the vector a slow rank is still
+    reading: alternate between two y_full buffers, or put a barrier in front of the next ``run``."""
 
     def __init__(self, y_full: torch.Tensor, shard: Shard, peer_views, group=None):
         assert y_full.dtype == torch.float32
@@ -272,23 +274,32 @@ class FusedFanout:
         self._token = None
 
     @staticmethod
-    def map_peers(y_full: torch.Tensor, shard: Shard, group=None):
-        """Every other rank's y_full mapped into this process (one node, one process per GPU): the CUDA IPC handle of
-        the local allocation is all-gathered as a picklable (rebuild, args) pair (torch.multiprocessing.reductions) and
-        opened with hipIpcOpenMemHandle on this side; peer access to the owning device is enabled through the C ABI.
-        Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC), which the environment exports."""
+    def export(y_full: torch.Tensor):
+        """(device index, picklable CUDA-IPC handle) of the local vector: what a peer needs to map it."""
         from torch.multiprocessing.reductions import reduce_tensor
+        return y_full.device.index, reduce_tensor(y_full)
+
+    @staticmethod
+    def open_peers(handles, rank: int):
+        """Map every OTHER rank's vector from the all-gathered `export()` results (no communication): the IPC handle is
+        opened with hipIpcOpenMemHandle on this side and peer access to the owning device is enabled through the C ABI.
+        Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC), which the environment exports."""
         from . import spmv as S
-        mine = reduce_tensor(y_full)
-        everyone = [None] * shard.world
-        dist.all_gather_object(everyone, (y_full.device.index, mine), group=group)
         views = []
-        for r, (dev, (rebuild, args)) in enumerate(everyone):
-            if r == shard.rank:
+        for r, (dev, (rebuild, args)) in enumerate(handles):
+            if r == rank:
                 continue
             S.enable_peer_access(dev)
             views.append(rebuild(*args))
         return views
+
+    @staticmethod
+    def map_peers(y_full: torch.Tensor, shard: Shard, group=None):
+        """Every other rank's y_full mapped into this process (one node, one process per GPU): export() all-gathered
+        over the process group, then open_peers().  Collective."""
+        everyone = [None] * shard.world
+        dist.all_gather_object(everyone, FusedFanout.export(y_full), group=group)
+        return FusedFanout.open_peers(everyone, shard.rank)
 
     def run(self, spmv_fanout) -> None:
         """spmv_fanout(y_slice, peer_slices): the product of this rank's shard with the fan-out destinations."""

@@ -31,6 +31,7 @@ def lib() -> C.CDLL:
         P.loops_probe_policy_name.argtypes = [ci]
         P.loops_probe_policy_name.restype = C.c_char_p
         P.loops_probe_merge_path_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+        P.loops_probe_merge_path_shape_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
         _probes = P
     return _probes
 
@@ -83,4 +84,27 @@ class PolicyRunner:
         L.check(lib().loops_probe_merge_path_f32(policy, stages, c.rows, c.cols, c.nnzs, _ptr(c.offsets), _ptr(c.indices),
                                                  _ptr(c.values), _ptr(x), _ptr(y), _ptr(self.scratch), _stream()),
                 "loops_probe_merge_path_f32")
+        return y
+
+
+SHAPES = ["512x8", "512x16", "1024x8", "1024x4", "256x8"]
+
+
+class ShapeRunner:
+    """merge_path_spmv_fused with tile shapes the product does not ship (loops_probe_merge_path_shape_f32)."""
+
+    def __init__(self, csr):
+        self.csr = csr
+        n = 4 * lib().loops_probe_merge_path_scratch_bytes(csr.rows, csr.nnzs)
+        self.scratch = {i: torch.empty(n, dtype=torch.uint8, device=csr.values.device) for i in range(len(SHAPES))}
+        self.built = set()
+
+    def run(self, shape: int, x, y, stages: int = 3):
+        c = self.csr
+        if shape not in self.built:
+            stages |= 4
+            self.built.add(shape)
+        L.check(lib().loops_probe_merge_path_shape_f32(shape, stages, c.rows, c.cols, c.nnzs, _ptr(c.offsets), _ptr(c.indices),
+                                                       _ptr(c.values), _ptr(x), _ptr(y), _ptr(self.scratch[shape]), _stream()),
+                "loops_probe_merge_path_shape_f32")
         return y

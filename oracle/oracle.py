@@ -64,6 +64,11 @@ def usable_cpus() -> int:
             n = max(1, min(n, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    # one process per GPU (torchrun): the ranks of a node share the CPUs
+    try:
+        n = max(1, n // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    except ValueError:
+        pass
     return n
 
 

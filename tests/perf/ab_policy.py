@@ -49,5 +49,22 @@ for p in only:
     us = a.elapsed_time(b) / args.iters * 1e3
     out[p] = {"name": names[p], "us": round(us, 2), "exact": ok}
     print(f"policy {p:2d} {names[p]:28s} {us:8.2f} us  exact={ok}", flush=True)
+# tile shapes the product does not ship (same kernel, plain loads)
+shapes = PR.ShapeRunner(csr)
+for i, name in enumerate(PR.SHAPES):
+    y.zero_()
+    shapes.run(i, x, y)
+    ok = bool(torch.equal(y, ref))
+    for _ in range(3):
+        shapes.run(i, x, y, stages=1)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.iters):
+        shapes.run(i, x, y, stages=1)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) / args.iters * 1e3
+    out[f"shape {name}"] = {"name": "tile " + name, "us": round(us, 2), "exact": ok}
+    print(f"tile shape {name:8s} {us:8.2f} us  exact={ok}", flush=True)
 if args.json:
     json.dump(out, open(args.json, "w"), indent=1)

@@ -233,7 +233,10 @@ def test_full_size_c2_bit_exact_and_properties():
                                             "parity_c2_fp32_tolerance.json"), "w"), indent=1)
     except OSError:
         pass
-    # the GPU's blocked summation must not be worse than the reference's sequential one on the long rows
+    # measured on MI355X (profiles/r02_parity_c2_fp32_tolerance.json): 2.4e-7 on the short rows, 2.0e-7 on the long ones
+    # (per-thread runs of <= 8 + a 64-lane tree), where the reference's sequential fp32 loop reaches 5.5e-6 and leaves
+    # 156 rows above 1e-6.  So the north star's bound is held on EVERY row, long ones included:
+    assert rel_gpu.max() <= 1e-6, rel_gpu.max()
     assert rel_gpu[~short].max() <= max(rel_seq[~short].max(), 1e-6)
 
 
