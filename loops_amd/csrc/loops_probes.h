@@ -19,6 +19,12 @@ extern "C" {
  * also quoted against.  dst == src selects a READ-ONLY stream (per-lane sums, nothing
  * written): the achievable read rate. */
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
+/* Read-only stream (16 B per lane, a contiguous chunk per wavefront) with SCALAR prefetch `distance` KB-steps ahead: one
+ * wave-uniform (SMEM) dword load per `line_words` words (32 = per 128-byte line, 16 = per 64 bytes); distance 0 = none.
+ * `waves_per_cu` resident wavefronts per CU (grid = 256 CUs x that).  Does the scalar path add memory-level parallelism
+ * on top of the vector L1's outstanding-read slots?  distance in {0,1,2,4,8,16} x line_words 32, {2,4,8} x 16. */
+int loops_stream_read_prefetch_f32(const float* src, float* sink, size_t n, int distance, int line_words, int waves_per_cu,
+                                   void* stream);
 /* out[i] = table[idx[i]] -- the L2 / Infinity-Cache gather rate that bounds x reads.
  * mode: 0 plain loads, 1 non-temporal, 2 agent-scope (sc1: bypass the CU's L1), 3 system-scope,
  * 4 plain gather with non-temporal index / output streams. */

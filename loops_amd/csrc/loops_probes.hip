@@ -130,6 +130,13 @@ int loops_probe_merge_path_shape_f32(int shape, int stages, int rows, int cols, 
   }
 }
 
+int loops_stream_read_prefetch_f32(const float* src, float* sink, size_t n, int distance, int line_words, int waves_per_cu,
+                                   void* stream) {
+  if (!src || !sink) return E_BADARG;
+  const int rc = kernels::launch_stream_read_prefetch(as_stream(stream), src, sink, n, distance, line_words, waves_per_cu);
+  return rc == -1 ? E_CONFIG : rc;
+}
+
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) {
   if (!src || !dst) return E_BADARG;
   return kernels::launch_stream_copy(as_stream(stream), src, dst, n);

@@ -91,6 +91,61 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const float4* __restri
   if (acc == -1.2345e30f) sink[0] = acc;
 }
 
+/// Read-only stream with SCALAR prefetch: a wavefront walks its own contiguous chunk, 1 KB (16 B per lane) per step
+/// with vector loads, and D steps ahead touches the same lines with wave-uniform (scalar, SMEM) loads -- one dword per
+/// LINE_WORDS words.  The scalar path has its own miss tracking (SQC), so the prefetches do not take the vector L1's
+/// outstanding-read slots (~94 per CU: the limiter of every kernel measured in DESIGN section 5); when the vector load
+/// arrives the line is already in L2.  D = 0: no prefetch (the same walk, for A/B).
+template <int D, int LINE_WORDS>
+__global__ void __launch_bounds__(256) stream_read_prefetch_kernel(const float* __restrict__ src, float* __restrict__ sink,
+                                                                   size_t n_words, size_t words_per_wave) {
+  constexpr int PER_STEP = 256 / LINE_WORDS;  // scalar touches per 1 KB step
+  const size_t wave = (static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x) / 64;
+  const int lane = threadIdx.x & 63;
+  size_t begin = wave * words_per_wave;
+  if (begin >= n_words) return;
+  size_t end = begin + words_per_wave;
+  end = end < n_words ? end : n_words;
+  // wave-uniform copies (the divergence analysis cannot see that a wavefront's 64 lanes share them): the touches below
+  // must have uniform addresses AND sit in a loop with a uniform trip count to become s_load_dword
+  const size_t steps = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>((end - begin) / 256));
+  const size_t ubegin = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(begin >> 8)) * size_t(256);
+  float acc = 0.f;
+  float pre[PER_STEP];
+#pragma unroll
+  for (int j = 0; j < PER_STEP; ++j) pre[j] = 0.f;
+  for (size_t i = 0; i < steps; ++i) {
+    float used = 0.f;
+    if constexpr (D > 0) {
+#pragma unroll
+      for (int j = 0; j < PER_STEP; ++j) used += pre[j];  // consumes the touches issued one step ago (forces their wait HERE)
+      size_t t = i + D < steps ? i + D : steps - 1;
+#pragma unroll
+      for (int j = 0; j < PER_STEP; ++j) pre[j] = src[ubegin + t * 256 + j * LINE_WORDS];  // uniform address -> s_load_dword
+    }
+    const float4 v = reinterpret_cast<const float4*>(src + ubegin + i * 256)[lane];
+    acc += (v.x + v.y) + (v.z + v.w) + used * 0.f;
+  }
+  if (acc == -1.2345e30f) sink[0] = acc;
+}
+
+inline int launch_stream_read_prefetch(hipStream_t stream, const float* src, float* sink, size_t n, int distance, int line_words,
+                                       int waves_per_cu) {
+  const size_t waves = static_cast<size_t>(256) * (waves_per_cu > 0 ? waves_per_cu : 32);
+  size_t per = (n / waves) / 256 * 256;
+  if (per == 0) return 0;
+  const dim3 g(static_cast<unsigned>(waves / 4)), b(256);
+#define LOOPS_PF(DD, LW)                                                                                              \
+  if (distance == DD && line_words == LW) {                                                                           \
+    hipLaunchKernelGGL((stream_read_prefetch_kernel<DD, LW>), g, b, 0, stream, src, sink, per * waves, per);          \
+    return static_cast<int>(hipGetLastError());                                                                       \
+  }
+  LOOPS_PF(0, 32) LOOPS_PF(1, 32) LOOPS_PF(2, 32) LOOPS_PF(4, 32) LOOPS_PF(8, 32) LOOPS_PF(16, 32)
+  LOOPS_PF(2, 16) LOOPS_PF(4, 16) LOOPS_PF(8, 16)
+#undef LOOPS_PF
+  return -1;
+}
+
 inline int launch_stream_copy(hipStream_t stream, const float* src, float* dst, size_t n) {
   const size_t n4 = n / 4;
   if (n4 == 0) return 0;

@@ -24,6 +24,7 @@ def lib() -> C.CDLL:
         vp, ci = C.c_void_p, C.c_int
         P.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
         P.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
+        P.loops_stream_read_prefetch_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, ci, vp]
         P.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         P.loops_row_gather_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, vp, vp]
         P.loops_probe_merge_path_scratch_bytes.argtypes = [ci, ci]
@@ -46,6 +47,11 @@ def _ptr(t):
 
 def stream_copy(src, dst):
     L.check(lib().loops_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "loops_stream_copy_f32")
+
+
+def stream_read_prefetch(src, sink, distance: int, line_words: int = 32, waves_per_cu: int = 32):
+    L.check(lib().loops_stream_read_prefetch_f32(_ptr(src), _ptr(sink), src.numel(), distance, line_words, waves_per_cu, _stream()),
+            "loops_stream_read_prefetch_f32")
 
 
 def gather(table, idx, out, mode: int = 0):

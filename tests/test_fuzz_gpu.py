@@ -49,7 +49,7 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         assert np.array_equal(S.spmv(sch, csr, x, y).cpu().numpy(), want), (sch,) + tag
     # held plan (self-completing single-kernel path when every tile head is short, two kernels otherwise)
     for tile in ("256x8", "128x7"):
-        for variant in (0, 4):   # 4 = bit-mask split
+        for variant in (0, 4):   # 0 = bit-mask split (the default), 4 = per-thread halving search
             y = torch.full((rows,), 5.0, device="cuda")
             S.merge_path_flat(csr, x, y, plan=S.MergePathPlan(csr, tile), variant=variant)
             assert np.array_equal(y.cpu().numpy(), want), ("planned", tile, variant) + tag
@@ -75,9 +75,25 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
             n = off[r + 1] - off[r]
             ind[r, :n] = idx[off[r]:off[r + 1]]
             ev[r, :n] = val[off[r]:off[r + 1]]
-        y = S.ell_spmv(rows, cols, pitch, torch.from_numpy(np.ascontiguousarray(ind)).cuda(),
-                       torch.from_numpy(np.ascontiguousarray(ev)).cuda(), x)
-        assert np.array_equal(y.cpu().numpy(), want), ("ell",) + tag
+        ind_d, ev_d = torch.from_numpy(np.ascontiguousarray(ind)).cuda(), torch.from_numpy(np.ascontiguousarray(ev)).cuda()
+        for mode in (True, "merge_path"):   # row-split kernel; merge_path_flat over the ELL cells on the fused engine
+            if rows == 0 or (mode == "merge_path" and pitch == 0):
+                continue
+            y = torch.full((rows,), 5.0, device="cuda")
+            S.ell_spmv(rows, cols, pitch, ind_d, ev_d, x, y, tuned=mode)
+            assert np.array_equal(y.cpu().numpy(), want), ("ell", mode) + tag
+    # DIA (small matrices only: one stored diagonal per distinct col - row), both kernels, f32 and f64
+    if 0 < rows <= 300 and cols <= 300 and idx.size:
+        d = idx.astype(np.int64) - ri.astype(np.int64)
+        diags = np.unique(d)
+        cells = np.zeros((diags.size, rows), np.float32)
+        cells[np.searchsorted(diags, d), ri] = val
+        for tuned in (False, True):
+            y = S.dia_spmv(rows, cols, torch.from_numpy(diags.astype(np.int32)).cuda(), torch.from_numpy(cells).cuda(), x, tuned=tuned)
+            assert np.array_equal(y.cpu().numpy(), want), ("dia", tuned) + tag
+            y = S.dia_spmv(rows, cols, torch.from_numpy(diags.astype(np.int32)).cuda(), torch.from_numpy(cells.astype(np.float64)).cuda(),
+                           x.double(), tuned=tuned)
+            assert np.array_equal(y.cpu().numpy(), want.astype(np.float64)), ("dia f64", tuned) + tag
     # CSC (built on the host from the CSR), both kernels
     order = np.lexsort((ri, idx))                      # by column, rows ascending inside a column
     coff = np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=cols))]).astype(np.int32)
