@@ -289,7 +289,9 @@ struct merge_tile_engine {
   static constexpr int KV = (NPROD + 4 * TPB - 1) / (4 * TPB);      // vector-load rounds per thread
 
   struct storage_t {
-    type_t prod[PAD ? NPROD + (NPROD >> 5) + 1 : NPROD];
+    // + a 4-slot dump group for the surplus lanes of the last STREAM round; 16-byte aligned so that unpadded engines
+    // store a lane's four products with one ds_write_b128 (4 x ds_write_b32 at a 16-byte lane stride conflict 4 ways)
+    alignas(16) type_t prod[PAD ? (NPROD + 4) + ((NPROD + 4) >> 5) + 1 : NPROD + 4];
     type_t wave_val[WAVES];
     int wave_head[WAVES];
     type_t carry;
@@ -373,14 +375,13 @@ struct merge_tile_engine {
       }
 #pragma unroll
       for (int k = 0; k < KV; ++k) {
-        const int i = (k * TPB + tid) * 4;
+        // the round that overhangs the array: a surplus lane's four products go to the dump group behind the array
+        // (NPROD is a multiple of 4, so a lane's vector is inside or outside as a whole; no branch: a predicated store
+        // would pull this round's gathers behind the other rounds' wait).  Unpadded engines: one ds_write_b128 per round.
+        int i = (k * TPB + tid) * 4;
+        if ((k + 1) * TPB * 4 > NPROD) i = i < NPROD ? i : NPROD;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // the round that overhangs the array: surplus lanes all write slot NPROD - 1, which is never read
-          // (no branch: a predicated store would pull this round's gathers behind the other rounds' wait)
-          const int slot = ((k + 1) * TPB * 4 <= NPROD || i + j < NPROD) ? i + j : NPROD - 1;
-          s.prod[detail::slot<PAD>(slot)] = product(col[k][j], val[k][j], xv[k][j]);
-        }
+        for (int j = 0; j < 4; ++j) s.prod[detail::slot<PAD>(i + j)] = product(col[k][j], val[k][j], xv[k][j]);
       }
       return;
     }
