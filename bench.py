@@ -221,12 +221,13 @@ def main():
     ap.add_argument("--ref-gpu", action="store_true",
                     help="also time the reference's own HIP kernels on this GPU (oracle/_ref/libloops_ref_gpu.so)")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
-    ap.add_argument("--overlap-chunks", type=int, default=2,
+    ap.add_argument("--overlap-chunks", default="2,4",
                     help="N > 1: also try the step with the SpMV cut into this many row chunks whose exchanges overlap "
-                         "the next chunk's kernel (0 = do not try); the fastest candidate of the start-up probe is used")
+                         "the next chunk's kernels (comma list, one candidate each: 'p2p-chunked' for the first, "
+                         "'p2p-chunked-C' for the others; 0 = do not try); the fastest candidate of the start-up probe is used")
     ap.add_argument("--no-fused-stores", action="store_true",
                     help="N > 1: do not try the exchange fused into the SpMV epilogue (peer-mapped stores, SURVEY 8 f2)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "padded", "p2p-chunked", "fused-stores"],
+    ap.add_argument("--exchange", default="auto",
                     help="N > 1: allgatherv implementation; auto = the fastest of the start-up probe")
     ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked"],
                     help="how a rank holds its row-range shard: 'csr' as sliced; 'blocked' = column-blocked by owner "
@@ -315,7 +316,11 @@ def main():
         else:
             S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant)
 
-    chunked = {"plans": None, "exchange": None}
+    chunked = {}  # exchange mode name -> {"plans": [(run, y_sub)], "exchange": ChunkedAllgatherv, "keep": [...], "chunks": C}
+    chunk_counts = [int(t) for t in str(args.overlap_chunks).split(",") if t.strip() and int(t) >= 2]
+
+    def chunk_mode(c):
+        return "p2p-chunked" if c == chunk_counts[0] else f"p2p-chunked-{c}"
 
     fused = {"fan": None, "run": None}
 
@@ -324,11 +329,12 @@ def main():
             fused["fan"].run(fused["run"])
             fused["fan"].finish()
             return
-        if gather_mode["mode"] == "p2p-chunked":
-            for c, (sub_run, y_sub) in enumerate(chunked["plans"]):
+        if gather_mode["mode"] in chunked:
+            ch = chunked[gather_mode["mode"]]
+            for c, (sub_run, y_sub) in enumerate(ch["plans"]):
                 sub_run(y_sub)
-                chunked["exchange"].post(c)
-            chunked["exchange"].finish()
+                ch["exchange"].post(c)
+            ch["exchange"].finish()
             return
         spmv_local()
         if world > 1:
@@ -354,8 +360,7 @@ def main():
                 run = (lambda sub, pl: (lambda y_sub: S.merge_path_flat(sub, x, y_sub, plan=pl, variant=args.variant)))(sub, pl)
             keep.append((sub, pl))
             plans.append((run, y_sub))
-        chunked["plans"], chunked["keep"] = plans, keep
-        chunked["exchange"] = P.ChunkedAllgatherv(y_full, shard, cb)
+        chunked[chunk_mode(chunks)] = {"plans": plans, "keep": keep, "exchange": P.ChunkedAllgatherv(y_full, shard, cb), "chunks": chunks}
 
     comm_dev = "cuda" if args.backend == "nccl" else "cpu"
 
@@ -403,21 +408,23 @@ def main():
                 continue
             exchange_probe[mode] = probe_ms()
         assert exchange_probe, "no allgatherv implementation works on this backend"
-        if args.overlap_chunks >= 2 and "p2p" in exchange_probe:
-            # third candidate: the same p2p exchange, posted per row chunk so that it overlaps the next chunk's kernel
+        for chunks in (chunk_counts if "p2p" in exchange_probe else []):
+            # further candidates: the same p2p exchange, posted per row chunk so that it overlaps the next chunk's kernels
+            # (at N = 8 a shard's y slice needs ~110 us of xGMI link time against ~570 us of kernels: with C chunks only
+            # the last chunk's 1 / C of it stays exposed, at the price of C smaller launches and C grouped p2p calls)
             ok = 1.0
             try:
-                build_chunked(args.overlap_chunks)
-                gather_mode["mode"] = "p2p-chunked"
-                step()
-                torch.cuda.synchronize()
+                build_chunked(chunks)
             except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] chunked overlap unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+                print(f"[rank {rank}] chunked overlap ({chunks}) unavailable ({type(e).__name__}: {e})", file=sys.stderr)
                 ok = 0.0
             flag = torch.tensor([ok], device=comm_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag) >= 1.0:
-                exchange_probe["p2p-chunked"] = probe_ms()
+                gather_mode["mode"] = chunk_mode(chunks)
+                exchange_probe[chunk_mode(chunks)] = probe_ms()
+            else:
+                chunked.pop(chunk_mode(chunks), None)
         if not args.no_fused_stores:
             # fourth candidate: no exchange step at all -- the kernels that finish rows of y also store them into every
             # peer's vector through peer-mapped memory (loops_spmv_*_fanout_f32); one tiny barrier ends the step.
@@ -754,7 +761,7 @@ def main():
                        "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
                                        f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)",
-                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (": finished rows stored to the peers from the kernels' epilogue + one barrier" if gather_mode['mode'] == 'fused-stores' else "") + (f", {args.overlap_chunks} chunks overlapping the SpMV" if gather_mode['mode'] == 'p2p-chunked' else "") + "]" if world > 1 else ""),
+                       "step_includes": "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "") + (f" + allgatherv(y) [{gather_mode['mode']}" + (": finished rows stored to the peers from the kernels' epilogue + one barrier" if gather_mode['mode'] == 'fused-stores' else "") + (f", {chunked[gather_mode['mode']]['chunks']} chunks overlapping the SpMV" if gather_mode['mode'] in chunked else "") + "]" if world > 1 else ""),
                        "ms_per_step_with_prepass": None if ms_with_prepass is None else round(ms_with_prepass, 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
                        "spmv_only_ms_per_step": round(spmv_only_ms, 5),

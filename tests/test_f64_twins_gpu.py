@@ -1,0 +1,77 @@
+"""fp64 twins of the format entry points of the C ABI (the reference builds every example as .f32 and .f64,
+examples/spmv/CMakeLists.txt:29-50): loops_spmv_{bcsr,coo,csc}_f64 and loops_spmm_merge_path_f64 against the oracle's fp64
+restatements, bit-exact on exactly-summable inputs.  (ELL / DIA f64: tests/test_ell_gpu.py, tests/test_dia_gpu.py.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _matrix(rows=4000, cols=6000, seed=3):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 50, size=rows)
+    lens[5] = 5000  # a row longer than a merge tile
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    idx = np.concatenate([np.sort(rng.choice(cols, size=n, replace=False)) for n in lens]).astype(np.int32)
+    val = (rng.integers(1, 9, size=idx.size) / 8.0).astype(np.float64)
+    return off, idx, val
+
+
+def test_coo_csc_f64():
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    off, idx, val = _matrix()
+    rows, cols = off.size - 1, 6000
+    xh = G.uniform_distribution_int(cols).astype(np.float64)
+    want = O.spmv_f64(off, idx, val, xh)
+    x = torch.from_numpy(xh).cuda()
+    ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(off))
+    for tuned in (False, True):
+        y = S.coo_spmv(rows, cols, torch.from_numpy(ri).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(val).cuda(), x, tuned=tuned)
+        assert y.dtype == torch.float64 and np.array_equal(y.cpu().numpy(), want), ("coo", tuned)
+    order = np.lexsort((ri, idx))
+    coff = np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=cols))]).astype(np.int32)
+    for tuned in (False, True):
+        y = S.csc_spmv(rows, cols, torch.from_numpy(coff).cuda(), torch.from_numpy(ri[order]).cuda(), torch.from_numpy(val[order]).cuda(),
+                       x, tuned=tuned)
+        assert y.dtype == torch.float64 and np.array_equal(y.cpu().numpy(), want), ("csc", tuned)
+
+
+@pytest.mark.parametrize("R", [2, 3, 4])
+def test_bcsr_f64(R):
+    """Register path in fp64 for every compiled block size; the MFMA modes are fp32-only and must say so."""
+    from loops_amd import spmv as S, generate as G, _lib
+    nbr, per = 512, 12
+    boff, bcols, _ = G.uniform_bcsr(nbr, nbr, per, R, R)
+    rng = np.random.default_rng(R)
+    bvals = (rng.integers(1, 9, size=bcols.size * R * R) / 8.0).astype(np.float64)
+    xh = G.uniform_distribution_int(nbr * R).astype(np.float64)
+    want = np.zeros(nbr * R, np.float64)
+    blocks = bvals.reshape(-1, R, R)
+    for br in range(nbr):
+        for b in range(boff[br], boff[br + 1]):
+            want[br * R:(br + 1) * R] += blocks[b] @ xh[bcols[b] * R:(bcols[b] + 1) * R]
+    b = S.BCSR(R, R, nbr * R, nbr * R, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    y = S.bcsr_thread_mapped(b, torch.from_numpy(xh).cuda())
+    assert y.dtype == torch.float64 and np.array_equal(y.cpu().numpy(), want)
+    if R == 4:
+        with pytest.raises(_lib.LoopsError, match="LOOPS_E_CONFIG"):
+            S.bcsr_thread_mapped(b, torch.from_numpy(xh).cuda(), mfma=True)
+
+
+@pytest.mark.parametrize("n", [1, 8, 10, 33])
+def test_spmm_plan_f64(n):
+    from loops_amd import spmv as S
+    from oracle import oracle as O
+    off, idx, val = _matrix(rows=3000, cols=2500, seed=8)
+    rows, cols = off.size - 1, 2500
+    rng = np.random.default_rng(n)
+    B = rng.integers(1, 11, size=(cols, n)).astype(np.float64)
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    plan = S.MergePathPlan(csr, "256x8")
+    got = S.spmm(csr, torch.from_numpy(B).cuda(), plan=plan).cpu().numpy()
+    want = np.stack([O.spmv_f64(off, idx, val, np.ascontiguousarray(B[:, j])) for j in range(n)], axis=1)
+    assert np.array_equal(got, want)
+    assert np.array_equal(S.spmm(csr, torch.from_numpy(B).cuda()).cpu().numpy(), want)  # plan-less f64 entry

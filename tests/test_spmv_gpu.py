@@ -364,10 +364,10 @@ def test_bench_two_ranks_functional():
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["shard_layout"] == "csr" and d["config"]["parity_vs_oracle_bit_exact"] is True
     probed = set(d["config"]["allgatherv_probe_ms_per_step"])
-    assert {"p2p", "padded", "p2p-chunked"} <= probed <= {"p2p", "padded", "p2p-chunked", "fused-stores"}
+    assert {"p2p", "padded", "p2p-chunked", "p2p-chunked-4"} <= probed <= {"p2p", "padded", "p2p-chunked", "p2p-chunked-4", "fused-stores"}
     # every exchange implementation, forced: same gathered vector (checked against the oracle inside bench.py)
     for exchange in ("padded", "p2p-chunked") + (("fused-stores",) if "fused-stores" in probed else ()):
-        r = subprocess.run(cmd + ["--exchange", exchange, "--overlap-chunks", "3"], capture_output=True, text=True,
+        r = subprocess.run(cmd + ["--exchange", exchange, "--overlap-chunks", "3,2"], capture_output=True, text=True,
                            timeout=300, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
