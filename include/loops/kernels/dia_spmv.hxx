@@ -48,14 +48,34 @@ dia_row4_spmv(const int rows, const int cols, const std::size_t stride, const in
         for (int k = 0; k < 4; ++k) v[u][k] = r0 + k < rows ? cell[k] : type_t(0);
       }
     }
+    // the four x values of a lane are consecutive (x[r0 + off .. r0 + off + 3]): one 16-byte load at 4-byte alignment
+    // when all four columns are inside the matrix, element-wise otherwise (cells outside are skipped, as in the reference)
+    type_t xv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long c0 = static_cast<long long>(r0) + off[u];
+      if (full && c0 >= 0 && c0 + 3 < cols) {
+        using v4u = type_t __attribute__((ext_vector_type(4), aligned(sizeof(type_t))));
+        const v4u t = *reinterpret_cast<const v4u*>(x + c0);
+        xv[u][0] = t.x;
+        xv[u][1] = t.y;
+        xv[u][2] = t.z;
+        xv[u][3] = t.w;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const long long c = c0 + k;
+          const bool ok = c >= 0 && c < cols && r0 + k < rows;
+          xv[u][k] = ok ? x[ok ? c : 0] : type_t(0);
+          if (!ok) v[u][k] = type_t(0);  // (an x of inf / NaN outside the matrix must not meet a stored 0)
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (d0 + u < num_diagonals) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const long long c = static_cast<long long>(r0 + k) + off[u];
-          if (c >= 0 && c < cols && r0 + k < rows) acc[k] += v[u][k] * x[c];  // cells outside the matrix are skipped, as in the reference
-        }
+        for (int k = 0; k < 4; ++k) acc[k] += v[u][k] * xv[u][k];
       }
     }
   }

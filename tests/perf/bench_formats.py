@@ -67,8 +67,65 @@ for tuned in (True, False):
     row["tuned" if tuned else "reference-shaped"] = {"ms": round(t, 4), "equal": bool(torch.equal(y, want))}
 t, yr = ref_format(2, rows, cols, eoff, ind.reshape(-1), ev_.reshape(-1), xh)
 row["reference build"] = {"ms": None if t is None else round(t, 4), "equal": None if yr is None else bool(np.array_equal(yr, want.cpu().numpy()))}
+# algorithms::spmv::ell_merge_path: ours on the fused engine vs the reference's atomic kernel (format 4)
+t = ev(lambda: S.ell_spmv(rows, cols, pitch, di, dv, x, y, tuned="merge_path"))
+row["ell_merge_path (fused engine)"] = {"ms": round(t, 4), "equal": bool(torch.equal(y, want))}
+t, yr = ref_format(4, rows, cols, eoff, ind.reshape(-1), ev_.reshape(-1), xh)
+row["ell_merge_path, reference build"] = {"ms": None if t is None else round(t, 4), "equal": None if yr is None else bool(np.array_equal(yr, want.cpu().numpy()))}
 out["ELL, 2^20 rows x pitch 16"] = row; print("ELL", row, file=sys.stderr, flush=True)
 del csr, di, dv
+
+# ---- ELL with uneven rows (the case ell_merge_path exists for): C2's degrees capped at 256, pitch 256
+deg = np.minimum(G.powerlaw_degrees(1 << 18, 1 << 22, cap=256), 256)
+r2 = deg.size
+uoff, uidx, uval = G.csr_from_degrees(deg, cols, 1)
+pitch2 = int(deg.max())
+ind2 = np.full((r2, pitch2), -1, np.int32); ev2 = np.zeros((r2, pitch2), np.float32)
+mask = np.arange(pitch2)[None, :] < deg[:, None]
+ind2[mask] = uidx; ev2[mask] = uval
+csr = S.CSR.from_numpy(r2, cols, uoff, uidx, uval); want2 = S.spmv("merge_path_flat", csr, x)
+di, dv = torch.from_numpy(ind2).cuda(), torch.from_numpy(ev2).cuda()
+y2 = torch.empty(r2, device="cuda")
+row = {"cells": int(r2 * pitch2), "nonzeros": int(uidx.size)}
+for name, mode in (("tuned (row split)", True), ("reference-shaped", False), ("ell_merge_path (fused engine)", "merge_path")):
+    t = ev(lambda: S.ell_spmv(r2, cols, pitch2, di, dv, x, y2, tuned=mode))
+    row[name] = {"ms": round(t, 4), "equal": bool(torch.equal(y2, want2))}
+for fmt, name in ((2, "reference build"), (4, "ell_merge_path, reference build")):
+    t, yr = ref_format(fmt, r2, cols, uoff, uidx, uval, xh)
+    row[name] = {"ms": None if t is None else round(t, 4), "equal": None if yr is None else bool(np.array_equal(yr, want2.cpu().numpy()))}
+out["ELL, 2^18 power-law rows (max 256), pitch 256"] = row; print("ELL uneven", row, file=sys.stderr, flush=True)
+del csr, di, dv
+
+# ---- DIA: 2^20 rows, 33 diagonals within +-512 of the main one, 80 % filled
+rngd = np.random.default_rng(1)
+offs = np.unique(np.concatenate([rngd.integers(-512, 513, size=32), [0]]))
+n = 1 << 20
+cells = np.zeros((offs.size, n), np.float32)
+rr, cc, vv = [], [], []
+for k, o in enumerate(offs):
+    r = np.arange(max(0, -o), min(n, n - o))
+    keep = rngd.random(r.size) < 0.8
+    v = (rngd.integers(1, 9, size=int(keep.sum())) / 8.0).astype(np.float32)
+    cells[k, r[keep]] = v
+    rr.append(r[keep]); cc.append(r[keep] + o); vv.append(v)
+rr, cc, vv = np.concatenate(rr), np.concatenate(cc), np.concatenate(vv)
+order = np.lexsort((cc, rr))
+doff = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=n))]).astype(np.int32)
+didx, dval = cc[order].astype(np.int32), vv[order]
+csr = S.CSR.from_numpy(n, n, doff, didx, dval); wantd = S.spmv("merge_path_flat", csr, x)
+dd, dc_ = torch.from_numpy(offs.astype(np.int32)).cuda(), torch.from_numpy(cells).cuda()
+yd = torch.empty(n, device="cuda")
+dia_bytes = cells.size * 4 + n * 8
+row = {"diagonals": int(offs.size), "stored_cells": int(cells.size), "nonzeros": int(didx.size)}
+for name, tuned in (("tuned (4 rows per lane)", True), ("reference-shaped", False)):
+    t = ev(lambda: S.dia_spmv(n, n, dd, dc_, x, yd, tuned=tuned), 30)
+    row[name] = {"ms": round(t, 4), "GBps": round(dia_bytes / t / 1e6, 1), "equal": bool(torch.equal(yd, wantd))}
+t, yr = ref_format(3, n, n, doff, didx, dval, xh)
+row["reference build"] = {"ms": None if t is None else round(t, 4), "equal": None if yr is None else bool(np.array_equal(yr, wantd.cpu().numpy()))}
+t = ev(lambda: S.spmv("merge_path_flat", csr, x, yd), 30)
+row["same matrix as CSR, merge_path_flat"] = {"ms": round(t, 4)}
+out["DIA, 2^20 rows x 33 diagonals"] = row; print("DIA", row, file=sys.stderr, flush=True)
+del csr, dd, dc_
 
 # ---- C4: BCSR 4x4
 nbr, per = 1 << 18, 16
