@@ -414,14 +414,11 @@ int spmv_ell(int mode, int rows, int cols, int pitch, const int* indices, const 
   if (static_cast<long long>(rows) * pitch + rows >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
   constexpr int IPT = sizeof(T) > 4 ? 4 : 8;
   int err = 0;
-  // the scratch plan is sized by merge items: ask for (rows, rows * pitch) at 8 items per thread (>= the 4-item need)
-  loops_merge_plan* p = scratch_plan(rows, rows * pitch, LOOPS_TILE_512x8, s, &err);
+  // scratch sized by merge tiles of 512 * IPT items: the 512 x 8 slot for fp32, the 256 x 8 slot (= 512 x 4 items) for fp64
+  loops_merge_plan* p = scratch_plan(rows, rows * pitch, sizeof(T) > 4 ? LOOPS_TILE_256x8 : LOOPS_TILE_512x8, s, &err);
   if (!p) return err;
   const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) * pitch + rows, 512ll * IPT));
-  if (m > p->capacity) {  // fp64: twice the tiles of the 512 x 8 sizing
-    p = scratch_plan(rows, 2 * (rows * pitch + rows), LOOPS_TILE_512x8, s, &err);
-    if (!p) return err;
-  }
+  if (m > p->capacity) return LOOPS_E_RANGE;  // (cannot happen: the slot was sized for exactly this tile count)
   err = kernels::launch_merge_path_coordinates_ell(s, rows, pitch, 512 * IPT, m, p->coords);
   if (err) return err;
   kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, m};

@@ -109,3 +109,18 @@ def test_measurement_code_lives_outside_the_product_library():
     for base, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "LOOPS_PROBE" not in open(os.path.join(base, f)).read(), f
+
+
+def test_argument_errors_of_the_round_2_entry_points():
+    L = _lib.lib()
+    # format twins / DIA / ELL engine mode: null pointers and unknown modes are rejected before any runtime call
+    assert L.loops_spmv_dia_f32(1, 4, 4, 2, 4, None, None, None, None, None) == -1
+    assert L.loops_spmv_dia_f64(1, 4, 4, 2, 2, None, None, None, 1, None) == -1          # stride < rows
+    assert L.loops_spmv_ell_f64(2, 4, 4, 2, None, None, None, None, None) == -1
+    assert L.loops_spmv_coo_f64(1, 4, 4, 4, None, None, None, None, None, None) == -1
+    assert L.loops_spmv_csc_f64(1, 4, 4, 4, None, None, None, None, None, None) == -1
+    assert L.loops_spmv_bcsr_f64(4, 4, 0, 4, 1, 1, None, None, None, None, None, None) == -1
+    assert L.loops_spmm_merge_path_f64(None, 4, 4, 4, None, None, None, None, 8, None, None) == -1
+    # fused allgatherv: a plan is required, at most 7 peers, peer pointers must be given
+    assert L.loops_spmv_merge_path_fanout_f32(None, 4, 4, 4, None, None, None, None, None, 0, None, None) == -1
+    assert L.loops_spmv_colblock_fanout_f32(None, None, None, 0, None, None) == -1

@@ -539,3 +539,39 @@ def test_non_finite_x_stays_in_its_rows():
             assert np.all(rel <= np.maximum(n, 1) * 2.0 ** -24), name
             continue
         assert rel.max() <= 1e-6, (name, rel.max())
+
+
+def test_held_plans_are_hip_graph_capturable():
+    """A step built from held plans (merge-path plan, column-blocked plan, BCSR) makes no allocation and no
+    synchronisation: it can be captured into a HIP graph on the caller's stream and replayed -- the launch-bound end of
+    the path (small matrices, many right-hand sides in a solver loop) without per-launch host work."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows = cols = 1 << 14
+    deg = G.powerlaw_degrees(rows, 1 << 18, cap=1 << 12)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    csr = _dev(off, idx, val, rows, cols)
+    plan = S.MergePathPlan(csr, "512x8")
+    cb = S.ColumnBlockedPlan(csr, 4)
+    xs = [G.uniform_distribution_int(cols, seed=s) for s in (42, 7)]
+    x = torch.from_numpy(xs[0]).cuda()
+    y1, y2 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):  # warm-up on the capture stream (lazy module loading must not happen inside a capture)
+        S.merge_path_flat(csr, x, y1, plan=plan)
+        cb.spmv(x, y2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        S.merge_path_flat(csr, x, y1, plan=plan)
+        cb.spmv(x, y2)
+    for xh in reversed(xs):   # replay on new data in the same buffers
+        x.copy_(torch.from_numpy(xh))
+        y1.fill_(-1.0)
+        y2.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = O.spmv_f32(off, idx, val, xh)
+        assert np.array_equal(y1.cpu().numpy(), ref) and np.array_equal(y2.cpu().numpy(), ref)
