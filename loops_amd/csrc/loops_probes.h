@@ -19,6 +19,10 @@ extern "C" {
  * also quoted against.  dst == src selects a READ-ONLY stream (per-lane sums, nothing
  * written): the achievable read rate. */
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
+/* out[i] = table[idx[i]] with `scalar_per_64` (0, 4, 8, 16, 24, 32, 64) of every 64 gathers of a wavefront issued through the
+ * scalar memory path (v_readlane -> s_load_dword -> select) and the rest as a divergent vector load: does the scalar path
+ * add gather throughput on top of the vector L1's outstanding-read capacity? */
+int loops_mixed_gather_f32(const float* table, const int* idx, float* out, size_t n, int scalar_per_64, void* stream);
 /* Read-only stream (16 B per lane, a contiguous chunk per wavefront) with SCALAR prefetch `distance` KB-steps ahead: one
  * wave-uniform (SMEM) dword load per `line_words` words (32 = per 128-byte line, 16 = per 64 bytes); distance 0 = none.
  * `waves_per_cu` resident wavefronts per CU (grid = 256 CUs x that).  Does the scalar path add memory-level parallelism

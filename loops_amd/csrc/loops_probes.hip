@@ -130,6 +130,12 @@ int loops_probe_merge_path_shape_f32(int shape, int stages, int rows, int cols, 
   }
 }
 
+int loops_mixed_gather_f32(const float* table, const int* idx, float* out, size_t n, int scalar_per_64, void* stream) {
+  if (!table || !idx || !out) return E_BADARG;
+  const int rc = kernels::launch_mixed_gather(as_stream(stream), table, idx, out, n, scalar_per_64);
+  return rc == -1 ? E_CONFIG : rc;
+}
+
 int loops_stream_read_prefetch_f32(const float* src, float* sink, size_t n, int distance, int line_words, int waves_per_cu,
                                    void* stream) {
   if (!src || !sink) return E_BADARG;

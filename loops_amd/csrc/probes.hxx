@@ -91,6 +91,54 @@ __global__ void __launch_bounds__(256) stream_read_kernel(const float4* __restri
   if (acc == -1.2345e30f) sink[0] = acc;
 }
 
+/// Mixed gather probe: out[i] = table[idx[i]] where, of every 64 gathers of a wavefront, the first K go through the
+/// SCALAR memory path (v_readlane -> s_load_dword -> v_writelane: tracked by the scalar cache, not by the vector L1's
+/// ~95 outstanding reads) and the other 64 - K through the ordinary divergent vector load.  Does the scalar path ADD
+/// gather throughput on top of the vector path's?  K = 0: the plain gather probe's inner loop.
+template <int K>
+__global__ void __launch_bounds__(256) mixed_gather_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                                           float* __restrict__ out, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  // trip count made wave-uniform so that the scalar loads below may live in the loop
+  const size_t first = static_cast<size_t>(blockIdx.x) * blockDim.x + (threadIdx.x & ~63);
+  const unsigned int trips = __builtin_amdgcn_readfirstlane(static_cast<unsigned int>(first < n ? (n - first + stride - 1) / stride : 0));
+  for (unsigned int t = 0; t < trips; ++t) {
+    const size_t i = first + static_cast<size_t>(t) * stride + lane;
+    const bool live = i < n;
+    const int c = live ? idx[i] : 0;
+    float v = 0.f;
+    if constexpr (K > 0) {
+      float sv[K];
+#pragma unroll
+      for (int l = 0; l < K; ++l) sv[l] = table[__builtin_amdgcn_readlane(c, l)];  // uniform address -> s_load_dword
+      if (lane >= K) v = table[c];                                                   // the rest: divergent vector load
+#pragma unroll
+      for (int l = 0; l < K; ++l) v = lane == l ? sv[l] : v;
+    } else {
+      v = table[c];
+    }
+    if (live) out[i] = v;
+  }
+}
+
+inline int launch_mixed_gather(hipStream_t stream, const float* table, const int* idx, float* out, size_t n, int k) {
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 256 * 8 * 4) blocks = 256 * 8 * 4;
+  const dim3 g(static_cast<unsigned>(blocks)), b(256);
+  switch (k) {
+    case 0: hipLaunchKernelGGL(mixed_gather_kernel<0>, g, b, 0, stream, table, idx, out, n); break;
+    case 4: hipLaunchKernelGGL(mixed_gather_kernel<4>, g, b, 0, stream, table, idx, out, n); break;
+    case 8: hipLaunchKernelGGL(mixed_gather_kernel<8>, g, b, 0, stream, table, idx, out, n); break;
+    case 16: hipLaunchKernelGGL(mixed_gather_kernel<16>, g, b, 0, stream, table, idx, out, n); break;
+    case 24: hipLaunchKernelGGL(mixed_gather_kernel<24>, g, b, 0, stream, table, idx, out, n); break;
+    case 32: hipLaunchKernelGGL(mixed_gather_kernel<32>, g, b, 0, stream, table, idx, out, n); break;
+    case 64: hipLaunchKernelGGL(mixed_gather_kernel<64>, g, b, 0, stream, table, idx, out, n); break;
+    default: return -1;
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
 /// Read-only stream with SCALAR prefetch: a wavefront walks its own contiguous chunk, 1 KB (16 B per lane) per step
 /// with vector loads, and D steps ahead touches the same lines with wave-uniform (scalar, SMEM) loads -- one dword per
 /// LINE_WORDS words.  The scalar path has its own miss tracking (SQC), so the prefetches do not take the vector L1's

@@ -25,6 +25,7 @@ def lib() -> C.CDLL:
         P.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
         P.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         P.loops_stream_read_prefetch_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, ci, vp]
+        P.loops_mixed_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         P.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         P.loops_row_gather_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, vp, vp]
         P.loops_probe_merge_path_scratch_bytes.argtypes = [ci, ci]
@@ -52,6 +53,10 @@ def stream_copy(src, dst):
 def stream_read_prefetch(src, sink, distance: int, line_words: int = 32, waves_per_cu: int = 32):
     L.check(lib().loops_stream_read_prefetch_f32(_ptr(src), _ptr(sink), src.numel(), distance, line_words, waves_per_cu, _stream()),
             "loops_stream_read_prefetch_f32")
+
+
+def mixed_gather(table, idx, out, scalar_per_64: int):
+    L.check(lib().loops_mixed_gather_f32(_ptr(table), _ptr(idx), _ptr(out), idx.numel(), scalar_per_64, _stream()), "loops_mixed_gather_f32")
 
 
 def gather(table, idx, out, mode: int = 0):
