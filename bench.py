@@ -122,6 +122,7 @@ def one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_gathered, iters=20):
     except Exception as e:  # noqa: BLE001 -- the plain-CSR figure stands on its own
         out["blocked_error"] = f"{type(e).__name__}: {e}"
     out["best_ms_per_spmv"] = min(v for k, v in out.items() if k.endswith("_ms_per_spmv"))
+    out["GFLOPs"] = round(2.0 * csr.nnzs / out["best_ms_per_spmv"] / 1e6, 2)  # the N = 1 `value` of THIS matrix (bench.py --gpus 1 runs C2)
     return out
 
 
