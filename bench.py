@@ -69,6 +69,29 @@ def pmc_traffic(args):
     return None, None
 
 
+def pmc_bound(args):
+    """What the committed counters of the dominant kernel say bounds it (same summary file as pmc_traffic):
+    L2 requests per launch, L2 hit rate, average L1 -> L2 round trip, reads in flight per CU, share of its active time the
+    vector L1 waits for data, L2 requests per clock and XCD.  None when the configuration differs from the profiled one."""
+    _, src = pmc_traffic(args)
+    if src is None:
+        return None
+    d = json.load(open(os.path.join(ROOT, src)))
+    for k, v in d.items():
+        if "merge_path_spmv_fused" in k and "stacked" not in k and isinstance(v, dict) and "TCP_TCC_READ_REQ_LATENCY_sum" in v:
+            m = {c: x["mean"] for c, x in v.items()}
+            cyc = m["GRBM_GUI_ACTIVE"] / 8
+            return {"l2_requests_per_launch": int(m["TCC_REQ_sum"]), "l2_hit_rate": round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4),
+                    "avg_l1_to_l2_round_trip_clks": round(m["TCP_TCC_READ_REQ_LATENCY_sum"] / m["TCP_TCC_READ_REQ_sum"], 1),
+                    "reads_in_flight_per_cu": round(m["TCP_TCC_READ_REQ_LATENCY_sum"] / cyc / 256, 1),
+                    "l1_waiting_for_data_frac": round(m["TCP_PENDING_STALL_CYCLES_sum"] / m["TCP_GATE_EN1_sum"], 3),
+                    "l2_requests_per_clk_per_xcd": round(m["TCC_REQ_sum"] / 8 / cyc, 2),
+                    "reading": "bound by the CU's outstanding-read capacity (~95 in flight) x round-trip latency, not by the L2 request "
+                               "path (16 per clk per XCD) nor by HBM bandwidth; calibration: profiles/r02_inflight_calibration.json",
+                    "source": src}
+    return None
+
+
 def full_matrix_on_device(G, S, torch, degrees, cols, chunks=8):
     """The whole synthetic matrix as one device CSR, generated and uploaded in row chunks (host memory stays at one
     chunk: C5 is 4.3 GB of indices + values)."""
@@ -676,7 +699,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "loops::kernels::merge_path_spmv_fused" + ("_stacked" if blocked is not None else ""),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "counters": pmc_bound(args),
                 "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": round(k_main_avg, 5),
                 "median_launch_ms": round(k_main_med, 5), "avg_launch_ms_event_pair_per_launch": round(k_main_single, 5), "fixup_avg_launch_ms": round(k_fix_avg, 5),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 4),
