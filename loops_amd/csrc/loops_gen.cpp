@@ -89,7 +89,11 @@ int loops_gen_csr_rows(const long long* degrees, const long long* offsets, long 
     for (long long r = 0; r < nrows; ++r) {
       const std::int64_t deg = degrees[r];
       const std::int64_t row_abs = r + row_begin;
-      if (deg > cols) { status = -1; continue; }
+      if (deg > cols) {
+#pragma omp atomic write
+        status = -1;
+        continue;
+      }
       col.resize(static_cast<std::size_t>(deg));
       item.resize(static_cast<std::size_t>(deg));
       for (std::int64_t k = 0; k < deg; ++k) col[k] = hash_col(seed, row_abs, k, 0, cols, window, deg);
