@@ -1,6 +1,6 @@
 """Soak: the tuned kernels launched back to back for a fixed wall time on C2 and on a self-completing band matrix; every
 result compared ON THE GPU with the first one (bit-equal) -- races / ordering bugs show up as a mismatch count > 0.
-usage: python tests/perf/soak.py [seconds per case, default 20]"""
+usage: python tests/perf/soak.py [seconds per case, default 20] [r2]     (r2 = only the kernels added in round 2)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -8,7 +8,70 @@ from loops_amd import generate as G, spmv as S
 from oracle import oracle as O
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+only_r2 = len(sys.argv) > 2 and sys.argv[2] == "r2"
 rows = cols = 1 << 20
+
+
+def soak(name, label, fn, ref, n_out):
+    y = torch.empty(n_out, device="cuda")
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    rounds, t0 = 0, time.time()
+    while time.time() - t0 < secs:
+        for _ in range(200):
+            y.fill_(float("nan"))
+            extra = fn(y)
+            bad += (y != ref).any()
+            for e in extra or ():
+                bad += (e != ref).any()
+        rounds += 200
+        torch.cuda.synchronize()
+    print(f"{name:7s} {label:46s} rounds {rounds:7d} mismatching rounds {int(bad.item())}", flush=True)
+
+
+# ---- round 2: ELL merge-path on the fused engine, DIA, epilogue fan-out (two stand-in peers on the same device)
+off, idx, val = G.csr_from_degrees(np.minimum(G.powerlaw_degrees(1 << 18, 1 << 22, cap=256), 256), cols, 1)
+r2 = off.size - 1
+deg = np.diff(off)
+pitch = int(deg.max())
+ind = np.full((r2, pitch), -1, np.int32); ev = np.zeros((r2, pitch), np.float32)
+m = np.arange(pitch)[None, :] < deg[:, None]
+ind[m] = idx; ev[m] = val
+xh = G.uniform_distribution_int(cols); x = torch.from_numpy(xh).cuda()
+ref = torch.from_numpy(O.spmv_f32(off, idx, val, xh, omp=True)).cuda()
+di, dv = torch.from_numpy(ind).cuda(), torch.from_numpy(ev).cuda()
+soak("ell", "ell_merge_path (fused engine), 2^18 x pitch 256", lambda y: (S.ell_spmv(r2, cols, pitch, di, dv, x, y, tuned="merge_path"), None)[1], ref, r2)
+del di, dv
+offs = np.arange(-16, 17, dtype=np.int32)
+n = 1 << 20
+cells = ((np.arange(offs.size * n, dtype=np.int64).reshape(offs.size, n) * 7 % 8 + 1) / 8.0).astype(np.float32)
+wantd = np.zeros(n, np.float64)
+for k, o in enumerate(offs):
+    r = np.arange(max(0, -o), min(n, n - o))
+    wantd[r] += cells[k, r].astype(np.float64) * xh[r + o]
+refd = torch.from_numpy(wantd.astype(np.float32)).cuda()
+dd, dc = torch.from_numpy(offs).cuda(), torch.from_numpy(cells).cuda()
+soak("dia", "dia_row4_spmv, 2^20 rows x 33 diagonals", lambda y: (S.dia_spmv(n, n, dd, dc, x, y, tuned=True), None)[1], refd, n)
+del dd, dc
+off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
+ref = torch.from_numpy(O.spmv_f32(off, idx, val, xh, omp=True)).cuda()
+csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+plan = S.MergePathPlan(csr, "512x8")
+cb = S.ColumnBlockedPlan(csr)
+peers = [torch.empty(rows, device="cuda") for _ in range(2)]
+def fan_csr(y):
+    for p in peers: p.fill_(float("nan"))
+    S.merge_path_flat_fanout(csr, x, y, plan, peers)
+    return peers
+def fan_blocked(y):
+    for p in peers: p.fill_(float("nan"))
+    cb.spmv_fanout(x, y, peers)
+    return peers
+soak("c2", "merge_path_flat + epilogue fan-out (2 peers)", fan_csr, ref, rows)
+soak("c2", "column-blocked + reduce fan-out (2 peers)", fan_blocked, ref, rows)
+del csr, plan, cb, peers
+if only_r2:
+    sys.exit(0)
+
 cases = {"c2": (G.powerlaw_degrees(rows, 1 << 24), None), "band64": (np.full(rows, 16, np.int64), 64)}
 for name, (deg, window) in cases.items():
     off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
