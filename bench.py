@@ -204,6 +204,10 @@ def context_schedules(S, torch, csr, x, ref_y, abytes, iters=50):
     whole call through loops_spmv_csr_f32 (work_oriented includes its coordinate pre-pass), bit-exact vs the headline y."""
     y = torch.empty_like(ref_y)
     out = {}
+    wplan = S.MergePathPlan(csr, "256x8")  # work_oriented with a held plan: the region the reference's timer brackets
+    ms = timed_ms(torch, lambda: S.work_oriented(csr, x, y, plan=wplan), iters)
+    out["work_oriented_held_plan"] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
+                                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
     for sched in ("work_oriented", "group_mapped"):
         ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
         out[sched] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),

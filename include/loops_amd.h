@@ -108,6 +108,14 @@ int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int r
                               const int* offsets, const int* indices, const double* values, const double* x,
                               double* y, void* stream);
 
+/* work_oriented with a prebuilt plan (tile config LOOPS_TILE_256x8 only, LOOPS_E_CONFIG otherwise): the persistent kernel of
+ * algorithms::spmv::work_oriented (algorithms/spmv/work_oriented.cuh:33-121) walks an even share of the plan's merge tiles
+ * per workgroup; no coordinate pre-pass per call. */
+int loops_spmv_work_oriented_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                                 const int* indices, const float* values, const float* x, float* y, void* stream);
+int loops_spmv_work_oriented_f64(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                                 const int* indices, const double* values, const double* x, double* y, void* stream);
+
 /* ---- multi-GPU: allgatherv(y) fused into the SpMV epilogue ----------------------------------------------
  * No reference counterpart (the reference is single-GPU).  A rank of a row-range sharded SpMV owns rows
  * [row_begin, row_end) of y; instead of exchanging its slice afterwards, the kernels that FINISH rows of y (the fused

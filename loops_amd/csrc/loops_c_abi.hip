@@ -354,6 +354,20 @@ int spmm_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
   }
 }
 
+// work_oriented over a held plan (256 x 8 tiles): the persistent kernel + its fix-up, no coordinate pre-pass per call
+template <typename T>
+int spmv_work_oriented_planned(const loops_merge_plan* plan, int rows, int cols, int nnz, const int* off, const int* idx,
+                                      const T* val, const T* x, T* y, hipStream_t stream) {
+  if (!plan) return LOOPS_E_BADARG;
+  int err = check_csr(rows, cols, nnz, off, idx, val, x, y);
+  if (err) return err;
+  if (rows != plan->rows || nnz != plan->nnz) return LOOPS_E_BADARG;
+  if (plan->tpb != 256 || plan->ipt != 8) return LOOPS_E_CONFIG;
+  if (rows == 0) return 0;
+  kernels::merge_plan_view view{plan->coords, plan->carry_row, plan->carry_val, plan->num_tiles};
+  return kernels::launch_work_oriented_fused<256, 8, true>(stream, view, rows, nnz, off, idx, val, x, y);
+}
+
 // ------------------------------------------------------------------------ other formats
 template <typename T>
 int spmv_bcsr(int R, int C, int mode, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
@@ -701,6 +715,15 @@ int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const floa
   int err = colblock_spmv<float>(plan, 3, x, y, as_stream(stream));  // tile kernel (+ fix-up) into the K partial vectors
   if (!err) err = kernels::launch_reduce_blocks_fanout<float>(as_stream(stream), static_cast<const float*>(plan->ys), plan->rows, plan->K, y, peers);
   return err;
+}
+
+int loops_spmv_work_oriented_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                                 const int* indices, const float* values, const float* x, float* y, void* stream) {
+  return spmv_work_oriented_planned<float>(plan, rows, cols, nnz, offsets, indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_work_oriented_f64(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
+                                 const int* indices, const double* values, const double* x, double* y, void* stream) {
+  return spmv_work_oriented_planned<double>(plan, rows, cols, nnz, offsets, indices, values, x, y, as_stream(stream));
 }
 
 int loops_spmv_merge_path_stage_f32(const loops_merge_plan_t* plan, int variant, int stage, int rows, int cols,

@@ -164,8 +164,17 @@ def merge_path_flat_stage(csr: CSR, x, y, plan: MergePathPlan, stage: int, varia
     return y
 
 
-def work_oriented(csr, x, y=None):
-    return spmv("work_oriented", csr, x, y)
+def work_oriented(csr, x, y=None, plan: MergePathPlan | None = None):
+    """algorithms::spmv::work_oriented; with a held ``plan`` (tile 256x8) the coordinate pre-pass is skipped."""
+    if plan is None:
+        return spmv("work_oriented", csr, x, y)
+    if y is None:
+        y = torch.empty(csr.rows, dtype=csr.values.dtype, device=csr.values.device)
+    csr.check(x, y)
+    fn = getattr(L.lib(), "loops_spmv_work_oriented_" + _suffix(csr.values))
+    L.check(fn(plan.handle, csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), _ptr(x),
+               _ptr(y), _stream()), "loops_spmv_work_oriented")
+    return y
 
 
 def thread_mapped(csr, x, y=None):

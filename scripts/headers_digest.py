@@ -1,7 +1,8 @@
-"""sha256 over every file under include/ (path + contents, sorted): identifies the header set a binary was built from."""
+"""sha256 over every file under include/loops/ (path + contents, sorted) -- the C++ header API, i.e. everything the example
+programs can include (the C ABI header include/loops_amd.h is not part of it): identifies the header set a binary was built from."""
 import hashlib, os, sys
 
-root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "loops")
 
 
 def digest() -> str:

@@ -193,6 +193,7 @@ def test_full_size_c2_bit_exact_and_properties():
         assert np.array_equal(y.cpu().numpy(), ref), variant
     for sched in ("merge_path_flat", "work_oriented", "thread_mapped", "group_mapped"):
         assert np.array_equal(S.spmv(sched, csr, xd).cpu().numpy(), ref), sched
+    assert np.array_equal(S.work_oriented(csr, xd, plan=plan).cpu().numpy(), ref)   # held 256x8 plan: no pre-pass per call
     # linearity: A(2x) == 2 A x exactly (power-of-two scaling), A(x + x2) == Ax + Ax2 (integers)
     y1 = S.merge_path_flat(csr, xd, plan=plan)
     y2 = S.merge_path_flat(csr, xd * 2, plan=plan)
