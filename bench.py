@@ -478,8 +478,7 @@ def main():
             ok = all(h is not None for h in handles)
             if ok:
                 try:
-                    views = P.FusedFanout.open_peers(handles, rank)
-                    fused["fan"] = P.FusedFanout(y_full, shard, views)
+                    fused["fan"] = P.FusedFanout(y_full, shard, P.FusedFanout.open_peers(handles, rank))
                     if blocked is not None:
                         fused["run"] = lambda y, peers: blocked.spmv_fanout(x, y, peers)
                     else:
@@ -813,6 +812,10 @@ def main():
         print(json.dumps(out))
     if world > 1:
         fused.clear()  # peer mappings go before the processes that own the memory do
+        handles = None
+        import gc
+        gc.collect()
+        torch.cuda.ipc_collect()
         barrier()
         dist.destroy_process_group()
 
