@@ -240,6 +240,8 @@ int loops_spmv_colblock_schedule_f32(const loops_colblock_plan_t* plan, int sche
  * reduce writes y and, with 16-byte non-temporal stores, the num_peers peer copies. */
 int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const float* x, float* y, int num_peers,
                                    float* const* h_peer_y, void* stream);
+int loops_spmv_colblock_fanout_f64(const loops_colblock_plan_t* plan, const double* x, double* y, int num_peers,
+                                   double* const* h_peer_y, void* stream);
 /* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);

@@ -41,7 +41,7 @@ SYMBOLS = [
     "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32",
     "loops_spmv_bcsr_f64", "loops_spmm_merge_path_f64", "loops_spmv_coo_f64", "loops_spmv_ell_f64", "loops_spmv_csc_f64",
     "loops_spmv_dia_f32", "loops_spmv_dia_f64",
-    "loops_spmv_work_oriented_f32", "loops_spmv_work_oriented_f64", "loops_enable_peer_access", "loops_spmv_merge_path_fanout_f32", "loops_spmv_colblock_fanout_f32",
+    "loops_spmv_work_oriented_f32", "loops_spmv_work_oriented_f64", "loops_enable_peer_access", "loops_spmv_merge_path_fanout_f32", "loops_spmv_colblock_fanout_f32", "loops_spmv_colblock_fanout_f64",
     "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64",
 ]
 
@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
         L.loops_enable_peer_access.argtypes = [ci]
         L.loops_spmv_merge_path_fanout_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmv_colblock_fanout_f32.argtypes = [vp, vp, vp, ci, vp, vp]
+        L.loops_spmv_colblock_fanout_f64.argtypes = [vp, vp, vp, ci, vp, vp]
         L.loops_spmv_merge_path_stage_f32.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_spmv_csr_schedule_api_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_schedule_dump_merge_path.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]

@@ -588,6 +588,50 @@ int colblock_refresh(loops_colblock_plan* plan, const T* values, hipStream_t str
 
 }  // namespace
 
+namespace {
+template <typename T>
+int fanout_peers(int num_peers, T* const* h_peer_y, kernels::peer_fanout<T>* peers) {
+  if (num_peers < 0 || num_peers > kernels::max_peers || (num_peers > 0 && !h_peer_y)) return LOOPS_E_BADARG;
+  *peers = kernels::peer_fanout<T>{};
+  peers->count = num_peers;
+  for (int p = 0; p < num_peers; ++p) {
+    if (!h_peer_y[p]) return LOOPS_E_BADARG;
+    peers->base[p] = h_peer_y[p];
+  }
+  return 0;
+}
+
+template <typename T>
+int merge_path_fanout(const loops_merge_plan* plan, int rows, int cols, int nnz, const int* offsets, const int* indices,
+                             const T* values, const T* x, T* y, int num_peers, T* const* h_peer_y, hipStream_t stream) {
+  if (!plan) return LOOPS_E_BADARG;
+  kernels::peer_fanout<T> peers;
+  int err = fanout_peers<T>(num_peers, h_peer_y, &peers);
+  if (!err) err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
+  if (err) return err;
+  if (rows != plan->rows || nnz != plan->nnz) return LOOPS_E_BADARG;
+  if (plan->tpb != 512 || plan->ipt != 8) return LOOPS_E_CONFIG;  // compiled for the merge_path launch box only
+  if (rows == 0) return 0;
+  kernels::merge_plan_view view{plan->coords, plan->carry_row, plan->carry_val, plan->num_tiles};
+  constexpr int IPT = sizeof(T) > 4 ? 4 : 8;  // (an fp64 plan of shape 512 x 8 is walked as 512 x 4 + 512 x 4: not compiled)
+  if constexpr (sizeof(T) > 4) return LOOPS_E_CONFIG;
+  else return kernels::launch_merge_path_fused_fanout<512, IPT>(stream, view, rows, nnz, offsets, indices, values, x, y, peers);
+}
+
+template <typename T>
+int colblock_fanout(const loops_colblock_plan* plan, const T* x, T* y, int num_peers, T* const* h_peer_y, hipStream_t stream) {
+  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  kernels::peer_fanout<T> peers;
+  int err = fanout_peers<T>(num_peers, h_peer_y, &peers);
+  if (err) return err;
+  if (plan->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
+  if (plan->rows == 0) return 0;
+  err = colblock_spmv<T>(plan, 3, x, y, stream);  // tile kernel (+ fix-up) into the K partial vectors
+  if (!err) err = kernels::launch_reduce_blocks_fanout<T>(stream, static_cast<const T*>(plan->ys), plan->rows, plan->K, y, peers);
+  return err;
+}
+}  // namespace
+
 // =============================================================================== extern "C"
 extern "C" {
 
@@ -684,37 +728,16 @@ int loops_enable_peer_access(int peer_device) {
 int loops_spmv_merge_path_fanout_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
                                      const int* indices, const float* values, const float* x, float* y, int num_peers,
                                      float* const* h_peer_y, void* stream) {
-  if (!plan || num_peers < 0 || num_peers > kernels::max_peers || (num_peers > 0 && !h_peer_y)) return LOOPS_E_BADARG;
-  int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
-  if (err) return err;
-  if (rows != plan->rows || nnz != plan->nnz) return LOOPS_E_BADARG;
-  if (plan->tpb != 512 || plan->ipt != 8) return LOOPS_E_CONFIG;  // compiled for the merge_path launch box only
-  if (rows == 0) return 0;
-  kernels::peer_fanout<float> peers{};
-  peers.count = num_peers;
-  for (int p = 0; p < num_peers; ++p) {
-    if (!h_peer_y[p]) return LOOPS_E_BADARG;
-    peers.base[p] = h_peer_y[p];
-  }
-  kernels::merge_plan_view view{plan->coords, plan->carry_row, plan->carry_val, plan->num_tiles};
-  return kernels::launch_merge_path_fused_fanout<512, 8>(as_stream(stream), view, rows, nnz, offsets, indices, values, x, y, peers);
+  return merge_path_fanout<float>(plan, rows, cols, nnz, offsets, indices, values, x, y, num_peers, h_peer_y, as_stream(stream));
 }
 
 int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const float* x, float* y, int num_peers,
                                    float* const* h_peer_y, void* stream) {
-  if (!plan || !y || (plan->nnz > 0 && !x) || num_peers < 0 || num_peers > kernels::max_peers || (num_peers > 0 && !h_peer_y))
-    return LOOPS_E_BADARG;
-  if (plan->vbytes != 4) return LOOPS_E_BADARG;
-  if (plan->rows == 0) return 0;
-  kernels::peer_fanout<float> peers{};
-  peers.count = num_peers;
-  for (int p = 0; p < num_peers; ++p) {
-    if (!h_peer_y[p]) return LOOPS_E_BADARG;
-    peers.base[p] = h_peer_y[p];
-  }
-  int err = colblock_spmv<float>(plan, 3, x, y, as_stream(stream));  // tile kernel (+ fix-up) into the K partial vectors
-  if (!err) err = kernels::launch_reduce_blocks_fanout<float>(as_stream(stream), static_cast<const float*>(plan->ys), plan->rows, plan->K, y, peers);
-  return err;
+  return colblock_fanout<float>(plan, x, y, num_peers, h_peer_y, as_stream(stream));
+}
+int loops_spmv_colblock_fanout_f64(const loops_colblock_plan_t* plan, const double* x, double* y, int num_peers,
+                                   double* const* h_peer_y, void* stream) {
+  return colblock_fanout<double>(plan, x, y, num_peers, h_peer_y, as_stream(stream));
 }
 
 int loops_spmv_work_oriented_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,

@@ -264,7 +264,7 @@ class FusedFanout:
     reading: alternate between two y_full buffers, or put a barrier in front of the next ``run``."""
 
     def __init__(self, y_full: torch.Tensor, shard: Shard, peer_views, group=None):
-        assert y_full.dtype == torch.float32
+        assert y_full.dtype in (torch.float32, torch.float64)  # (fp64: column-blocked shards only)
         self.y_full, self.shard, self.group = y_full, shard, group
         self.peer_views = list(peer_views)  # keep the mappings alive
         a, b = int(shard.bounds[shard.rank]), int(shard.bounds[shard.rank + 1])

@@ -267,10 +267,11 @@ class ColumnBlockedPlan:
     def spmv_fanout(self, x, y, peers):
         """``spmv`` whose block reduce also stores the finished y to ``peers`` (loops_spmv_colblock_fanout_f32; see
         merge_path_flat_fanout)."""
-        assert self.dtype == torch.float32 and x.dtype == torch.float32 and y.dtype == torch.float32
+        assert x.dtype == self.dtype and y.dtype == self.dtype
         assert x.numel() == self.cols and y.numel() == self.rows and x.is_contiguous() and y.is_contiguous()
         arr, n = _peer_array(peers)
-        L.check(L.lib().loops_spmv_colblock_fanout_f32(self._h, _ptr(x), _ptr(y), n, arr, _stream()), "loops_spmv_colblock_fanout_f32")
+        fn = L.lib().loops_spmv_colblock_fanout_f32 if self.dtype == torch.float32 else L.lib().loops_spmv_colblock_fanout_f64
+        L.check(fn(self._h, _ptr(x), _ptr(y), n, arr, _stream()), "loops_spmv_colblock_fanout")
         return y
 
     def spmv_schedule(self, schedule: str, x, y=None):

@@ -483,6 +483,20 @@ def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
             torch.cuda.synchronize()
         for rank in range(world):
             assert np.array_equal(fulls[rank].cpu().numpy(), ref), (layout, world, rank)
+    if layout == "blocked":  # the fp64 twin of the block-reduce fan-out
+        world = 3
+        ref64 = O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64))
+        bounds = P.row_ranges(off.astype(np.int64), world)
+        fulls = [torch.full((rows,), float("nan"), device="cuda", dtype=torch.float64) for _ in range(world)]
+        for rank in range(world):
+            shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
+            so, si, sv = P.slice_csr(off, idx, val, shard.row_begin, shard.row_end)
+            cb = S.ColumnBlockedPlan(_dev(so, si, sv.astype(np.float64), shard.row_end - shard.row_begin, cols), 4)
+            fan = P.FusedFanout(fulls[rank], shard, [fulls[p] for p in range(world) if p != rank])
+            fan.run(lambda y, peers: cb.spmv_fanout(x.double(), y, peers))
+            torch.cuda.synchronize()
+        for rank in range(world):
+            assert np.array_equal(fulls[rank].cpu().numpy(), ref64), ("blocked f64", rank)
 
 
 @pytest.mark.parametrize("schedule", TUNED)
