@@ -23,6 +23,7 @@ ap.add_argument("--tag", default="c2")
 ap.add_argument("--rows", type=int, default=0, help="exact row count (overrides --log2-rows)")
 ap.add_argument("--nnz", type=int, default=0, help="exact nonzero count (overrides --log2-nnz)")
 ap.add_argument("--cap", type=int, default=1 << 14)
+ap.add_argument("--tuned-only", action="store_true", help="skip the schedule-API (atomic) kernels: profiling runs")
 ap.add_argument("--mtx", default="", help="Matrix-Market coordinate file to run instead of a generated matrix (BASELINE C3: "
                 "SuiteSparse LAW/indochina-2004, datasets/suitesparse.txt:2052 in the reference; not shipped). Loaded as the "
                 "reference's loader does (container/market.hxx:100-289): pattern entries = 1, symmetric files mirrored, "
@@ -59,9 +60,9 @@ def rec(name, fn, check=True):
     res["rows"][name] = {"ms": round(ms, 4), "GFLOPs": round(2 * nnz / ms / 1e6, 1), "GBps": round(abytes / ms / 1e6, 1), "bit_exact": ok}
     print(f"{name:42s} {ms*1e3:9.1f} us {2*nnz/ms/1e6:8.1f} GFLOP/s {abytes/ms/1e6:8.1f} GB/s exact={ok}", file=sys.stderr, flush=True)
 rec("merge_path_flat (planned, fused+fixup)", lambda: S.merge_path_flat(csr, x, y, plan=plan))
-for sched in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "original", "flat_partitioned"):
+for sched in ("merge_path_flat", "work_oriented", "group_mapped") + (() if args.tuned_only else ("thread_mapped", "original", "flat_partitioned")):
     rec(f"tuned {sched}", lambda: S.spmv(sched, csr, x, y))
-for sched in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "flat_partitioned"):
+for sched in () if args.tuned_only else ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "flat_partitioned"):
     rec(f"schedule-API {sched} (incl. y zero-fill)", lambda: S.spmv_schedule_api(sched, csr, x, y))
 so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "libloops_ref_gpu.so")
 if args.ref_gpu and os.path.exists(so):
