@@ -68,6 +68,21 @@ struct column_blocked_t {
                                           y.data().get());
   }
 
+  /// y = A x for one rank of a row-range sharded multi-GPU SpMV: the block reduce also stores the finished y to the
+  /// peer-mapped vectors `peers` (kernels::reduce_blocks_x4_fanout; see merge_path_flat_fanout_async).  Asynchronous.
+  void spmv_fanout_async(vector_t<type_t>& x, vector_t<type_t>& y, const kernels::peer_fanout<type_t>& peers,
+                         xpu::stream_t stream = 0) {
+    constexpr int block_size = merge_path_launch_t<type_t>::block_size;
+    constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
+    kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                  static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
+    kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
+        stream, view, static_cast<int>(num_blocks * rows), static_cast<int>(nnzs), offsets.data().get(),
+        indices.data().get(), values.data().get(), x.data().get(), partial.data().get(), 3, true);
+    kernels::launch_reduce_blocks_fanout<type_t>(stream, partial.data().get(), static_cast<int>(rows), num_blocks,
+                                                 y.data().get(), peers);
+  }
+
   util::timer_t spmv(vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
     util::timer_t timer(stream);
     timer.start();

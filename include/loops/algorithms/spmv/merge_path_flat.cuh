@@ -50,6 +50,26 @@ void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& p
       csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
 }
 
+/// The same product for one rank of a row-range sharded multi-GPU SpMV: every finished row of y is ALSO stored to the same
+/// element of `peers.count` peer-mapped vectors (loops/kernels/merge_path_spmv.hxx `fanout_store`; `peers.base[p]` = where
+/// this shard's y[0] lives in peer p's full-length vector) -- the allgatherv(y) issued from the kernels' epilogue
+/// (no reference counterpart).  Asynchronous on `stream`; one barrier among the ranks remains per step.
+template <typename index_t, typename offset_t, typename type_t>
+void merge_path_flat_fanout_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,
+                                  csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
+                                  const kernels::peer_fanout<type_t>& peers, xpu::stream_t stream = 0) {
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "merge_path_flat_fanout: rows + nnz must stay below 2^31");
+  error::throw_if_exception(peers.count < 0 || peers.count > kernels::max_peers, "merge_path_flat_fanout: at most 7 peers");
+  constexpr int block_size = merge_path_launch_t<type_t>::block_size;
+  constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
+  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                static_cast<int>(plan.merge_tiles())};
+  kernels::launch_merge_path_fused_fanout<block_size, items_per_thread>(
+      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(), csr.indices.data().get(),
+      csr.values.data().get(), x.data().get(), y.data().get(), peers);
+}
+
 template <typename index_t, typename offset_t, typename type_t>
 util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                               xpu::stream_t stream = 0) {

@@ -25,6 +25,26 @@ namespace algorithms {
 namespace spmv {
 
 template <typename index_t, typename offset_t, typename type_t>
+using work_oriented_plan_t = schedule::merge_path::preprocess_t<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread,
+                                                                index_t, offset_t, std::size_t, std::size_t>;
+
+/// work_oriented over a caller-held plan (built once per sparsity structure with `prepass_always`): the persistent kernel
+/// + its fix-up, no coordinate pre-pass and no synchronisation per call.
+template <typename index_t, typename offset_t, typename type_t>
+void work_oriented_async(const work_oriented_plan_t<index_t, offset_t, type_t>& plan, csr_t<index_t, offset_t, type_t>& csr,
+                         vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "work_oriented: rows + nnz must stay below 2^31");
+  constexpr int block_size = launch_t<type_t>::block_size;
+  constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
+  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                static_cast<int>(plan.merge_tiles())};
+  kernels::launch_work_oriented_fused<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
+      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
+}
+
+template <typename index_t, typename offset_t, typename type_t>
 void work_oriented(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                    xpu::stream_t stream = 0) {
   error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,

@@ -143,6 +143,29 @@ static void run_battery() {
         check_y("merge_path_flat_async(plan)", m, y, reference::spmv(h, xh));
         if (seed == 8u) plan.classify();  // third round: the single-kernel path where the rows are short
       }
+      // the multi-GPU epilogue fan-out (two stand-in "peers" on this device): y and both peer copies must equal the plain result
+      {
+        vector_t<T> x2(xh), y = vector_t<T>(h.rows, T(-1)), p0 = vector_t<T>(h.rows, T(-2)), p1 = vector_t<T>(h.rows, T(-3));
+        kernels::peer_fanout<T> peers{};
+        peers.count = 2;
+        peers.base[0] = p0.data().get();
+        peers.base[1] = p1.data().get();
+        algorithms::spmv::merge_path_flat_fanout_async(plan, csr, x2, y, peers);
+        (void)xpu::stream_synchronize(0);
+        auto want = reference::spmv(h, xh);
+        check_y("merge_path_flat_fanout_async y", m, y, want);
+        check_y("merge_path_flat_fanout_async peer 0", m, p0, want);
+        check_y("merge_path_flat_fanout_async peer 1", m, p1, want);
+      }
+      // work_oriented over a held plan (its launch box: 256 x 8 / 256 x 4)
+      {
+        using wplan_t = algorithms::spmv::work_oriented_plan_t<int, int, T>;
+        wplan_t wplan(typename wplan_t::layout_t(csr.offsets.data().get(), static_cast<int>(csr.rows), static_cast<int>(csr.nnzs)), 0, wplan_t::prepass_always);
+        vector_t<T> x2(xh), y = vector_t<T>(h.rows, T(-1));
+        algorithms::spmv::work_oriented_async(wplan, csr, x2, y);
+        (void)xpu::stream_synchronize(0);
+        check_y("work_oriented_async(plan)", m, y, reference::spmv(h, xh));
+      }
     }
     ++m;
   }
@@ -192,6 +215,17 @@ static void misc() {
       bool same = true;
       for (std::size_t i = 0; i < h0.size(); ++i) same = same && std::fabs(h0[i] - h1[i]) <= 1e-3f + 1e-5f * std::fabs(h0[i]);
       CHECK(same);
+      // block reduce with the peer fan-out: y and the stand-in peer equal the blocked result bit for bit
+      vector_t<float> y2(hf.rows, -1.f), peer(hf.rows, -2.f);
+      kernels::peer_fanout<float> peers{};
+      peers.count = 1;
+      peers.base[0] = peer.data().get();
+      blocked.spmv_fanout_async(xb, y2, peers);
+      (void)xpu::stream_synchronize(0);
+      vector_t<float, H> h2(y2), hp(peer);
+      bool equal = true;
+      for (std::size_t i = 0; i < h1.size(); ++i) equal = equal && h2[i] == h1[i] && hp[i] == h1[i];
+      CHECK(equal);
     }
   // tuned SpMM == reference-shaped SpMM (every battery matrix, several widths of B, f32 + f64)
   for (auto& dense : battery())
