@@ -118,3 +118,23 @@ def test_chunk_bounds_from_degrees_cover_each_slice():
     assert len(cb) == 4
     for r in range(4):
         assert cb[r][0] == bounds[r] and cb[r][-1] == bounds[r + 1] and cb[r].size == 4 and (np.diff(cb[r]) >= 0).all()
+
+
+def test_column_block_bounds_respect_owners_and_budget():
+    """Column blocks of a shard's blocked layout: the owners' row ranges are always block boundaries (block k of x is the
+    slice some rank sends), the pieces are cut towards ~2 MB of x without exceeding the block budget, and the bounds are a
+    valid partition of the columns -- for the world sizes and budgets bench.py uses (C2-like: 8, C5: 16)."""
+    from loops_amd import partition as P
+    for world in (1, 2, 3, 4, 8):
+        for cols, max_blocks in ((1 << 20, 8), (1 << 24, 16), (999_983, 8), (1 << 24, 64)):
+            rng = np.random.default_rng(world + max_blocks)
+            cuts = np.sort(rng.choice(np.arange(1, cols), size=world - 1, replace=False)) if world > 1 else np.zeros(0, np.int64)
+            owners = np.concatenate([[0], cuts, [cols]]).astype(np.int64)
+            b = P.column_block_bounds(owners, max_blocks=max(max_blocks, world))
+            assert b[0] == 0 and b[-1] == cols and np.all(np.diff(b) >= 0)
+            assert set(owners.tolist()) <= set(b.tolist())                       # owners' boundaries are kept
+            k = b.size - 1
+            assert k % world == 0 and k <= max(max_blocks, world)                # s pieces per owner, within the budget
+            s = k // world
+            if world * s * 2 <= max(max_blocks, world):                          # stopped early only because pieces are small enough
+                assert int(np.diff(owners).max()) * 4 // s <= (2 << 20)
