@@ -49,6 +49,39 @@ __global__ void __launch_bounds__(256) gather_kernel(const float* __restrict__ t
   }
 }
 
+/// The gather probe with LDS-DIRECT loads: out[i] = table[idx[i]] where the gathered dword does not return to a VGPR but
+/// is written by the memory pipeline straight into LDS (`global_load_lds_dword`, M0 = LDS base, lane l lands at
+/// base + 4 l), U x 4 gathers per lane in flight.  Does the direct-to-LDS return path carry more outstanding reads per
+/// CU than the VGPR return path (~95)?
+template <int U>
+__global__ void __launch_bounds__(256) gather_lds_kernel(const float* __restrict__ table, const int* __restrict__ idx,
+                                                         float* __restrict__ out, size_t n) {
+  __shared__ float buf[U * 4][256];
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x * 4 * U;
+  const int t = threadIdx.x;
+  float* wave_base = &buf[0][t & ~63];
+  for (size_t i0 = (static_cast<size_t>(blockIdx.x) * blockDim.x + t) * 4; i0 + 3 + (U - 1) * (stride / U) < n; i0 += stride) {
+    using i4 = int __attribute__((ext_vector_type(4)));
+    i4 c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) c[u] = *reinterpret_cast<const i4*>(idx + i0 + u * (stride / U));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      __builtin_amdgcn_global_load_lds(table + c[u].x, wave_base + (u * 4 + 0) * 256, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(table + c[u].y, wave_base + (u * 4 + 1) * 256, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(table + c[u].z, wave_base + (u * 4 + 2) * 256, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(table + c[u].w, wave_base + (u * 4 + 3) * 256, 4, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the LDS writes of this wavefront have landed (vmcnt(0))
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      using f4 = float __attribute__((ext_vector_type(4)));
+      const f4 v = {buf[u * 4 + 0][t], buf[u * 4 + 1][t], buf[u * 4 + 2][t], buf[u * 4 + 3][t]};
+      *reinterpret_cast<f4*>(out + i0 + u * (stride / U)) = v;
+    }
+  }
+}
+
 /// Address-rate probe: no index / output streams, every lane issues `reps` 4-byte loads from a
 /// table that fits L1 (pattern 0: consecutive lanes -> consecutive words; 1: hashed within the
 /// table; 2: all lanes the same word).  Measures what the CU's address path (TA/TCP) sustains.
@@ -221,6 +254,9 @@ inline int launch_gather(hipStream_t stream, const float* table, const int* idx,
     case 2: hipLaunchKernelGGL(gather_kernel<2>, g, b, 0, stream, table, idx, out, n); break;
     case 3: hipLaunchKernelGGL(gather_kernel<3>, g, b, 0, stream, table, idx, out, n); break;
     case 4: hipLaunchKernelGGL(gather_kernel<4>, g, b, 0, stream, table, idx, out, n); break;
+    case 5: hipLaunchKernelGGL(gather_lds_kernel<1>, g, b, 0, stream, table, idx, out, n); break;  // LDS-direct, 4 per lane
+    case 6: hipLaunchKernelGGL(gather_lds_kernel<2>, dim3(g.x / 2), b, 0, stream, table, idx, out, n); break;  // 8 per lane
+    case 7: hipLaunchKernelGGL(gather_lds_kernel<4>, dim3(g.x / 4), b, 0, stream, table, idx, out, n); break;  // 16 per lane
     default: hipLaunchKernelGGL(gather_kernel<0>, g, b, 0, stream, table, idx, out, n); break;
   }
   return static_cast<int>(hipGetLastError());
