@@ -590,3 +590,22 @@ def test_held_plans_are_hip_graph_capturable():
         torch.cuda.synchronize()
         ref = O.spmv_f32(off, idx, val, xh)
         assert np.array_equal(y1.cpu().numpy(), ref) and np.array_equal(y2.cpu().numpy(), ref)
+
+
+def test_c4_full_size_bcsr_bit_exact():
+    """BASELINE config C4 at FULL size (BCSR 4x4, 2^18 block-rows x 16 blocks = 4 194 304 blocks, 295 MB): the MFMA kernel
+    (automatic shape, a few tuning shapes incl. several groups per wavefront) and the thread-per-block-row kernel, bit-exact
+    against the oracle's BCSR restatement (exactly-summable inputs; fp32 MFMA is exact fp32 FMA)."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    nbr, per = 1 << 18, 16
+    boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, per)
+    assert bcols.size == 4_194_304
+    xh = G.uniform_distribution_int(nbr * 4)
+    want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)
+    b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    x = torch.from_numpy(xh).cuda()
+    for mode in (0, 1, 142, 144, 2142, 8124, 16182):
+        y = torch.full((nbr * 4,), -1.0, device="cuda")
+        S.bcsr_thread_mapped(b, x, y, mfma=mode)
+        assert np.array_equal(y.cpu().numpy(), want), mode
