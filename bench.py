@@ -194,6 +194,15 @@ def context_c3_standins(G, S, O, torch, iters=10):
             ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
             res[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
                           "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+        if window is None:  # x (30 MB) is far larger than an L2: the same three schedules over the column-blocked copy
+            cb = S.ColumnBlockedPlan(csr)
+            blocked = {"blocks": cb.num_blocks, "note": "plan-time re-ordered copy (column_blocked.hxx); same fused kernels + K-way row reduce"}
+            for sched in ("group_mapped", "work_oriented", "merge_path_flat"):
+                ms = timed_ms(torch, lambda: cb.spmv_schedule(sched, x, y), iters)
+                blocked[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                                  "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+            res["column_blocked"] = blocked
+            cb.close()
         out[tag] = res
         del csr, off, idx, val, y
     return out
