@@ -27,7 +27,9 @@ def _random_csr(rng, rows, cols, kind):
     return off, idx, val
 
 
-CASES = [(seed, kind) for seed in range(20) for kind in ("empty", "uniform", "skewed", "ragged")]
+import os
+# LOOPS_FUZZ_SEEDS=N widens the sweep (default 20 seeds x 4 kinds = 80 matrices; a 200-seed run takes a few GPU-minutes)
+CASES = [(seed, kind) for seed in range(int(os.environ.get("LOOPS_FUZZ_SEEDS", "20"))) for kind in ("empty", "uniform", "skewed", "ragged")]
 
 
 @pytest.mark.parametrize("seed,kind", CASES)
