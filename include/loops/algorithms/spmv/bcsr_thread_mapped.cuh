@@ -3,8 +3,9 @@
  * @brief `algorithms::spmv::bcsr_thread_mapped<R, C>(bcsr, x, y, stream) -> util::timer_t`
  * (reference include/loops/algorithms/spmv/bcsr_thread_mapped.cuh:36-123).  4 x 4 fp32 blocks
  * take the MFMA path (four chained v_mfma_f32_4x4x1_16b_f32 per block, 16 block-rows per
- * wavefront); every other shape runs the thread-per-block-row schedule-API kernel.  x must be
- * padded to num_block_cols * C entries.
+ * wavefront); every other shape and fp64 run the coalesced lane-group kernels of kernels/bcsr_spmv.hxx
+ * (launch_bcsr_coalesced); index types other than int keep the thread-per-block-row schedule-API kernel.
+ * x must be padded to num_block_cols * C entries.
  */
 #pragma once
 
@@ -35,6 +36,14 @@ util::timer_t bcsr_thread_mapped(bcsr_t<R, C, index_t, offset_t, type_t>& bcsr, 
                                  static_cast<int>(bcsr.num_blocks), bcsr.block_offsets.data().get(),
                                  bcsr.block_col_indices.data().get(), bcsr.values.data().get(), x.data().get(),
                                  y.data().get());
+  } else if constexpr (std::is_same<index_t, int>::value && std::is_same<offset_t, int>::value &&
+                       (std::is_same<type_t, float>::value || std::is_same<type_t, double>::value)) {
+    // every other shape / fp64: the coalesced lane-group kernels (whole lines of consecutive blocks per slot of lanes,
+    // block inner product on the VALU) -- the 2 x 2 example of the reference takes this path
+    kernels::launch_bcsr_coalesced<static_cast<int>(R), static_cast<int>(C), type_t>(
+        stream, static_cast<int>(bcsr.rows), static_cast<int>(bcsr.num_block_rows), static_cast<int>(bcsr.num_blocks),
+        bcsr.block_offsets.data().get(), bcsr.block_col_indices.data().get(), bcsr.values.data().get(), x.data().get(),
+        y.data().get());
   } else {
     using layout_t = layout::bcsr<index_t, offset_t>;
     using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t, std::size_t,

@@ -72,6 +72,8 @@ struct column_blocked_t {
   /// peer-mapped vectors `peers` (kernels::reduce_blocks_x4_fanout; see merge_path_flat_fanout_async).  Asynchronous.
   void spmv_fanout_async(vector_t<type_t>& x, vector_t<type_t>& y, const kernels::peer_fanout<type_t>& peers,
                          xpu::stream_t stream = 0) {
+    error::throw_if_exception(peers.count < 0 || peers.count > kernels::max_peers,
+                              "column_blocked_t::spmv_fanout_async: peers.count must be 0 .. 7");
     constexpr int block_size = merge_path_launch_t<type_t>::block_size;
     constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
     kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),

@@ -2,9 +2,11 @@
  * @file flat_partitioned.cuh
  * @brief `algorithms::spmv::flat_partitioned<K = 8>(csr, x, y, stream) -> util::timer_t`:
  * thread_mapped over `layout::flat_uniform_occupancy<K, layout::csr>` -- perfectly balanced
- * K-nonzero tiles; the original row is recovered with `base().tile_of` once per thread and followed
- * along the thread's K atoms, one atomicAdd per run of same-row atoms (the reference-shaped per-atom
- * kernel stays available as kernels::flat_partitioned_spmv)
+ * K-nonzero tiles; a lane reads its K atoms with 16-byte loads, recovers the original row with ONE
+ * `base().tile_of` and follows the row ends along its atoms; runs of same-row products are stitched
+ * across the 64 lanes and ONE atomicAdd per row and wavefront reaches y
+ * (kernels::flat_partitioned_stitched_spmv; the reference-shaped per-atom kernel stays available as
+ * kernels::flat_partitioned_spmv, the per-thread-run kernel of round 1 as flat_partitioned_runs_spmv)
  * (reference include/loops/algorithms/spmv/flat_partitioned.cuh:46-110).  y must be zero-filled
  * (a freshly constructed vector_t is).
  */

@@ -209,6 +209,11 @@ inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows,
                                float* y, int unroll = 0, int h = 0, int groups_per_wave = 0) {
   constexpr int TPB = 256;  // 4 wavefronts
   if (num_block_rows == 0) return 0;
+  if (num_blocks == 0) {
+    // no block at all: y = 0.  The kernel's masked-off steps read block 0 ("an in-bounds index whenever a block
+    // exists"), and the caller may pass null block_cols / values / x for an empty matrix.
+    return rows > 0 ? static_cast<int>(hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), stream)) : 0;
+  }
   const double mean = static_cast<double>(num_blocks) / num_block_rows;
   if (h == 0) h = mean < 1.5 ? 1 : mean < 3 ? 2 : 4;
   if (unroll == 0) {  // two batches per block-row: the second batch's HBM reads fly behind the first one's gathers + MFMAs
@@ -241,6 +246,288 @@ inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows,
     case 2: with_h(std::integral_constant<int, 2>{}); break;
     case 4: with_h(std::integral_constant<int, 4>{}); break;
     default: with_h(std::integral_constant<int, 8>{}); break;
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Coalesced BCSR SpMV for every block shape and both precisions.  What made the 4 x 4 MFMA kernel fast
+// was not the MFMA but the block stream: a slot of lanes reads WHOLE lines of consecutive blocks of one block-row, 16
+// bytes per lane, non-temporally.  The two kernels below give that stream to the shapes the reference ships and tests
+// (examples/spmv/bcsr_thread_mapped.cu:31-32: 2 x 2; unittests/test_spmv_bcsr.cu:24-36: 2 x 2, 3 x 3; every example also
+// as .f64) with the block inner product on the VALU:
+//
+//  * bcsr_vector_mapped_spmv<R, C, T>   R * C * sizeof(T) a power-of-two multiple of 16 bytes (2x2, 4x4, 8x8, ...): the
+//    values of a block-row are a flat run of 16-byte vectors; G = H * VPB consecutive lanes take the VPB vectors of H
+//    consecutive blocks per step (lane (h, q) = vector q of block k * H + h), so a slot reads G * 16 contiguous bytes.  A
+//    vector is a piece of ONE block row (C * sizeof(T) >= 16: row q / PPR, columns (q % PPR) * VW ...) or VW / C whole
+//    block rows (2 x 2 fp32: the block IS the vector); the matching x piece is one aligned load.  Partial sums of a row
+//    live in lanes that differ in h and in the piece index: log2(H * PPR) xor-shuffles after the loop.
+//  * bcsr_block_mapped_spmv<R, C, T>    any other shape (3 x 3: 36-byte blocks): G = H lanes per block-row, lane h owns
+//    block k * H + h entirely and reads it with the widest loads 4-byte (8-byte) alignment allows; consecutive lanes
+//    read consecutive blocks, i.e. the wavefront still covers one contiguous span per step.
+//
+// Same result contract as bcsr_thread_mapped_spmv (rows of y >= `rows` are not written); summation order differs from
+// the reference's (blocks of a block-row are dealt round-robin to H lanes): bit-exact on exactly summable inputs.
+namespace detail {
+constexpr bool bcsr_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+/// N consecutive elements at `p` (aligned to sizeof(T) only) with the widest loads: 16-byte pieces, then the rest.
+template <int N, bool NT, typename T>
+__device__ __forceinline__ void load_run(const T* __restrict__ p, T (&out)[N]) {
+  constexpr int VW = 16 / static_cast<int>(sizeof(T));
+  using vu = T __attribute__((ext_vector_type(VW), aligned(sizeof(T))));
+  constexpr int full = N / VW;
+#pragma unroll
+  for (int v = 0; v < full; ++v) {
+    vu t;
+    if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const vu*>(p + v * VW));
+    else t = *reinterpret_cast<const vu*>(p + v * VW);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) out[v * VW + e] = t[e];
+  }
+  constexpr int rem = N - full * VW;
+  if constexpr (rem == 1) {
+    if constexpr (NT) out[N - 1] = __builtin_nontemporal_load(p + N - 1);
+    else out[N - 1] = p[N - 1];
+  } else if constexpr (rem > 1) {  // one 8- or 12-byte load for the tail
+    using ru = T __attribute__((ext_vector_type(rem), aligned(sizeof(T))));
+    ru t;
+    if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const ru*>(p + full * VW));
+    else t = *reinterpret_cast<const ru*>(p + full * VW);
+#pragma unroll
+    for (int e = 0; e < rem; ++e) out[full * VW + e] = t[e];
+  }
+}
+}  // namespace detail
+
+template <int R, int C, typename T>
+struct bcsr_vector_shape {
+  static constexpr int VW = 16 / static_cast<int>(sizeof(T));  ///< elements per 16-byte vector
+  static constexpr int BE = R * C;
+  static constexpr bool pieces = C % VW == 0;                   ///< a vector is a piece of one block row
+  static constexpr bool whole_rows = !pieces && VW % C == 0;    ///< a vector holds VW / C whole block rows
+  static constexpr bool ok = BE % VW == 0 && detail::bcsr_pow2(BE / VW) && BE / VW <= 64 &&
+                             (pieces ? detail::bcsr_pow2(C / VW) : whole_rows);
+  static constexpr int VPB = ok ? BE / VW : 1;                  ///< vectors per block
+  static constexpr int PPR = pieces ? C / VW : 1;               ///< pieces per block row
+  static constexpr int RPV = pieces ? 1 : VW / C;               ///< block rows per vector
+};
+
+template <int R, int C, typename T, int TPB, int H, int U>
+__global__ void __launch_bounds__(TPB)
+bcsr_vector_mapped_spmv(const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
+                        const int* __restrict__ block_cols, const T* __restrict__ values, const T* __restrict__ x,
+                        T* __restrict__ y) {
+  using shape = bcsr_vector_shape<R, C, T>;
+  static_assert(shape::ok, "bcsr_vector_mapped_spmv: block bytes must be a power-of-two multiple of 16");
+  constexpr int VW = shape::VW, VPB = shape::VPB, PPR = shape::PPR, RPV = shape::RPV, BE = shape::BE;
+  constexpr int G = H * VPB;        // lanes per block-row
+  static_assert(G <= wave::size && detail::bcsr_pow2(H), "H * vectors per block must fit a wavefront");
+  constexpr int SLOTS = wave::size / G;
+  constexpr bool NT = G >= 8;       // whole 128-byte lines per slot and step: read once, keep them out of the caches
+  using vec_t = T __attribute__((ext_vector_type(VW)));
+  using vec_ld_t = T __attribute__((ext_vector_type(VW), aligned(sizeof(T))));  // (bases are element-aligned at least)
+  const int lane = wave::lane();
+  const int q = lane % VPB;         // vector of the block
+  const int h = (lane / VPB) % H;   // which of the H concurrent blocks
+  const int slot = lane / G;
+  const long long gwave = (static_cast<long long>(blockIdx.x) * TPB + threadIdx.x) / wave::size;
+  const long long br = gwave * SLOTS + slot;
+  if (gwave * SLOTS >= num_block_rows) return;  // (wave-uniform)
+  int beg = 0, len = 0;
+  if (br < num_block_rows) {
+    beg = block_offsets[br];
+    len = block_offsets[br + 1] - beg;
+  }
+  int steps = (len + H - 1) / H;
+#pragma unroll
+  for (int d = wave::size / 2; d >= G; d >>= 1) {
+    const int o = __shfl_xor(steps, d);
+    steps = o > steps ? o : steps;
+  }
+  T acc[RPV];
+#pragma unroll
+  for (int r = 0; r < RPV; ++r) acc[r] = T(0);
+  for (int k0 = 0; k0 < steps; k0 += U) {
+    vec_t a[U];
+    int bc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (k0 + u) * H + h;
+      const bool live = k < len;
+      const int b = live ? beg + k : 0;  // block 0 for masked-off steps (in bounds: the launcher handles num_blocks == 0)
+      const vec_ld_t* src = reinterpret_cast<const vec_ld_t*>(values + static_cast<size_t>(b) * BE + q * VW);
+      if constexpr (NT) {
+        a[u] = __builtin_nontemporal_load(src);
+        bc[u] = __builtin_nontemporal_load(block_cols + b);
+      } else {
+        a[u] = *src;
+        bc[u] = block_cols[b];
+      }
+      if (!live) a[u] = vec_t(T(0));
+    }
+    if constexpr (shape::pieces) {
+      vec_t xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        xv[u] = *reinterpret_cast<const vec_ld_t*>(x + static_cast<size_t>(bc[u]) * C + (q % PPR) * VW);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) acc[0] += a[u][e] * xv[u][e];
+      }
+    } else {
+      T xs[U][C];
+#pragma unroll
+      for (int u = 0; u < U; ++u) detail::load_run<C, false>(x + static_cast<size_t>(bc[u]) * C, xs[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int r = 0; r < RPV; ++r) {
+#pragma unroll
+          for (int j = 0; j < C; ++j) acc[r] += a[u][r * C + j] * xs[u][j];
+        }
+      }
+    }
+  }
+  // partial sums of one row sit in the lanes of its PPR pieces (neighbouring q) and in the H concurrent blocks
+#pragma unroll
+  for (int r = 0; r < RPV; ++r) {
+#pragma unroll
+    for (int d = 1; d < PPR; d <<= 1) acc[r] += __shfl_xor(acc[r], d);
+#pragma unroll
+    for (int d = VPB; d < G; d <<= 1) acc[r] += __shfl_xor(acc[r], d);
+  }
+  if (h == 0 && q % PPR == 0 && br < num_block_rows) {
+    const long long r0 = br * R + static_cast<long long>(q / PPR) * RPV;
+#pragma unroll
+    for (int r = 0; r < RPV; ++r)
+      if (r0 + r < rows) y[r0 + r] = acc[r];
+  }
+}
+
+template <int R, int C, typename T, int TPB, int H, int U>
+__global__ void __launch_bounds__(TPB)
+bcsr_block_mapped_spmv(const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
+                       const int* __restrict__ block_cols, const T* __restrict__ values, const T* __restrict__ x,
+                       T* __restrict__ y) {
+  static_assert(H <= wave::size && detail::bcsr_pow2(H), "H: power of two <= 64");
+  constexpr int BE = R * C;
+  constexpr int SLOTS = wave::size / H;
+  constexpr bool NT = H * BE * static_cast<int>(sizeof(T)) >= 128;
+  const int lane = wave::lane();
+  const int h = lane % H;
+  const int slot = lane / H;
+  const long long gwave = (static_cast<long long>(blockIdx.x) * TPB + threadIdx.x) / wave::size;
+  const long long br = gwave * SLOTS + slot;
+  if (gwave * SLOTS >= num_block_rows) return;  // (wave-uniform)
+  int beg = 0, len = 0;
+  if (br < num_block_rows) {
+    beg = block_offsets[br];
+    len = block_offsets[br + 1] - beg;
+  }
+  int steps = (len + H - 1) / H;
+#pragma unroll
+  for (int d = wave::size / 2; d >= H; d >>= 1) {
+    const int o = __shfl_xor(steps, d);
+    steps = o > steps ? o : steps;
+  }
+  T acc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) acc[i] = T(0);
+  for (int k0 = 0; k0 < steps; k0 += U) {
+    T a[U][BE];
+    int bc[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = (k0 + u) * H + h;
+      live[u] = k < len;
+      const int b = live[u] ? beg + k : 0;
+      detail::load_run<BE, NT>(values + static_cast<size_t>(b) * BE, a[u]);
+      bc[u] = block_cols[b];
+    }
+    T xs[U][C];
+#pragma unroll
+    for (int u = 0; u < U; ++u) detail::load_run<C, false>(x + static_cast<size_t>(bc[u]) * C, xs[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < C; ++j) s += a[u][i * C + j] * xs[u][j];
+        acc[i] += live[u] ? s : T(0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+#pragma unroll
+    for (int d = 1; d < H; d <<= 1) acc[i] += __shfl_xor(acc[i], d);
+  }
+  if (h == 0 && br < num_block_rows) {
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+      if (br * R + i < rows) y[br * R + i] = acc[i];
+  }
+}
+
+/// Coalesced BCSR SpMV for block shape R x C (vector-mapped where the block bytes allow, block-mapped otherwise).
+/// `h`: blocks of one block-row per step (power of two; 0 = automatic: a slot should read about 256 contiguous bytes per
+/// step without idling more than half its lanes on the mean block-row); `unroll`: steps in flight (1, 2, 4; 0 = automatic).
+template <int R, int C, typename T>
+int launch_bcsr_coalesced(hipStream_t stream, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
+                          const int* block_cols, const T* values, const T* x, T* y, int h = 0, int unroll = 0) {
+  constexpr int TPB = 256;
+  if (num_block_rows == 0) return 0;
+  if (num_blocks == 0)
+    return rows > 0 ? static_cast<int>(hipMemsetAsync(y, 0, sizeof(T) * static_cast<size_t>(rows), stream)) : 0;
+  using shape = bcsr_vector_shape<R, C, T>;
+  constexpr bool vector_path = shape::ok;
+  constexpr int lanes_per_block = vector_path ? shape::VPB : 1;
+  constexpr int bytes_per_lane = vector_path ? 16 : R * C * static_cast<int>(sizeof(T));
+  constexpr int h_cap = wave::size / lanes_per_block < 16 ? wave::size / lanes_per_block : 16;
+  const double mean = static_cast<double>(num_blocks) / num_block_rows;
+  if (h == 0) {
+    h = 1;
+    while (h * 2 <= h_cap && h * lanes_per_block * bytes_per_lane < 256 && h * 2 <= mean) h *= 2;
+  }
+  if (h > h_cap) h = h_cap;
+  h = h >= 16 ? 16 : h >= 4 ? 4 : 1;  // compiled: 1, 4, 16
+  if (h > h_cap) h = h_cap >= 4 ? 4 : 1;
+  if (unroll == 0) {
+    unroll = 1;
+    while (unroll < 4 && 2 * unroll * h < mean) unroll *= 2;
+  }
+  unroll = unroll >= 4 ? 4 : unroll >= 2 ? 2 : 1;
+  auto go = [&](auto h_tag, auto u_tag) {
+    constexpr int HH = decltype(h_tag)::value, UU = decltype(u_tag)::value;
+    constexpr int slots = wave::size / (HH * lanes_per_block);
+    const long long waves = math::ceil_div(static_cast<long long>(num_block_rows), static_cast<long long>(slots));
+    const dim3 grid(static_cast<unsigned>(math::ceil_div(waves, static_cast<long long>(TPB / wave::size))));
+    if constexpr (vector_path)
+      hipLaunchKernelGGL((bcsr_vector_mapped_spmv<R, C, T, TPB, HH, UU>), grid, dim3(TPB), 0, stream, rows, num_block_rows,
+                         block_offsets, block_cols, values, x, y);
+    else
+      hipLaunchKernelGGL((bcsr_block_mapped_spmv<R, C, T, TPB, HH, UU>), grid, dim3(TPB), 0, stream, rows, num_block_rows,
+                         block_offsets, block_cols, values, x, y);
+  };
+  auto with_u = [&](auto h_tag) {
+    switch (unroll) {
+      case 1: go(h_tag, std::integral_constant<int, 1>{}); break;
+      case 2: go(h_tag, std::integral_constant<int, 2>{}); break;
+      default: go(h_tag, std::integral_constant<int, 4>{}); break;
+    }
+  };
+  if (h == 16) {
+    if constexpr (h_cap >= 16) with_u(std::integral_constant<int, 16>{});
+  } else if (h == 4) {
+    if constexpr (h_cap >= 4) with_u(std::integral_constant<int, 4>{});
+  } else {
+    with_u(std::integral_constant<int, 1>{});
   }
   return static_cast<int>(hipGetLastError());
 }

@@ -238,6 +238,7 @@ int launch_reduce_blocks(hipStream_t stream, const type_t* ys, int rows, int K, 
 template <typename type_t>
 int launch_reduce_blocks_fanout(hipStream_t stream, const type_t* ys, int rows, int K, type_t* y,
                                 const peer_fanout<type_t>& peers) {
+  if (peers.count < 0 || peers.count > max_peers) return static_cast<int>(hipErrorInvalidValue);  // as launch_merge_path_fused_fanout
   if (rows == 0) return 0;
   if constexpr (std::is_same<type_t, float>::value) {
     std::uintptr_t bits = reinterpret_cast<std::uintptr_t>(ys) | reinterpret_cast<std::uintptr_t>(y);

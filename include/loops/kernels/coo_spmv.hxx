@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/kernels/run_stitch.hxx>
 #include <loops/util/math.hxx>
 #include <loops/util/wave.hxx>
 
@@ -71,41 +72,7 @@ coo_runs_spmv(const std::size_t nnz, const index_t* __restrict__ row_indices, co
   type_t p[IPT];
 #pragma unroll
   for (int k = 0; k < IPT; ++k) p[k] = (full || base + k < nnz) ? v[k] * x[c[k]] : type_t(0);
-  // runs of equal row indices inside the lane: the first one and the open last one are combined
-  // across the wavefront below; the ones in between go straight to y
-  index_t row = r[0];
-  type_t sum = p[0];
-  index_t first_row = row;
-  type_t first_sum = type_t(0);
-  bool closed = false;
-#pragma unroll
-  for (int k = 1; k < IPT; ++k) {
-    if (r[k] != row) {
-      if (!closed) {
-        first_sum = sum;
-        closed = true;
-      } else if (row >= 0) {
-        atomicAdd(&y[row], sum);
-      }
-      row = r[k];
-      sum = type_t(0);
-    }
-    sum += p[k];
-  }
-  // Wavefront stitch (one atomicAdd per run and wavefront instead of per lane): segmented prefix
-  // sum of the lanes' open tails; a lane's tail starts a new segment if the lane closed a run or its
-  // first row differs from the previous lane's last row.
-  const int lane = wave::lane();
-  const index_t prev_last = wave::shift_up1(row, index_t(-2));  // lane 0: never equal
-  const bool continues = first_row == prev_last;                 // my first run continues the previous lane's tail
-  type_t run = sum;
-  bool head = closed || !continues;
-  wave::segmented_inclusive_sum(run, head);
-  const type_t prev_run = wave::shift_up1(run, type_t(0));
-  const int next_continues = __shfl_down(static_cast<int>(continues), 1);
-  if (closed && first_row >= 0) atomicAdd(&y[first_row], first_sum + (continues ? prev_run : type_t(0)));
-  const bool tail_ends_here = lane == wave::size - 1 || !next_continues;
-  if (tail_ends_here && row >= 0) atomicAdd(&y[row], run);
+  add_row_runs<IPT>(r, p, y);
 }
 
 template <typename index_t, typename type_t>

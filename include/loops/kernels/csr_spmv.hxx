@@ -25,6 +25,8 @@
 
 #include <loops/schedule.hxx>
 #include <loops/container/layout.hxx>
+#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/kernels/run_stitch.hxx>
 
 namespace loops {
 namespace kernels {
@@ -245,6 +247,73 @@ __global__ void flat_partitioned_runs_spmv(setup_t config, const index_t* indice
     }
     if (run != type_t(0)) atomicAdd(&y[row], run);
   }
+}
+
+/// The tuned flat_partitioned kernel.  Same schedule -- thread t owns tile t of
+/// flat_uniform_occupancy<K, csr>, i.e. the K consecutive nonzeros [t K, (t + 1) K) -- but
+///  * the lane's nonzeros arrive as 16-byte loads (K / 4 per array; consecutive lanes, consecutive vectors),
+///  * the row is looked up ONCE per lane (base().tile_of of its first atom) and then followed along the row ends,
+///  * runs of same-row products are summed in registers and stitched across the 64 lanes (add_row_runs): one
+///    atomicAdd per row and wavefront instead of one per nonzero (reference) or per run and thread (flat_partitioned_runs_spmv).
+/// One tile per thread: the grid covers every tile in one pass and no lane leaves before the wavefront stitch.
+/// y must be zero-filled (the reference's precondition, flat_partitioned.cuh:99-101).
+template <int K, bool VEC, typename part_t, typename index_t, typename type_t>
+__global__ void __launch_bounds__(256)
+flat_partitioned_stitched_spmv(const part_t part, const index_t* __restrict__ indices, const type_t* __restrict__ values,
+                               const type_t* __restrict__ x, type_t* __restrict__ y) {
+  using atom_t = typename part_t::atom_id_t;
+  const auto& base = part.base();
+  const long long chunk = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long nnz = static_cast<long long>(part.num_atoms());
+  const long long first = chunk * K;  // == part.tile_begin(chunk) (container/partitioning.hxx: fixed_tiling::first)
+  const bool any = first < nnz;
+  const bool full = first + K <= nnz;
+  index_t c[K];
+  type_t v[K];
+  if constexpr (VEC && K % 4 == 0) {
+    if (full) {
+#pragma unroll
+      for (int k = 0; k < K; k += 4) {
+        index_t c4[4];
+        type_t v4[4];
+        detail::load4<index_t, false>(indices + first + k, c4);
+        detail::load4<type_t, false>(values + first + k, v4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          c[k + j] = c4[j];
+          v[k + j] = v4[j];
+        }
+      }
+    }
+  }
+  if (!(VEC && K % 4 == 0 && full)) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const bool ok = first + k < nnz;
+      c[k] = ok ? indices[first + k] : index_t(0);
+      v[k] = ok ? values[first + k] : type_t(0);
+    }
+  }
+  type_t p[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) p[k] = (full || first + k < nnz) ? v[k] * x[c[k]] : type_t(0);
+  // the row of every atom: one search, then a walk along the row ends (empty rows are skipped)
+  int r[K];
+  int row = -1;
+  atom_t row_end = 0;
+  if (any) {
+    row = static_cast<int>(base.tile_of(static_cast<atom_t>(first)));
+    row_end = base.tile_end(row);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const bool ok = first + k < nnz;
+    if (ok) {
+      while (static_cast<atom_t>(first + k) >= row_end) row_end = base.tile_end(++row);
+    }
+    r[k] = ok ? row : -1;
+  }
+  add_row_runs<K>(r, p, y);
 }
 
 }  // namespace kernels

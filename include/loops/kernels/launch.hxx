@@ -311,11 +311,13 @@ int launch_work_oriented_atomic(hipStream_t stream, std::size_t rows, std::size_
 }
 
 /// thread_mapped over flat_uniform_occupancy<K, csr>: atomics, y must be zero-filled.
-/// `per_atom` selects the reference-shaped kernel (one tile_of search + one atomic per nonzero);
-/// the default walks row runs (one search per thread, one atomic per run).
+/// `shape` 0 (default): the tuned kernel -- 16-byte loads, one tile_of per lane, runs stitched across the wavefront,
+/// one atomic per row and wavefront (flat_partitioned_stitched_spmv); 1: the reference-shaped kernel (one tile_of
+/// search + one atomic per nonzero); 2: row runs per thread (one search per thread, one atomic per run; round 1).
 template <std::size_t K, typename index_t, typename offset_t, typename T>
 int launch_flat_partitioned(hipStream_t stream, std::size_t rows, std::size_t nnz, const offset_t* offsets,
-                            const index_t* indices, const T* values, const T* x, T* y, bool per_atom = false) {
+                            const index_t* indices, const T* values, const T* x, T* y, int shape = 0) {
+  const bool per_atom = shape == 1;
   using base_t = layout::csr<index_t, offset_t>;
   using part_t = layout::flat_uniform_occupancy<K, base_t>;
   using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t, std::size_t,
@@ -326,6 +328,17 @@ int launch_flat_partitioned(hipStream_t stream, std::size_t rows, std::size_t nn
   constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
   setup_t config(part);
   const dim3 grid(static_cast<unsigned>(math::ceil_div(chunks, block)));
+  if (shape == 0) {
+    const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+    const dim3 wide(static_cast<unsigned>(math::ceil_div(chunks, std::size_t(256))));
+    if (aligned)
+      hipLaunchKernelGGL((flat_partitioned_stitched_spmv<static_cast<int>(K), true, part_t, index_t, T>), wide, dim3(256), 0,
+                         stream, part, indices, values, x, y);
+    else
+      hipLaunchKernelGGL((flat_partitioned_stitched_spmv<static_cast<int>(K), false, part_t, index_t, T>), wide, dim3(256), 0,
+                         stream, part, indices, values, x, y);
+    return launch_status();
+  }
   if (per_atom)
     launch::non_cooperative(stream, flat_partitioned_spmv<setup_t, index_t, T>, grid, dim3(block), config, indices,
                             values, x, y);

@@ -54,13 +54,20 @@ enum loops_tile_config {
 /* ---- library / device ------------------------------------------------------------------ */
 const char* loops_version(void);                 /* "0.2.0-mi355x" (CMakeLists.txt:41: 0.2.0) */
 int loops_device_compute_units(int* out);        /* util/device.hxx:93-108 multi_processor_count */
+/* Frees the CALLING THREAD's cached scratch of the plan-less entry points (see "Concurrency" below); returns the number
+ * of buffers released (>= 0).  The cache is per host thread and is not released when a thread exits: a thread that
+ * rotates through many streams, or is about to end, calls this.  hipFree synchronises the device. */
+int loops_release_scratch(void);
 
 /* ---- merge-path plan ---------------------------------------------------------------------
  * Replaces schedule::merge_path::preprocess_t (schedule/merge_path_flat.hxx:99-172) and its
  * pre-pass kernel generate_search_coordinates (:45-76).  A plan holds the M + 1 per-workgroup
  * start coordinates for (offsets, rows, nnz, tile shape) and the carry-out scratch of the
  * fused kernel; it depends on the sparsity structure only and may be reused for any number
- * of SpMVs with the same offsets array. */
+ * of SpMVs with the same offsets array.
+ * ONE PRODUCT IN FLIGHT PER PLAN: a plan owns a single set of carry-out buffers that every product through it writes,
+ * so two products that use the same plan must be ordered (same stream, or an event between them).  The same holds for
+ * loops_colblock_plan_t (its partial-result vectors).  One plan per stream for concurrent products. */
 typedef struct loops_merge_plan loops_merge_plan_t;
 
 int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_config, void* stream,
@@ -88,7 +95,9 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  * (coordinates, carry-outs) in one lazily grown buffer per (host thread, device, stream, tile shape): calls on
  * the same stream reuse it in stream order, calls on different streams or devices never share it, so products
  * issued from one thread on several streams may overlap.  (At most 16 such buffers are cached per thread; the
- * least recently used is released first.)  A held plan (loops_merge_plan_t, loops_colblock_plan_t) owns ONE set of
+ * least recently used is released first.  Growing or evicting a buffer calls hipFree, which waits for the DEVICE:
+ * an otherwise asynchronous call then blocks once -- steady-state calls on up to 16 (stream, tile shape) pairs per
+ * thread never do; entries of destroyed streams stay until evicted or loops_release_scratch() is called.)  A held plan (loops_merge_plan_t, loops_colblock_plan_t) owns ONE set of
  * scratch buffers and is passed as const only because its coordinates are read-only: it serves one product at a
  * time -- do not run the same plan on two streams or from two threads concurrently; create one plan per stream. */
 int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
@@ -168,7 +177,14 @@ int loops_work_oriented_grid(int* out_blocks);
 /* ---- BCSR SpMV (R x C dense blocks), thread-per-block-row and the MFMA path -------------------
  * Replaces algorithms::spmv::bcsr_thread_mapped<R, C> (algorithms/spmv/bcsr_thread_mapped.cuh:91-123).
  * x must be padded to num_block_cols * C; rows of y >= `rows` are not written.
- * mode 0: register accumulation (any of 2x2, 3x3, 4x4); mode 1: MFMA 4x4x1 block inner product
+ * Block shapes compiled into the library: 2x2, 3x3, 4x4, 8x8 (fp32 and fp64); anything else returns LOOPS_E_CONFIG (the
+ * header API instantiates any <R, C>).
+ * mode 3: the tuned kernel of the shape (what algorithms::spmv::bcsr_thread_mapped<R, C> launches): mode 1 for 4x4 fp32,
+ * mode 2 otherwise.  mode 2: coalesced lane-group kernel, any shape, fp32 / fp64 -- a slot of lanes reads whole lines of
+ * consecutive blocks of one block-row, 16 bytes per lane (36-byte 3x3 blocks: lane per block), block inner product on the
+ * VALU, log2 cross-lane reduce; tuning aid 100000 + 100 h + u = h in {1,4,16} blocks of a block-row per step, u in {1,2,4}
+ * steps in flight.
+ * mode 0: register accumulation, thread per block-row (the reference's kernel shape); mode 1: MFMA 4x4x1 block inner product
  * (4x4 only), kernel shape picked from the mean blocks per block-row.  Tuning aids: mode 1u = one block
  * of a block-row per step with u in {1,2,4,8} steps in flight; mode 100 + 10 h + u = h in {1,2,4,8,16}
  * consecutive blocks of a block-row per step (h * 64 contiguous bytes per request); + 1000 g = a wavefront
@@ -176,7 +192,7 @@ int loops_work_oriented_grid(int* out_blocks);
 int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
                         const int* block_offsets, const int* block_cols, const float* block_values,
                         const float* x_padded, float* y, void* stream);
-/* fp64 blocks (the reference builds every example as .f32 and .f64, examples/spmv/CMakeLists.txt:29-50): mode 0 only --
+/* fp64 blocks (the reference builds every example as .f32 and .f64, examples/spmv/CMakeLists.txt:29-50): modes 0, 2, 3 --
  * the MFMA kernel is fp32 (v_mfma_f32_4x4x1); any MFMA mode returns LOOPS_E_CONFIG. */
 int loops_spmv_bcsr_f64(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
                         const int* block_offsets, const int* block_cols, const double* block_values,

@@ -29,7 +29,7 @@ TILES = {"256x8": (0, 256, 8), "128x7": (1, 128, 7), "4x2": (2, 4, 2), "256x7": 
 
 # every symbol include/loops_amd.h declares (tests/test_c_abi.py checks the export table)
 SYMBOLS = [
-    "loops_version", "loops_device_compute_units",
+    "loops_version", "loops_device_compute_units", "loops_release_scratch",
     "loops_merge_plan_create", "loops_merge_plan_destroy", "loops_merge_plan_refresh",
     "loops_merge_plan_num_tiles", "loops_merge_plan_coords", "loops_merge_plan_self_complete",
     "loops_spmv_csr_f32", "loops_spmv_csr_f64", "loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64",
@@ -50,19 +50,52 @@ class LoopsError(RuntimeError):
     pass
 
 
+def source_digest(deps) -> str:
+    """sha256 over the CONTENTS of every file a library is compiled from (paths relative to the repository, sorted).
+    What decides whether a built library is current: modification times do not survive a snapshot copy to another
+    machine, and a `.so` newer than its sources says nothing about which sources it was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(set(deps)):
+        h.update(os.path.relpath(path, _ROOT).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
 def _compile(src: str, out: str, extra_deps=(), force: bool = False, verbose: bool = False, defines=()) -> str:
+    """hipcc `src` -> `out` unless `out` was built from exactly these sources (digest recorded next to it in
+    `<out>.srcdigest`).  `force` -- or LOOPS_FORCE_BUILD=1 in the environment -- always compiles."""
     deps = [src, *extra_deps]
     for base, _, files in os.walk(INCLUDE_DIR):
         deps += [os.path.join(base, f) for f in files]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    digest = source_digest(deps) + " " + " ".join(sorted(defines))
+    stamp = out + ".srcdigest"
+    force = force or os.environ.get("LOOPS_FORCE_BUILD", "0") not in ("", "0")
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == digest.strip():
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DLOOPS_TARGET_GFX=0x950",
            *["-D" + d for d in defines], "-I" + INCLUDE_DIR, src, "-o", out]
     if verbose:
         print(" ".join(cmd))
+    if os.path.exists(stamp):
+        os.remove(stamp)
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
     return out
+
+
+def built_from_current_sources(out: str = None, src: str = None, extra_deps=()) -> bool:
+    """True when `out` (default: the product library) carries the digest of the sources as they are now."""
+    out, src = out or LIB_PATH, src or SRC_PATH
+    deps = [src, *extra_deps]
+    for base, _, files in os.walk(INCLUDE_DIR):
+        deps += [os.path.join(base, f) for f in files]
+    stamp = out + ".srcdigest"
+    return os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().split()[0] == source_digest(deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -152,9 +152,23 @@ void plan_release(loops_merge_plan* p) {
   delete p;
 }
 
+// (namespace scope so that loops_release_scratch() can reach the calling thread's cache; trivially destructible:
+// a thread that exits without releasing leaves its device buffers to process teardown)
+thread_local scratch_slot scratch_slots[kScratchSlots] = {};
+thread_local unsigned long long scratch_tick = 0;
+
+int scratch_release_all() {
+  int freed = 0;
+  for (scratch_slot& c : scratch_slots) {
+    if (c.plan) { plan_release(c.plan); ++freed; }
+    c = scratch_slot{};
+  }
+  return freed;
+}
+
 loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, hipStream_t stream, int* err) {
-  thread_local scratch_slot slots[kScratchSlots] = {};
-  thread_local unsigned long long tick = 0;
+  auto& slots = scratch_slots;
+  auto& tick = scratch_tick;
   tile_shape s;
   if (!shape_of(cfg, &s)) { *err = LOOPS_E_CONFIG; return nullptr; }
   int device = 0;
@@ -253,7 +267,7 @@ int spmv_schedule_api(int schedule, int cfg, int rows, int cols, int nnz, const 
     case LOOPS_ORIGINAL: return kernels::launch_original(stream, R, C, N, off, idx, val, x, y);
     case LOOPS_GROUP_MAPPED: return kernels::launch_group_mapped_atomic(stream, R, C, N, off, idx, val, x, y);
     case LOOPS_WORK_ORIENTED: return kernels::launch_work_oriented_atomic(stream, R, C, N, off, idx, val, x, y);
-    case LOOPS_FLAT_PARTITIONED: return kernels::launch_flat_partitioned<8>(stream, R, N, off, idx, val, x, y, true);
+    case LOOPS_FLAT_PARTITIONED: return kernels::launch_flat_partitioned<8>(stream, R, N, off, idx, val, x, y, /*reference shape*/ 1);
     case LOOPS_MERGE_PATH_FLAT: {
       switch (cfg) {
         case LOOPS_TILE_256x8: return kernels::launch_merge_path_atomic<256, 8>(stream, R, C, N, off, idx, val, x, y);
@@ -375,6 +389,22 @@ int spmv_bcsr(int R, int C, int mode, int rows, int num_block_rows, int num_bloc
   if (!block_offsets || !y || rows < 0 || num_block_rows < 0 || num_blocks < 0) return LOOPS_E_BADARG;
   if (num_blocks > 0 && (!block_cols || !block_values || !x_padded)) return LOOPS_E_BADARG;
   if (num_block_rows == 0) return 0;
+  if (mode == 3)  // tuned: the MFMA kernel where it exists (4 x 4 fp32), the coalesced lane-group kernel otherwise
+    mode = (R == 4 && C == 4 && std::is_same<T, float>::value) ? 1 : 2;
+  if (mode == 2 || mode >= 100000) {
+    // coalesced lane-group kernels (bcsr_vector_mapped_spmv / bcsr_block_mapped_spmv).  2: automatic shape;
+    // tuning aid 100000 + 100 h + u: h in {1, 4, 16} blocks of a block-row per step, u in {1, 2, 4} steps in flight
+    int h = 0, u = 0;
+    if (mode >= 100000) { h = (mode - 100000) / 100; u = (mode - 100000) % 100; }
+    if (mode >= 100000 && ((h != 1 && h != 4 && h != 16) || (u != 1 && u != 2 && u != 4))) return LOOPS_E_BADARG;
+#define LOOPS_BCSR_COALESCED(RR, CC)                                                                                        \
+    if (R == RR && C == CC)                                                                                                \
+      return kernels::launch_bcsr_coalesced<RR, CC, T>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols,     \
+                                                      block_values, x_padded, y, h, u);
+    LOOPS_BCSR_COALESCED(2, 2) LOOPS_BCSR_COALESCED(3, 3) LOOPS_BCSR_COALESCED(4, 4) LOOPS_BCSR_COALESCED(8, 8)
+#undef LOOPS_BCSR_COALESCED
+    return LOOPS_E_CONFIG;
+  }
   if (mode == 1 || (mode > 10 && mode < 20) || mode >= 100) {
     // MFMA path.  1: automatic shape; tuning aids: 1u = one block per block-row per step, u steps in
     // flight; 100 + 10 h + u = h blocks of a block-row per step (1, 2, 4, 8, 16), u steps in flight;
@@ -398,6 +428,7 @@ int spmv_bcsr(int R, int C, int mode, int rows, int num_block_rows, int num_bloc
   if (R == 2 && C == 2) return kernels::launch_bcsr_thread_mapped<2, 2>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
   if (R == 3 && C == 3) return kernels::launch_bcsr_thread_mapped<3, 3>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
   if (R == 4 && C == 4) return kernels::launch_bcsr_thread_mapped<4, 4>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
+  if (R == 8 && C == 8) return kernels::launch_bcsr_thread_mapped<8, 8>(s, rows, num_block_rows, num_blocks, block_offsets, block_cols, block_values, x_padded, y);
   return LOOPS_E_CONFIG;
 }
 
@@ -636,6 +667,8 @@ int colblock_fanout(const loops_colblock_plan* plan, const T* x, T* y, int num_p
 extern "C" {
 
 const char* loops_version(void) { return "0.2.0-mi355x"; }
+
+int loops_release_scratch(void) { return scratch_release_all(); }
 
 int loops_device_compute_units(int* out) {
   if (!out) return LOOPS_E_BADARG;

@@ -400,8 +400,16 @@ class BCSR:
         return (self.cols + self.C - 1) // self.C
 
 
-def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool | int = False):
-    """algorithms::spmv::bcsr_thread_mapped<R, C>; ``mfma=True`` selects the 4x4 MFMA kernel."""
+BCSR_MODES = {"thread": 0, "mfma": 1, "coalesced": 2, "tuned": 3}
+
+
+def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool | int | str = False):
+    """algorithms::spmv::bcsr_thread_mapped<R, C>.  ``mfma`` is the `mode` of loops_spmv_bcsr_*: False / "thread" =
+    thread per block-row (the reference's kernel shape), True / "mfma" = the 4x4 fp32 MFMA kernel, "coalesced" = the
+    lane-group kernel of any shape / precision, "tuned" = what the C++ wrapper launches (MFMA for 4x4 fp32, coalesced
+    otherwise); integers pass through (tuning shapes, include/loops_amd.h)."""
+    if isinstance(mfma, str):
+        mfma = BCSR_MODES[mfma]
     if y is None:
         y = torch.empty(b.rows, dtype=b.values.dtype, device=b.values.device)
     assert x_padded.numel() >= b.num_block_cols * b.C and x_padded.dtype == b.values.dtype == y.dtype

@@ -127,6 +127,32 @@ static int dump_mp(long rows, long nnz, const int* h_off, unsigned* h_thread_sta
   return 0;
 }
 
+// The reference's bcsr_thread_mapped<R, R> on this GPU, from ready block arrays (its host-side
+// CSR -> BCSR builder is not what is being timed).  x_padded has num_block_cols * R entries.
+template <std::size_t R, typename T>
+static int ref_bcsr(long rows, long cols, long num_block_rows, long num_block_cols, long num_blocks,
+                    const int* block_offsets, const int* block_cols, const T* block_values, const T* x_padded, T* y,
+                    int iters, float* ms) {
+  try {
+    bcsr_t<R, R, int, int, T> b;
+    b.rows = rows; b.cols = cols; b.nnzs = num_blocks * R * R;
+    b.num_block_rows = num_block_rows; b.num_block_cols = num_block_cols; b.num_blocks = num_blocks;
+    b.block_offsets = vector_t<int>(block_offsets, block_offsets + num_block_rows + 1);
+    b.block_col_indices = vector_t<int>(block_cols, block_cols + num_blocks);
+    b.values = vector_t<T>(block_values, block_values + num_blocks * R * R);
+    vector_t<T> dx(x_padded, x_padded + num_block_cols * R);
+    vector_t<T> dy(rows);
+    float best = 1e30f;
+    for (int it = 0; it < iters; ++it) {
+      auto timer = algorithms::spmv::bcsr_thread_mapped(b, dx, dy);
+      best = std::min(best, timer.milliseconds());
+    }
+    if (ms) *ms = best;
+    thrust::copy(dy.begin(), dy.end(), y);
+    return 0;
+  } catch (...) { return 1; }
+}
+
 extern "C" {
 
 // kind: 0 thread_mapped, 1 work_oriented, 2 merge_path_flat.  y is zero-filled first, as the
@@ -233,29 +259,29 @@ int refgpu_format_spmv_f32(int format, long rows, long cols, long nnz, const int
   } catch (...) { return 1; }
 }
 
-// The reference's bcsr_thread_mapped<4, 4> on this GPU, from ready block arrays (its host-side
-// CSR -> BCSR builder is not what is being timed).  x_padded has num_block_cols * 4 entries.
 int refgpu_bcsr4x4_spmv_f32(long rows, long cols, long num_block_rows, long num_block_cols, long num_blocks,
                             const int* block_offsets, const int* block_cols, const float* block_values,
                             const float* x_padded, float* y, int iters, float* ms) {
-  try {
-    bcsr_t<4, 4, int, int, float> b;
-    b.rows = rows; b.cols = cols; b.nnzs = num_blocks * 16;
-    b.num_block_rows = num_block_rows; b.num_block_cols = num_block_cols; b.num_blocks = num_blocks;
-    b.block_offsets = vector_t<int>(block_offsets, block_offsets + num_block_rows + 1);
-    b.block_col_indices = vector_t<int>(block_cols, block_cols + num_blocks);
-    b.values = vector_t<float>(block_values, block_values + num_blocks * 16);
-    vector_t<float> dx(x_padded, x_padded + num_block_cols * 4);
-    vector_t<float> dy(rows);
-    float best = 1e30f;
-    for (int it = 0; it < iters; ++it) {
-      auto timer = algorithms::spmv::bcsr_thread_mapped(b, dx, dy);
-      best = std::min(best, timer.milliseconds());
-    }
-    if (ms) *ms = best;
-    thrust::copy(dy.begin(), dy.end(), y);
-    return 0;
-  } catch (...) { return 1; }
+  return ref_bcsr<4, float>(rows, cols, num_block_rows, num_block_cols, num_blocks, block_offsets, block_cols, block_values,
+                            x_padded, y, iters, ms);
+}
+
+// Any of the square block shapes this repository compiles (2, 3, 4, 8), fp32 (`f64` = 0) or fp64 (`f64` = 1: the value
+// pointers are double*).  Returns 2 for a shape that is not instantiated here.
+int refgpu_bcsr_spmv(int R, int f64, long rows, long cols, long num_block_rows, long num_block_cols, long num_blocks,
+                     const int* block_offsets, const int* block_cols, const void* block_values, const void* x_padded,
+                     void* y, int iters, float* ms) {
+#define REF_BCSR(RR)                                                                                                     \
+  if (R == RR)                                                                                                           \
+    return f64 ? ref_bcsr<RR, double>(rows, cols, num_block_rows, num_block_cols, num_blocks, block_offsets, block_cols, \
+                                      static_cast<const double*>(block_values), static_cast<const double*>(x_padded),   \
+                                      static_cast<double*>(y), iters, ms)                                               \
+               : ref_bcsr<RR, float>(rows, cols, num_block_rows, num_block_cols, num_blocks, block_offsets, block_cols,  \
+                                     static_cast<const float*>(block_values), static_cast<const float*>(x_padded),      \
+                                     static_cast<float*>(y), iters, ms);
+  REF_BCSR(2) REF_BCSR(3) REF_BCSR(4) REF_BCSR(8)
+#undef REF_BCSR
+  return 2;
 }
 
 // Merge-path assignment as handed out by the reference's device schedule.

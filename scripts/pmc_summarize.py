@@ -15,6 +15,19 @@ for f in sorted(glob.glob(d + "/p*/**/*counter_collection.csv", recursive=True))
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (k, c), v in agg.items():
         out[k][c] = {"dispatches": len(v), "mean": sum(v) / len(v)}
+# tie the counters to the code they were collected from: bench.py prints `traffic: null` + the reason when the digest of the
+# headline kernel's sources differs from this one (bench.kernel_sources_digest)
+import os, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import bench
+    out["_kernel_sources_sha256"] = bench.kernel_sources_digest()
+    out["_kernel_sources"] = list(bench.KERNEL_SOURCES)
+except Exception as e:  # noqa: BLE001
+    print("no source digest:", e)
+out["_kernel_build"] = os.environ.get("LOOPS_GIT_HEAD", "")
 json.dump(out, open(d + "/summary.json", "w"), indent=1)
 for k, v in out.items():
+    if not isinstance(v, dict):
+        continue
     print(k[-110:], {c: round(x["mean"]) for c, x in v.items()})

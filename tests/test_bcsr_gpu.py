@@ -1,0 +1,132 @@
+"""BCSR SpMV for the block shapes the reference ships and tests (examples/spmv/bcsr_thread_mapped.cu:31-32: 2 x 2;
+unittests/test_spmv_bcsr.cu:24-36: 2 x 2 and 3 x 3; every example also as .f64) plus 4 x 4 and 8 x 8, fp32 and fp64:
+the coalesced lane-group kernels (loops_spmv_bcsr_* mode 2 / 3, kernels/bcsr_spmv.hxx) against the oracle, against a
+numpy block product, and against the REFERENCE'S OWN bcsr_thread_mapped<R, R> executed on this GPU (oracle/_ref).
+Inputs are exactly summable (cells k/8, integer x), so every comparison is BIT-EXACT whatever the summation order."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
+SHAPES = [2, 3, 4, 8]
+EXPLICIT = tuple(100000 + 100 * h + u for h in (1, 4, 16) for u in (1, 2, 4))  # every compiled kernel shape
+
+
+def _blocks(R, nbr, nbc, lens, seed, dtype):
+    rng = np.random.default_rng(seed)
+    boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    bcols = np.concatenate([np.sort(rng.choice(nbc, size=int(n), replace=False)) for n in lens]
+                           + [np.zeros(0, np.int64)]).astype(np.int32)
+    bvals = (rng.integers(-8, 9, size=bcols.size * R * R) / 8.0).astype(dtype)
+    x = rng.integers(1, 11, size=nbc * R).astype(dtype)
+    return boff, bcols, bvals, x
+
+
+def _numpy_product(R, rows, boff, bcols, bvals, x):
+    nbr = boff.size - 1
+    y = np.zeros(nbr * R, np.float64)
+    blocks = bvals.reshape(-1, R, R).astype(np.float64)
+    xs = x.reshape(-1, R).astype(np.float64)
+    prod = np.einsum("bij,bj->bi", blocks, xs[bcols])            # exact: cells k/8, x small integers
+    np.add.at(y.reshape(nbr, R), np.repeat(np.arange(nbr), np.diff(boff)), prod)
+    return y[:rows].astype(bvals.dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("R", SHAPES)
+def test_every_mode_matches_the_block_product(R, dtype):
+    from loops_amd import spmv as S
+    from oracle import oracle as O
+    cases = {
+        "uniform16": (700, 900, np.full(700, 16)),
+        "ragged": (1000, 1000, np.random.default_rng(R).integers(0, 41, size=1000)),          # 0 .. 40 blocks: no multiple of any h
+        "short": (3000, 500, np.random.default_rng(R + 1).integers(0, 3, size=3000)),          # mean ~1: h = 1
+        "one_long_row": (65, 4096, np.concatenate([[3000], np.random.default_rng(R + 2).integers(0, 5, size=64)])),
+    }
+    for name, (nbr, nbc, lens) in cases.items():
+        boff, bcols, bvals, x = _blocks(R, nbr, nbc, lens, seed=10 * R + len(name), dtype=dtype)
+        rows = nbr * R - (R - 1)                                   # last block-row partly outside the matrix: guarded stores
+        want = _numpy_product(R, rows, boff, bcols, bvals, x)
+        if dtype == np.float32:
+            assert np.array_equal(want, O.bcsr_spmv_f32(R, R, rows, boff, bcols, bvals, x)), (name, "oracle")
+        b = S.BCSR(R, R, rows, nbc * R, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+        xd = torch.from_numpy(x).cuda()
+        modes = ("thread", "coalesced", "tuned") + EXPLICIT + (("mfma",) if R == 4 and dtype == np.float32 else ())
+        for mode in modes:
+            y = torch.full((rows + R,), 7.0, dtype=xd.dtype, device="cuda")   # rows >= `rows` must stay untouched
+            S.bcsr_thread_mapped(b, xd, y, mfma=mode)
+            got = y.cpu().numpy()
+            assert np.array_equal(got[:rows], want), (R, dtype.__name__, name, mode)
+            assert np.all(got[rows:] == 7.0), (R, dtype.__name__, name, mode, "wrote past `rows`")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("R", SHAPES)
+def test_matrix_without_blocks(R, dtype):
+    """num_block_rows > 0, num_blocks == 0 (null block arrays): y = 0 from every mode, nothing is dereferenced."""
+    from loops_amd import spmv as S
+    nbr = 37
+    boff = torch.zeros(nbr + 1, dtype=torch.int32, device="cuda")
+    empty_i = torch.zeros(0, dtype=torch.int32, device="cuda")
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    b = S.BCSR(R, R, nbr * R - 1, nbr * R, boff, empty_i, torch.zeros(0, dtype=tdt, device="cuda"))
+    x = torch.ones(nbr * R, dtype=tdt, device="cuda")
+    for mode in ("thread", "coalesced", "tuned") + (("mfma", 144) if R == 4 and dtype == np.float32 else ()):
+        y = torch.full((nbr * R - 1,), 5.0, dtype=tdt, device="cuda")
+        S.bcsr_thread_mapped(b, x, y, mfma=mode)
+        assert torch.count_nonzero(y).item() == 0, (R, mode)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("R", SHAPES)
+def test_against_the_reference_kernel_on_this_gpu(R, dtype):
+    """The reference's own bcsr_thread_mapped<R, R> (compiled in place from /root/reference, oracle/ref_gpu_shim.cpp)
+    on the same block arrays, same GPU."""
+    assert os.path.exists(REF_SO), "oracle/_ref/libloops_ref_gpu.so missing: run __graft_entry__.build() where /root/reference exists"
+    from loops_amd import _lib, spmv as S
+    ref = _lib.load_shared(REF_SO)
+    assert hasattr(ref, "refgpu_bcsr_spmv"), "oracle/_ref/libloops_ref_gpu.so is stale (no refgpu_bcsr_spmv): rebuild it"
+    nbr = nbc = 2048
+    lens = np.random.default_rng(100 + R).integers(0, 33, size=nbr)
+    boff, bcols, bvals, x = _blocks(R, nbr, nbc, lens, seed=R, dtype=dtype)
+    rows = nbr * R
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    yr = np.zeros(rows, dtype)
+    ms = C.c_float()
+    rc = ref.refgpu_bcsr_spmv(R, int(dtype == np.float64), C.c_long(rows), C.c_long(nbc * R), C.c_long(nbr), C.c_long(nbc),
+                              C.c_long(bcols.size), p(boff), p(bcols), p(bvals), p(x), p(yr), 1, C.byref(ms))
+    assert rc == 0
+    assert np.array_equal(yr, _numpy_product(R, rows, boff, bcols, bvals, x))
+    b = S.BCSR(R, R, rows, nbc * R, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    for mode in ("coalesced", "tuned"):
+        got = S.bcsr_thread_mapped(b, torch.from_numpy(x).cuda(), mfma=mode).cpu().numpy()
+        assert np.array_equal(got, yr), (R, dtype.__name__, mode)
+
+
+def test_real_valued_blocks_within_the_fp32_bound():
+    """Real-valued cells and x: |y - y64| <= 2e-6 * sum |a x| per row (the reference's Wilkinson-style criterion,
+    util/reference.hxx:278-337, at the tolerance measured for the CSR kernels)."""
+    from loops_amd import spmv as S
+    rng = np.random.default_rng(5)
+    for R in SHAPES:
+        nbr = nbc = 1500
+        lens = rng.integers(0, 25, size=nbr)
+        boff, bcols, _, _ = _blocks(R, nbr, nbc, lens, seed=R, dtype=np.float32)
+        bvals = rng.uniform(-1.0, 1.0, size=bcols.size * R * R).astype(np.float32)
+        x = rng.uniform(-1.0, 1.0, size=nbc * R).astype(np.float32)
+        blocks, xs = bvals.reshape(-1, R, R).astype(np.float64), x.reshape(-1, R).astype(np.float64)
+        y64, l1 = np.zeros((nbr, R)), np.zeros((nbr, R))
+        owner = np.repeat(np.arange(nbr), np.diff(boff))
+        np.add.at(y64, owner, np.einsum("bij,bj->bi", blocks, xs[bcols]))
+        np.add.at(l1, owner, np.einsum("bij,bj->bi", np.abs(blocks), np.abs(xs[bcols])))
+        b = S.BCSR(R, R, nbr * R, nbc * R, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+        for mode in ("thread", "tuned"):
+            got = S.bcsr_thread_mapped(b, torch.from_numpy(x).cuda(), mfma=mode).cpu().numpy().astype(np.float64)
+            assert np.all(np.abs(got - y64.ravel()) <= 2e-6 * l1.ravel() + 1e-30), (R, mode)

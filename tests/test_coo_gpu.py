@@ -30,7 +30,7 @@ def test_battery(tuned, order):
         y = torch.full((r,), 7.0, device="cuda")
         S.coo_spmv(r, c, torch.from_numpy(ri).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda(), x, y, tuned=tuned)
         ref, l1 = g[f"{name}.y_int"], g[f"{name}.l1_int"]
-        assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= 8e-6 * l1 + 1e-30), (name, tuned, order)
+        assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= 2e-6 * l1 + 1e-30), (name, tuned, order)
 
 
 @pytest.mark.parametrize("shift", [0, 1, 3])

@@ -87,7 +87,7 @@ def test_real_values_within_tolerance():
     ref = O.spmm(off, idx, val.astype(np.float64), B.astype(np.float64))  # f64 reference
     l1 = O.spmm(off, idx, np.abs(val).astype(np.float64), np.abs(B).astype(np.float64))
     got = S.spmm(_dev(off, idx, val, rows, cols), torch.from_numpy(B).cuda()).cpu().numpy()
-    assert np.all(np.abs(got - ref) <= 1e-6 * 8 * l1 + 1e-30)
+    assert np.all(np.abs(got - ref) <= 2e-6 * l1 + 1e-30)
 
 
 @pytest.mark.parametrize("shift", [1, 2])

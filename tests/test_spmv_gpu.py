@@ -21,9 +21,11 @@ def _dev(off, idx, val, rows, cols):
     return S.CSR.from_numpy(rows, cols, off, idx, val)
 
 
-def _close(y, ref, l1, rel=1e-6):
-    # |y - ref| <= rel * sum_k |a_k x_k|  (+ tiny floor): order-independent fp32 bound
-    return np.all(np.abs(y.astype(np.float64) - ref.astype(np.float64)) <= rel * l1.astype(np.float64) * 8 + 1e-30)
+def _close(y, ref, l1, rel=2e-6):
+    # |y - ref| <= 2e-6 * sum_k |a_k x_k|  (+ tiny floor): the order-independent fp32 bound at the level MEASURED for these
+    # kernels (profiles/r02_parity_c2_fp32_tolerance.json: 2.4e-7 relative on C2 without cancellation; `ref` itself is a
+    # sequential fp32 sum, util/reference.hxx:61-76, and carries most of the difference).  Rounds 1-2 allowed 8e-6.
+    return np.all(np.abs(y.astype(np.float64) - ref.astype(np.float64)) <= rel * l1.astype(np.float64) + 1e-30)
 
 
 def test_library_is_the_hip_extension():
@@ -497,6 +499,66 @@ def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
             torch.cuda.synchronize()
         for rank in range(world):
             assert np.array_equal(fulls[rank].cpu().numpy(), ref64), ("blocked f64", rank)
+
+
+def test_c5_full_size_all_eight_shards_with_fanout():
+    """BASELINE config C5 at FULL size on one GPU: the 2^24-row / 2^29-nnz matrix cut into the 8 owner row ranges
+    bench.py --gpus 8 uses; every shard is run in the N > 1 default layout (column-blocked by owner, 16 blocks) through
+    the fan-out entry with the other seven y_full buffers as its peers -- the full-size twin of
+    test_fused_allgatherv_epilogue_stores_on_one_gpu.  Each of the eight vectors must equal the oracle's y AND the y of
+    the whole matrix as ONE unmodified CSR on this GPU, bit for bit.  The chunked-overlap candidate's kernels (each
+    shard as 2 row chunks with their own plans) must reassemble to the same slice."""
+    import bench
+    from loops_amd import spmv as S, generate as G, partition as P
+    from oracle import oracle as O
+    world, rows, nnz = 8, 1 << 24, 1 << 29
+    cols = rows
+    degrees = G.powerlaw_degrees(rows, nnz)
+    assert int(degrees.sum()) == nnz
+    bounds = P.row_ranges_from_degrees(degrees, world)
+    col_bounds = P.column_block_bounds(bounds, max_blocks=16)   # bench.py's choice at 32 nnz / row
+    assert col_bounds.size - 1 == 16
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    fulls = [torch.full((rows,), float("nan"), device="cuda") for _ in range(world)]
+    ref = np.empty(rows, np.float32)
+    chunk_bounds = P.chunk_bounds_from_degrees(degrees, bounds, 2)
+    for rank in range(world):
+        a, b = int(bounds[rank]), int(bounds[rank + 1])
+        shard = P.Shard(rank, world, a, b, bounds)
+        off, idx, val = G.csr_from_degrees(degrees[a:b], cols, seed=1, row_begin=a)
+        assert abs(idx.size - nnz // world) < nnz // world // 50     # balanced by rows + nnz: within 2 % of 2^26
+        ref[a:b] = O.spmv_f32(off, idx, val, xh, omp=True)
+        csr = S.CSR.from_numpy(b - a, cols, off, idx, val)
+        cb = S.ColumnBlockedPlan(csr, block_bounds=col_bounds)
+        fan = P.FusedFanout(fulls[rank], shard, [fulls[p] for p in range(world) if p != rank])
+        fan.run(lambda y, peers: cb.spmv_fanout(x, y, peers))
+        torch.cuda.synchronize()
+        cb.close()
+        # the chunked candidate: two row chunks with their own column-blocked plans
+        y_chunks = torch.full((b - a,), float("nan"), device="cuda")
+        mine = chunk_bounds[rank] - a
+        for c in range(2):
+            ca, cz = int(mine[c]), int(mine[c + 1])
+            so, si, sv = P.slice_csr(off, idx, val, ca, cz)
+            sub = S.CSR.from_numpy(cz - ca, cols, so, si, sv)
+            pl = S.ColumnBlockedPlan(sub, block_bounds=col_bounds)
+            pl.spmv(x, y_chunks[ca:cz])
+            torch.cuda.synchronize()
+            pl.close()
+            del sub
+        assert np.array_equal(y_chunks.cpu().numpy(), ref[a:b]), ("chunked", rank)
+        del csr, off, idx, val
+    ref_d = torch.from_numpy(ref).cuda()
+    for rank in range(world):
+        assert torch.equal(fulls[rank], ref_d), ("fan-out", rank)
+    del fulls
+    whole = bench.full_matrix_on_device(G, S, torch, degrees, cols)
+    assert whole.nnzs == nnz
+    plan = S.MergePathPlan(whole, "512x8")
+    y = S.merge_path_flat(whole, x, plan=plan)
+    assert torch.equal(y, ref_d), "one-GPU CSR y of the same matrix"
+    plan.close()
 
 
 @pytest.mark.parametrize("schedule", TUNED)
