@@ -214,6 +214,14 @@ def one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_gathered, iters=20):
         cb.close()
     except Exception as e:  # noqa: BLE001 -- the plain-CSR figure stands on its own
         out["blocked_error"] = f"{type(e).__name__}: {e}"
+    try:  # what a caller gets by default from a held plan: loops_spmv_plan_* picks tile shape and layout by measurement
+        sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
+        ms_p = timed_ms(torch, lambda: sp.spmv(x, y), iters)
+        out.update({"planned_ms_per_spmv": round(ms_p, 5), "planned_choice": sp.info,
+                    "planned_equals_gathered_y_bit_for_bit": bool(torch.equal(y, y_gathered))})
+        sp.close()
+    except Exception as e:  # noqa: BLE001
+        out["planned_error"] = f"{type(e).__name__}: {e}"
     out["best_ms_per_spmv"] = min(v for k, v in out.items() if k.endswith("_ms_per_spmv"))
     out["GFLOPs"] = round(2.0 * csr.nnzs / out["best_ms_per_spmv"] / 1e6, 2)  # the N = 1 `value` of THIS matrix (bench.py --gpus 1 runs C2)
     return out
@@ -244,7 +252,7 @@ def context_c3_standins(G, S, O, torch, iters=10):
     """BASELINE config C3 next to the headline (context): `group_mapped` vs `work_oriented` (+ merge_path_flat) on generated
     stand-ins of indochina-2004's exact shape -- 7 414 866 rows / 194 109 311 nnz; the SuiteSparse file is not shipped
     (datasets/suitesparse.txt:2052 in the reference): scale-free degrees with uniformly random columns (no locality: a lower
-    bound for a crawl-ordered web graph) and with columns in a 65 536-wide band.  Whole calls through loops_spmv_csr_f32,
+    bound for a crawl-ordered web graph), with columns in a 65 536-wide band, and host-blocked (how LAW graphs are laid out).  Whole calls through loops_spmv_csr_f32,
     bit-exact against the oracle."""
     rows = cols = 7_414_866
     nnz = 194_109_311
@@ -254,8 +262,10 @@ def context_c3_standins(G, S, O, torch, iters=10):
     abytes = algorithmic_bytes(rows, cols, nnz)
     out = {"shape": f"{rows} rows / {nnz} nnz (LAW/indochina-2004's), fp32", "algorithmic_bytes": abytes,
            "note": "generated stand-ins: the SuiteSparse file is not available offline; tests/perf/bench_schedules.py --mtx PATH runs the real one"}
-    for tag, window in (("uniform_columns", None), ("band_65536", 65536)):
-        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
+    for tag, window in (("uniform_columns", None), ("band_65536", 65536), ("host_blocked", G.HOST_BLOCKED)):
+        # host_blocked: the locality class LAW graphs belong to -- consecutive ids form hosts of power-law size (generate.host_blocks:
+        # >= 256 ids, Pareto 1.1, <= 2^17), 3 of 4 links stay inside the row's host, the rest go anywhere
+        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=G.host_blocks(cols) if window == G.HOST_BLOCKED else None)
         csr = S.CSR.from_numpy(rows, cols, off, idx, val)
         ref = O.spmv_f32(off, idx, val, xh, omp=True)
         y = torch.empty(rows, device="cuda")
@@ -270,6 +280,13 @@ def context_c3_standins(G, S, O, torch, iters=10):
             res[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
                           "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
         mplan.close()
+        # what a caller gets by default from a held plan (loops_spmv_plan_*: tile shape + layout picked by measurement)
+        sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
+        ms = timed_ms(torch, lambda: sp.spmv(x, y), iters)
+        res["held_spmv_plan"] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
+                                 "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "choice": sp.info,
+                                 "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+        sp.close()
         if window is None:  # x (30 MB) is far larger than an L2: the same three schedules over the column-blocked copy
             cb = S.ColumnBlockedPlan(csr)
             blocked = {"blocks": cb.num_blocks, "note": "plan-time re-ordered copy (column_blocked.hxx); same fused kernels + K-way row reduce"}

@@ -34,20 +34,34 @@ using merge_path_plan_t =
                                        merge_path_launch_t<type_t>::items_per_thread, index_t,
                                        offset_t, std::size_t, std::size_t>;
 
-/// SpMV with a prebuilt plan; asynchronous on `stream`.
+/// The plan of an explicit tile shape, and the small-tile plan of the launch box (`launch_t`: 256 x 8 / 256 x 4): the shape
+/// matrices whose rows are all short run best with -- one kernel, no carry-outs (`preprocess_t::classify`).
+template <std::size_t TPB, std::size_t IPT, typename index_t, typename offset_t>
+using merge_path_plan_of_t = schedule::merge_path::preprocess_t<TPB, IPT, index_t, offset_t, std::size_t, std::size_t>;
+template <typename index_t, typename offset_t, typename type_t>
+using merge_path_small_plan_t = merge_path_plan_of_t<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread, index_t, offset_t>;
+
+/// SpMV with a prebuilt plan of tile shape TPB x IPT; asynchronous on `stream`.
+template <std::size_t TPB, std::size_t IPT, typename index_t, typename offset_t, typename type_t>
+void merge_path_flat_async_with(const merge_path_plan_of_t<TPB, IPT, index_t, offset_t>& plan,
+                                csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
+                                xpu::stream_t stream = 0) {
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
+  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
+  kernels::launch_merge_path_fused<static_cast<int>(TPB), static_cast<int>(IPT), (IPT % 2 == 0), false>(
+      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
+}
+
+/// SpMV with a prebuilt plan (the merge_path launch box: 512 x 8 / 512 x 4); asynchronous on `stream`.
 template <typename index_t, typename offset_t, typename type_t>
 void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,
                            csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
                            xpu::stream_t stream = 0) {
-  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
-                            "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
-  constexpr int block_size = merge_path_launch_t<type_t>::block_size;
-  constexpr int items_per_thread = merge_path_launch_t<type_t>::items_per_thread;
-  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
-                                static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
-  kernels::launch_merge_path_fused<block_size, items_per_thread, (items_per_thread % 2 == 0), false>(
-      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
-      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
+  merge_path_flat_async_with<merge_path_launch_t<type_t>::block_size, merge_path_launch_t<type_t>::items_per_thread>(plan, csr, x, y,
+                                                                                                                      stream);
 }
 
 /// The same product for one rank of a row-range sharded multi-GPU SpMV: every finished row of y is ALSO stored to the same
@@ -76,12 +90,26 @@ util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<ty
   error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
                             "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
   using plan_t = merge_path_plan_t<index_t, offset_t, type_t>;
-  // Coordinates for every merge tile (the fused kernel always consumes the table).
-  plan_t plan(typename plan_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows),
-                                        static_cast<offset_t>(csr.nnzs)),
-              stream, plan_t::prepass_always);
-  plan.classify(stream);  // short rows only -> one kernel, no carry-outs (part of the untimed plan set-up)
+  using small_t = merge_path_small_plan_t<index_t, offset_t, type_t>;
+  // The tile shape follows the structure (part of the untimed plan set-up, like the reference's pre-pass): if no merge tile of
+  // the small shape starts more than a workgroup's worth of nonzeros inside a row, the product runs as ONE kernel over
+  // 256 x 8 tiles -- band / FEM / short-row matrices (25 us against 29-35 with larger tiles on the 2^20 x 16 band matrix);
+  // otherwise (rows longer than a tile) 512 x 8 tiles + the carry-out fix-up (C2: 94.4 against 95.9 us).
+  const typename small_t::layout_t lay(csr.offsets.data().get(), static_cast<index_t>(csr.rows), static_cast<offset_t>(csr.nnzs));
   util::timer_t timer(stream);
+  {
+    small_t small(lay, stream, small_t::prepass_always);
+    if (small.classify(stream) || small.merge_tiles() <= 1) {
+      timer.start();
+      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(small, csr, x, y, stream);
+      (void)xpu::stream_synchronize(stream);
+      timer.stop();
+      return timer;
+    }
+  }
+  // Coordinates for every merge tile (the fused kernel always consumes the table).
+  plan_t plan(lay, stream, plan_t::prepass_always);
+  plan.classify(stream);
   timer.start();
   merge_path_flat_async(plan, csr, x, y, stream);
   (void)xpu::stream_synchronize(stream);

@@ -1,0 +1,122 @@
+/**
+ * @file spmv_plan.cuh
+ * @brief `algorithms::spmv::spmv_plan_t<index_t, offset_t, type_t>`: what an iterative caller holds for ONE matrix -- the
+ * merge-path plan of the unmodified CSR in the tile shape that suits its structure, or, if the caller allows a copy and it
+ * is measurably faster, the column-blocked copy of the matrix (column_blocked.cuh: x larger than the per-XCD L2).  The
+ * header-API twin of loops_spmv_plan_* (include/loops_amd.h).  The reference fixes the tile shape per architecture at
+ * compile time (algorithms/spmv/launch_box.hxx:56-90) and always runs the CSR as given; no counterpart there.
+ *
+ *   algorithms::spmv::spmv_plan_t<int, int, float> plan(csr);            // measures 256 x 8, 512 x 8 and the blocked copy
+ *   for (...) plan.spmv_async(csr, x, y, stream);                         // y = csr * x with whatever won
+ *
+ * One product in flight per plan (it owns one set of carry-out / partial-result buffers).
+ */
+#pragma once
+
+#include <memory>
+
+#include <loops/algorithms/spmv/column_blocked.cuh>
+#include <loops/algorithms/spmv/merge_path_flat.cuh>
+
+namespace loops {
+namespace algorithms {
+namespace spmv {
+
+template <typename index_t, typename offset_t, typename type_t>
+struct spmv_plan_t {
+  enum layout_kind { csr_layout = 0, column_blocked_layout = 1 };
+  using small_t = merge_path_small_plan_t<index_t, offset_t, type_t>;  // 256 x 8 (256 x 4 for 8-byte values)
+  using large_t = merge_path_plan_t<index_t, offset_t, type_t>;        // 512 x 8 (512 x 4)
+  using blocked_t = column_blocked_t<index_t, offset_t, type_t>;
+
+  layout_kind layout = csr_layout;
+  float ms_small = -1.f, ms_large = -1.f, ms_blocked = -1.f;  ///< measured ms per product (-1: not timed)
+  std::unique_ptr<small_t> small;
+  std::unique_ptr<large_t> large;
+  std::unique_ptr<blocked_t> blocked;
+
+  /// @param allow_copy the plan may keep a column-blocked copy of `csr` (adopted when >= 5 % faster than the best CSR shape;
+  ///        without `measure`: when cols * sizeof(type_t) > 6 MB and the mean row holds >= 8 nonzeros)
+  /// @param measure time the candidates (`repeats` products each) instead of choosing by structure alone
+  explicit spmv_plan_t(csr_t<index_t, offset_t, type_t>& csr, bool allow_copy = true, bool measure = true, int repeats = 10,
+                       xpu::stream_t stream = 0) {
+    const typename small_t::layout_t lay(csr.offsets.data().get(), static_cast<index_t>(csr.rows), static_cast<offset_t>(csr.nnzs));
+    small = std::make_unique<small_t>(lay, stream, small_t::prepass_always);
+    const bool short_rows = small->classify(stream) || small->merge_tiles() <= 1;
+    const bool work = csr.rows > 0 && csr.nnzs > 0;
+    const std::size_t x_bytes = csr.cols * sizeof(type_t);
+    if (!measure || !work) {
+      if (!short_rows) {
+        large = std::make_unique<large_t>(lay, stream, large_t::prepass_always);
+        large->classify(stream);
+        small.reset();
+      }
+      if (allow_copy && work && x_bytes > (std::size_t(6) << 20) && csr.nnzs / csr.rows >= 8 && fits_blocked(csr)) {
+        blocked = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
+        layout = column_blocked_layout;
+        small.reset();
+        large.reset();
+      }
+      return;
+    }
+    vector_t<type_t> x(csr.cols), y(csr.rows);
+    large = std::make_unique<large_t>(lay, stream, large_t::prepass_always);
+    large->classify(stream);
+    ms_small = time_ms(repeats, stream, [&] {
+      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream);
+    });
+    ms_large = time_ms(repeats, stream, [&] { merge_path_flat_async(*large, csr, x, y, stream); });
+    // (a shape must be measurably -- > 1 % -- faster to displace the structural choice)
+    const bool keep_small = ms_small < 0.99f * ms_large || (short_rows && ms_small <= 1.01f * ms_large);
+    float best = keep_small ? ms_small : ms_large;
+    if (keep_small) large.reset();
+    else small.reset();
+    if (allow_copy && x_bytes >= (std::size_t(2) << 20) && fits_blocked(csr)) {
+      auto cb = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
+      ms_blocked = time_ms(repeats, stream, [&] { cb->spmv_async(x, y, stream); });
+      if (ms_blocked < 0.95f * best) {
+        blocked = std::move(cb);
+        layout = column_blocked_layout;
+        small.reset();
+        large.reset();
+      }
+    }
+  }
+
+  /// y = csr * x on `stream` (asynchronous).  `csr` must be the matrix the plan was built from.
+  void spmv_async(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
+    if (blocked) blocked->spmv_async(x, y, stream);
+    else if (small)
+      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream);
+    else merge_path_flat_async(*large, csr, x, y, stream);
+  }
+
+  util::timer_t spmv(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
+    util::timer_t timer(stream);
+    timer.start();
+    spmv_async(csr, x, y, stream);
+    (void)xpu::stream_synchronize(stream);
+    timer.stop();
+    return timer;
+  }
+
+ private:
+  static bool fits_blocked(const csr_t<index_t, offset_t, type_t>& csr) {
+    const int k = blocked_t::automatic_blocks(csr.cols, csr.rows, csr.nnzs);
+    return static_cast<unsigned long long>(k) * csr.rows + csr.nnzs < (1ull << 31) - 4096;
+  }
+  template <typename fn_t>
+  static float time_ms(int repeats, xpu::stream_t stream, fn_t&& run) {
+    if (repeats < 1) repeats = 10;
+    run();
+    run();
+    util::timer_t timer(stream);
+    timer.start();
+    for (int i = 0; i < repeats; ++i) run();
+    return timer.stop() / static_cast<float>(repeats);
+  }
+};
+
+}  // namespace spmv
+}  // namespace algorithms
+}  // namespace loops

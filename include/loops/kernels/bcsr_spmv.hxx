@@ -476,8 +476,8 @@ bcsr_block_mapped_spmv(const int rows, const int num_block_rows, const int* __re
 }
 
 /// Coalesced BCSR SpMV for block shape R x C (vector-mapped where the block bytes allow, block-mapped otherwise).
-/// `h`: blocks of one block-row per step (power of two; 0 = automatic: a slot should read about 256 contiguous bytes per
-/// step without idling more than half its lanes on the mean block-row); `unroll`: steps in flight (1, 2, 4; 0 = automatic).
+/// `h`: blocks of one block-row per step (1, 4, 16; 0 = automatic, from the shape and the mean block-row length);
+/// `unroll`: steps in flight (1, 2, 4; 0 = automatic).
 template <int R, int C, typename T>
 int launch_bcsr_coalesced(hipStream_t stream, int rows, int num_block_rows, int num_blocks, const int* block_offsets,
                           const int* block_cols, const T* values, const T* x, T* y, int h = 0, int unroll = 0) {
@@ -488,19 +488,30 @@ int launch_bcsr_coalesced(hipStream_t stream, int rows, int num_block_rows, int 
   using shape = bcsr_vector_shape<R, C, T>;
   constexpr bool vector_path = shape::ok;
   constexpr int lanes_per_block = vector_path ? shape::VPB : 1;
-  constexpr int bytes_per_lane = vector_path ? 16 : R * C * static_cast<int>(sizeof(T));
   constexpr int h_cap = wave::size / lanes_per_block < 16 ? wave::size / lanes_per_block : 16;
   const double mean = static_cast<double>(num_blocks) / num_block_rows;
+  // Measured on C4-sized inputs of every compiled shape (tests/perf/bench_bcsr_shapes.py --explicit, profiles/r03_bcsr_shapes.json):
+  // vector-mapped kernels are best with 4 blocks of a block-row per step and every step of the row in flight (h = 4, u = 4:
+  // 4x4 fp32 62 us against 65-77 for the other shapes, 8x8 fp32 192 against 208-241, 4x4 fp64 119 against 121-138); blocks
+  // of one vector (2x2 fp32) whose stream exceeds the Infinity Cache prefer whole 256-byte runs per slot (h = 16, u = 1:
+  // 158 against 175 us); block-mapped kernels (3x3: a lane reads a whole 36- / 72-byte block) want 16 consecutive blocks per
+  // step so that a wavefront instruction covers one contiguous span (h = 16, u = 2: 64 against 78-99 us).
   if (h == 0) {
-    h = 1;
-    while (h * 2 <= h_cap && h * lanes_per_block * bytes_per_lane < 256 && h * 2 <= mean) h *= 2;
+    if constexpr (!vector_path) {
+      h = mean >= 8 ? 16 : mean >= 2 ? 4 : 1;
+      if (unroll == 0) unroll = 2;  // (also at h = 16 with 16 blocks per row: the masked second step costs less than the shorter pipeline)
+    } else {
+      const double stream_bytes = static_cast<double>(num_blocks) * (R * C * sizeof(T) + 4);
+      if (lanes_per_block == 1 && stream_bytes > 256e6 && mean >= 12) h = 16;
+      else h = mean >= 3 ? 4 : 1;
+    }
   }
   if (h > h_cap) h = h_cap;
   h = h >= 16 ? 16 : h >= 4 ? 4 : 1;  // compiled: 1, 4, 16
   if (h > h_cap) h = h_cap >= 4 ? 4 : 1;
   if (unroll == 0) {
-    unroll = 1;
-    while (unroll < 4 && 2 * unroll * h < mean) unroll *= 2;
+    const double steps = mean / h;
+    unroll = steps > 2 ? 4 : steps > 1 ? 2 : 1;
   }
   unroll = unroll >= 4 ? 4 : unroll >= 2 ? 2 : 1;
   auto go = [&](auto h_tag, auto u_tag) {

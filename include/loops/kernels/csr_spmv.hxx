@@ -297,13 +297,42 @@ flat_partitioned_stitched_spmv(const part_t part, const index_t* __restrict__ in
   type_t p[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) p[k] = (full || first + k < nnz) ? v[k] * x[c[k]] : type_t(0);
-  // the row of every atom: one search, then a walk along the row ends (empty rows are skipped)
+  // The row of every atom: base().tile_of of the lane's first atom, then a walk along the row ends (empty rows are
+  // skipped).  tile_of is evaluated in two levels: the rows of the WAVEFRONT's first and last atom are found with
+  // wave-uniform searches -- scalar loads, tracked by their own counter, so the two ~20-step chains run underneath the
+  // vector loads above instead of in front of them -- and a lane then searches only the few rows in between.
   int r[K];
   int row = -1;
   atom_t row_end = 0;
-  if (any) {
-    row = static_cast<int>(base.tile_of(static_cast<atom_t>(first)));
-    row_end = base.tile_end(row);
+  {
+    const int wave_first = __builtin_amdgcn_readfirstlane(static_cast<int>(first - static_cast<long long>(wave::lane()) * K));
+    const int num_rows = static_cast<int>(base.num_tiles());
+    int wave_last = wave_first + wave::size * K - 1;
+    wave_last = wave_last < static_cast<int>(nnz) - 1 ? wave_last : static_cast<int>(nnz) - 1;
+    // smallest t with tile_end(t) > a (layout::csr::tile_of, container/layout.hxx), both targets in one loop
+    int lo = 0, lo_n = num_rows, hi = 0, hi_n = num_rows;
+    while (lo_n > 0 || hi_n > 0) {
+      if (lo_n > 0) {
+        const int half = lo_n >> 1;
+        if (static_cast<int>(base.tile_end(lo + half)) <= wave_first) { lo += half + 1; lo_n -= half + 1; }
+        else lo_n = half;
+      }
+      if (hi_n > 0) {
+        const int half = hi_n >> 1;
+        if (static_cast<int>(base.tile_end(hi + half)) <= wave_last) { hi += half + 1; hi_n -= half + 1; }
+        else hi_n = half;
+      }
+    }
+    if (any) {
+      row = lo;
+      int count = hi - lo;  // the lane's row lies in [lo, hi]
+      while (count > 0) {
+        const int half = count >> 1;
+        if (static_cast<long long>(base.tile_end(row + half)) <= first) { row += half + 1; count -= half + 1; }
+        else count = half;
+      }
+      row_end = base.tile_end(row);
+    }
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {

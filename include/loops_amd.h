@@ -48,7 +48,10 @@ enum loops_tile_config {
   LOOPS_TILE_256x7 = 3,
   LOOPS_TILE_512x8 = 4,
   LOOPS_TILE_256x16 = 5, /* 4096-item tiles: twice the bytes in flight per lane */
-  LOOPS_TILE_DEFAULT = 0
+  LOOPS_TILE_DEFAULT = 0,
+  /* loops_merge_plan_create only: the shape is picked from the structure -- 256 x 8 when the plan is self-completing with it
+   * (no row needs a carry-out: one kernel per product), 512 x 8 otherwise (rows longer than a merge tile) */
+  LOOPS_TILE_AUTO = -1
 };
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -261,6 +264,38 @@ int loops_spmv_colblock_fanout_f64(const loops_colblock_plan_t* plan, const doub
 /* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);
+
+/* ---- SpMV plan: tile shape AND layout chosen at plan time ------------------------------------------------
+ * What an iterative caller holds for one matrix.  The reference fixes both at compile time (launch_box.hxx:56-90) and always
+ * runs the CSR as given; here the plan decides per matrix, once:
+ *   flags & LOOPS_PLAN_MEASURE     time the candidates on the device at creation (256 x 8 and 512 x 8 merge tiles over the
+ *                                  unmodified CSR; `repeats` launches each, <= 0: 10) instead of choosing by structure alone;
+ *   flags & LOOPS_PLAN_ALLOW_COPY  the plan may keep a column-blocked COPY of the matrix (see "column-blocked CSR" above:
+ *                                  + nnz * (8 + sizeof(T)) + K * rows * (4 + sizeof(T)) bytes) when x exceeds the per-XCD L2;
+ *                                  with MEASURE it is adopted only if >= 5 % faster than the best CSR shape, without MEASURE
+ *                                  when cols * sizeof(T) > 6 MB and the mean row holds >= 8 nonzeros.
+ * Without ALLOW_COPY the product always runs on the caller's arrays.  Creation is synchronous.  One product in flight per plan.
+ * loops_spmv_planned_*: y = A x; offsets / indices / values are the arrays the plan was created from (ignored -- may be NULL
+ * -- when the plan holds the copy; after changing the VALUES of the matrix call loops_spmv_plan_refresh_values_* first).
+ * loops_spmv_plan_info: layout (LOOPS_LAYOUT_*), tile config, number of column blocks (0 for CSR), and ms3[3] = measured ms per
+ * product of {CSR 256 x 8, CSR 512 x 8, column-blocked}, -1 where not timed.  Any output pointer may be NULL. */
+#define LOOPS_PLAN_MEASURE 1
+#define LOOPS_PLAN_ALLOW_COPY 2
+#define LOOPS_LAYOUT_CSR 0
+#define LOOPS_LAYOUT_COLUMN_BLOCKED 1
+typedef struct loops_spmv_plan loops_spmv_plan_t;
+int loops_spmv_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                               int flags, int repeats, void* stream, loops_spmv_plan_t** out);
+int loops_spmv_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                               int flags, int repeats, void* stream, loops_spmv_plan_t** out);
+void loops_spmv_plan_destroy(loops_spmv_plan_t* plan);
+int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms3);
+int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream);
+int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream);
+int loops_spmv_planned_f32(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const float* values,
+                           const float* x, float* y, void* stream);
+int loops_spmv_planned_f64(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const double* values,
+                           const double* x, double* y, void* stream);
 
 /* ---- COO SpMV ------------------------------------------------------------------------------------
  * Replaces algorithms::spmv::coo_thread_mapped (algorithms/spmv/coo_thread_mapped.cuh:37-100).

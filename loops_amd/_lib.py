@@ -25,6 +25,7 @@ SCHEDULES = {
     "group_mapped": GROUP_MAPPED, "original": ORIGINAL, "flat_partitioned": FLAT_PARTITIONED,
 }
 # enum loops_tile_config: name -> (id, threads per block, items per thread)
+TILE_AUTO = -1  # LOOPS_TILE_AUTO (loops_merge_plan_create): 256x8 when self-completing with it, 512x8 otherwise
 TILES = {"256x8": (0, 256, 8), "128x7": (1, 128, 7), "4x2": (2, 4, 2), "256x7": (3, 256, 7), "512x8": (4, 512, 8), "256x16": (5, 256, 16)}
 
 # every symbol include/loops_amd.h declares (tests/test_c_abi.py checks the export table)
@@ -43,6 +44,8 @@ SYMBOLS = [
     "loops_spmv_dia_f32", "loops_spmv_dia_f64",
     "loops_spmv_work_oriented_f32", "loops_spmv_work_oriented_f64", "loops_enable_peer_access", "loops_spmv_merge_path_fanout_f32", "loops_spmv_colblock_fanout_f32", "loops_spmv_colblock_fanout_f64",
     "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64",
+    "loops_spmv_plan_create_f32", "loops_spmv_plan_create_f64", "loops_spmv_plan_destroy", "loops_spmv_plan_info",
+    "loops_spmv_plan_refresh_values_f32", "loops_spmv_plan_refresh_values_f64", "loops_spmv_planned_f32", "loops_spmv_planned_f64",
 ]
 
 
@@ -183,6 +186,13 @@ def lib() -> C.CDLL:
             getattr(L, "loops_spmv_ell_" + sfx).argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]
             getattr(L, "loops_spmv_csc_" + sfx).argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
             getattr(L, "loops_spmv_dia_" + sfx).argtypes = [ci, ci, ci, ci, C.c_size_t, vp, vp, vp, vp, vp]
+        for sfx in ("f32", "f64"):
+            getattr(L, "loops_spmv_plan_create_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
+            getattr(L, "loops_spmv_plan_refresh_values_" + sfx).argtypes = [vp, vp, vp]
+            getattr(L, "loops_spmv_planned_" + sfx).argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.loops_spmv_plan_destroy.argtypes = [vp]
+        L.loops_spmv_plan_destroy.restype = None
+        L.loops_spmv_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), vp]
         L.loops_autotune_merge_path_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]
         _lib = L
     return _lib

@@ -152,6 +152,28 @@ void plan_release(loops_merge_plan* p) {
   delete p;
 }
 
+// LOOPS_TILE_AUTO: the shape a held plan should have on THIS structure.  256 x 8 when the plan is self-completing with it
+// (no tile starts more than 256 nonzeros inside a row: one kernel, no carry-outs -- band / FEM / short-row matrices, where
+// 256 x 8 measured 25 us against 29-35 for the larger tiles); 512 x 8 otherwise (rows longer than a tile: every power-law
+// input of profiles/r02_structure_sweep.json, C2 94.4 against 95.9 us).  One or two coordinate pre-passes + one stream
+// synchronisation each, at plan creation only.
+int plan_create_auto(int rows, int nnz, const int* offsets, hipStream_t stream, loops_merge_plan** out) {
+  loops_merge_plan* p = nullptr;
+  int err = plan_alloc(rows, nnz, LOOPS_TILE_256x8, &p);
+  if (!err) err = plan_compute(p, offsets, stream);
+  if (!err) err = plan_classify(p, offsets, stream);
+  if (err) { plan_release(p); return err; }
+  if (p->self_complete || p->num_tiles <= 1) { *out = p; return 0; }
+  plan_release(p);
+  p = nullptr;
+  err = plan_alloc(rows, nnz, LOOPS_TILE_512x8, &p);
+  if (!err) err = plan_compute(p, offsets, stream);
+  if (!err) err = plan_classify(p, offsets, stream);
+  if (err) { plan_release(p); return err; }
+  *out = p;
+  return 0;
+}
+
 // (namespace scope so that loops_release_scratch() can reach the calling thread's cache; trivially destructible:
 // a thread that exits without releasing leaves its device buffers to process teardown)
 thread_local scratch_slot scratch_slots[kScratchSlots] = {};
@@ -663,6 +685,139 @@ int colblock_fanout(const loops_colblock_plan* plan, const T* x, T* y, int num_p
 }
 }  // namespace
 
+// ------------------------------------------------------------------ SpMV plan: tile shape AND layout chosen at plan time
+// What a caller that performs many products with one matrix should hold (loops_spmv_plan_*): the merge-path plan of the
+// unmodified CSR in the best tile shape, or -- if the caller allows a copy and it is measurably faster -- the column-blocked
+// copy of the matrix (x larger than an L2: C3-like and C5-like inputs run 2.1-2.4 x faster from it).
+struct loops_spmv_plan {
+  int rows, cols, nnz, vbytes, flags;
+  int layout;                   // LOOPS_LAYOUT_CSR / LOOPS_LAYOUT_COLUMN_BLOCKED
+  loops_merge_plan* merge;      // held for LOOPS_LAYOUT_CSR
+  loops_colblock_plan* blocked; // held for LOOPS_LAYOUT_COLUMN_BLOCKED
+  float ms[3];                  // measured ms per product: [0] CSR 256 x 8, [1] CSR 512 x 8, [2] column-blocked; -1 = not timed
+};
+
+namespace {
+
+void spmv_plan_free(loops_spmv_plan* p) {
+  if (!p) return;
+  plan_release(p->merge);
+  colblock_free(p->blocked);
+  delete p;
+}
+
+template <typename fn_t>
+int time_ms(hipStream_t st, int repeats, float* ms, fn_t&& run) {
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess) return static_cast<int>(hipGetLastError());
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return static_cast<int>(hipGetLastError()); }
+  int err = 0;
+  for (int it = 0; !err && it < 2; ++it) err = run();
+  if (!err) {
+    (void)hipEventRecord(e0, st);
+    for (int it = 0; !err && it < repeats; ++it) err = run();
+    (void)hipEventRecord(e1, st);
+    if (!err) err = static_cast<int>(hipEventSynchronize(e1));
+    if (!err) err = static_cast<int>(hipEventElapsedTime(ms, e0, e1));
+    *ms /= static_cast<float>(repeats);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return err;
+}
+
+template <typename T>
+int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx, const T* val, int flags, int repeats,
+                     hipStream_t st, loops_spmv_plan** out) {
+  if (!out || !off || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!idx || !val))) return LOOPS_E_BADARG;
+  if (static_cast<long long>(rows) + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  if (repeats < 1) repeats = 10;
+  auto* p = new (std::nothrow) loops_spmv_plan();
+  if (!p) return static_cast<int>(hipErrorOutOfMemory);
+  p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T)); p->flags = flags;
+  p->layout = LOOPS_LAYOUT_CSR;
+  p->ms[0] = p->ms[1] = p->ms[2] = -1.f;
+  const bool measure = (flags & LOOPS_PLAN_MEASURE) != 0 && rows > 0 && nnz > 0;
+  const bool may_copy = (flags & LOOPS_PLAN_ALLOW_COPY) != 0 && rows > 0 && nnz > 0;
+  const long long x_bytes = static_cast<long long>(cols) * static_cast<long long>(sizeof(T));
+  int err = 0;
+  if (!measure) {
+    // structural choice only: tile by the self-completing test; the copy when x exceeds 1.5 per-XCD L2s and rows are long
+    // enough to be cut into blocks (the regime in which the blocked layout won every measurement so far)
+    err = plan_create_auto(rows, nnz, off, st, &p->merge);
+    if (!err && may_copy && x_bytes > (6ll << 20) && nnz / (rows > 0 ? rows : 1) >= 8) {
+      err = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &p->blocked);
+      if (!err) { p->layout = LOOPS_LAYOUT_COLUMN_BLOCKED; plan_release(p->merge); p->merge = nullptr; }
+      else if (err == LOOPS_E_RANGE || err == LOOPS_E_CONFIG) err = 0;  // K * rows + nnz does not fit: stay on the CSR
+    }
+    if (err) { spmv_plan_free(p); return err; }
+    *out = p;
+    return 0;
+  }
+  // measured choice: the candidates are timed on this device with this matrix (x values do not matter to the time)
+  T *x = nullptr, *y = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&x), sizeof(T) * static_cast<size_t>(cols > 0 ? cols : 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&y), sizeof(T) * static_cast<size_t>(rows));
+  if (e == hipSuccess) e = hipMemsetAsync(x, 0, sizeof(T) * static_cast<size_t>(cols > 0 ? cols : 1), st);
+  err = static_cast<int>(e);
+  loops_merge_plan* best = nullptr;
+  float best_ms = 0.f;
+  const int shapes[2] = {LOOPS_TILE_256x8, LOOPS_TILE_512x8};
+  for (int i = 0; !err && i < 2; ++i) {
+    loops_merge_plan* m = nullptr;
+    err = plan_alloc(rows, nnz, shapes[i], &m);
+    if (!err) err = plan_compute(m, off, st);
+    if (!err) err = plan_classify(m, off, st);
+    float ms = 0.f;
+    if (!err) err = time_ms(st, repeats, &ms, [&]() { return spmv_merge_path<T>(m, 0, rows, nnz, off, idx, val, x, y, st); });
+    if (err) { plan_release(m); break; }
+    p->ms[i] = ms;
+    // 512 x 8 must be measurably (> 1 %) faster to displace 256 x 8 and vice versa: ties go to the structural choice
+    const bool better = !best || ms < 0.99f * best_ms;
+    if (better) { plan_release(best); best = m; best_ms = ms; }
+    else plan_release(m);
+  }
+  p->merge = best;
+  if (!err && may_copy && x_bytes >= (2ll << 20)) {
+    loops_colblock_plan* cb = nullptr;
+    int cerr = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &cb);
+    if (!cerr) {
+      float ms = 0.f;
+      cerr = time_ms(st, repeats, &ms, [&]() { return colblock_spmv<T>(cb, 7, x, y, st); });
+      if (!cerr) p->ms[2] = ms;
+      if (!cerr && ms < 0.95f * best_ms) {  // the copy doubles the matrix's footprint: it has to pay for it
+        p->blocked = cb;
+        p->layout = LOOPS_LAYOUT_COLUMN_BLOCKED;
+        plan_release(p->merge);
+        p->merge = nullptr;
+        cb = nullptr;
+      }
+    }
+    colblock_free(cb);
+    if (cerr && cerr != LOOPS_E_RANGE && cerr != LOOPS_E_CONFIG && cerr != static_cast<int>(hipErrorOutOfMemory)) err = cerr;
+    if (cerr == static_cast<int>(hipErrorOutOfMemory)) (void)hipGetLastError();  // no room for the copy: stay on the CSR
+  }
+  if (!err) err = static_cast<int>(hipStreamSynchronize(st));
+  (void)hipFree(x);
+  (void)hipFree(y);
+  if (err) { spmv_plan_free(p); return err; }
+  *out = p;
+  return 0;
+}
+
+template <typename T>
+int spmv_planned(const loops_spmv_plan* p, const int* off, const int* idx, const T* val, const T* x, T* y, hipStream_t st) {
+  if (!p || p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
+  if (p->rows == 0) return 0;
+  if (!y || (p->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  if (p->layout == LOOPS_LAYOUT_COLUMN_BLOCKED) return colblock_spmv<T>(p->blocked, 7, x, y, st);
+  int err = check_csr(p->rows, p->cols, p->nnz, off, idx, val, x, y);
+  if (err) return err;
+  return spmv_merge_path<T>(p->merge, 0, p->rows, p->nnz, off, idx, val, x, y, st);
+}
+
+}  // namespace
+
 // =============================================================================== extern "C"
 extern "C" {
 
@@ -681,6 +836,11 @@ int loops_device_compute_units(int* out) {
 int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_config, void* stream,
                             loops_merge_plan_t** out) {
   if (!out || !offsets) return LOOPS_E_BADARG;
+  if (tile_config == LOOPS_TILE_AUTO) {
+    if (rows < 0 || nnz < 0) return LOOPS_E_BADARG;
+    if (static_cast<long long>(rows) + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+    return plan_create_auto(rows, nnz, offsets, as_stream(stream), out);
+  }
   loops_merge_plan* p = nullptr;
   int err = plan_alloc(rows, nnz, tile_config, &p);
   if (err) return err;
@@ -1030,6 +1190,40 @@ int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_off
 int loops_spmv_csc_f64(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
                        const double* values, const double* x, double* y, void* stream) {
   return spmv_csc<double>(mode, rows, cols, nnz, col_offsets, row_indices, values, x, y, as_stream(stream));
+}
+
+int loops_spmv_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                               int flags, int repeats, void* stream, loops_spmv_plan_t** out) {
+  return spmv_plan_create<float>(rows, cols, nnz, offsets, indices, values, flags, repeats, as_stream(stream), out);
+}
+int loops_spmv_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                               int flags, int repeats, void* stream, loops_spmv_plan_t** out) {
+  return spmv_plan_create<double>(rows, cols, nnz, offsets, indices, values, flags, repeats, as_stream(stream), out);
+}
+void loops_spmv_plan_destroy(loops_spmv_plan_t* plan) { spmv_plan_free(plan); }
+int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms3) {
+  if (!plan) return LOOPS_E_BADARG;
+  if (layout) *layout = plan->layout;
+  if (tile_config) *tile_config = plan->merge ? plan->merge->cfg : COLBLOCK_TILE;
+  if (num_blocks) *num_blocks = plan->blocked ? plan->blocked->K : 0;
+  if (ms3) for (int i = 0; i < 3; ++i) ms3[i] = plan->ms[i];
+  return 0;
+}
+int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream) {
+  if (!plan || plan->vbytes != 4) return LOOPS_E_BADARG;
+  return plan->blocked ? colblock_refresh<float>(plan->blocked, values, as_stream(stream)) : 0;
+}
+int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream) {
+  if (!plan || plan->vbytes != 8) return LOOPS_E_BADARG;
+  return plan->blocked ? colblock_refresh<double>(plan->blocked, values, as_stream(stream)) : 0;
+}
+int loops_spmv_planned_f32(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const float* values,
+                           const float* x, float* y, void* stream) {
+  return spmv_planned<float>(plan, offsets, indices, values, x, y, as_stream(stream));
+}
+int loops_spmv_planned_f64(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const double* values,
+                           const double* x, double* y, void* stream) {
+  return spmv_planned<double>(plan, offsets, indices, values, x, y, as_stream(stream));
 }
 
 }  // extern "C"

@@ -23,11 +23,21 @@ inline std::uint64_t splitmix64(std::uint64_t z) {
 // generate.py::_hash_cols for window in {none (< 0 here: LOOPS_GEN_UNIFORM), runs (-1), band (> 0)}
 constexpr std::int64_t kUniform = INT64_MIN;
 
+// host-blocked columns (window == -4, generate.py::_hash_cols): `hb`, `he` = the block of consecutive ids ("host") the row
+// belongs to.  14 of 16 links stay inside the host when it can hold twice the row's degree; the rest go anywhere.
+constexpr std::int64_t kHostBlocked = -4;
+
 inline std::int64_t hash_col(std::uint64_t seed, std::int64_t row_abs, std::int64_t k, std::uint64_t attempt,
-                             std::int64_t cols, std::int64_t window, std::int64_t deg) {
+                             std::int64_t cols, std::int64_t window, std::int64_t deg, std::int64_t hb = 0, std::int64_t he = 0) {
   const std::uint64_t h = splitmix64(splitmix64(seed + static_cast<std::uint64_t>(row_abs)) + static_cast<std::uint64_t>(k) +
                                      (attempt << 40));
   if (window == kUniform) return static_cast<std::int64_t>(h % static_cast<std::uint64_t>(cols));
+  if (window == kHostBlocked) {
+    const std::int64_t size = he - hb;
+    const bool local = ((h >> 60) < 14ull) && size >= 2 * deg;
+    if (local) return hb + static_cast<std::int64_t>((h & 0xFFFFFFFFFFFFull) % static_cast<std::uint64_t>(size));
+    return static_cast<std::int64_t>(splitmix64(h) % static_cast<std::uint64_t>(cols));
+  }
   if (window == -1) {  // runs: consecutive columns from a hashed start
     const std::uint64_t start = splitmix64(seed * 31ull + static_cast<std::uint64_t>(row_abs)) % static_cast<std::uint64_t>(cols);
     return (static_cast<std::int64_t>(start) + k) % cols;
@@ -77,9 +87,9 @@ void loops_gen_perm_keys(unsigned long long seed, long long n, unsigned long lon
 // (int64, prefix sums of `degrees`, computed by the caller), per-row distinct columns sorted ascending, values
 // k/8 (exact != 0) or U[0.5, 1.5).  window: LLONG_MIN = uniform columns, -1 = runs, > 0 = band.
 // Returns 0, or -1 if a row cannot hold `degree` distinct columns.
-int loops_gen_csr_rows(const long long* degrees, const long long* offsets, long long nrows, long long cols,
-                       unsigned long long seed, long long row_begin, int exact, long long window, int* indices,
-                       float* values) {
+static int gen_csr_rows(const long long* degrees, const long long* offsets, long long nrows, long long cols,
+                        unsigned long long seed, long long row_begin, int exact, long long window, int* indices,
+                        float* values, const long long* hosts, long long num_hosts) {
   int status = 0;
 #pragma omp parallel
   {
@@ -96,7 +106,14 @@ int loops_gen_csr_rows(const long long* degrees, const long long* offsets, long 
       }
       col.resize(static_cast<std::size_t>(deg));
       item.resize(static_cast<std::size_t>(deg));
-      for (std::int64_t k = 0; k < deg; ++k) col[k] = hash_col(seed, row_abs, k, 0, cols, window, deg);
+      std::int64_t hb = 0, he = cols;
+      if (window == kHostBlocked) {  // the host of id min(row, cols - 1): last boundary <= id
+        const std::int64_t id = row_abs < cols ? row_abs : cols - 1;
+        const long long* up = std::upper_bound(hosts, hosts + num_hosts + 1, static_cast<long long>(id));
+        hb = *(up - 1);
+        he = *up;
+      }
+      for (std::int64_t k = 0; k < deg; ++k) col[k] = hash_col(seed, row_abs, k, 0, cols, window, deg, hb, he);
       std::uint64_t attempt = 0;
       for (;;) {
         for (std::int64_t k = 0; k < deg; ++k) item[k] = {col[k], k};
@@ -106,7 +123,7 @@ int loops_gen_csr_rows(const long long* degrees, const long long* offsets, long 
           if (item[i].first == item[i - 1].first) {  // every later entry of an equal run is redrawn
             if (!dup) { dup = true; ++attempt; }
             const std::int64_t k = item[i].second;
-            col[k] = hash_col(seed, row_abs, k, attempt, cols, window, deg);
+            col[k] = hash_col(seed, row_abs, k, attempt, cols, window, deg, hb, he);
           }
         }
         if (!dup) break;
@@ -124,6 +141,21 @@ int loops_gen_csr_rows(const long long* degrees, const long long* offsets, long 
     }
   }
   return status;
+}
+
+int loops_gen_csr_rows(const long long* degrees, const long long* offsets, long long nrows, long long cols,
+                       unsigned long long seed, long long row_begin, int exact, long long window, int* indices,
+                       float* values) {
+  if (window == kHostBlocked) return -2;  // needs the host table: loops_gen_csr_rows_hosts
+  return gen_csr_rows(degrees, offsets, nrows, cols, seed, row_begin, exact, window, indices, values, nullptr, 0);
+}
+
+// window = -4 ("host-blocked"): hosts[0 .. num_hosts] = ascending id boundaries, hosts[0] = 0, hosts[num_hosts] = cols
+int loops_gen_csr_rows_hosts(const long long* degrees, const long long* offsets, long long nrows, long long cols,
+                             unsigned long long seed, long long row_begin, int exact, const long long* hosts,
+                             long long num_hosts, int* indices, float* values) {
+  if (!hosts || num_hosts < 1 || hosts[0] != 0 || hosts[num_hosts] != cols) return -2;
+  return gen_csr_rows(degrees, offsets, nrows, cols, seed, row_begin, exact, kHostBlocked, indices, values, hosts, num_hosts);
 }
 
 // x[i] = reference x generator for INT bounds (generate.py::uniform_distribution_int, util/generate.hxx:33-79)

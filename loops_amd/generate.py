@@ -73,6 +73,7 @@ def native(required: bool = False):
         L.loops_gen_perm_keys.argtypes = [C.c_ulonglong, ll, vp]
         L.loops_gen_perm_keys.restype = None
         L.loops_gen_csr_rows.argtypes = [vp, vp, ll, ll, C.c_ulonglong, ll, C.c_int, ll, vp, vp]
+        L.loops_gen_csr_rows_hosts.argtypes = [vp, vp, ll, ll, C.c_ulonglong, ll, C.c_int, vp, ll, vp, vp]
         L.loops_gen_x_int.argtypes = [ll, ll, C.c_int, C.c_int, C.c_uint, vp]
         L.loops_gen_x_int.restype = None
         L.loops_gen_set_threads.argtypes = [C.c_int]
@@ -175,11 +176,46 @@ def powerlaw_degrees(rows, nnz, alpha=0.8, cap=1 << 14, perm_seed=0x5EED, native
     return out
 
 
-def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None):
+HOST_BLOCKED = -4  # `window` value: columns drawn "host-blocked" (needs `hosts`, see host_blocks)
+
+
+def host_blocks(n, seed=11, smin=256, smax=1 << 17, alpha=1.1):
+    """Boundaries of consecutive-id blocks ("hosts") covering [0, n) with power-law sizes -- how a crawl-ordered web graph
+    such as LAW/indochina-2004 is laid out: pages of one host get consecutive ids and most links stay inside the host.
+    size_i = clamp(floor(smin * u_i^(-1 / alpha)), smin, smax), u_i hashed from (seed, i); the last block is cut at n.
+    Returns int64 boundaries b[0] = 0 < ... < b[H] = n."""
+    out = [0]
+    i = 0
+    while out[-1] < n:
+        m = max(1024, (n - out[-1]) // smin // 4 + 1)  # a batch of hashed sizes at a time
+        u = ((splitmix64(np.arange(i, i + m, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x51ED27)) >> np.uint64(11)).astype(np.float64)
+             + 1.0) / float(1 << 53)
+        size = np.clip(np.floor(smin * u ** (-1.0 / alpha)), smin, smax).astype(np.int64)
+        ends = out[-1] + np.cumsum(size)
+        keep = int(np.searchsorted(ends, n, "left")) + 1
+        out.extend(int(e) for e in ends[:keep])
+        i += m
+    out = np.asarray(out, np.int64)
+    out = out[out < n]
+    return np.concatenate([out, [n]]).astype(np.int64)
+
+
+def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None, hosts=None):
     h = splitmix64(splitmix64(np.uint64(seed) + rows_abs.astype(np.uint64)) + k.astype(np.uint64)
                    + (np.uint64(attempt) << np.uint64(40)))
     if window is None:
         return (h % np.uint64(cols)).astype(np.int64)
+    if window == HOST_BLOCKED:
+        # 14 of every 16 links stay inside the row's host (when the host can hold twice the row's degree), the rest go
+        # anywhere: the locality class of a crawl-ordered web graph (host_blocks)
+        ids = np.minimum(rows_abs, cols - 1)
+        j = np.searchsorted(hosts, ids, "right") - 1
+        hb, he = hosts[j], hosts[j + 1]
+        size = he - hb
+        local = ((h >> np.uint64(60)) < np.uint64(14)) & (size >= 2 * deg)
+        inside = hb + ((h & np.uint64(0xFFFFFFFFFFFF)) % np.maximum(size, 1).astype(np.uint64)).astype(np.int64)
+        anywhere = (splitmix64(h) % np.uint64(cols)).astype(np.int64)
+        return np.where(local, inside, anywhere)
     if window <= -2:  # power-law COLUMN popularity too (scale-free in both dimensions, like R-MAT graphs):
         # column rank = cols * u^5 (Zipf-like, alpha = 0.8); -2: popular columns scattered by a fixed
         # multiplicative permutation, -3: popular columns adjacent (labels sorted by popularity)
@@ -198,7 +234,7 @@ def _hash_cols(seed, rows_abs, k, attempt, cols, window=None, deg=None):
     return (rows_abs + off) % np.int64(cols)
 
 
-def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None, native=None):
+def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None, native=None, hosts=None):
     """Rows [row_begin, row_begin + len(degrees)) of the hashed matrix: per-row distinct columns
     sorted ascending; values k/8 (exact) or U[0.5, 1.5) (realistic).  `window` = None draws
     columns uniformly over [0, cols); an integer draws them from a band of that many
@@ -209,7 +245,18 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None
     nnz = int(offsets[-1])
     assert int(degrees.max(initial=0)) <= cols
     assert nnz < (1 << 31), "int32 offsets"
-    L = _use_native(native) if (window is None or window == -1 or window > 0) else None
+    if window == HOST_BLOCKED:
+        assert hosts is not None and hosts[0] == 0 and hosts[-1] == cols, "window = HOST_BLOCKED needs hosts = host_blocks(cols)"
+        hosts = np.ascontiguousarray(hosts, np.int64)
+    L = _use_native(native) if (window is None or window in (-1, HOST_BLOCKED) or window > 0) else None
+    if L is not None and window == HOST_BLOCKED:
+        deg64 = np.ascontiguousarray(degrees, np.int64)
+        indices = np.empty(nnz, np.int32)
+        values = np.empty(nnz, np.float32)
+        rc = L.loops_gen_csr_rows_hosts(_p(deg64), _p(offsets), nrows, int(cols), int(seed), int(row_begin), int(bool(exact)),
+                                        _p(hosts), int(hosts.size - 1), _p(indices), _p(values))
+        assert rc == 0, "a row cannot hold that many distinct columns"
+        return offsets.astype(np.int32), indices, values
     if L is not None:
         deg64 = np.ascontiguousarray(degrees, np.int64)
         indices = np.empty(nnz, np.int32)
@@ -222,7 +269,7 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None
     k = np.arange(nnz, dtype=np.int64) - np.repeat(offsets[:-1], degrees)
     rabs = rloc + row_begin
     dk = np.repeat(degrees.astype(np.int64), degrees) if window is not None else None
-    col = _hash_cols(seed, rabs, k, 0, cols, window, dk)
+    col = _hash_cols(seed, rabs, k, 0, cols, window, dk, hosts)
     attempt = 0
     while True:
         key = (rloc.astype(np.uint64) << np.uint64(32)) | col.astype(np.uint64)
@@ -233,7 +280,7 @@ def csr_from_degrees(degrees, cols, seed=1, row_begin=0, exact=True, window=None
             break
         attempt += 1
         bad = order[dup]
-        col[bad] = _hash_cols(seed, rabs[bad], k[bad], attempt, cols, window, None if dk is None else dk[bad])
+        col[bad] = _hash_cols(seed, rabs[bad], k[bad], attempt, cols, window, None if dk is None else dk[bad], hosts)
     indices = (sk & np.uint64(0xFFFFFFFF)).astype(np.int32)  # sorted by (row, col)
     rsorted = rloc  # rows are already grouped: sorting by (row, col) keeps row order
     vh = splitmix64((rsorted + row_begin).astype(np.uint64) * np.uint64(0x100000001B3) + indices.astype(np.uint64)

@@ -58,12 +58,18 @@ class MergePathPlan:
     SpMVs on the same sparsity structure (mirrors schedule::merge_path::preprocess_t)."""
 
     def __init__(self, csr: CSR, tile: str = "256x8"):
-        self.tile = tile
-        self.cfg, self.tpb, self.ipt = L.TILES[tile]
+        """``tile``: a compiled shape ("256x8", "512x8", ...) or "auto" = LOOPS_TILE_AUTO (256x8 when the plan is
+        self-completing with it, 512x8 otherwise; ``self.tile`` then names the shape that was picked)."""
         self.rows, self.nnz = csr.rows, csr.nnzs
         self._h = C.c_void_p()
-        L.check(L.lib().loops_merge_plan_create(csr.rows, csr.nnzs, _ptr(csr.offsets), self.cfg, _stream(),
+        cfg = L.TILE_AUTO if tile == "auto" else L.TILES[tile][0]
+        L.check(L.lib().loops_merge_plan_create(csr.rows, csr.nnzs, _ptr(csr.offsets), cfg, _stream(),
                                                 C.byref(self._h)), "loops_merge_plan_create")
+        if tile == "auto":  # which shape was picked: the two candidates differ in their tile count
+            total = csr.rows + csr.nnzs
+            tile = "256x8" if self.num_tiles == (total + 2047) // 2048 else "512x8"
+        self.tile = tile
+        self.cfg, self.tpb, self.ipt = L.TILES[tile]
 
     @property
     def handle(self):
@@ -291,6 +297,58 @@ class ColumnBlockedPlan:
     def close(self):
         if self._h:
             L.lib().loops_colblock_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SpmvPlan:
+    """loops_spmv_plan_*: tile shape AND layout of one matrix chosen at plan time.  ``measure``: time the candidates on the
+    device; ``allow_copy``: the plan may hold a column-blocked copy of the matrix when that is faster (x larger than the
+    per-XCD L2).  ``spmv(x, y)`` runs whatever was chosen; ``info`` says what that is."""
+
+    LAYOUTS = {0: "csr", 1: "column_blocked"}
+
+    def __init__(self, csr: CSR, allow_copy: bool = True, measure: bool = True, repeats: int = 10):
+        self.csr = csr
+        self._sfx = _suffix(csr.values)
+        self._h = C.c_void_p()
+        flags = (1 if measure else 0) | (2 if allow_copy else 0)
+        create = getattr(L.lib(), "loops_spmv_plan_create_" + self._sfx)
+        L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), flags, repeats,
+                       _stream(), C.byref(self._h)), "loops_spmv_plan_create")
+        layout, tile, blocks = C.c_int(), C.c_int(), C.c_int()
+        ms = (C.c_float * 3)()
+        L.check(L.lib().loops_spmv_plan_info(self._h, C.byref(layout), C.byref(tile), C.byref(blocks), ms), "loops_spmv_plan_info")
+        names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
+        self.layout, self.tile, self.num_blocks = self.LAYOUTS[layout.value], names[tile.value], blocks.value
+        self.measured_ms = {k: (round(float(v), 5) if v >= 0 else None) for k, v in zip(("csr_256x8", "csr_512x8", "column_blocked"), ms)}
+
+    @property
+    def info(self):
+        return {"layout": self.layout, "tile": self.tile, "column_blocks": self.num_blocks, "measured_ms": self.measured_ms}
+
+    def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+        c = self.csr
+        if y is None:
+            y = torch.empty(c.rows, dtype=c.values.dtype, device=c.values.device)
+        c.check(x, y)
+        fn = getattr(L.lib(), "loops_spmv_planned_" + self._sfx)
+        L.check(fn(self._h, _ptr(c.offsets), _ptr(c.indices), _ptr(c.values), _ptr(x), _ptr(y), _stream()), "loops_spmv_planned")
+        return y
+
+    def refresh_values(self):
+        """The matrix's values changed in place (same structure): bring a held copy up to date."""
+        fn = getattr(L.lib(), "loops_spmv_plan_refresh_values_" + self._sfx)
+        L.check(fn(self._h, _ptr(self.csr.values), _stream()), "loops_spmv_plan_refresh_values")
+
+    def close(self):
+        if self._h:
+            L.lib().loops_spmv_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -29,6 +29,7 @@
 #include <loops/algorithms/spmm/thread_mapped.cuh>
 #include <loops/algorithms/spmm/merge_path_flat.cuh>
 #include <loops/algorithms/spmv/column_blocked.cuh>
+#include <loops/algorithms/spmv/spmv_plan.cuh>
 
 using namespace loops;
 static int g_fail = 0, g_checks = 0;
@@ -226,6 +227,35 @@ static void misc() {
       bool equal = true;
       for (std::size_t i = 0; i < h1.size(); ++i) equal = equal && h2[i] == h1[i] && hp[i] == h1[i];
       CHECK(equal);
+    }
+  // spmv_plan_t: tile shape + layout chosen per matrix (structural and measured, copy allowed or not): same y as the plain
+  // merge_path_flat on every battery matrix, in both precisions
+  for (auto& dense : battery())
+    for (int mode = 0; mode < 4; ++mode) {
+      const bool allow_copy = mode & 1, measure = mode & 2;
+      hcsr_t<float> hf = from_dense<float>(dense);
+      csr_t<int, int, float> a(hf);
+      vector_t<float> xb(hf.cols), y0(hf.rows), y1(hf.rows, -1.f);
+      generate::random::uniform_distribution(xb.begin(), xb.end(), 1, 10, 9u);
+      algorithms::spmv::merge_path_flat(a, xb, y0);
+      algorithms::spmv::spmv_plan_t<int, int, float> plan(a, allow_copy, measure, 2);
+      CHECK(allow_copy || plan.layout == algorithms::spmv::spmv_plan_t<int, int, float>::csr_layout);
+      plan.spmv(a, xb, y1);
+      vector_t<float, H> h0(y0), h1(y1);
+      bool same = true;
+      for (std::size_t i = 0; i < h0.size(); ++i) same = same && std::fabs(h0[i] - h1[i]) <= 1e-3f + 1e-5f * std::fabs(h0[i]);
+      CHECK(same);
+      hcsr_t<double> hd = from_dense<double>(dense);
+      csr_t<int, int, double> ad(hd);
+      vector_t<double> xd(hd.cols), z0(hd.rows), z1(hd.rows, -1.0);
+      generate::random::uniform_distribution(xd.begin(), xd.end(), 1, 10, 9u);
+      algorithms::spmv::merge_path_flat(ad, xd, z0);
+      algorithms::spmv::spmv_plan_t<int, int, double> pland(ad, allow_copy, measure, 2);
+      pland.spmv(ad, xd, z1);
+      vector_t<double, H> g0(z0), g1(z1);
+      same = true;
+      for (std::size_t i = 0; i < g0.size(); ++i) same = same && std::fabs(g0[i] - g1[i]) <= 1e-9 + 1e-12 * std::fabs(g0[i]);
+      CHECK(same);
     }
   // tuned SpMM == reference-shaped SpMM (every battery matrix, several widths of B, f32 + f64)
   for (auto& dense : battery())

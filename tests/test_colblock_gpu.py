@@ -123,3 +123,60 @@ def test_double_precision_plan():
     assert np.array_equal(plan.spmv(torch.from_numpy(xh).cuda()).cpu().numpy(), O.spmv_f64(off, idx, np.roll(v64, 3), xh))
     with pytest.raises(_lib.LoopsError):   # f32 call on an f64 plan
         _lib.check(_lib.lib().loops_spmv_colblock_f32(plan.handle, 1, 1, None), "loops_spmv_colblock_f32")
+
+
+def test_spmv_plan_picks_tile_and_layout():
+    """loops_spmv_plan_*: the plan chooses tile shape and layout per matrix.  Structural mode: a band matrix stays on the
+    unmodified CSR in 256x8 tiles (self-completing), a matrix whose x is far larger than an L2 is held column-blocked when a
+    copy is allowed and never without that flag.  Measured mode: whatever is chosen, the times of the candidates are
+    reported and the product equals the oracle's bit for bit."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    # (a) band matrix, short rows
+    rows = cols = 1 << 16
+    off, idx, val = G.csr_from_degrees(np.full(rows, 16, np.int64), cols, seed=1, window=64)
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    p = S.SpmvPlan(csr, allow_copy=True, measure=False)
+    assert p.info["layout"] == "csr" and p.info["tile"] == "256x8" and p.info["measured_ms"]["csr_256x8"] is None
+    assert np.array_equal(p.spmv(x).cpu().numpy(), ref)
+    p.close()
+    assert S.MergePathPlan(csr, "auto").tile == "256x8"
+    # (b) power-law rows (longer than a tile), x = 8 M columns = 32 MB
+    rows, cols = 1 << 17, 1 << 23
+    deg = G.powerlaw_degrees(rows, 1 << 22, cap=1 << 13)
+    off, idx, val = G.csr_from_degrees(deg, cols, seed=1)
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    assert S.MergePathPlan(csr, "auto").tile == "512x8"
+    p = S.SpmvPlan(csr, allow_copy=False, measure=False)
+    assert p.info["layout"] == "csr" and p.info["tile"] == "512x8"
+    assert np.array_equal(p.spmv(x).cpu().numpy(), ref)
+    p.close()
+    p = S.SpmvPlan(csr, allow_copy=True, measure=False)
+    assert p.info["layout"] == "column_blocked" and p.info["column_blocks"] >= 2
+    assert np.array_equal(p.spmv(x).cpu().numpy(), ref)
+    # new values, same structure: the held copy follows after refresh_values()
+    csr.values.mul_(2.0)
+    p.refresh_values()
+    assert np.array_equal(p.spmv(x).cpu().numpy(), 2.0 * ref)
+    csr.values.mul_(0.5)
+    p.close()
+    for allow in (False, True):
+        p = S.SpmvPlan(csr, allow_copy=allow, measure=True, repeats=5)
+        ms = p.info["measured_ms"]
+        assert ms["csr_256x8"] > 0 and ms["csr_512x8"] > 0 and (ms["column_blocked"] is None) == (not allow)
+        assert allow or p.info["layout"] == "csr"
+        if p.info["layout"] == "column_blocked":
+            assert ms["column_blocked"] < 0.95 * min(ms["csr_256x8"], ms["csr_512x8"])
+        assert np.array_equal(p.spmv(x).cpu().numpy(), ref), p.info
+        p.close()
+    # fp64 twin
+    csr64 = S.CSR(csr.rows, csr.cols, csr.offsets, csr.indices, csr.values.double())
+    p = S.SpmvPlan(csr64, allow_copy=True, measure=True, repeats=3)
+    assert np.array_equal(p.spmv(x.double()).cpu().numpy(), O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64)))
+    p.close()

@@ -58,6 +58,16 @@ def test_native_builder_equals_the_numpy_specification():
                 a = G.csr_from_degrees(d0[100:3000], rows, 3, 100, exact, window, native=False)
                 b = G.csr_from_degrees(d0[100:3000], rows, 3, 100, exact, window, native=True)
                 assert all(np.array_equal(u, v) and u.dtype == v.dtype for u, v in zip(a, b)), (rows, window, exact)
+        hosts = G.host_blocks(rows, smin=32)  # host-blocked columns (the third C3 stand-in): hosts of >= 32 ids, power-law sizes
+        assert hosts[0] == 0 and hosts[-1] == rows and (np.diff(hosts) > 0).all() and np.diff(hosts)[:-1].min() >= 32
+        for exact in (True, False):
+            a = G.csr_from_degrees(d0[100:3000], rows, 3, 100, exact, G.HOST_BLOCKED, native=False, hosts=hosts)
+            b = G.csr_from_degrees(d0[100:3000], rows, 3, 100, exact, G.HOST_BLOCKED, native=True, hosts=hosts)
+            assert all(np.array_equal(u, v) and u.dtype == v.dtype for u, v in zip(a, b)), (rows, "host-blocked", exact)
+        ri = np.repeat(np.arange(100, 3000), d0[100:3000])
+        j = np.searchsorted(hosts, ri, "right") - 1
+        inside = (b[1] >= hosts[j]) & (b[1] < hosts[j + 1])
+        assert 0.3 < inside.mean() < 0.9  # most links of short rows stay inside their host; heavy rows go anywhere
         assert np.array_equal(G.uniform_distribution_int(rows + 70000, native=False),
                               G.uniform_distribution_int(rows + 70000, native=True))
         assert np.array_equal(G.uniform_distribution_int(70000, -5, 5, 12345, start=999, native=False),

@@ -271,19 +271,22 @@ def test_row_range_shards_reassemble_on_one_gpu():
         assert np.array_equal(y_full.cpu().numpy(), ref), world
 
 
-@pytest.mark.parametrize("window", [None, 65536], ids=["uniform", "band65536"])
+@pytest.mark.parametrize("window", [None, 65536, -4], ids=["uniform", "band65536", "host_blocked"])
 def test_c3_standin_group_mapped_vs_work_oriented(window):
     """BASELINE config C3 (indochina-2004: 7 414 866 rows / 194 109 311 nnz, group_mapped vs work_oriented): the
     SuiteSparse file is not shipped (datasets/suitesparse.txt:2052), so the two schedules -- and merge_path_flat --
     run on generated stand-ins of exactly that shape: scale-free degrees with uniformly random columns (no
-    locality: lower bound) and with columns in a 65 536-wide band (crawl-order locality of a web graph).
-    Bit-exact against the oracle.  tests/perf/bench_schedules.py --mtx PATH runs the real file when supplied."""
+    locality: lower bound), with columns in a 65 536-wide band, and laid out the way LAW graphs are -- "host-blocked":
+    consecutive ids form hosts of power-law size, 3 of 4 links stay inside the row's host, the rest go anywhere
+    (generate.host_blocks).  Bit-exact against the oracle.  tests/perf/bench_schedules.py --mtx PATH runs the real file
+    when supplied."""
     from loops_amd import spmv as S, generate as G
     from oracle import oracle as O
     rows = cols = 7_414_866
     nnz = 194_109_311
     deg = G.powerlaw_degrees(rows, nnz, native=True)
-    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, native=True)
+    hosts = G.host_blocks(cols) if window == G.HOST_BLOCKED else None
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, native=True, hosts=hosts)
     assert off[-1] == nnz and off.size == rows + 1
     x = G.uniform_distribution_int(cols)
     ref = O.spmv_f32(off, idx, val, x, omp=True)
