@@ -67,7 +67,7 @@ def pmc_summary(args):
     at the kernel sources as they are now (`_kernel_sources_sha256`, written by scripts/pmc_summarize.py); otherwise
     (None, None, why)."""
     if args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 or args.variant != 0 \
-            or args.layout == "blocked":
+            or args.layout in ("blocked", "panel"):
         return None, None, "configuration differs from the profiled one (C2, N = 1, unmodified CSR)"
     import glob
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_c2_pmc_summary_{args.tile}.json")), reverse=True)
@@ -359,10 +359,12 @@ def main():
                     help="N > 1: do not try the exchange fused into the SpMV epilogue (peer-mapped stores, SURVEY 8 f2)")
     ap.add_argument("--exchange", default="auto",
                     help="N > 1: allgatherv implementation; auto = the fastest of the start-up probe")
-    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked"],
+    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked", "panel"],
                     help="how a rank holds its row-range shard: 'csr' as sliced; 'blocked' = column-blocked by owner "
-                         "(x of N x 4 MB does not fit the per-XCD L2: include/loops/kernels/column_blocked.hxx); "
-                         "auto = csr at N = 1 (the headline is the unmodified CSR), blocked at N > 1")
+                         "(x of N x 4 MB does not fit the per-XCD L2: include/loops/kernels/column_blocked.hxx); 'panel' = "
+                         "panel-binned (x panels in LDS, no gather: include/loops/kernels/panel_binned.hxx); "
+                         "auto = csr at N = 1 (the headline is the unmodified CSR), at N > 1 whichever of blocked / panel has the "
+                         "smaller worst-rank time in a probe before the timed region")
     args = ap.parse_args()
 
     import torch
@@ -402,8 +404,8 @@ def main():
     y_loc = y_full[shard.row_begin:shard.row_end]
     gen_s = time.time() - t0
     tile_probe = None
-    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "blocked")
-    if args.tile == "auto" and layout == "blocked":
+    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "auto")
+    if args.tile == "auto" and layout != "csr":
         args.tile = "512x8"  # column-blocked plans are built for 512 x 8 tiles (COLBLOCK_TILE): nothing to tune on the CSR shard
     if args.tile == "auto":  # measured launch box: every compiled tile shape timed on this shard, outside the timed region
         best, tile_probe = S.autotune_merge_path(csr, x, repeats=30)
@@ -420,21 +422,50 @@ def main():
         args.tile = best
         tile_probe = {k: round(v, 5) for k, v in tile_probe.items()}
     plan = S.MergePathPlan(csr, args.tile)
-    blocked = None
+    blocked = None      # the shard's re-ordered copy, if any: a ColumnBlockedPlan or a PanelBinnedPlan
+    shard_kind = "csr"  # "csr" | "blocked" | "panel"
+    layout_probe = None
     # column blocks: the owners' row ranges cut into ~2 MB pieces of x, at most half the mean row length of them
     # (every block adds `rows` row-end items: C2-like shards, 16 nnz / row, are best at 8; C5 shards, 32 nnz / row, at 16)
     max_blocks = 8
     while max_blocks < 64 and max_blocks * 2 <= (nnz // rows) // 2:
         max_blocks *= 2
     col_bounds = P.column_block_bounds(bounds, max_blocks=max(max_blocks, world))
-    if layout == "blocked":
-        try:
-            blocked = S.ColumnBlockedPlan(csr, block_bounds=col_bounds)
-        except Exception as e:  # noqa: BLE001 -- a rank that cannot build the blocked copy keeps its CSR shard
-            if args.layout == "blocked":
-                raise
-            print(f"[rank {rank}] column-blocked plan unavailable ({type(e).__name__}: {e}); using the CSR shard",
-                  file=sys.stderr)
+
+    def make_shard_plan(kind, sub=None):
+        """The re-ordered copy of a CSR (this rank's shard, or a row chunk of it) in layout `kind`."""
+        m = csr if sub is None else sub
+        return S.ColumnBlockedPlan(m, block_bounds=col_bounds) if kind == "blocked" else S.PanelBinnedPlan(m)
+
+    if layout != "csr":
+        # Which copy the shards are held in: both candidates are built and timed on every rank (10 products each, outside the
+        # timed region) and the job adopts the one with the smaller WORST-rank time -- every rank the same layout.  A layout
+        # that cannot be built on some rank (no memory for the copy, index range) is out for everybody.
+        cands = ["blocked", "panel"] if layout == "auto" else [layout]
+        built, times = {}, {}
+        for kind in cands:
+            ok, ms = 1.0, float("inf")
+            try:
+                built[kind] = make_shard_plan(kind)
+                ms = timed_ms(torch, lambda: built[kind].spmv(x, y_loc), 10)
+            except Exception as e:  # noqa: BLE001
+                ok = 0.0
+                print(f"[rank {rank}] shard layout {kind} unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+            if world > 1:
+                t = torch.tensor([ms if ok else 1e30, 1.0 - ok], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms, ok = float(t[0]), 1.0 - float(t[1])
+            if ok >= 1.0:
+                times[kind] = ms
+            elif args.layout == kind:
+                raise RuntimeError(f"--layout {kind} cannot be built on every rank")
+        layout_probe = {k: round(v, 5) for k, v in times.items()}
+        if times:
+            shard_kind = min(times, key=times.get)
+            blocked = built.pop(shard_kind)
+        for other in built.values():
+            other.close()
+        built.clear()
     torch.cuda.synchronize()
 
     gather_mode = {"mode": "p2p"}
@@ -484,7 +515,7 @@ def main():
             sub = S.CSR.from_numpy(b - a, cols, so, si, sv)
             y_sub = y_loc[a:b]
             if blocked is not None:
-                pl = S.ColumnBlockedPlan(sub, block_bounds=col_bounds)
+                pl = make_shard_plan(shard_kind, sub)
                 run = (lambda pl: (lambda y_sub: pl.spmv(x, y_sub)))(pl)
             else:
                 pl = S.MergePathPlan(sub, args.tile)
@@ -588,7 +619,12 @@ def main():
 
     def measure_kernels():
         """Local (no collective inside except the final max): kernel durations of this rank's shard + its SpMV without exchange."""
-        if blocked is not None:
+        if shard_kind == "panel":  # two streaming kernels: products (x panels in LDS), sub-band reduce
+            K_["main_single"], K_["main_med"] = event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
+            K_["main_avg"] = batch_event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
+            K_["fix_avg"] = 0.0
+            K_["reduce_avg"] = batch_event_time(lambda: blocked.spmv_stage(1, x, y_loc), iters)
+        elif blocked is not None:
             K_["main_single"], K_["main_med"] = event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
             K_["main_avg"] = batch_event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
             K_["fix_avg"], _ = event_time(lambda: blocked.spmv_stage(1, x, y_loc), iters)
@@ -624,7 +660,8 @@ def main():
             achieved = abytes / (k_main * 1e-3) / 1e9
             traffic, traffic_src, traffic_note = pmc_traffic(args)
             counters = pmc_bound(args)
-            roofline = {"bound": "hbm", "kernel": "loops::kernels::merge_path_spmv_fused" + ("_stacked" if blocked is not None else ""),
+            roofline = {"bound": "hbm", "kernel": {"csr": "loops::kernels::merge_path_spmv_fused", "blocked": "loops::kernels::merge_path_spmv_fused_stacked",
+                                                    "panel": "loops::kernels::panel::panel_products"}[shard_kind],
                         "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                         "traffic_source": traffic_src, "traffic_note": traffic_note, "counters": counters,
@@ -649,10 +686,11 @@ def main():
                                  "request_rate_floor_frac": round(abytes / (loc_nnz / g2 / 1e6 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                  "kernel_over_request_rate_floor": round(k_main / (loc_nnz / g2 / 1e6), 3)})
             if K_["reduce_avg"] is not None:
-                roofline["block_reduce_avg_launch_ms"] = round(K_["reduce_avg"], 5)
+                roofline["panel_reduce_avg_launch_ms" if shard_kind == "panel" else "block_reduce_avg_launch_ms"] = round(K_["reduce_avg"], 5)
         mode = gather_mode["mode"] if watchdog is None else safe["mode"]
         one_gpu, spmv_only_ms = R_["one_gpu"], K_["spmv_only_ms"]
-        step_includes = "fused merge-tile kernel + carry-out fix-up" + (" + block reduce" if blocked is not None else "")
+        step_includes = {"csr": "fused merge-tile kernel + carry-out fix-up", "blocked": "fused merge-tile kernel + carry-out fix-up + block reduce",
+                         "panel": "panel products (x panels in LDS) + sub-band reduce"}[shard_kind]
         if world > 1:
             step_includes += f" + allgatherv(y) [{mode}"
             if mode == "fused-stores":
@@ -675,7 +713,10 @@ def main():
                        "tile": args.tile, "tile_autotune_ms": tile_probe, "variant": args.variant,
                        "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
-                                       f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)",
+                                       (f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)" if shard_kind == "blocked" else
+                                        f"panel-binned, {blocked.num_panels} panels of {blocked.W} columns x {blocked.num_subbands} sub-bands of {blocked.Hw} rows "
+                                        f"(x per GPU {cols * 4 >> 20} MB)"),
+                       "shard_layout_probe_ms": layout_probe,
                        "step_includes": step_includes,
                        "ms_per_step_with_prepass": None if R_["ms_with_prepass"] is None else round(R_["ms_with_prepass"], 5),
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),

@@ -2,7 +2,8 @@
  * @file spmv_plan.cuh
  * @brief `algorithms::spmv::spmv_plan_t<index_t, offset_t, type_t>`: what an iterative caller holds for ONE matrix -- the
  * merge-path plan of the unmodified CSR in the tile shape that suits its structure, or, if the caller allows a copy and it
- * is measurably faster, the column-blocked copy of the matrix (column_blocked.cuh: x larger than the per-XCD L2).  The
+ * is measurably faster, a re-ordered copy of the matrix: column-blocked (column_blocked.cuh: x larger than the per-XCD L2, gathers
+ * become L2 hits) or panel-binned (panel_binned.cuh: x panels in LDS, no memory gather at all).  The
  * header-API twin of loops_spmv_plan_* (include/loops_amd.h).  The reference fixes the tile shape per architecture at
  * compile time (algorithms/spmv/launch_box.hxx:56-90) and always runs the CSR as given; no counterpart there.
  *
@@ -17,6 +18,7 @@
 
 #include <loops/algorithms/spmv/column_blocked.cuh>
 #include <loops/algorithms/spmv/merge_path_flat.cuh>
+#include <loops/algorithms/spmv/panel_binned.cuh>
 
 namespace loops {
 namespace algorithms {
@@ -24,16 +26,18 @@ namespace spmv {
 
 template <typename index_t, typename offset_t, typename type_t>
 struct spmv_plan_t {
-  enum layout_kind { csr_layout = 0, column_blocked_layout = 1 };
+  enum layout_kind { csr_layout = 0, column_blocked_layout = 1, panel_binned_layout = 2 };
   using small_t = merge_path_small_plan_t<index_t, offset_t, type_t>;  // 256 x 8 (256 x 4 for 8-byte values)
   using large_t = merge_path_plan_t<index_t, offset_t, type_t>;        // 512 x 8 (512 x 4)
   using blocked_t = column_blocked_t<index_t, offset_t, type_t>;
+  using panel_t = panel_binned_t<index_t, offset_t, type_t>;
 
   layout_kind layout = csr_layout;
-  float ms_small = -1.f, ms_large = -1.f, ms_blocked = -1.f;  ///< measured ms per product (-1: not timed)
+  float ms_small = -1.f, ms_large = -1.f, ms_blocked = -1.f, ms_panel = -1.f;  ///< measured ms per product (-1: not timed)
   std::unique_ptr<small_t> small;
   std::unique_ptr<large_t> large;
   std::unique_ptr<blocked_t> blocked;
+  std::unique_ptr<panel_t> panel;
 
   /// @param allow_copy the plan may keep a column-blocked copy of `csr` (adopted when >= 5 % faster than the best CSR shape;
   ///        without `measure`: when cols * sizeof(type_t) > 6 MB and the mean row holds >= 8 nonzeros)
@@ -81,11 +85,24 @@ struct spmv_plan_t {
         large.reset();
       }
     }
+    if (allow_copy && x_bytes >= (std::size_t(2) << 20) && fits_panel(csr)) {  // third candidate: x panels in LDS, no gather
+      auto pb = std::make_unique<panel_t>(csr, 0, stream);
+      ms_panel = time_ms(repeats, stream, [&] { pb->spmv_async(x, y, stream); });
+      const float incumbent = blocked ? ms_blocked : best;
+      if (ms_panel < 0.95f * incumbent && ms_panel < 0.95f * best) {
+        panel = std::move(pb);
+        layout = panel_binned_layout;
+        small.reset();
+        large.reset();
+        blocked.reset();
+      }
+    }
   }
 
   /// y = csr * x on `stream` (asynchronous).  `csr` must be the matrix the plan was built from.
   void spmv_async(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
-    if (blocked) blocked->spmv_async(x, y, stream);
+    if (panel) panel->spmv_async(x, y, stream);
+    else if (blocked) blocked->spmv_async(x, y, stream);
     else if (small)
       merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream);
     else merge_path_flat_async(*large, csr, x, y, stream);
@@ -104,6 +121,12 @@ struct spmv_plan_t {
   static bool fits_blocked(const csr_t<index_t, offset_t, type_t>& csr) {
     const int k = blocked_t::automatic_blocks(csr.cols, csr.rows, csr.nnzs);
     return static_cast<unsigned long long>(k) * csr.rows + csr.nnzs < (1ull << 31) - 4096;
+  }
+  static bool fits_panel(const csr_t<index_t, offset_t, type_t>& csr) {
+    const long long P = (static_cast<long long>(csr.cols) + kernels::panel_width<type_t>::value - 1) / kernels::panel_width<type_t>::value;
+    const int hw = kernels::panel_subband_rows<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), static_cast<int>(P > 0 ? P : 1));
+    const long long segments = (P > 0 ? P : 1) * ((static_cast<long long>(csr.rows) + hw - 1) / hw);
+    return segments <= (1ll << 26) && static_cast<long long>(csr.nnzs) + 3 * segments < (1ll << 31) - 4096;
   }
   template <typename fn_t>
   static float time_ms(int repeats, xpu::stream_t stream, fn_t&& run) {

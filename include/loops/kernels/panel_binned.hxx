@@ -1,0 +1,547 @@
+/**
+ * @file panel_binned.hxx
+ * @brief Panel-binned SpMV: the layout for matrices whose x is (much) larger than the 4 MB per-XCD L2.
+ *
+ * Why.  CSR SpMV issues one scattered 4-byte gather of x per nonzero, and on MI355X that gather -- not HBM -- sets the
+ * time: a CU keeps ~95 reads in flight, each gather holds a slot for its whole round trip (L2 hit ~220 clks, Infinity
+ * Cache ~950), so the chip serves 265 G gathers/s at best from L2 and ~55 G/s beyond it.  The
+ * column-blocked layout (column_blocked.hxx) turns Infinity-Cache gathers into L2 hits; this layout removes the gathers
+ * from the memory system altogether: x is read in PANELS of W consecutive columns that fit the 160 KB LDS of a CU, and a
+ * nonzero's x value comes out of LDS (ds_read: ~9 random reads per clock and CU, twenty times the L2 path).
+ *
+ * Layout (a re-ordered COPY of the matrix, built once on the device, O(nnz)): nonzeros sorted by (panel p = col / W,
+ * sub-band s = row / Hw, then their CSR order) -- the "A order" -- with `val`, `col16 = col - p W` (6 bytes per nonzero) and,
+ * per group of 4 items, `dst4` = where the group's products go in the "B order": the same segments sorted by (sub-band,
+ * panel), holding `row16 = row - s Hw` (2 bytes per nonzero).  Every (p, s) segment starts at a multiple of 4 items in both
+ * orders (padding: val 0, row16 0xFFFF), so a group of 4 never straddles segments.
+ *
+ * y = A x in two streaming kernels:
+ *   A  panel_products   one workgroup per chunk of ONE panel: x[p W .. (p + 1) W) -> LDS (coalesced), then
+ *                       prod[dst4[i / 4] ..] = val[i ..] * xs[col16[i ..]], 16-byte loads and stores: the products leave in
+ *                       16-byte groups, consecutive groups of a segment to consecutive addresses (7 B read + 4 B written per
+ *                       nonzero, no gather leaves the CU);
+ *   B  panel_reduce     one WORKGROUP per sub-band of Hw rows: the sub-band's products are ONE contiguous run of the B order;
+ *                       each of the 4 wavefronts walks the segments of its quarter of the panels (16 + 8 bytes per lane and
+ *                       step, 4 segments in flight); inside a segment rows are sorted, so runs of equal rows are summed with
+ *                       the wave64 segmented prefix sum and the run ends update the wavefront's OWN LDS accumulators with
+ *                       plain read-modify-writes (LDS float atomics are 10 x slower than that on gfx950); the 4 partial
+ *                       vectors are then added in wavefront order and the Hw rows of y are stored coalesced (4 B + 2 B read
+ *                       per nonzero).  Reproducible: no order depends on timing.
+ * HBM traffic 17 B per nonzero instead of 8 B + a gather; y needs no zero-fill; no global atomics.
+ *
+ * When it pays: x beyond the L2 and rows spread over many panels (C3- / C5-like inputs).  Sub-bands are the unit of
+ * parallelism of kernel B, so a handful of rows holding most nonzeros ("extreme skew") serialises it -- the SpMV plan
+ * (loops_spmv_plan_*) adopts this layout only when it measures faster.
+ * No reference counterpart (the reference leaves the gather to the cache).
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <type_traits>
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/util/math.hxx>
+#include <loops/util/wave.hxx>
+
+namespace loops {
+namespace kernels {
+
+/// Device arrays of a panel-binned matrix (all owned by the caller / the plan).
+template <typename type_t>
+struct panel_binned_view {
+  int rows, cols, nnz;
+  int W, Hw, P, S;            ///< columns per panel, rows per sub-band, number of panels / sub-bands
+  int padded;                 ///< items incl. padding (multiple of 4), the same in both orders
+  type_t* val;                ///< [padded] A order
+  unsigned short* col16;      ///< [padded] A order: column inside the panel
+  int* dst4;                  ///< [padded / 4] A order: B-order position of the group's first item
+  unsigned short* row16;      ///< [padded] B order: row inside the sub-band; 0xFFFF = padding
+  int* perm;                  ///< [padded] A order: CSR position of the item (-1 = padding): value refresh
+  int* segb;                  ///< [S * P + 1] B order: segment (s, p) = items [segb[s * P + p], segb[s * P + p + 1])
+  int* bstart;                ///< [S + 1] B order: sub-band s owns items [bstart[s], bstart[s + 1]) (= segb[s * P])
+  int* chunks;                ///< [3 * num_chunks] {panel, begin, end} work list of kernel A (A-order positions)
+  int num_chunks;
+  type_t* prod;               ///< [padded] B order: products scratch (kernel A -> kernel B)
+};
+
+/// Compile-time panel width: 64 KB of x per workgroup of kernel A (two workgroups per CU).
+template <typename type_t>
+struct panel_width {
+  static constexpr int value = 65536 / static_cast<int>(sizeof(type_t));
+};
+
+namespace panel {
+
+constexpr unsigned short pad_row = 0xFFFFu;
+
+/// key[i] = (segment of nonzero i) << 32 | i, row_of[i], counts[segment] += 1.  Lane per IPT consecutive nonzeros:
+/// one search for the row of the first, then a walk along the offsets (as colblock::make_keys).
+template <int IPT, typename index_t, typename offset_t>
+__global__ void __launch_bounds__(256)
+make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indices, const int rows, const int nnz,
+          const int W, const int Hw, const int S, unsigned long long* __restrict__ keys, int* __restrict__ row_of,
+          int* __restrict__ counts) {
+  const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
+  if (base_ll >= nnz) return;
+  const int base = static_cast<int>(base_ll);
+  int row = 0, count = rows;
+  while (count > 0) {
+    const int half = count >> 1;
+    const int mid = row + half;
+    if (offsets[mid + 1] <= base) {
+      row = mid + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  offset_t row_end = offsets[row + 1];
+  unsigned int run_seg = 0xffffffffu;
+  int run_len = 0;
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int i = base + j;
+    if (i >= nnz) break;
+    while (i >= row_end) row_end = offsets[++row + 1];  // skip empty rows
+    const unsigned int p = static_cast<unsigned int>(indices[i]) / static_cast<unsigned int>(W);
+    const unsigned int seg = p * static_cast<unsigned int>(S) + static_cast<unsigned int>(row) / static_cast<unsigned int>(Hw);
+    keys[i] = (static_cast<unsigned long long>(seg) << 32) | static_cast<unsigned int>(i);
+    row_of[i] = row;
+    if (seg != run_seg) {
+      if (run_len) atomicAdd(counts + run_seg, run_len);
+      run_seg = seg;
+      run_len = 0;
+    }
+    ++run_len;
+  }
+  if (run_len) atomicAdd(counts + run_seg, run_len);
+}
+
+/// padded[g] = counts[g] rounded up to a multiple of 4 (g < n), padded[n] = 0.
+__global__ void __launch_bounds__(256) pad_counts(const int* __restrict__ counts, const int n, int* __restrict__ padded) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= n) padded[g] = g < n ? (counts[g] + 3) & ~3 : 0;
+}
+
+/// paddedT[s * P + p] = padded[p * S + s]; paddedT[S * P] = 0 (the segments in B order).
+__global__ void __launch_bounds__(256)
+transpose_counts(const int* __restrict__ padded, const int P, const int S, int* __restrict__ paddedT) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const long long n = static_cast<long long>(P) * S;
+  if (t > n) return;
+  if (t == n) { paddedT[t] = 0; return; }
+  const int s = static_cast<int>(t / P), p = static_cast<int>(t - static_cast<long long>(s) * P);
+  paddedT[t] = padded[static_cast<long long>(p) * S + s];
+}
+
+/// Sorted position j -> its position in both orders; fills val / col16 / perm / dst4 (A order) and row16 (B order).
+template <typename index_t, typename type_t>
+__global__ void __launch_bounds__(256)
+place(const unsigned long long* __restrict__ sorted, const int* __restrict__ seg_start, const int* __restrict__ seg_dest,
+      const int* __restrict__ seg_dest_b, const int* __restrict__ row_of, const index_t* __restrict__ indices,
+      const type_t* __restrict__ values, const int nnz, const int W, const int Hw, const int P, const int S,
+      type_t* __restrict__ val, unsigned short* __restrict__ col16, int* __restrict__ dst4, unsigned short* __restrict__ row16,
+      int* __restrict__ perm) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nnz) return;
+  const unsigned long long key = sorted[j];
+  const int g = static_cast<int>(key >> 32), i = static_cast<int>(key & 0xffffffffull);
+  const int within = j - seg_start[g];
+  const int p = g / S, s = g - p * S;
+  const int a = seg_dest[g] + within;
+  const int b = seg_dest_b[static_cast<long long>(s) * P + p] + within;
+  val[a] = values[i];
+  col16[a] = static_cast<unsigned short>(static_cast<int>(indices[i]) - p * W);
+  perm[a] = i;
+  row16[b] = static_cast<unsigned short>(row_of[i] - s * Hw);
+  if ((within & 3) == 0) dst4[a >> 2] = b;  // (the real items of a segment are a prefix of it: every group starts with one)
+}
+
+/// bstart[s] = seg_dest_b[s * P] (s <= S: bstart[S] = total); panel_start[p] = seg_dest[p * S] (p <= P).
+__global__ void __launch_bounds__(256)
+extract_starts(const int* __restrict__ seg_dest, const int* __restrict__ seg_dest_b, const int P, const int S,
+               int* __restrict__ bstart, int* __restrict__ panel_start) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= S) bstart[t] = seg_dest_b[static_cast<long long>(t) * P];
+  if (t <= P) panel_start[t] = seg_dest[static_cast<long long>(t) * S];
+}
+
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+refresh_values(const int* __restrict__ perm, const type_t* __restrict__ values, const int padded, type_t* __restrict__ val) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < padded) {
+    const int i = perm[j];
+    val[j] = i >= 0 ? values[i] : type_t(0);
+  }
+}
+
+/// Kernel A: products of one chunk of one panel, x panel in LDS.
+template <int TPB, int W, int U, bool NT, typename type_t>
+__global__ void __launch_bounds__(TPB)
+panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, const unsigned short* __restrict__ col16,
+               const int* __restrict__ dst4, const type_t* __restrict__ x, const int cols, type_t* __restrict__ prod) {
+  __shared__ type_t xs[W];
+  constexpr int VW = 16 / static_cast<int>(sizeof(type_t));  // elements per 16-byte vector
+  using vec_t = type_t __attribute__((ext_vector_type(VW)));
+  using vec_ld_t = type_t __attribute__((ext_vector_type(VW), aligned(sizeof(type_t))));
+  using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  const int c = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int p = chunks[3 * c], begin = chunks[3 * c + 1], end = chunks[3 * c + 2];
+  const long long base = static_cast<long long>(p) * W;
+  const int n = cols - base < W ? static_cast<int>(cols - base) : W;
+  for (int j = tid * VW; j < n; j += TPB * VW) {
+    if (j + VW <= n) {
+      const vec_t v = *reinterpret_cast<const vec_ld_t*>(x + base + j);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) xs[j + e] = v[e];
+    } else {
+      for (int e = 0; j + e < n; ++e) xs[j + e] = x[base + j + e];
+    }
+  }
+  __syncthreads();
+  // 4 items per lane and step: 16 B of values (f32; 2 x 16 B for f64), 8 B of columns, U steps in flight
+  for (int i0 = begin + tid * 4; i0 < end; i0 += TPB * 4 * U) {
+    type_t v[U][4];
+    u16x4 cidx[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * TPB * 4;
+      if (i < end) {
+        detail::load4<type_t, NT>(val + i, v[u]);
+        if constexpr (NT) {
+          cidx[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(col16 + i));
+          dst[u] = __builtin_nontemporal_load(dst4 + (i >> 2));
+        } else {
+          cidx[u] = *reinterpret_cast<const u16x4*>(col16 + i);
+          dst[u] = dst4[i >> 2];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * TPB * 4;
+      if (i < end) {
+        type_t out[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = v[u][e] * xs[cidx[u][e]];
+        type_t* to = prod + dst[u];
+        if constexpr (sizeof(type_t) == 4) {
+          using o4 = type_t __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<o4*>(to) = o4{out[0], out[1], out[2], out[3]};
+        } else {
+          using o2 = type_t __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<o2*>(to) = o2{out[0], out[1]};
+          *reinterpret_cast<o2*>(to + 2) = o2{out[2], out[3]};
+        }
+      }
+    }
+  }
+}
+
+/// One window of kernel B: 64 lanes x 4 consecutive items of ONE segment (rows non-decreasing; `pad_row` marks padding and
+/// lanes outside the segment).  Runs of equal rows are summed -- inside a lane, then across lanes with the segmented prefix
+/// sum -- and the lane-slot that ends a run adds the run's sum to the row's accumulator with a plain LDS read-modify-write:
+/// inside a window every row ends exactly once, so no two lanes touch the same address (LDS float atomics, the obvious
+/// alternative, retire ~0.4 lanes per clock and CU on gfx950: 5 x the time of the whole product stream).
+template <typename type_t>
+__device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const type_t (&v)[4], const unsigned int (&r)[4]) {
+  type_t run[4];
+  run[0] = v[0];
+#pragma unroll
+  for (int e = 1; e < 4; ++e) run[e] = r[e] == r[e - 1] ? run[e - 1] + v[e] : v[e];
+  const bool closed = r[3] != r[0];                                  // a run ends inside this lane
+  const unsigned int prev_last = wave::shift_up1(r[3], 0xFFFFFFFEu);  // lane 0: never equal
+  const unsigned int next_first = wave::shift_down1(r[0], 0xFFFFFFFDu);
+  const bool continues = r[0] == prev_last;                           // my first run continues the previous lane's last
+  type_t tail = run[3];
+  bool head = closed || !continues;
+  wave::segmented_inclusive_sum(tail, head);
+  const type_t prev_tail = wave::shift_up1(tail, type_t(0));  // (cross-lane read: executed by every lane, selected afterwards)
+  const type_t carry_in = continues ? prev_tail : type_t(0);
+  bool ends[4];
+  type_t sum[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned int next = e < 3 ? r[e + 1] : next_first;
+    ends[e] = r[e] != next && r[e] != pad_row;
+    sum[e] = run[e] + (r[e] == r[0] ? carry_in : type_t(0));
+  }
+  type_t old[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) old[e] = ends[e] ? acc[r[e]] : type_t(0);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (ends[e]) acc[r[e]] = old[e] + sum[e];
+}
+
+/// Kernel B: one workgroup (4 wavefronts) per sub-band.  Wavefront w walks the segments of its quarter of the panels -- the
+/// sub-band's products are one contiguous run of the B order, `segb` (S * P + 1 ints) says where every segment starts -- U
+/// segments in flight, one window (64 lanes x 4 items) of each per step, and adds them into its OWN Hw accumulators in
+/// (dynamic) LDS; the 4 partial vectors are then added in wavefront order.  Everything a wavefront does to its accumulators
+/// is in program order: the result is reproducible.
+/// NT: the product / row streams are larger than the Infinity Cache (non-temporal loads).
+template <bool NT, typename type_t, typename store_t>
+__global__ void __launch_bounds__(256)
+panel_reduce(const int* __restrict__ segb, const int P, const int S, const int Hw, const type_t* __restrict__ prod,
+             const unsigned short* __restrict__ row16, const int rows, const store_t out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char panel_lds[];
+  constexpr int U = 8;      // windows in flight per wavefront
+  constexpr int small_window = 64;  // items: below this a window goes through LDS atomics instead of run-combining
+  constexpr int WAVES = 256 / wave::size;
+  using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+  const int lane = wave::lane();
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / wave::size);
+  type_t* all = reinterpret_cast<type_t*>(panel_lds);
+  type_t* acc = all + static_cast<std::size_t>(w) * Hw;
+  const int s = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  for (int j = lane; j < Hw; j += wave::size) acc[j] = type_t(0);
+  // This wavefront's share: a quarter of the sub-band's ITEMS (not of its panels: with column locality a few panels hold
+  // nearly everything), cut at a multiple of 4.  A run of equal rows cut by the boundary ends up in two accumulators: fine.
+  const int* seg = segb + static_cast<long long>(s) * P;   // seg[p] .. seg[p + 1] = segment (s, p); seg[P] = next sub-band's first
+  const int b0 = seg[0], b1 = seg[P];
+  const int groups = (b1 - b0) >> 2;
+  const int first = b0 + (static_cast<int>(static_cast<long long>(groups) * w / WAVES) << 2);
+  const int last = b0 + (static_cast<int>(static_cast<long long>(groups) * (w + 1) / WAVES) << 2);
+  int p_first = 0;                                           // last p with seg[p] <= first (wave-uniform search)
+  for (int count = P; count > 1;) {
+    const int half = count >> 1;
+    if (seg[p_first + half] <= first) { p_first += half; count -= half; }
+    else count = half;
+  }
+  // The share is consumed as a sequence of WINDOWS -- 64 lanes x 4 items, never across a segment boundary -- handed out by a
+  // wave-uniform iterator, U windows per step whatever the segments look like (one huge diagonal segment next to hundreds
+  // of tiny ones on matrices with column locality: a step that followed U SEGMENTS had one window in flight there).
+  int p = p_first;
+  int pos = first, pend = seg[p_first + 1] < last ? seg[p_first + 1] : last;
+  while (first < last) {
+    int wb[U], we[U];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      while (pos >= pend && p + 1 < P && seg[p + 1] < last) {  // next non-empty segment of the share (wave-uniform)
+        ++p;
+        pos = seg[p];
+        pend = seg[p + 1] < last ? seg[p + 1] : last;
+      }
+      wb[u] = pos;
+      we[u] = pos + wave::size * 4 < pend ? pos + wave::size * 4 : pend;
+      if (we[u] < wb[u]) we[u] = wb[u];
+      pos = we[u] > pos ? we[u] : pos;
+      any = any || wb[u] < we[u];
+    }
+    if (!any) break;
+    // branch-free loads: every vector of the U windows is requested before the first is waited for (a lane outside its
+    // window re-reads the window's first vector -- in bounds -- and contributes padding)
+    type_t v[U][4];
+    u16x4 r16v[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = wb[u] + lane * 4;
+      live[u] = i < we[u];
+      const int at = live[u] ? i : (wb[u] < we[u] ? wb[u] : first);
+      detail::load4<type_t, NT>(prod + at, v[u]);
+      if constexpr (NT) r16v[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(row16 + at));
+      else r16v[u] = *reinterpret_cast<const u16x4*>(row16 + at);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (wb[u] < we[u]) {  // (wave-uniform)
+        if (we[u] - wb[u] <= small_window) {
+          // a window of a few items (the thin remainder of a matrix with column locality: hundreds of such segments per
+          // sub-band): LDS atomics cost ~2.5 clks per LANE, the run-combining path ~200 instructions per WINDOW
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (live[u] && r16v[u][e] != pad_row) atomicAdd(&acc[r16v[u][e]], v[u][e]);
+        } else {
+          unsigned int r[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
+          panel_window_add<type_t>(acc, v[u], r);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const long long row0 = static_cast<long long>(s) * Hw;
+  for (int j = threadIdx.x; j < Hw && row0 + j < rows; j += 256) {
+    type_t sum = all[j];
+#pragma unroll
+    for (int k = 1; k < WAVES; ++k) sum += all[static_cast<std::size_t>(k) * Hw + j];
+    out(static_cast<int>(row0 + j), sum);
+  }
+}
+
+}  // namespace panel
+
+/// Sub-band height (rows per workgroup of kernel B): what matters is the size of a (panel, sub-band) segment, nnz Hw / (rows P)
+/// items -- kernel B handles them in windows of 256 and kernel A stores their products as one run -- so Hw is the power of two
+/// that brings a segment to ~192 items, within [256, 16 KB of accumulators per wavefront], halved while fewer than 512
+/// sub-bands would be left.  Measured (tests/perf/bench_panel.py with PANEL_HW): C5 shard 802 / 536 / 402 / 353 us for
+/// Hw = 512 / 1024 / 2048 / 4096 (16 .. 128 items per segment), C2 86 / 88 / 94 / 116 us (128 .. 1024 items).
+template <typename type_t>
+inline int panel_subband_rows(int rows, int nnz, int P) {
+  const int hw_max = 16384 / static_cast<int>(sizeof(type_t));
+  const double want = nnz > 0 ? 192.0 * static_cast<double>(rows) * static_cast<double>(P) / static_cast<double>(nnz) : 256.0;
+  int hw = 256;
+  while (hw < hw_max && hw < want) hw *= 2;
+  while (hw > 256 && static_cast<long long>(rows) / hw < 512) hw /= 2;
+  return hw;
+}
+
+/// Bytes of temporary device storage build_panel_binned needs.
+inline std::size_t panel_binned_temp_bytes(int nnz, long long segments) {
+  std::size_t sort_bytes = 0, scan_bytes = 0;
+  unsigned long long* k = nullptr;
+  int* c = nullptr;
+  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, k, k, nnz, 32, 64);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c, c, static_cast<int>(segments + 1));
+  const std::size_t a = (sort_bytes + 255) & ~std::size_t(255), b = (scan_bytes + 255) & ~std::size_t(255);
+  const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
+  const std::size_t row_bytes = (static_cast<std::size_t>(nnz) * 4 + 255) & ~std::size_t(255);
+  const std::size_t seg_bytes = (static_cast<std::size_t>(segments + 1) * 4 + 255) & ~std::size_t(255);
+  return 2 * key_bytes + row_bytes + 6 * seg_bytes + (a > b ? a : b);
+}
+
+/// Device-side part of the build (asynchronous on `stream`): everything but the chunk list, which the caller derives
+/// from `panel_start_host` after synchronising.  `seg_dest` (segments + 1 ints inside `temp`) is returned through
+/// `padded_total_dev` = pointer to the device int holding the padded item count (seg_dest[segments]).
+/// Stage 1 (sizes): counts, scans -> *padded_total_dev.  The caller reads it, allocates val / col16 / row16 / perm / prod,
+/// and calls stage 2 (placement).  Both stages share `temp`.
+template <typename index_t, typename offset_t>
+int build_panel_binned_stage1(hipStream_t stream, const offset_t* offsets, const index_t* indices, int rows, int nnz, int W,
+                              int Hw, int P, int S, void* temp, std::size_t temp_bytes, const int** padded_total_dev) {
+  const long long segments = static_cast<long long>(P) * S;
+  const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
+  const std::size_t row_bytes = (static_cast<std::size_t>(nnz) * 4 + 255) & ~std::size_t(255);
+  const std::size_t seg_bytes = (static_cast<std::size_t>(segments + 1) * 4 + 255) & ~std::size_t(255);
+  char* base = static_cast<char*>(temp);
+  auto* keys_in = reinterpret_cast<unsigned long long*>(base);
+  auto* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
+  int* row_of = reinterpret_cast<int*>(base + 2 * key_bytes);
+  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);
+  const std::size_t seg_ints = seg_bytes / 4;
+  int* seg_start = counts + seg_ints;        // unpadded start of segment g in the sorted keys
+  int* padded = counts + 2 * seg_ints;       // padded size of segment g
+  int* seg_dest = counts + 3 * seg_ints;     // A-order start of segment g = p * S + s
+  int* padded_t = counts + 4 * seg_ints;     // padded sizes in B order (s * P + p)
+  int* seg_dest_b = counts + 5 * seg_ints;   // B-order start of segment (s, p)
+  void* cub_temp = base + 2 * key_bytes + row_bytes + 6 * seg_bytes;
+  const std::size_t cub_avail = temp_bytes - (2 * key_bytes + row_bytes + 6 * seg_bytes);
+  std::size_t cub_bytes = cub_avail;
+  hipError_t e = hipMemsetAsync(counts, 0, seg_bytes, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  constexpr int KEYS_PER_LANE = 8;
+  if (nnz > 0) {
+    hipLaunchKernelGGL((panel::make_keys<KEYS_PER_LANE, index_t, offset_t>), dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), dim3(256), 0,
+                       stream, offsets, indices, rows, nnz, W, Hw, S, keys_in, row_of, counts);
+    int end_bit = 33;
+    while (end_bit < 64 && (static_cast<unsigned long long>(segments) >> (end_bit - 32)) != 0) ++end_bit;
+    e = hipcub::DeviceRadixSort::SortKeys(cub_temp, cub_bytes, keys_in, keys_out, nnz, 32, end_bit, stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  const int nseg = static_cast<int>(segments);
+  hipLaunchKernelGGL(panel::pad_counts, dim3(math::ceil_div(nseg + 1, 256)), dim3(256), 0, stream, counts, nseg, padded);
+  hipLaunchKernelGGL(panel::transpose_counts, dim3(math::ceil_div(nseg + 1, 256)), dim3(256), 0, stream, padded, P, S, padded_t);
+  cub_bytes = cub_avail;
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, counts, seg_start, nseg + 1, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  cub_bytes = cub_avail;
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, padded, seg_dest, nseg + 1, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  cub_bytes = cub_avail;
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, padded_t, seg_dest_b, nseg + 1, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  *padded_total_dev = seg_dest + nseg;
+  return static_cast<int>(hipGetLastError());
+}
+
+/// Stage 2: place every nonzero in both orders, extract the sub-band starts (out.bstart) and the panel starts
+/// (`panel_start_dev`: P + 1 ints, A order).  `out.val / col16 / row16 / perm / dst4` must hold out.padded (/ 4) items.
+template <typename index_t, typename type_t>
+int build_panel_binned_stage2(hipStream_t stream, const index_t* indices, const type_t* values, const panel_binned_view<type_t>& out,
+                              void* temp, int* panel_start_dev) {
+  const int nnz = out.nnz;
+  const long long segments = static_cast<long long>(out.P) * out.S;
+  const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
+  const std::size_t row_bytes = (static_cast<std::size_t>(nnz) * 4 + 255) & ~std::size_t(255);
+  const std::size_t seg_bytes = (static_cast<std::size_t>(segments + 1) * 4 + 255) & ~std::size_t(255);
+  char* base = static_cast<char*>(temp);
+  auto* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
+  int* row_of = reinterpret_cast<int*>(base + 2 * key_bytes);
+  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);
+  const std::size_t seg_ints = seg_bytes / 4;
+  int* seg_start = counts + seg_ints;
+  int* seg_dest = counts + 3 * seg_ints;
+  int* seg_dest_b = counts + 5 * seg_ints;
+  const std::size_t n = static_cast<std::size_t>(out.padded);
+  hipError_t e = hipMemsetAsync(out.val, 0, sizeof(type_t) * n, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.col16, 0, sizeof(unsigned short) * n, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.row16, 0xFF, sizeof(unsigned short) * n, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.perm, 0xFF, sizeof(int) * n, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.dst4, 0, sizeof(int) * (n / 4 + 1), stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (nnz > 0)
+    hipLaunchKernelGGL((panel::place<index_t, type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, seg_start,
+                       seg_dest, seg_dest_b, row_of, indices, values, nnz, out.W, out.Hw, out.P, out.S, out.val, out.col16, out.dst4,
+                       out.row16, out.perm);
+  e = hipMemcpyAsync(out.segb, seg_dest_b, sizeof(int) * static_cast<std::size_t>(segments + 1), hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const int m = (out.S > out.P ? out.S : out.P) + 1;
+  hipLaunchKernelGGL(panel::extract_starts, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, seg_dest, seg_dest_b, out.P, out.S,
+                     out.bstart, panel_start_dev);
+  return static_cast<int>(hipGetLastError());
+}
+
+/// y = A x over a panel-binned matrix: kernel A then kernel B.  stages: bit 0 = products, bit 1 = reduce.
+/// Streams larger than the Infinity Cache are read non-temporally (they are read once per product); smaller ones with plain
+/// loads (the products kernel A wrote are then still cached when kernel B reads them).
+template <typename type_t, typename store_t>
+int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& m, const type_t* x, const store_t out, int stages = 3) {
+  if (m.rows == 0) return 0;
+  constexpr int W = panel_width<type_t>::value;
+  if (m.W != W) return static_cast<int>(hipErrorInvalidValue);
+  const bool nt = static_cast<double>(m.padded) * (2.0 * sizeof(type_t) + 4.0) > 200e6;
+  if ((stages & 1) && m.num_chunks > 0) {
+    if (nt)
+      hipLaunchKernelGGL((panel::panel_products<512, W, 4, true, type_t>), dim3(m.num_chunks), dim3(512), 0, stream, m.chunks, m.val,
+                         m.col16, m.dst4, x, m.cols, m.prod);
+    else
+      hipLaunchKernelGGL((panel::panel_products<512, W, 4, false, type_t>), dim3(m.num_chunks), dim3(512), 0, stream, m.chunks, m.val,
+                         m.col16, m.dst4, x, m.cols, m.prod);
+  }
+  if (stages & 2) {
+    const std::size_t lds = static_cast<std::size_t>(256 / wave::size) * m.Hw * sizeof(type_t);
+    if (nt)
+      hipLaunchKernelGGL((panel::panel_reduce<true, type_t, store_t>), dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod,
+                         m.row16, m.rows, out);
+    else
+      hipLaunchKernelGGL((panel::panel_reduce<false, type_t, store_t>), dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod,
+                         m.row16, m.rows, out);
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
+template <typename type_t>
+int launch_panel_binned(hipStream_t stream, const panel_binned_view<type_t>& m, const type_t* x, type_t* y, int stages = 3) {
+  return launch_panel_binned_to(stream, m, x, plain_store<type_t>{y}, stages);
+}
+
+/// The same product with the finished rows of y also stored to `peers.count` peer-mapped vectors (multi-GPU epilogue
+/// fan-out; see fanout_store).
+template <typename type_t>
+int launch_panel_binned_fanout(hipStream_t stream, const panel_binned_view<type_t>& m, const type_t* x, type_t* y,
+                               const peer_fanout<type_t>& peers) {
+  if (peers.count < 0 || peers.count > max_peers) return static_cast<int>(hipErrorInvalidValue);
+  return launch_panel_binned_to(stream, m, x, fanout_store<type_t>{y, peers}, 3);
+}
+
+}  // namespace kernels
+}  // namespace loops

@@ -29,7 +29,7 @@ namespace dpp {
 // DPP control words (gfx9): row_shr:n = 0x110 + n, wave_shr:1 = 0x138, row_bcast:15 = 0x142,
 // row_bcast:31 = 0x143.
 constexpr int row_shr1 = 0x111, row_shr2 = 0x112, row_shr4 = 0x114, row_shr8 = 0x118;
-constexpr int wave_shr1 = 0x138, row_bcast15 = 0x142, row_bcast31 = 0x143;
+constexpr int wave_shr1 = 0x138, wave_shl1 = 0x130, row_bcast15 = 0x142, row_bcast31 = 0x143;
 
 /// Lane i receives `v` of the lane selected by CTRL; lanes without a source (or masked out by
 /// ROW_MASK) receive `fill`.
@@ -90,6 +90,12 @@ __device__ __forceinline__ T reduce_sum(T v) {
 template <typename T>
 __device__ __forceinline__ T shift_up1(T v, T fill) {
   return dpp::move<dpp::wave_shr1>(v, fill);
+}
+
+/// Value of the next lane (lane 63 receives `fill`).
+template <typename T>
+__device__ __forceinline__ T shift_down1(T v, T fill) {
+  return dpp::move<dpp::wave_shl1>(v, fill);
 }
 
 /**

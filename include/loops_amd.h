@@ -265,6 +265,44 @@ int loops_spmv_colblock_fanout_f64(const loops_colblock_plan_t* plan, const doub
 int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
                                   void* stream);
 
+/* ---- panel-binned layout: SpMV without a gather, for x far larger than the per-XCD L2 ------------------------------
+ * No reference counterpart.  The plan holds a re-ordered COPY of the matrix (include/loops/kernels/panel_binned.hxx): nonzeros
+ * sorted by (panel of W = 64 KB / sizeof(T) consecutive columns, sub-band of Hw consecutive rows) -- value + 16-bit column
+ * inside the panel + one int per 4 items saying where their products go -- and, in (sub-band, panel) order, the 16-bit row
+ * inside the sub-band + a products scratch.  y = A x runs as two streaming kernels: products with the x panel held in LDS
+ * (the x value of a nonzero is an LDS read, not a memory gather), stored in 16-byte groups so that every sub-band's products
+ * form one contiguous run; then one workgroup per sub-band adds its run into LDS-resident accumulators (one set per
+ * wavefront, combined in wavefront order) and stores its rows of y.  17 bytes of HBM traffic per nonzero and no scattered
+ * read; y needs no zero-fill; reproducible (no floating-point atomics on global memory; LDS adds in program order).
+ * Creation is synchronous (device radix sort + scans, O(nnz)); LOOPS_E_RANGE when panels x sub-bands exceed 2^26 or
+ * nnz + padding reaches 2^31.  info7 = {W, Hw, panels, sub-bands, items incl. padding, kernel-A chunks, sizeof(T)}.
+ * loops_panel_plan_arrays: HOST copies (any pointer may be NULL) for inspection and tests: values / col16 / perm [padded]
+ * and dst4 [padded / 4] in (panel, sub-band) order, row16 [padded] in (sub-band, panel) order, subband_start [sub-bands + 1].
+ * The fan-out entries store the finished rows of y to the peers as well (see loops_spmv_merge_path_fanout_f32).
+ * One product in flight per plan. */
+typedef struct loops_panel_plan loops_panel_plan_t;
+/* subband_rows: 0 = automatic (the power of two that brings a (panel, sub-band) segment to ~192 nonzeros, within 256 rows ..
+ * 16 KB of accumulators per wavefront, at least 512 sub-bands when the matrix has the rows for it), or an explicit power of
+ * two in [64, 16384 / sizeof(T)] (LOOPS_E_BADARG otherwise). */
+int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                                int subband_rows, void* stream, loops_panel_plan_t** out);
+int loops_panel_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                                int subband_rows, void* stream, loops_panel_plan_t** out);
+void loops_panel_plan_destroy(loops_panel_plan_t* plan);
+int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7);
+int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsigned short* col16, int* dst4, unsigned short* row16,
+                            int* perm, int* subband_start);
+int loops_panel_plan_refresh_values_f32(loops_panel_plan_t* plan, const float* values, void* stream);
+int loops_panel_plan_refresh_values_f64(loops_panel_plan_t* plan, const double* values, void* stream);
+int loops_spmv_panel_f32(const loops_panel_plan_t* plan, const float* x, float* y, void* stream);
+int loops_spmv_panel_f64(const loops_panel_plan_t* plan, const double* x, double* y, void* stream);
+/* one kernel at a time for timing: stage 0 = products, 1 = sub-band reduce */
+int loops_spmv_panel_stage_f32(const loops_panel_plan_t* plan, int stage, const float* x, float* y, void* stream);
+int loops_spmv_panel_fanout_f32(const loops_panel_plan_t* plan, const float* x, float* y, int num_peers, float* const* h_peer_y,
+                                void* stream);
+int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x, double* y, int num_peers, double* const* h_peer_y,
+                                void* stream);
+
 /* ---- SpMV plan: tile shape AND layout chosen at plan time ------------------------------------------------
  * What an iterative caller holds for one matrix.  The reference fixes both at compile time (launch_box.hxx:56-90) and always
  * runs the CSR as given; here the plan decides per matrix, once:
@@ -277,19 +315,22 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
  * Without ALLOW_COPY the product always runs on the caller's arrays.  Creation is synchronous.  One product in flight per plan.
  * loops_spmv_planned_*: y = A x; offsets / indices / values are the arrays the plan was created from (ignored -- may be NULL
  * -- when the plan holds the copy; after changing the VALUES of the matrix call loops_spmv_plan_refresh_values_* first).
- * loops_spmv_plan_info: layout (LOOPS_LAYOUT_*), tile config, number of column blocks (0 for CSR), and ms3[3] = measured ms per
- * product of {CSR 256 x 8, CSR 512 x 8, column-blocked}, -1 where not timed.  Any output pointer may be NULL. */
+ * With ALLOW_COPY and MEASURE the panel-binned copy ("panel-binned layout" below) is the third candidate, adopted under the
+ * same 5 % rule.
+ * loops_spmv_plan_info: layout (LOOPS_LAYOUT_*), tile config, number of column blocks / panels (0 for CSR), and ms4[4] = measured
+ * ms per product of {CSR 256 x 8, CSR 512 x 8, column-blocked, panel-binned}, -1 where not timed.  Any output pointer may be NULL. */
 #define LOOPS_PLAN_MEASURE 1
 #define LOOPS_PLAN_ALLOW_COPY 2
 #define LOOPS_LAYOUT_CSR 0
 #define LOOPS_LAYOUT_COLUMN_BLOCKED 1
+#define LOOPS_LAYOUT_PANEL_BINNED 2
 typedef struct loops_spmv_plan loops_spmv_plan_t;
 int loops_spmv_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
                                int flags, int repeats, void* stream, loops_spmv_plan_t** out);
 int loops_spmv_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
                                int flags, int repeats, void* stream, loops_spmv_plan_t** out);
 void loops_spmv_plan_destroy(loops_spmv_plan_t* plan);
-int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms3);
+int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4);
 int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream);
 int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream);
 int loops_spmv_planned_f32(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const float* values,

@@ -46,6 +46,9 @@ SYMBOLS = [
     "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64",
     "loops_spmv_plan_create_f32", "loops_spmv_plan_create_f64", "loops_spmv_plan_destroy", "loops_spmv_plan_info",
     "loops_spmv_plan_refresh_values_f32", "loops_spmv_plan_refresh_values_f64", "loops_spmv_planned_f32", "loops_spmv_planned_f64",
+    "loops_panel_plan_create_f32", "loops_panel_plan_create_f64", "loops_panel_plan_destroy", "loops_panel_plan_info",
+    "loops_panel_plan_arrays", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
+    "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
 
 
@@ -190,6 +193,16 @@ def lib() -> C.CDLL:
             getattr(L, "loops_spmv_plan_create_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
             getattr(L, "loops_spmv_plan_refresh_values_" + sfx).argtypes = [vp, vp, vp]
             getattr(L, "loops_spmv_planned_" + sfx).argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        for sfx in ("f32", "f64"):
+            getattr(L, "loops_panel_plan_create_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, C.POINTER(vp)]
+            getattr(L, "loops_panel_plan_refresh_values_" + sfx).argtypes = [vp, vp, vp]
+            getattr(L, "loops_spmv_panel_" + sfx).argtypes = [vp, vp, vp, vp]
+            getattr(L, "loops_spmv_panel_fanout_" + sfx).argtypes = [vp, vp, vp, ci, vp, vp]
+        L.loops_panel_plan_destroy.argtypes = [vp]
+        L.loops_panel_plan_destroy.restype = None
+        L.loops_panel_plan_info.argtypes = [vp, vp]
+        L.loops_panel_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.loops_spmv_panel_stage_f32.argtypes = [vp, ci, vp, vp, vp]
         L.loops_spmv_plan_destroy.argtypes = [vp]
         L.loops_spmv_plan_destroy.restype = None
         L.loops_spmv_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), vp]

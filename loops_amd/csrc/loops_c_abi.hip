@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <limits>
 #include <new>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -20,6 +21,7 @@
 #include <loops/util/math.hxx>
 #include <loops/kernels/launch.hxx>
 #include <loops/kernels/column_blocked.hxx>
+#include <loops/kernels/panel_binned.hxx>
 #include <loops/kernels/coo_spmv.hxx>
 #include <loops/kernels/ell_spmv.hxx>
 #include <loops/kernels/dia_spmv.hxx>
@@ -685,6 +687,119 @@ int colblock_fanout(const loops_colblock_plan* plan, const T* x, T* y, int num_p
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------ panel-binned layout
+struct loops_panel_plan {
+  int rows, cols, nnz, vbytes;
+  int W, Hw, P, S, padded, num_chunks;
+  void *val, *prod;
+  unsigned short *col16, *row16;
+  int *perm, *dst4, *segb, *bstart, *chunks;
+};
+
+namespace {
+
+void panel_free(loops_panel_plan* p) {
+  if (!p) return;
+  (void)hipFree(p->val); (void)hipFree(p->prod); (void)hipFree(p->col16); (void)hipFree(p->row16);
+  (void)hipFree(p->perm); (void)hipFree(p->dst4); (void)hipFree(p->segb); (void)hipFree(p->bstart); (void)hipFree(p->chunks);
+  delete p;
+}
+
+template <typename T>
+kernels::panel_binned_view<T> panel_view(const loops_panel_plan* p) {
+  return kernels::panel_binned_view<T>{p->rows, p->cols, p->nnz, p->W, p->Hw, p->P, p->S, p->padded, static_cast<T*>(p->val),
+                                       p->col16, p->dst4, p->row16, p->perm, p->segb, p->bstart, p->chunks, p->num_chunks,
+                                       static_cast<T*>(p->prod)};
+}
+
+template <typename T>
+int panel_create(int rows, int cols, int nnz, const int* offsets, const int* indices, const T* values, hipStream_t st,
+                 loops_panel_plan** out, int subband_rows = 0) {
+  if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
+  auto* p = new (std::nothrow) loops_panel_plan();
+  if (!p) return static_cast<int>(hipErrorOutOfMemory);
+  p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T));
+  p->W = kernels::panel_width<T>::value;
+  p->P = cols > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(cols), static_cast<long long>(p->W))) : 1;
+  p->Hw = kernels::panel_subband_rows<T>(rows, nnz, p->P);
+  if (subband_rows != 0) {  // explicit: a power of two, 64 .. 16 KB of accumulators per wavefront
+    if (subband_rows < 64 || subband_rows > 16384 / static_cast<int>(sizeof(T)) || (subband_rows & (subband_rows - 1))) { delete p; return LOOPS_E_BADARG; }
+    p->Hw = subband_rows;
+  }
+  p->S = rows > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(rows), static_cast<long long>(p->Hw))) : 1;
+  const long long segments = static_cast<long long>(p->P) * p->S;
+  // every segment may carry up to 3 padding items
+  if (segments > (1ll << 26) || static_cast<long long>(nnz) + 3 * segments >= (1ll << 31) - 4096) { delete p; return LOOPS_E_RANGE; }
+  if (rows == 0) { *out = p; return 0; }
+  void* temp = nullptr;
+  int* panel_start = nullptr;
+  const size_t temp_bytes = kernels::panel_binned_temp_bytes(nnz, segments);
+  hipError_t e = hipMalloc(&temp, temp_bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&panel_start), sizeof(int) * (static_cast<size_t>(p->P) + 1));
+  int err = static_cast<int>(e);
+  const int* padded_dev = nullptr;
+  if (!err) err = kernels::build_panel_binned_stage1(st, offsets, indices, rows, nnz, p->W, p->Hw, p->P, p->S, temp, temp_bytes, &padded_dev);
+  if (!err) err = static_cast<int>(hipMemcpyAsync(&p->padded, padded_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (!err) err = static_cast<int>(hipStreamSynchronize(st));
+  if (!err) {
+    const size_t n = static_cast<size_t>(p->padded > 0 ? p->padded : 4);
+    auto alloc = [&](auto** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes); };
+    alloc(&p->val, sizeof(T) * n);
+    alloc(&p->prod, sizeof(T) * n);
+    alloc(&p->col16, sizeof(unsigned short) * n);
+    alloc(&p->row16, sizeof(unsigned short) * n);
+    alloc(&p->perm, sizeof(int) * n);
+    alloc(&p->dst4, sizeof(int) * (n / 4 + 1));
+    alloc(&p->segb, sizeof(int) * (static_cast<size_t>(segments) + 1));
+    alloc(&p->bstart, sizeof(int) * (static_cast<size_t>(p->S) + 1));
+    err = static_cast<int>(e);
+  }
+  if (!err) err = kernels::build_panel_binned_stage2<int, T>(st, indices, values, panel_view<T>(p), temp, panel_start);
+  std::vector<int> ps(static_cast<size_t>(p->P) + 1, 0);
+  if (!err) err = static_cast<int>(hipMemcpyAsync(ps.data(), panel_start, sizeof(int) * ps.size(), hipMemcpyDeviceToHost, st));
+  if (!err) err = static_cast<int>(hipStreamSynchronize(st));
+  if (!err) {
+    // kernel A's work list: chunks of one panel, at most 65536 items each (the 64 KB x panel is then <= 10 % of a chunk's traffic)
+    constexpr int CH = 65536;
+    std::vector<int> chunks;
+    for (int k = 0; k < p->P; ++k)
+      for (int b = ps[k]; b < ps[k + 1]; b += CH) {
+        chunks.push_back(k);
+        chunks.push_back(b);
+        chunks.push_back(b + CH < ps[k + 1] ? b + CH : ps[k + 1]);
+      }
+    p->num_chunks = static_cast<int>(chunks.size() / 3);
+    e = hipMalloc(reinterpret_cast<void**>(&p->chunks), sizeof(int) * (chunks.empty() ? 3 : chunks.size()));
+    if (e == hipSuccess && !chunks.empty())
+      e = hipMemcpy(p->chunks, chunks.data(), sizeof(int) * chunks.size(), hipMemcpyHostToDevice);
+    err = static_cast<int>(e);
+  }
+  (void)hipFree(temp);
+  (void)hipFree(panel_start);
+  if (err) { panel_free(p); return err; }
+  *out = p;
+  return 0;
+}
+
+template <typename T>
+int panel_spmv(const loops_panel_plan* p, int stages, const T* x, T* y, hipStream_t st) {
+  if (!p || p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
+  if (p->rows == 0) return 0;
+  if (!y || (p->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  return kernels::launch_panel_binned<T>(st, panel_view<T>(p), x, y, stages);
+}
+
+template <typename T>
+int panel_refresh(loops_panel_plan* p, const T* values, hipStream_t st) {
+  if (!p || p->vbytes != static_cast<int>(sizeof(T)) || (p->nnz > 0 && !values)) return LOOPS_E_BADARG;
+  if (p->rows == 0 || p->padded == 0) return 0;
+  hipLaunchKernelGGL((kernels::panel::refresh_values<T>), dim3(math::ceil_div(p->padded, 256)), dim3(256), 0, st, p->perm, values,
+                     p->padded, static_cast<T*>(p->val));
+  return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------ SpMV plan: tile shape AND layout chosen at plan time
 // What a caller that performs many products with one matrix should hold (loops_spmv_plan_*): the merge-path plan of the
 // unmodified CSR in the best tile shape, or -- if the caller allows a copy and it is measurably faster -- the column-blocked
@@ -694,7 +809,8 @@ struct loops_spmv_plan {
   int layout;                   // LOOPS_LAYOUT_CSR / LOOPS_LAYOUT_COLUMN_BLOCKED
   loops_merge_plan* merge;      // held for LOOPS_LAYOUT_CSR
   loops_colblock_plan* blocked; // held for LOOPS_LAYOUT_COLUMN_BLOCKED
-  float ms[3];                  // measured ms per product: [0] CSR 256 x 8, [1] CSR 512 x 8, [2] column-blocked; -1 = not timed
+  loops_panel_plan* panel;      // held for LOOPS_LAYOUT_PANEL_BINNED
+  float ms[4];                  // measured ms per product: CSR 256 x 8, CSR 512 x 8, column-blocked, panel-binned; -1 = not timed
 };
 
 namespace {
@@ -703,6 +819,7 @@ void spmv_plan_free(loops_spmv_plan* p) {
   if (!p) return;
   plan_release(p->merge);
   colblock_free(p->blocked);
+  panel_free(p->panel);
   delete p;
 }
 
@@ -736,7 +853,7 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
   if (!p) return static_cast<int>(hipErrorOutOfMemory);
   p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T)); p->flags = flags;
   p->layout = LOOPS_LAYOUT_CSR;
-  p->ms[0] = p->ms[1] = p->ms[2] = -1.f;
+  p->ms[0] = p->ms[1] = p->ms[2] = p->ms[3] = -1.f;
   const bool measure = (flags & LOOPS_PLAN_MEASURE) != 0 && rows > 0 && nnz > 0;
   const bool may_copy = (flags & LOOPS_PLAN_ALLOW_COPY) != 0 && rows > 0 && nnz > 0;
   const long long x_bytes = static_cast<long long>(cols) * static_cast<long long>(sizeof(T));
@@ -797,6 +914,29 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
     if (cerr && cerr != LOOPS_E_RANGE && cerr != LOOPS_E_CONFIG && cerr != static_cast<int>(hipErrorOutOfMemory)) err = cerr;
     if (cerr == static_cast<int>(hipErrorOutOfMemory)) (void)hipGetLastError();  // no room for the copy: stay on the CSR
   }
+  if (!err && may_copy && x_bytes >= (2ll << 20)) {
+    // third candidate: the panel-binned copy (x panels in LDS, no gather leaves the CU): adopted like the blocked copy
+    loops_panel_plan* pp = nullptr;
+    int perr = panel_create<T>(rows, cols, nnz, off, idx, val, st, &pp);
+    if (!perr) {
+      float ms = 0.f;
+      perr = time_ms(st, repeats, &ms, [&]() { return panel_spmv<T>(pp, 3, x, y, st); });
+      if (!perr) p->ms[3] = ms;
+      const float incumbent = p->blocked ? p->ms[2] : best_ms;
+      if (!perr && ms < 0.95f * incumbent && ms < 0.95f * best_ms) {
+        p->panel = pp;
+        p->layout = LOOPS_LAYOUT_PANEL_BINNED;
+        plan_release(p->merge);
+        p->merge = nullptr;
+        colblock_free(p->blocked);
+        p->blocked = nullptr;
+        pp = nullptr;
+      }
+    }
+    panel_free(pp);
+    if (perr && perr != LOOPS_E_RANGE && perr != LOOPS_E_CONFIG && perr != static_cast<int>(hipErrorOutOfMemory)) err = perr;
+    if (perr == static_cast<int>(hipErrorOutOfMemory)) (void)hipGetLastError();
+  }
   if (!err) err = static_cast<int>(hipStreamSynchronize(st));
   (void)hipFree(x);
   (void)hipFree(y);
@@ -811,6 +951,7 @@ int spmv_planned(const loops_spmv_plan* p, const int* off, const int* idx, const
   if (p->rows == 0) return 0;
   if (!y || (p->nnz > 0 && !x)) return LOOPS_E_BADARG;
   if (p->layout == LOOPS_LAYOUT_COLUMN_BLOCKED) return colblock_spmv<T>(p->blocked, 7, x, y, st);
+  if (p->layout == LOOPS_LAYOUT_PANEL_BINNED) return panel_spmv<T>(p->panel, 3, x, y, st);
   int err = check_csr(p->rows, p->cols, p->nnz, off, idx, val, x, y);
   if (err) return err;
   return spmv_merge_path<T>(p->merge, 0, p->rows, p->nnz, off, idx, val, x, y, st);
@@ -1201,20 +1342,22 @@ int loops_spmv_plan_create_f64(int rows, int cols, int nnz, const int* offsets, 
   return spmv_plan_create<double>(rows, cols, nnz, offsets, indices, values, flags, repeats, as_stream(stream), out);
 }
 void loops_spmv_plan_destroy(loops_spmv_plan_t* plan) { spmv_plan_free(plan); }
-int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms3) {
+int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4) {
   if (!plan) return LOOPS_E_BADARG;
   if (layout) *layout = plan->layout;
   if (tile_config) *tile_config = plan->merge ? plan->merge->cfg : COLBLOCK_TILE;
-  if (num_blocks) *num_blocks = plan->blocked ? plan->blocked->K : 0;
-  if (ms3) for (int i = 0; i < 3; ++i) ms3[i] = plan->ms[i];
+  if (num_blocks) *num_blocks = plan->blocked ? plan->blocked->K : plan->panel ? plan->panel->P : 0;
+  if (ms4) for (int i = 0; i < 4; ++i) ms4[i] = plan->ms[i];
   return 0;
 }
 int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream) {
   if (!plan || plan->vbytes != 4) return LOOPS_E_BADARG;
+  if (plan->panel) return panel_refresh<float>(plan->panel, values, as_stream(stream));
   return plan->blocked ? colblock_refresh<float>(plan->blocked, values, as_stream(stream)) : 0;
 }
 int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream) {
   if (!plan || plan->vbytes != 8) return LOOPS_E_BADARG;
+  if (plan->panel) return panel_refresh<double>(plan->panel, values, as_stream(stream));
   return plan->blocked ? colblock_refresh<double>(plan->blocked, values, as_stream(stream)) : 0;
 }
 int loops_spmv_planned_f32(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const float* values,
@@ -1224,6 +1367,73 @@ int loops_spmv_planned_f32(const loops_spmv_plan_t* plan, const int* offsets, co
 int loops_spmv_planned_f64(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const double* values,
                            const double* x, double* y, void* stream) {
   return spmv_planned<double>(plan, offsets, indices, values, x, y, as_stream(stream));
+}
+
+int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                                int subband_rows, void* stream, loops_panel_plan_t** out) {
+  return panel_create<float>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows);
+}
+int loops_panel_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                                int subband_rows, void* stream, loops_panel_plan_t** out) {
+  return panel_create<double>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows);
+}
+void loops_panel_plan_destroy(loops_panel_plan_t* plan) { panel_free(plan); }
+int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7) {
+  if (!plan || !info7) return LOOPS_E_BADARG;
+  const int v[7] = {plan->W, plan->Hw, plan->P, plan->S, plan->padded, plan->num_chunks, plan->vbytes};
+  for (int i = 0; i < 7; ++i) info7[i] = v[i];
+  return 0;
+}
+int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsigned short* col16, int* dst4, unsigned short* row16,
+                            int* perm, int* subband_start) {
+  if (!plan) return LOOPS_E_BADARG;
+  if (plan->rows == 0) return 0;
+  const size_t n = static_cast<size_t>(plan->padded);
+  hipError_t e = hipDeviceSynchronize();
+  auto copy = [&](void* dst, const void* src, size_t bytes) {
+    if (e == hipSuccess && dst && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+  };
+  copy(values, plan->val, static_cast<size_t>(plan->vbytes) * n);
+  copy(col16, plan->col16, sizeof(unsigned short) * n);
+  copy(row16, plan->row16, sizeof(unsigned short) * n);
+  copy(perm, plan->perm, sizeof(int) * n);
+  copy(dst4, plan->dst4, sizeof(int) * (n / 4));
+  copy(subband_start, plan->bstart, sizeof(int) * (static_cast<size_t>(plan->S) + 1));
+  return static_cast<int>(e);
+}
+int loops_panel_plan_refresh_values_f32(loops_panel_plan_t* plan, const float* values, void* stream) {
+  return panel_refresh<float>(plan, values, as_stream(stream));
+}
+int loops_panel_plan_refresh_values_f64(loops_panel_plan_t* plan, const double* values, void* stream) {
+  return panel_refresh<double>(plan, values, as_stream(stream));
+}
+int loops_spmv_panel_f32(const loops_panel_plan_t* plan, const float* x, float* y, void* stream) {
+  return panel_spmv<float>(plan, 3, x, y, as_stream(stream));
+}
+int loops_spmv_panel_f64(const loops_panel_plan_t* plan, const double* x, double* y, void* stream) {
+  return panel_spmv<double>(plan, 3, x, y, as_stream(stream));
+}
+int loops_spmv_panel_stage_f32(const loops_panel_plan_t* plan, int stage, const float* x, float* y, void* stream) {
+  if (stage < 0 || stage > 1) return LOOPS_E_BADARG;
+  return panel_spmv<float>(plan, 1 << stage, x, y, as_stream(stream));
+}
+int loops_spmv_panel_fanout_f32(const loops_panel_plan_t* plan, const float* x, float* y, int num_peers, float* const* h_peer_y,
+                                void* stream) {
+  if (!plan || plan->vbytes != 4 || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  kernels::peer_fanout<float> peers;
+  int err = fanout_peers<float>(num_peers, h_peer_y, &peers);
+  if (err) return err;
+  if (plan->rows == 0) return 0;
+  return kernels::launch_panel_binned_fanout<float>(as_stream(stream), panel_view<float>(plan), x, y, peers);
+}
+int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x, double* y, int num_peers, double* const* h_peer_y,
+                                void* stream) {
+  if (!plan || plan->vbytes != 8 || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
+  kernels::peer_fanout<double> peers;
+  int err = fanout_peers<double>(num_peers, h_peer_y, &peers);
+  if (err) return err;
+  if (plan->rows == 0) return 0;
+  return kernels::launch_panel_binned_fanout<double>(as_stream(stream), panel_view<double>(plan), x, y, peers);
 }
 
 }  // extern "C"

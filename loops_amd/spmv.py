@@ -306,12 +306,85 @@ class ColumnBlockedPlan:
             pass
 
 
+class PanelBinnedPlan:
+    """Panel-binned copy of a CSR (loops_panel_plan_*; include/loops/kernels/panel_binned.hxx): SpMV without a memory gather
+    -- x panels in LDS, products streamed, one wavefront per sub-band of rows adds them up in LDS.  For x far larger than
+    the per-XCD L2."""
+
+    def __init__(self, csr: CSR, subband_rows: int = 0):
+        assert csr.values.dtype in (torch.float32, torch.float64)
+        self.dtype = csr.values.dtype
+        self._sfx = _suffix(csr.values)
+        self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
+        self._h = C.c_void_p()
+        create = getattr(L.lib(), "loops_panel_plan_create_" + self._sfx)
+        L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), int(subband_rows),
+                       _stream(), C.byref(self._h)), "loops_panel_plan_create")
+        info = (C.c_int * 7)()
+        L.check(L.lib().loops_panel_plan_info(self._h, info), "loops_panel_plan_info")
+        self.W, self.Hw, self.num_panels, self.num_subbands, self.padded, self.num_chunks, _ = list(info)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def arrays(self):
+        """(values, col16, dst4, row16, perm, subband_start) copied to the host: values / col16 / perm [padded] and dst4
+        [padded / 4] in (panel, sub-band) order, row16 [padded] in (sub-band, panel) order."""
+        val = np.zeros(self.padded, np.float32 if self.dtype == torch.float32 else np.float64)
+        col16, row16 = np.zeros(self.padded, np.uint16), np.zeros(self.padded, np.uint16)
+        perm, dst4 = np.zeros(self.padded, np.int32), np.zeros(self.padded // 4, np.int32)
+        bstart = np.zeros(self.num_subbands + 1, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        L.check(L.lib().loops_panel_plan_arrays(self._h, p(val), p(col16), p(dst4), p(row16), p(perm), p(bstart)), "loops_panel_plan_arrays")
+        return val, col16, dst4, row16, perm, bstart
+
+    def refresh_values(self, values: torch.Tensor):
+        assert values.dtype == self.dtype and values.numel() == self.nnz
+        L.check(getattr(L.lib(), "loops_panel_plan_refresh_values_" + self._sfx)(self._h, _ptr(values), _stream()),
+                "loops_panel_plan_refresh_values")
+
+    def _check(self, x, y):
+        assert x.dtype == self.dtype and y.dtype == self.dtype and x.numel() >= self.cols and y.numel() >= self.rows
+        assert x.is_contiguous() and y.is_contiguous()
+
+    def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+        if y is None:
+            y = torch.empty(self.rows, dtype=self.dtype, device=x.device)
+        self._check(x, y)
+        L.check(getattr(L.lib(), "loops_spmv_panel_" + self._sfx)(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_panel")
+        return y
+
+    def spmv_stage(self, stage: int, x, y):
+        L.check(L.lib().loops_spmv_panel_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_panel_stage_f32")
+        return y
+
+    def spmv_fanout(self, x, y, peers):
+        """``spmv`` whose sub-band store also goes to ``peers`` (loops_spmv_panel_fanout_*; see merge_path_flat_fanout)."""
+        self._check(x, y)
+        arr, n = _peer_array(peers)
+        L.check(getattr(L.lib(), "loops_spmv_panel_fanout_" + self._sfx)(self._h, _ptr(x), _ptr(y), n, arr, _stream()),
+                "loops_spmv_panel_fanout")
+        return y
+
+    def close(self):
+        if self._h:
+            L.lib().loops_panel_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SpmvPlan:
     """loops_spmv_plan_*: tile shape AND layout of one matrix chosen at plan time.  ``measure``: time the candidates on the
     device; ``allow_copy``: the plan may hold a column-blocked copy of the matrix when that is faster (x larger than the
     per-XCD L2).  ``spmv(x, y)`` runs whatever was chosen; ``info`` says what that is."""
 
-    LAYOUTS = {0: "csr", 1: "column_blocked"}
+    LAYOUTS = {0: "csr", 1: "column_blocked", 2: "panel_binned"}
 
     def __init__(self, csr: CSR, allow_copy: bool = True, measure: bool = True, repeats: int = 10):
         self.csr = csr
@@ -322,11 +395,11 @@ class SpmvPlan:
         L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), flags, repeats,
                        _stream(), C.byref(self._h)), "loops_spmv_plan_create")
         layout, tile, blocks = C.c_int(), C.c_int(), C.c_int()
-        ms = (C.c_float * 3)()
+        ms = (C.c_float * 4)()
         L.check(L.lib().loops_spmv_plan_info(self._h, C.byref(layout), C.byref(tile), C.byref(blocks), ms), "loops_spmv_plan_info")
         names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
         self.layout, self.tile, self.num_blocks = self.LAYOUTS[layout.value], names[tile.value], blocks.value
-        self.measured_ms = {k: (round(float(v), 5) if v >= 0 else None) for k, v in zip(("csr_256x8", "csr_512x8", "column_blocked"), ms)}
+        self.measured_ms = {k: (round(float(v), 5) if v >= 0 else None) for k, v in zip(("csr_256x8", "csr_512x8", "column_blocked", "panel_binned"), ms)}
 
     @property
     def info(self):

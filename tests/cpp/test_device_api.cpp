@@ -228,6 +228,31 @@ static void misc() {
       for (std::size_t i = 0; i < h1.size(); ++i) equal = equal && h2[i] == h1[i] && hp[i] == h1[i];
       CHECK(equal);
     }
+  // panel-binned layout: same y as the plain merge_path_flat (f32 bit-exact on these integer x / positive values is not
+  // guaranteed -- real values -- so within the usual bound), automatic and smallest sub-bands, with the peer fan-out
+  for (auto& dense : battery())
+    for (int hw : {0, 64}) {
+      hcsr_t<float> hf = from_dense<float>(dense);
+      csr_t<int, int, float> a(hf);
+      vector_t<float> xb(hf.cols), y0(hf.rows), y1(hf.rows, -1.f), y2(hf.rows, -1.f), peer(hf.rows, -2.f);
+      generate::random::uniform_distribution(xb.begin(), xb.end(), 1, 10, 9u);
+      algorithms::spmv::merge_path_flat(a, xb, y0);
+      algorithms::spmv::panel_binned_t<int, int, float> pb(a, hw);
+      pb.spmv(xb, y1);
+      kernels::peer_fanout<float> peers{};
+      peers.count = 1;
+      peers.base[0] = peer.data().get();
+      pb.spmv_fanout_async(xb, y2, peers);
+      (void)xpu::stream_synchronize(0);
+      vector_t<float, H> h0(y0), h1(y1), h2(y2), hp(peer);
+      bool same = true, equal = true;
+      for (std::size_t i = 0; i < h0.size(); ++i) {
+        same = same && std::fabs(h0[i] - h1[i]) <= 1e-3f + 1e-5f * std::fabs(h0[i]);
+        equal = equal && h2[i] == h1[i] && hp[i] == h1[i];
+      }
+      CHECK(same);
+      CHECK(equal);
+    }
   // spmv_plan_t: tile shape + layout chosen per matrix (structural and measured, copy allowed or not): same y as the plain
   // merge_path_flat on every battery matrix, in both precisions
   for (auto& dense : battery())

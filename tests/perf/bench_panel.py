@@ -1,0 +1,72 @@
+"""Panel-binned layout vs plain CSR vs column-blocked on the configurations whose x exceeds (or fills) an L2: C2, one rank's
+shard of C5, the C3 stand-ins.  Times per product (back-to-back batch between one event pair), stage times of the
+panel-binned kernels, bytes moved per nonzero, equality of the three results.  usage: bench_panel.py [case ...]"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from loops_amd import generate as G, spmv as S
+
+
+def batch_ms(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+CASES = {
+    "c2": (1 << 20, 1 << 20, 1 << 24, None),
+    "c5_shard": (1 << 21, 1 << 24, 1 << 26, None),
+    "c3_uniform": (7_414_866, 7_414_866, 194_109_311, None),
+    "c3_host_blocked": (7_414_866, 7_414_866, 194_109_311, G.HOST_BLOCKED),
+    "c3_band65536": (7_414_866, 7_414_866, 194_109_311, 65536),
+    "short_rows_8M": (1 << 23, 1 << 23, 1 << 24, None),
+}
+want = [a for a in sys.argv[1:] if a in CASES] or ["c2", "c5_shard", "c3_uniform", "c3_host_blocked"]
+out = {}
+for name in want:
+    rows, cols, nnz, window = CASES[name]
+    deg = G.powerlaw_degrees(rows, nnz, cap=min(1 << 14, cols)) if name != "short_rows_8M" else np.full(rows, 2, np.int64)
+    hosts = G.host_blocks(cols) if window == G.HOST_BLOCKED else None
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=hosts)
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
+    y0, y1, y2 = (torch.empty(rows, device="cuda") for _ in range(3))
+    abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
+    mp = S.MergePathPlan(csr, "512x8")
+    t_csr = batch_ms(lambda: S.merge_path_flat(csr, x, y0, plan=mp))
+    cb = S.ColumnBlockedPlan(csr)
+    t_cb = batch_ms(lambda: cb.spmv(x, y1))
+    blocks = cb.num_blocks
+    cb.close()
+    for hw in [int(t) for t in os.environ.get("PANEL_HW", "").split(",") if t]:  # tuning aid: explicit sub-band heights
+        pv = S.PanelBinnedPlan(csr, hw)
+        print(name, "Hw", hw, "subbands", pv.num_subbands, "total %.1f us  products %.1f  reduce %.1f" % (
+            batch_ms(lambda: pv.spmv(x, y2)) * 1e3, batch_ms(lambda: pv.spmv_stage(0, x, y2)) * 1e3, batch_ms(lambda: pv.spmv_stage(1, x, y2)) * 1e3),
+            file=sys.stderr, flush=True)
+        pv.close()
+    pb = S.PanelBinnedPlan(csr)
+    t_pb = batch_ms(lambda: pb.spmv(x, y2))
+    t_a = batch_ms(lambda: pb.spmv_stage(0, x, y2))
+    t_b = batch_ms(lambda: pb.spmv_stage(1, x, y2))
+    pb.spmv(x, y2)
+    row = {"rows": rows, "cols": cols, "nnz": nnz, "x_MB": cols * 4 >> 20, "algorithmic_bytes": abytes,
+           "csr_512x8_ms": round(t_csr, 4), "column_blocked_ms": round(t_cb, 4), "column_blocks": blocks,
+           "panel_binned_ms": round(t_pb, 4), "panel_products_ms": round(t_a, 4), "panel_reduce_ms": round(t_b, 4),
+           "panel": {"W": pb.W, "Hw": pb.Hw, "panels": pb.num_panels, "subbands": pb.num_subbands, "padding_items": pb.padded - nnz,
+                     "chunks": pb.num_chunks, "items_per_segment": round(nnz / (pb.num_panels * pb.num_subbands), 1)},
+           "frac_csr": round(abytes / t_csr / 1e6 / 8000, 4), "frac_blocked": round(abytes / t_cb / 1e6 / 8000, 4),
+           "frac_panel": round(abytes / t_pb / 1e6 / 8000, 4),
+           "products_GBps": round(pb.padded * 11 / t_a / 1e6, 1), "reduce_GBps": round(pb.padded * 6 / t_b / 1e6, 1),
+           "equal": bool(torch.equal(y0, y1) and torch.equal(y0, y2))}
+    out[name] = row
+    print(name, json.dumps(row), file=sys.stderr, flush=True)
+    pb.close()
+    mp.close()
+    del csr, x, y0, y1, y2, off, idx, val
+print(json.dumps(out))

@@ -166,13 +166,22 @@ def test_spmv_plan_picks_tile_and_layout():
     assert np.array_equal(p.spmv(x).cpu().numpy(), 2.0 * ref)
     csr.values.mul_(0.5)
     p.close()
+    p = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)   # whichever copy it holds must follow a refresh too
+    csr.values.mul_(2.0)
+    p.refresh_values()
+    assert np.array_equal(p.spmv(x).cpu().numpy(), 2.0 * ref), p.info
+    csr.values.mul_(0.5)
+    p.close()
     for allow in (False, True):
         p = S.SpmvPlan(csr, allow_copy=allow, measure=True, repeats=5)
         ms = p.info["measured_ms"]
         assert ms["csr_256x8"] > 0 and ms["csr_512x8"] > 0 and (ms["column_blocked"] is None) == (not allow)
+        assert (ms["panel_binned"] is None) == (not allow)
         assert allow or p.info["layout"] == "csr"
         if p.info["layout"] == "column_blocked":
             assert ms["column_blocked"] < 0.95 * min(ms["csr_256x8"], ms["csr_512x8"])
+        if p.info["layout"] == "panel_binned":
+            assert ms["panel_binned"] < 0.95 * min(ms["csr_256x8"], ms["csr_512x8"], ms["column_blocked"])
         assert np.array_equal(p.spmv(x).cpu().numpy(), ref), p.info
         p.close()
     # fp64 twin

@@ -63,6 +63,14 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         assert np.array_equal(cb.spmv(x).cpu().numpy(), want), ("blocked", K) + tag
         for sch in ("work_oriented", "group_mapped"):
             assert np.array_equal(cb.spmv_schedule(sch, x).cpu().numpy(), want), ("blocked", K, sch) + tag
+    # panel-binned copy (automatic and smallest sub-bands) and the measured SpMV plan that may pick it
+    for hw in (0, 64):
+        pb = S.PanelBinnedPlan(csr, hw)
+        assert np.array_equal(pb.spmv(x).cpu().numpy(), want), ("panel", hw) + tag
+        pb.close()
+    sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=1)
+    assert np.array_equal(sp.spmv(x).cpu().numpy(), want), ("spmv_plan", sp.info["layout"]) + tag
+    sp.close()
     # COO (sorted and shuffled) and ELL
     ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(off))
     for perm in (np.arange(idx.size), rng.permutation(idx.size)):

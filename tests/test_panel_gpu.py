@@ -1,0 +1,160 @@
+"""Panel-binned layout (loops_panel_plan_*, include/loops/kernels/panel_binned.hxx): the device-built layout against its
+specification (every nonzero exactly once, in (panel, sub-band, CSR order), 4-item aligned segments, the segment table), and
+the SpMV over it against the oracle -- bit for bit on exactly summable inputs, within the measured fp32 bound otherwise,
+reproducible from run to run, with the peer fan-out, in f32 and f64, from the battery up to BASELINE C2 / C3 / C5-shard
+sizes."""
+import numpy as np
+import pytest
+
+from conftest import battery, load_golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _dev(off, idx, val, rows, cols):
+    from loops_amd import spmv as S
+    return S.CSR.from_numpy(rows, cols, off, idx, val)
+
+
+def _check_layout(plan, off, idx, val):
+    """The layout contract, from the host copies: every nonzero exactly once in (panel, sub-band, CSR) order; groups of 4 never
+    straddle segments; dst4 maps every group to where the same items sit in (sub-band, panel, CSR) order; padding is inert."""
+    v, c16, dst4, r16, perm, bstart = plan.arrays()
+    rows, nnz = off.size - 1, idx.size
+    W, Hw, P, S = plan.W, plan.Hw, plan.num_panels, plan.num_subbands
+    if rows == 0:
+        return
+    assert plan.padded % 4 == 0 and bstart[0] == 0 and bstart[-1] == plan.padded and np.all(np.diff(bstart) >= 0) and np.all(bstart % 4 == 0)
+    real = perm >= 0
+    assert real.sum() == nnz and np.array_equal(np.sort(perm[real]), np.arange(nnz))            # every nonzero exactly once
+    assert np.all(v[~real] == 0)                                                                 # padding multiplies to 0
+    row_of = np.repeat(np.arange(rows), np.diff(off))
+    a = np.flatnonzero(real)                                                                      # A-order positions of the real items
+    i = perm[a]
+    assert np.array_equal(v[a], val[i])
+    p, s = idx[i] // W, row_of[i] // Hw
+    assert np.array_equal(c16[a].astype(np.int64), idx[i] - p * W)
+    g = p.astype(np.int64) * S + s
+    assert np.all(np.diff(g) >= 0) and np.array_equal(np.lexsort((i, g)), np.arange(i.size))     # (panel, sub-band), then CSR order
+    grp = a // 4
+    same_group = grp[1:] == grp[:-1]
+    assert np.all(g[1:][same_group] == g[:-1][same_group])                                        # a group of 4 holds ONE segment
+    b = dst4[grp] + (a % 4)                                                                       # where the item's product goes
+    assert np.unique(b).size == b.size and b.max(initial=-1) < plan.padded
+    assert np.array_equal(r16[b].astype(np.int64), row_of[i] - s * Hw)
+    assert np.all((b >= bstart[s]) & (b < bstart[s + 1]))                                         # inside its sub-band's run
+    order_b = np.argsort(b, kind="stable")
+    gb = s[order_b].astype(np.int64) * P + p[order_b]
+    assert np.all(np.diff(gb) >= 0) and np.array_equal(np.lexsort((i[order_b], gb)), np.arange(i.size))  # (sub-band, panel), CSR order
+    untouched = np.ones(plan.padded, bool)
+    untouched[b] = False
+    assert np.all(r16[untouched] == 0xFFFF)                                                       # padding rows are marked
+
+
+def test_battery_layout_and_product():
+    from loops_amd import spmv as S
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val, r, c)
+        plan = S.PanelBinnedPlan(csr)
+        _check_layout(plan, off, idx, val)
+        for tag in ("int", "real"):
+            x = torch.from_numpy(g[f"{name}.x_{tag}"]).cuda()
+            y = torch.full((r,), 7.0, device="cuda")          # y must not need a zero-fill
+            plan.spmv(x, y)
+            ref, l1 = g[f"{name}.y_{tag}"], g[f"{name}.l1_{tag}"]
+            assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= 2e-6 * l1 + 1e-30), (name, tag)
+        plan.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_many_panels_and_subbands_bit_exact(dtype):
+    """More columns than one panel and more rows than one sub-band, rows longer than a panel's share, empty rows, a ragged
+    tail: bit-exact vs the oracle, the fan-out twin, a value refresh, and two runs give identical bits."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows, cols = 70_001, 150_001
+    deg = G.powerlaw_degrees(rows, 1 << 21, cap=1 << 13)
+    deg[::7] = 0
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    xh = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    csr = _dev(off, idx, val.astype(dtype), rows, cols)
+    x = torch.from_numpy(xh.astype(dtype)).cuda()
+    plan = S.PanelBinnedPlan(csr)
+    assert plan.num_panels == -(-cols // plan.W) >= 5 and plan.num_subbands == -(-rows // plan.Hw) > 4
+    _check_layout(plan, off, idx, val.astype(dtype))
+    y = plan.spmv(x)
+    assert np.array_equal(y.cpu().numpy(), ref.astype(dtype))
+    assert torch.equal(plan.spmv(x), y)
+    peers = [torch.full((rows,), -1.0, dtype=y.dtype, device="cuda") for _ in range(3)]
+    y2 = torch.empty_like(y)
+    plan.spmv_fanout(x, y2, peers)
+    assert torch.equal(y2, y) and all(torch.equal(p, y) for p in peers)
+    csr.values.mul_(2.0)
+    plan.refresh_values(csr.values)
+    assert np.array_equal(plan.spmv(x).cpu().numpy(), 2 * ref.astype(dtype))
+    plan.close()
+
+
+def test_empty_and_degenerate_shapes():
+    from loops_amd import spmv as S
+    for rows, cols in ((0, 5), (5, 0), (6, 4), (1, 1)):
+        off = np.zeros(rows + 1, np.int32)
+        csr = _dev(off, np.zeros(0, np.int32), np.zeros(0, np.float32), rows, cols)
+        plan = S.PanelBinnedPlan(csr)
+        y = torch.full((rows,), 3.0, device="cuda")
+        plan.spmv(torch.ones(max(cols, 1), device="cuda"), y)
+        assert torch.count_nonzero(y).item() == 0
+        plan.close()
+
+
+def test_real_values_within_the_fp32_bound_and_reproducible():
+    from loops_amd import spmv as S, generate as G
+    rows = cols = 1 << 18
+    deg = G.powerlaw_degrees(rows, 1 << 22, cap=1 << 13)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, False)       # values U[0.5, 1.5)
+    xh = G.realistic_x(cols)
+    csr = _dev(off, idx, val, rows, cols)
+    plan = S.PanelBinnedPlan(csr)
+    x = torch.from_numpy(xh).cuda()
+    y = plan.spmv(x)
+    ref = np.add.reduceat((val.astype(np.float64) * xh[idx].astype(np.float64)), off[:-1].astype(np.int64))
+    ref[np.diff(off) == 0] = 0
+    rel = np.abs(y.cpu().numpy().astype(np.float64) - ref) / np.maximum(np.abs(ref), 1e-30)
+    # No cancellation here (all terms positive): relative to |y| itself.  A row's products are added in column order, one
+    # after the other, into (at most four) LDS accumulators -- the summation order of the reference's own CPU path
+    # (util/reference.hxx:61-76), which reaches 5.5e-6 on the 16 384-nonzero rows of C2; the merge-path kernels'
+    # tree order (<= 2.4e-7) is the more accurate one.  Measured here: 2.2e-6 on rows of up to 8 192 nonzeros.
+    assert rel.max() <= 5e-6, rel.max()
+    short = np.diff(off) <= 64
+    assert rel[short].max() <= 1e-6, rel[short].max()
+    for _ in range(5):
+        assert torch.equal(plan.spmv(x), y)
+    plan.close()
+
+
+@pytest.mark.parametrize("case", ["c2", "c3_uniform", "c5_shard"])
+def test_full_size_configurations_bit_exact(case):
+    """BASELINE C2, the C3 stand-in with uniform columns and one C5 shard through the panel-binned plan: equal to the planned
+    merge_path_flat product over the unmodified CSR, bit for bit (the latter is pinned against the oracle in test_spmv_gpu.py)."""
+    from loops_amd import spmv as S, generate as G
+    if case == "c2":
+        rows, cols, nnz = 1 << 20, 1 << 20, 1 << 24
+    elif case == "c3_uniform":
+        rows, cols, nnz = 7_414_866, 7_414_866, 194_109_311
+    else:
+        rows, cols, nnz = 1 << 21, 1 << 24, 1 << 26
+    deg = G.powerlaw_degrees(rows, nnz)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
+    csr = _dev(off, idx, val, rows, cols)
+    mp = S.MergePathPlan(csr, "512x8")
+    want = S.merge_path_flat(csr, x, plan=mp)
+    plan = S.PanelBinnedPlan(csr)
+    assert plan.padded - nnz <= 3 * plan.num_panels * plan.num_subbands
+    got = plan.spmv(x)
+    assert torch.equal(got, want), case
+    plan.close()

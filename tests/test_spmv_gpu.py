@@ -357,7 +357,15 @@ def test_bench_two_ranks_functional():
     assert one["best_ms_per_spmv"] > 0 and d["config"]["speedup_vs_one_gpu_same_matrix"]["spmv_plus_allgatherv"] > 0
     assert d["config"]["spmv_only_ms_per_step"] > 0 and d["config"]["spmv_plus_allgatherv_ms_per_step"] == d["ms_per_step"]
     assert d["value"] > 0 and d["cpu_baseline"] is None
-    assert d["config"]["shard_layout"].startswith("column-blocked by owner")  # the N > 1 default
+    # the N > 1 default: whichever re-ordered copy probes faster on the worst rank, the same on every rank
+    assert d["config"]["shard_layout"].startswith(("column-blocked by owner", "panel-binned"))
+    assert set(d["config"]["shard_layout_probe_ms"]) == {"blocked", "panel"}
+    for forced, prefix in (("blocked", "column-blocked by owner"), ("panel", "panel-binned")):
+        r = subprocess.run(cmd + ["--layout", forced, "--no-one-gpu-reference"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        dl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert dl["config"]["shard_layout"].startswith(prefix) and dl["config"]["parity_vs_oracle_bit_exact"] is True
+        assert {"p2p", "padded"} <= set(dl["config"]["allgatherv_probe_ms_per_step"])
     # round-1 mode kept for context: N x C2, weak
     cmd = cmd + ["--scaling", "weak"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
@@ -538,6 +546,14 @@ def test_c5_full_size_all_eight_shards_with_fanout():
         fan.run(lambda y, peers: cb.spmv_fanout(x, y, peers))
         torch.cuda.synchronize()
         cb.close()
+        # the other shard layout of bench.py --gpus N: panel-binned, same fan-out contract (into rank (r + 1) % 8's buffer only:
+        # every buffer already holds this slice, so a wrong store would show)
+        pb = S.PanelBinnedPlan(csr)
+        y_pb = torch.full((b - a,), float("nan"), device="cuda")
+        pb.spmv_fanout(x, y_pb, [fulls[(rank + 1) % world][a:b]])
+        torch.cuda.synchronize()
+        assert np.array_equal(y_pb.cpu().numpy(), ref[a:b]), ("panel-binned", rank)
+        pb.close()
         # the chunked candidate: two row chunks with their own column-blocked plans
         y_chunks = torch.full((b - a,), float("nan"), device="cuda")
         mine = chunk_bounds[rank] - a
