@@ -251,7 +251,8 @@ panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, c
 /// inside a window every row ends exactly once, so no two lanes touch the same address (LDS float atomics, the obvious
 /// alternative, retire ~0.4 lanes per clock and CU on gfx950: 5 x the time of the whole product stream).
 template <typename type_t>
-__device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const type_t (&v)[4], const unsigned int (&r)[4]) {
+__device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const int dump, const type_t (&v)[4],
+                                                 const unsigned int (&r)[4]) {
   type_t run[4];
   run[0] = v[0];
 #pragma unroll
@@ -265,20 +266,21 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
   wave::segmented_inclusive_sum(tail, head);
   const type_t prev_tail = wave::shift_up1(tail, type_t(0));  // (cross-lane read: executed by every lane, selected afterwards)
   const type_t carry_in = continues ? prev_tail : type_t(0);
-  bool ends[4];
-  type_t sum[4];
+  // Branch-free read-modify-write: a slot that ends no run targets the lane's private dump word (index `dump`) and adds 0,
+  // so all four reads and then all four writes are issued by every lane without touching the execution mask.
+  int at[4];
+  type_t add[4], old[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const unsigned int next = e < 3 ? r[e + 1] : next_first;
-    ends[e] = r[e] != next && r[e] != pad_row;
-    sum[e] = run[e] + (r[e] == r[0] ? carry_in : type_t(0));
+    const bool ends = r[e] != next && r[e] != pad_row;
+    at[e] = ends ? static_cast<int>(r[e]) : dump;
+    add[e] = ends ? run[e] + (r[e] == r[0] ? carry_in : type_t(0)) : type_t(0);
   }
-  type_t old[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) old[e] = ends[e] ? acc[r[e]] : type_t(0);
+  for (int e = 0; e < 4; ++e) old[e] = acc[at[e]];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (ends[e]) acc[r[e]] = old[e] + sum[e];
+  for (int e = 0; e < 4; ++e) acc[at[e]] = old[e] + add[e];
 }
 
 /// Kernel B: one workgroup (4 wavefronts) per sub-band.  Wavefront w walks the segments of its quarter of the panels -- the
@@ -299,9 +301,11 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
   const int lane = wave::lane();
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / wave::size);
   type_t* all = reinterpret_cast<type_t*>(panel_lds);
-  type_t* acc = all + static_cast<std::size_t>(w) * Hw;
+  const int stride = Hw + wave::size;                       // Hw accumulators + one private dump word per lane
+  type_t* acc = all + static_cast<std::size_t>(w) * stride;
+  const int dump = Hw + lane;
   const int s = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
-  for (int j = lane; j < Hw; j += wave::size) acc[j] = type_t(0);
+  for (int j = lane; j < stride; j += wave::size) acc[j] = type_t(0);
   // This wavefront's share: a quarter of the sub-band's ITEMS (not of its panels: with column locality a few panels hold
   // nearly everything), cut at a multiple of 4.  A run of equal rows cut by the boundary ends up in two accumulators: fine.
   const int* seg = segb + static_cast<long long>(s) * P;   // seg[p] .. seg[p + 1] = segment (s, p); seg[P] = next sub-band's first
@@ -364,7 +368,7 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
           unsigned int r[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
-          panel_window_add<type_t>(acc, v[u], r);
+          panel_window_add<type_t>(acc, dump, v[u], r);
         }
       }
     }
@@ -374,7 +378,7 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
   for (int j = threadIdx.x; j < Hw && row0 + j < rows; j += 256) {
     type_t sum = all[j];
 #pragma unroll
-    for (int k = 1; k < WAVES; ++k) sum += all[static_cast<std::size_t>(k) * Hw + j];
+    for (int k = 1; k < WAVES; ++k) sum += all[static_cast<std::size_t>(k) * stride + j];
     out(static_cast<int>(row0 + j), sum);
   }
 }
@@ -518,13 +522,18 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
                          m.col16, m.dst4, x, m.cols, m.prod);
   }
   if (stages & 2) {
-    const std::size_t lds = static_cast<std::size_t>(256 / wave::size) * m.Hw * sizeof(type_t);
-    if (nt)
-      hipLaunchKernelGGL((panel::panel_reduce<true, type_t, store_t>), dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod,
-                         m.row16, m.rows, out);
-    else
-      hipLaunchKernelGGL((panel::panel_reduce<false, type_t, store_t>), dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod,
-                         m.row16, m.rows, out);
+    const std::size_t lds = static_cast<std::size_t>(256 / wave::size) * (m.Hw + wave::size) * sizeof(type_t);
+    auto go = [&](auto kernel) {
+      // (66.5 KB at Hw = 16 KB / sizeof(T): above the 64 KB a kernel may use without asking)
+      static bool raised = false;  // once per instantiation
+      if (!raised && lds > 65536) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
+        raised = true;
+      }
+      hipLaunchKernelGGL(kernel, dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod, m.row16, m.rows, out);
+    };
+    if (nt) go(panel::panel_reduce<true, type_t, store_t>);
+    else go(panel::panel_reduce<false, type_t, store_t>);
   }
   return static_cast<int>(hipGetLastError());
 }
