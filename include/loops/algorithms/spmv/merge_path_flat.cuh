@@ -45,14 +45,14 @@ using merge_path_small_plan_t = merge_path_plan_of_t<launch_t<type_t>::block_siz
 template <std::size_t TPB, std::size_t IPT, typename index_t, typename offset_t, typename type_t>
 void merge_path_flat_async_with(const merge_path_plan_of_t<TPB, IPT, index_t, offset_t>& plan,
                                 csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
-                                xpu::stream_t stream = 0) {
+                                xpu::stream_t stream = 0, bool planned = false) {
   error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
                             "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
   kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
                                 static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
   kernels::launch_merge_path_fused<static_cast<int>(TPB), static_cast<int>(IPT), (IPT % 2 == 0), false>(
       stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
-      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get(), 3, false, planned);
 }
 
 /// SpMV with a prebuilt plan (the merge_path launch box: 512 x 8 / 512 x 4); asynchronous on `stream`.

@@ -67,9 +67,11 @@ struct spmv_plan_t {
     large = std::make_unique<large_t>(lay, stream, large_t::prepass_always);
     large->classify(stream);
     ms_small = time_ms(repeats, stream, [&] {
-      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream);
+      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream, true);
     });
-    ms_large = time_ms(repeats, stream, [&] { merge_path_flat_async(*large, csr, x, y, stream); });
+    ms_large = time_ms(repeats, stream, [&] {
+      merge_path_flat_async_with<merge_path_launch_t<type_t>::block_size, merge_path_launch_t<type_t>::items_per_thread>(*large, csr, x, y, stream, true);
+    });
     // (a shape must be measurably -- > 1 % -- faster to displace the structural choice)
     const bool keep_small = ms_small < 0.99f * ms_large || (short_rows && ms_small <= 1.01f * ms_large);
     float best = keep_small ? ms_small : ms_large;
@@ -104,8 +106,9 @@ struct spmv_plan_t {
     if (panel) panel->spmv_async(x, y, stream);
     else if (blocked) blocked->spmv_async(x, y, stream);
     else if (small)
-      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream);
-    else merge_path_flat_async(*large, csr, x, y, stream);
+      merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream, true);
+    else
+      merge_path_flat_async_with<merge_path_launch_t<type_t>::block_size, merge_path_launch_t<type_t>::items_per_thread>(*large, csr, x, y, stream, true);
   }
 
   util::timer_t spmv(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {

@@ -70,13 +70,14 @@ inline int launch_merge_path_coordinates_ell(hipStream_t stream, int rows, int p
 }
 
 /// Fused merge-path SpMV (+ fix-up).  stages: bit 0 = tile kernel, bit 1 = fix-up.
-/// `stacked`: the matrix is a column-blocked CSR -- same code under its own kernel symbol.
+/// `stacked`: the matrix is a column-blocked CSR -- same code under its own kernel symbol; `planned`: the product comes from an
+/// SpMV plan handle -- again the same code under its own symbol.
 /// MASK (default): bit-mask split instead of the per-thread search (merge_tile_engine<..., MASK = true>):
 /// 1-2 % faster on every input measured (C2 103.3 -> 102.5 us, band-8192 50.4 -> 49.5, runs 43.7 -> 42.7).
 template <int TPB, int IPT, bool PAD, int NT, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
                             const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
-                            int stages = 3, bool stacked = false) {
+                            int stages = 3, bool stacked = false, bool planned = false) {
   const int m = plan.num_merge_tiles;
   if (m == 0) return 0;
   if (m == 1) stages &= ~2;  // one tile holds every row completely: no carry-out to add (launch-bound sizes: 1 kernel)
@@ -103,6 +104,9 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
     if (stacked) {
       if (aligned) go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
       else go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);
+    } else if (planned) {  // (same code under the symbol of SpMV-plan handles: profile attribution only)
+      if (aligned) go(merge_path_spmv_fused_planned<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
+      else go(merge_path_spmv_fused_planned<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);
     } else {
       if (aligned) go(merge_path_spmv_fused<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
       else go(merge_path_spmv_fused<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);

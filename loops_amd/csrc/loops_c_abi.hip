@@ -228,15 +228,15 @@ loops_merge_plan* scratch_plan(int rows, int nnz, int cfg, hipStream_t stream, i
 // stages: bit 0 = fused tile kernel, bit 1 = fix-up (3 = the whole SpMV)
 template <int TPB, int IPT, bool PAD, int NT, typename T, bool MASK = false>  // false: the search-based tuning variants
 int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, const int* off, const int* idx,
-                 const T* val, const T* x, T* y, hipStream_t stream, int stages) {
+                 const T* val, const T* x, T* y, hipStream_t stream, int stages, bool planned = false) {
   kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles, p->self_complete != 0, p->head_start};
   return kernels::launch_merge_path_fused<TPB, IPT, PAD, NT, int, int, T, MASK>(stream, view, rows, nnz, off, idx, val, x, y,
-                                                                                  stages);
+                                                                                  stages, false, planned);
 }
 
 template <typename T>
 int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, const int* off, const int* idx,
-                    const T* val, const T* x, T* y, hipStream_t stream, int stages = 3) {
+                    const T* val, const T* x, T* y, hipStream_t stream, int stages = 3, bool planned = false) {
   const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(p->tpb) * p->ipt));
   if (rows != p->rows || nnz != p->nnz) return LOOPS_E_BADARG;
   // variant 0 = the default kernel (bit-mask split, padded LDS products, temporal loads).  Tuning aids, all with
@@ -244,7 +244,7 @@ int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, c
   // streaming loads, bit 1 = unpadded LDS product array (1, 2, 3)
   const bool nt = variant & 1, nopad = variant & 2, mask = variant == 0;
 #define LOOPS_FUSED(TPB, IPT)                                                                                    \
-  if (mask) return launch_fused<TPB, IPT, true, false, T, true>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
+  if (mask) return launch_fused<TPB, IPT, true, false, T, true>(p, m, rows, nnz, off, idx, val, x, y, stream, stages, planned); \
   if (!nopad && !nt) return launch_fused<TPB, IPT, true, false, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
   if (!nopad && nt) return launch_fused<TPB, IPT, true, true, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages);   \
   if (nopad && !nt) return launch_fused<TPB, IPT, false, false, T>(p, m, rows, nnz, off, idx, val, x, y, stream, stages); \
@@ -886,7 +886,7 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
     if (!err) err = plan_compute(m, off, st);
     if (!err) err = plan_classify(m, off, st);
     float ms = 0.f;
-    if (!err) err = time_ms(st, repeats, &ms, [&]() { return spmv_merge_path<T>(m, 0, rows, nnz, off, idx, val, x, y, st); });
+    if (!err) err = time_ms(st, repeats, &ms, [&]() { return spmv_merge_path<T>(m, 0, rows, nnz, off, idx, val, x, y, st, 3, true); });
     if (err) { plan_release(m); break; }
     p->ms[i] = ms;
     // 512 x 8 must be measurably (> 1 %) faster to displace 256 x 8 and vice versa: ties go to the structural choice
@@ -954,7 +954,7 @@ int spmv_planned(const loops_spmv_plan* p, const int* off, const int* idx, const
   if (p->layout == LOOPS_LAYOUT_PANEL_BINNED) return panel_spmv<T>(p->panel, 3, x, y, st);
   int err = check_csr(p->rows, p->cols, p->nnz, off, idx, val, x, y);
   if (err) return err;
-  return spmv_merge_path<T>(p->merge, 0, p->rows, p->nnz, off, idx, val, x, y, st);
+  return spmv_merge_path<T>(p->merge, 0, p->rows, p->nnz, off, idx, val, x, y, st, 3, /*planned=*/true);
 }
 
 }  // namespace
