@@ -1,6 +1,6 @@
 """Soak: the tuned kernels launched back to back for a fixed wall time on C2 and on a self-completing band matrix; every
 result compared ON THE GPU with the first one (bit-equal) -- races / ordering bugs show up as a mismatch count > 0.
-usage: python tests/perf/soak.py [seconds per case, default 20] [r2]     (r2 = only the kernels added in round 2)"""
+usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3]     (r2 / r3 = only the kernels added in that round)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -9,6 +9,7 @@ from oracle import oracle as O
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
 only_r2 = len(sys.argv) > 2 and sys.argv[2] == "r2"
+only_r3 = len(sys.argv) > 2 and sys.argv[2] == "r3"
 rows = cols = 1 << 20
 
 
@@ -27,6 +28,47 @@ def soak(name, label, fn, ref, n_out):
         torch.cuda.synchronize()
     print(f"{name:7s} {label:46s} rounds {rounds:7d} mismatching rounds {int(bad.item())}", flush=True)
 
+
+# ---- round 3: panel-binned (plain and fan-out; reproducibility of its LDS accumulation is the point), the stitched
+# flat_partitioned (atomics: exactly summable inputs make every order give the same bits), coalesced BCSR, the measured SpMV plan
+def round3():
+    off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    ref = torch.from_numpy(O.spmv_f32(off, idx, val, xh, omp=True)).cuda()
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    pb = S.PanelBinnedPlan(csr)
+    peers = [torch.empty(rows, device="cuda") for _ in range(2)]
+    def fan_panel(y):
+        for p in peers: p.fill_(float("nan"))
+        pb.spmv_fanout(x, y, peers)
+        return peers
+    soak("c2", "panel_binned (products + sub-band reduce)", lambda y: (pb.spmv(x, y), None)[1], ref, rows)
+    soak("c2", "panel_binned + fan-out (2 peers)", fan_panel, ref, rows)
+    soak("c2", "flat_partitioned (wavefront-stitched)", lambda y: (S.spmv("flat_partitioned", csr, x, y), None)[1], ref, rows)
+    sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
+    soak("c2", f"held SpMV plan ({sp.layout}, {sp.tile})", lambda y: (sp.spmv(x, y), None)[1], ref, rows)
+    # realistic values: the panel-binned result must be the same bits every time (no order depends on timing)
+    off2, idx2, val2 = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1, 0, False)
+    csr2 = S.CSR.from_numpy(rows, cols, off2, idx2, val2)
+    xr = torch.from_numpy(G.realistic_x(cols)).cuda()
+    pb2 = S.PanelBinnedPlan(csr2)
+    first = pb2.spmv(xr).clone()
+    soak("c2real", "panel_binned, real values: run-to-run bit identity", lambda y: (pb2.spmv(xr, y), None)[1], first, rows)
+    del pb, pb2, sp, csr, csr2
+    for R, dt in ((2, np.float32), (3, np.float32), (8, np.float32)):
+        nbr = 1 << 16
+        boff, bcols, _ = G.uniform_bcsr(nbr, nbr, 16, R, R)
+        bvals = (np.random.default_rng(R).integers(1, 9, size=bcols.size * R * R) / 8.0).astype(dt)
+        xb = torch.from_numpy(G.uniform_distribution_int(nbr * R)).cuda()
+        b = S.BCSR(R, R, nbr * R, nbr * R, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+        want = S.bcsr_thread_mapped(b, xb, mfma="thread").clone()
+        soak("bcsr", f"coalesced BCSR {R}x{R}, 2^16 block-rows x 16", lambda y, b=b, xb=xb: (S.bcsr_thread_mapped(b, xb, y, mfma="tuned"), None)[1], want, nbr * R)
+
+
+if only_r3:
+    round3()
+    sys.exit(0)
 
 # ---- round 2: ELL merge-path on the fused engine, DIA, epilogue fan-out (two stand-in peers on the same device)
 off, idx, val = G.csr_from_degrees(np.minimum(G.powerlaw_degrees(1 << 18, 1 << 22, cap=256), 256), cols, 1)
@@ -71,6 +113,7 @@ soak("c2", "column-blocked + reduce fan-out (2 peers)", fan_blocked, ref, rows)
 del csr, plan, cb, peers
 if only_r2:
     sys.exit(0)
+round3()
 
 cases = {"c2": (G.powerlaw_degrees(rows, 1 << 24), None), "band64": (np.full(rows, 16, np.int64), 64)}
 for name, (deg, window) in cases.items():
