@@ -647,7 +647,7 @@ def main():
     exchange_dropped = {}
     safe = {"mode": None, "ms_per_step": None, "parity": None}
     R_ = {"one_gpu": None, "ms_with_prepass": None, "blocked_info": None, "local_info": None, "schedules_info": None, "c4_info": None,
-          "c3_info": None, "copy_gbps": None, "gather_gps": None, "ref_gpu": None, "cpu": None, "fused_note": None, "l2_gather_gps": None}
+          "c3_info": None, "copy_gbps": None, "gather_gps": None, "ref_gpu": None, "cpu": None, "fused_note": None, "l2_gather_gps": None, "panel_info": None}
 
     def record(ms_per_step, parity, watchdog=None):
         """The one JSON line, from whatever has been measured so far (the watchdog calls it with the safe exchange's figures)."""
@@ -738,6 +738,7 @@ def main():
                        "watchdog": watchdog,
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
                        "column_blocked_layout_same_matrix": R_["blocked_info"],
+                       "panel_binned_layout_same_matrix": R_["panel_info"],
                        "same_kernel_local_columns": R_["local_info"],
                        "schedules_c2": R_["schedules_info"],
                        "c4_bcsr_mfma": R_["c4_info"],
@@ -952,6 +953,24 @@ def main():
                               "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/column_blocked.hxx); "
                                       "same fused kernel + K-way row reduce; not the headline"}
         cb.close()
+
+    # for context at N = 1: the same SpMV from the panel-binned copy (x panels in LDS, no memory gather; never `value`)
+    if world == 1 and blocked is None and rank == 0 and not args.no_context:
+        pb = S.PanelBinnedPlan(csr)
+        yp = torch.empty_like(y_loc)
+        ms_p = batch_event_time(lambda: pb.spmv(x, yp), iters)
+        ms_pa = batch_event_time(lambda: pb.spmv_stage(0, x, yp), iters)
+        ms_pb = batch_event_time(lambda: pb.spmv_stage(1, x, yp), iters)
+        pb.spmv(x, yp)
+        torch.cuda.synchronize()
+        ab = algorithmic_bytes(csr.rows, cols, csr.nnzs)
+        R_["panel_info"] = {"panels": pb.num_panels, "panel_columns": pb.W, "subbands": pb.num_subbands, "subband_rows": pb.Hw,
+                            "ms_per_step": round(ms_p, 5), "products_ms": round(ms_pa, 5), "reduce_ms": round(ms_pb, 5),
+                            "GFLOPs": round(2.0 * nnz / (ms_p * 1e-3) / 1e9, 2), "frac": round(ab / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "equal_to_csr_result": bool(torch.equal(yp, y_loc)),
+                            "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/panel_binned.hxx): 17 B of streamed traffic per "
+                                    "nonzero instead of 8 B + a gather; not the headline"}
+        pb.close()
 
     # for context at N = 1: the SAME kernel on a matrix of the same size whose columns are local (16 per row inside a
     # 64-column band): what the kernel does when the x gather is served by L1 -- its roofline fraction as a kernel,
