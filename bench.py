@@ -803,6 +803,24 @@ def main():
             barrier()
             if why is None and not torch.equal(y_full, y_exchanged):
                 why = "result differs from the exchanged vector"
+            if why is None:
+                # ... and the NEXT product must arrive too: with x doubled every element of y doubles exactly, so a rank that still
+                # sees last step's values somewhere (a line of its y_full cached from before a peer's store) is caught here
+                try:
+                    x.mul_(2.0)
+                    barrier()
+                    step()
+                    barrier()
+                    if not torch.equal(y_full, 2.0 * y_exchanged):
+                        why = "a second product (x doubled) did not arrive everywhere"
+                    x.mul_(0.5)
+                    barrier()
+                    step()
+                    barrier()
+                    if why is None and not torch.equal(y_full, y_exchanged):
+                        why = "a third product (x restored) did not arrive everywhere"
+                except Exception as e:  # noqa: BLE001
+                    why = f"{type(e).__name__}: {e}"
             ok, bad = agreed(why is None, why)
             if not ok:
                 exchange_dropped[name] = bad
@@ -878,9 +896,19 @@ def main():
 
     # ------------------------------------------------------------------ parity (outside timing)
     if not args.no_check:
-        step()
-        torch.cuda.synchronize()
-        parity = check_gathered_parity()
+        # the adopted exchange must reproduce the oracle; one that does not is dropped (reason recorded) and the next fastest
+        # takes its place -- a wrong candidate costs that candidate, not the run
+        order = [gather_mode["mode"]] if (world == 1 or args.exchange != "auto") else sorted(exchange_probe, key=exchange_probe.get)
+        for mode in order:
+            gather_mode["mode"] = mode
+            step()
+            torch.cuda.synchronize()
+            parity = check_gathered_parity()
+            if parity:
+                break
+            if world > 1:
+                exchange_dropped[mode] = {"all ranks": "the gathered y differed from the oracle after adoption"}
+                exchange_probe.pop(mode, None)
         assert parity, "GPU result differs from the oracle"
 
     # ------------------------------------------------------------------ timed region

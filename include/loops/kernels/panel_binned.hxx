@@ -21,10 +21,11 @@
  *                       16-byte groups, consecutive groups of a segment to consecutive addresses (7 B read + 4 B written per
  *                       nonzero, no gather leaves the CU);
  *   B  panel_reduce     one WORKGROUP per sub-band of Hw rows: the sub-band's products are ONE contiguous run of the B order;
- *                       each of the 4 wavefronts walks the segments of its quarter of the panels (16 + 8 bytes per lane and
- *                       step, 4 segments in flight); inside a segment rows are sorted, so runs of equal rows are summed with
- *                       the wave64 segmented prefix sum and the run ends update the wavefront's OWN LDS accumulators with
- *                       plain read-modify-writes (LDS float atomics are 10 x slower than that on gfx950); the 4 partial
+ *                       each of the 4 wavefronts takes a quarter of the run's items and walks it in windows of 64 lanes x 4
+ *                       items that never cross a segment boundary (16 + 8 bytes per lane, 8 windows in flight); inside a
+ *                       window rows are sorted, so runs of equal rows are summed with the wave64 segmented prefix sum and the
+ *                       run ends update the wavefront's OWN LDS accumulators with plain read-modify-writes (LDS float
+ *                       atomics retire ~0.4 lanes per clock and CU on gfx950: used for windows of <= 64 items only); the 4 partial
  *                       vectors are then added in wavefront order and the Hw rows of y are stored coalesced (4 B + 2 B read
  *                       per nonzero).  Reproducible: no order depends on timing.
  * HBM traffic 17 B per nonzero instead of 8 B + a gather; y needs no zero-fill; no global atomics.
