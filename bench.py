@@ -447,10 +447,18 @@ def main():
             ok, ms = 1.0, float("inf")
             try:
                 built[kind] = make_shard_plan(kind)
-                ms = timed_ms(torch, lambda: built[kind].spmv(x, y_loc), 10)
             except Exception as e:  # noqa: BLE001
                 ok = 0.0
                 print(f"[rank {rank}] shard layout {kind} unavailable ({type(e).__name__}: {e})", file=sys.stderr)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()  # every rank times the same candidate at the same time (ranks sharing a GPU in the functional test compete evenly)
+            if ok:
+                try:
+                    ms = timed_ms(torch, lambda: built[kind].spmv(x, y_loc), 10)
+                except Exception as e:  # noqa: BLE001
+                    ok = 0.0
+                    print(f"[rank {rank}] shard layout {kind} failed ({type(e).__name__}: {e})", file=sys.stderr)
             if world > 1:
                 t = torch.tensor([ms if ok else 1e30, 1.0 - ok], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
