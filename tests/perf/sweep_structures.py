@@ -75,6 +75,7 @@ for name, (deg, cols, window) in cases.items():
     for label, fn in (("merge_path_flat", lambda: S.merge_path_flat(csr, x, y, plan=plan)),
                       ("work_oriented", lambda: S.spmv("work_oriented", csr, x, y)),
                       ("group_mapped", lambda: S.spmv("group_mapped", csr, x, y)),
+                      ("flat_partitioned", lambda: S.spmv("flat_partitioned", csr, x, y)),
                       ("thread_mapped", lambda: S.spmv("thread_mapped", csr, x, y))):
         ms = ev(fn, iters=10 if label == "thread_mapped" else 20)
         ok = bool(np.array_equal(y.cpu().numpy(), ref))
@@ -84,6 +85,16 @@ for name, (deg, cols, window) in cases.items():
     row["column_blocked"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "blocks": cb.num_blocks,
                              "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
     cb.close()
+    pb = S.PanelBinnedPlan(csr)     # x panels in LDS, no memory gather (round 3)
+    ms = ev(lambda: pb.spmv(x, y))
+    row["panel_binned"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "subband_rows": pb.Hw,
+                           "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+    pb.close()
+    sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=10)   # what a caller holding ONE handle gets (round 3)
+    ms = ev(lambda: sp.spmv(x, y))
+    row["held_spmv_plan"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "layout": sp.layout, "tile": sp.tile,
+                             "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+    sp.close()
     if R is not None:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         for kind, label in ((2, "ref_hip_merge_path"), (1, "ref_hip_work_oriented"), (0, "ref_hip_thread_mapped")):
