@@ -36,7 +36,7 @@ struct panel_binned_t {
   /// @param subband_rows 0 = automatic (kernels::panel_subband_rows), or a power of two in [64, 16384 / sizeof(type_t)]
   explicit panel_binned_t(csr_t<index_t, offset_t, type_t>& csr, int subband_rows = 0, xpu::stream_t stream = 0)
       : rows(csr.rows), cols(csr.cols), nnzs(csr.nnzs) {
-    W = kernels::panel_width<type_t>::value;
+    W = kernels::panel_columns<type_t>(static_cast<int>(rows), static_cast<int>(cols), static_cast<int>(nnzs));
     P = cols ? static_cast<int>((cols + W - 1) / W) : 1;
     Hw = subband_rows ? subband_rows : kernels::panel_subband_rows<type_t>(static_cast<int>(rows), static_cast<int>(nnzs), P);
     error::throw_if_exception(Hw < 64 || Hw > 16384 / static_cast<int>(sizeof(type_t)) || (Hw & (Hw - 1)),

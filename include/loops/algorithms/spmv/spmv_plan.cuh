@@ -126,7 +126,8 @@ struct spmv_plan_t {
     return static_cast<unsigned long long>(k) * csr.rows + csr.nnzs < (1ull << 31) - 4096;
   }
   static bool fits_panel(const csr_t<index_t, offset_t, type_t>& csr) {
-    const long long P = (static_cast<long long>(csr.cols) + kernels::panel_width<type_t>::value - 1) / kernels::panel_width<type_t>::value;
+    const int w = kernels::panel_columns<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.cols), static_cast<int>(csr.nnzs));
+    const long long P = (static_cast<long long>(csr.cols) + w - 1) / w;
     const int hw = kernels::panel_subband_rows<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), static_cast<int>(P > 0 ? P : 1));
     const long long segments = (P > 0 ? P : 1) * ((static_cast<long long>(csr.rows) + hw - 1) / hw);
     return segments <= (1ll << 26) && static_cast<long long>(csr.nnzs) + 3 * segments < (1ll << 31) - 4096;

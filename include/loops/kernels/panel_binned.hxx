@@ -69,11 +69,24 @@ struct panel_binned_view {
   type_t* prod;               ///< [padded] B order: products scratch (kernel A -> kernel B)
 };
 
-/// Compile-time panel width: 64 KB of x per workgroup of kernel A (two workgroups per CU).
+/// Panel widths kernel A is compiled for: 64 KB of x per workgroup (512 threads, two workgroups per CU) and 128 KB (1024
+/// threads, one workgroup per CU).  `value` = the narrow one.
 template <typename type_t>
 struct panel_width {
   static constexpr int value = 65536 / static_cast<int>(sizeof(type_t));
+  static constexpr int wide = 2 * value;
 };
+
+/// Panel width for (rows, cols, nnz): 128 KB of x per panel whenever the matrix has at least four narrow panels -- half as
+/// many panels means (panel, sub-band) segments twice as long (fuller windows in kernel B, longer store runs in kernel A) and
+/// half as many of them; measured better or equal on every input with x >= 4 MB (C2 86 -> 73 us, C5 shard 345 -> 272,
+/// C3 stand-ins 0.83 -> 0.73 / 1.21 -> 0.89 / 0.73 -> 0.62 ms, profiles/r03_panel_binned.json).
+template <typename type_t>
+inline int panel_columns(int /*rows*/, int cols, int /*nnz*/) {
+  const int w = panel_width<type_t>::value;
+  const long long P = cols > 0 ? (static_cast<long long>(cols) + w - 1) / w : 1;
+  return P >= 4 ? panel_width<type_t>::wide : w;
+}
 
 namespace panel {
 
@@ -409,16 +422,20 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
 }  // namespace panel
 
 /// Sub-band height (rows per workgroup of kernel B): what matters is the size of a (panel, sub-band) segment, nnz Hw / (rows P)
-/// items -- kernel B handles them in windows of 256 and kernel A stores their products as one run -- so Hw is the power of two
-/// that brings a segment to ~192 items, within [256, 16 KB of accumulators per wavefront], halved while fewer than 512
-/// sub-bands would be left.  Measured (tests/perf/bench_panel.py with PANEL_HW): C5 shard 802 / 536 / 402 / 353 us for
-/// Hw = 512 / 1024 / 2048 / 4096 (16 .. 128 items per segment), C2 86 / 88 / 94 / 116 us (128 .. 1024 items).
+/// items -- kernel B handles them in windows of 256 and kernel A stores their products as one run: Hw = the power of two
+/// that brings a segment to ~192 items, at least 256 rows; at most HALF of the 16 KB of accumulators a wavefront may have
+/// (4 instead of 2 workgroups per CU) unless segments would then hold fewer than 96 items; halved while fewer than 512
+/// sub-bands would be left.  Measured with 128 KB panels (tests/perf/bench_panel.py, PANEL_W / PANEL_HW): C2 84 / 73 / 84 / 90
+/// / 104 us for Hw = 256 / 512 / 1024 / 2048 / 4096 (128 .. 2048 items per segment), C5 shard 700 / 583 / 444 / 272 / 295 us
+/// (16 .. 256 items), C3 uniform stand-in 1631 / 1277 / 740 / 730 / 765 us.
 template <typename type_t>
 inline int panel_subband_rows(int rows, int nnz, int P) {
   const int hw_max = 16384 / static_cast<int>(sizeof(type_t));
-  const double want = nnz > 0 ? 192.0 * static_cast<double>(rows) * static_cast<double>(P) / static_cast<double>(nnz) : 256.0;
+  const double per_row = rows > 0 && P > 0 ? static_cast<double>(nnz) / (static_cast<double>(rows) * static_cast<double>(P)) : 0.0;
+  const double want = per_row > 0 ? 192.0 / per_row : 256.0;
   int hw = 256;
   while (hw < hw_max && hw < want) hw *= 2;
+  if (hw == hw_max && per_row * (hw_max / 2) >= 96.0) hw = hw_max / 2;
   while (hw > 256 && static_cast<long long>(rows) / hw < 512) hw /= 2;
   return hw;
 }
@@ -533,16 +550,20 @@ int build_panel_binned_stage2(hipStream_t stream, const index_t* indices, const 
 template <typename type_t, typename store_t>
 int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& m, const type_t* x, const store_t out, int stages = 3) {
   if (m.rows == 0) return 0;
-  constexpr int W = panel_width<type_t>::value;
-  if (m.W != W) return static_cast<int>(hipErrorInvalidValue);
+  constexpr int W = panel_width<type_t>::value, W2 = panel_width<type_t>::wide;
+  if (m.W != W && m.W != W2) return static_cast<int>(hipErrorInvalidValue);
   const bool nt = static_cast<double>(m.padded) * (2.0 * sizeof(type_t) + 4.0) > 200e6;
   if ((stages & 1) && m.num_chunks > 0) {
-    if (nt)
-      hipLaunchKernelGGL((panel::panel_products<512, W, 4, true, type_t>), dim3(m.num_chunks), dim3(512), 0, stream, m.chunks, m.val,
-                         m.col16, m.dst4, x, m.cols, m.prod);
-    else
-      hipLaunchKernelGGL((panel::panel_products<512, W, 4, false, type_t>), dim3(m.num_chunks), dim3(512), 0, stream, m.chunks, m.val,
-                         m.col16, m.dst4, x, m.cols, m.prod);
+    auto go = [&](auto kernel, int threads) {
+      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(threads), 0, stream, m.chunks, m.val, m.col16, m.dst4, x, m.cols, m.prod);
+    };
+    if (m.W == W) {
+      if (nt) go(panel::panel_products<512, W, 4, true, type_t>, 512);
+      else go(panel::panel_products<512, W, 4, false, type_t>, 512);
+    } else {
+      if (nt) go(panel::panel_products<1024, W2, 4, true, type_t>, 1024);
+      else go(panel::panel_products<1024, W2, 4, false, type_t>, 1024);
+    }
   }
   if (stages & 2) {
     const std::size_t lds = static_cast<std::size_t>(256 / wave::size) * (m.Hw + wave::size) * sizeof(type_t);

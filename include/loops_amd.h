@@ -267,7 +267,7 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
 
 /* ---- panel-binned layout: SpMV without a gather, for x far larger than the per-XCD L2 ------------------------------
  * No reference counterpart.  The plan holds a re-ordered COPY of the matrix (include/loops/kernels/panel_binned.hxx): nonzeros
- * sorted by (panel of W = 64 KB / sizeof(T) consecutive columns, sub-band of Hw consecutive rows) -- value + 16-bit column
+ * sorted by (panel of W = 64 KB (or 128 KB) / sizeof(T) consecutive columns, sub-band of Hw consecutive rows) -- value + 16-bit column
  * inside the panel + one int per 4 items saying where their products go -- and, in (sub-band, panel) order, the 16-bit row
  * inside the sub-band + a products scratch.  y = A x runs as two streaming kernels: products with the x panel held in LDS
  * (the x value of a nonzero is an LDS read, not a memory gather), stored in 16-byte groups so that every sub-band's products
@@ -284,10 +284,12 @@ typedef struct loops_panel_plan loops_panel_plan_t;
 /* subband_rows: 0 = automatic (the power of two that brings a (panel, sub-band) segment to ~192 nonzeros, within 256 rows ..
  * 16 KB of accumulators per wavefront, at least 512 sub-bands when the matrix has the rows for it), or an explicit power of
  * two in [64, 16384 / sizeof(T)] (LOOPS_E_BADARG otherwise). */
+/* panel_columns: 0 = automatic (64 KB of x per panel, 128 KB when the segments would otherwise stay below ~160 nonzeros), or
+ * explicitly 65536 / sizeof(T) or 131072 / sizeof(T) (LOOPS_E_BADARG otherwise). */
 int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
-                                int subband_rows, void* stream, loops_panel_plan_t** out);
+                                int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out);
 int loops_panel_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
-                                int subband_rows, void* stream, loops_panel_plan_t** out);
+                                int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out);
 void loops_panel_plan_destroy(loops_panel_plan_t* plan);
 int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7);
 int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsigned short* col16, int* dst4, unsigned short* row16,

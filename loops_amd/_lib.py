@@ -194,7 +194,7 @@ def lib() -> C.CDLL:
             getattr(L, "loops_spmv_plan_refresh_values_" + sfx).argtypes = [vp, vp, vp]
             getattr(L, "loops_spmv_planned_" + sfx).argtypes = [vp, vp, vp, vp, vp, vp, vp]
         for sfx in ("f32", "f64"):
-            getattr(L, "loops_panel_plan_create_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, C.POINTER(vp)]
+            getattr(L, "loops_panel_plan_create_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
             getattr(L, "loops_panel_plan_refresh_values_" + sfx).argtypes = [vp, vp, vp]
             getattr(L, "loops_spmv_panel_" + sfx).argtypes = [vp, vp, vp, vp]
             getattr(L, "loops_spmv_panel_fanout_" + sfx).argtypes = [vp, vp, vp, ci, vp, vp]

@@ -714,12 +714,16 @@ kernels::panel_binned_view<T> panel_view(const loops_panel_plan* p) {
 
 template <typename T>
 int panel_create(int rows, int cols, int nnz, const int* offsets, const int* indices, const T* values, hipStream_t st,
-                 loops_panel_plan** out, int subband_rows = 0) {
+                 loops_panel_plan** out, int subband_rows = 0, int panel_cols = 0) {
   if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
   auto* p = new (std::nothrow) loops_panel_plan();
   if (!p) return static_cast<int>(hipErrorOutOfMemory);
   p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T));
-  p->W = kernels::panel_width<T>::value;
+  p->W = kernels::panel_columns<T>(rows, cols, nnz);
+  if (panel_cols != 0) {  // explicit: one of the two compiled widths
+    if (panel_cols != kernels::panel_width<T>::value && panel_cols != kernels::panel_width<T>::wide) { delete p; return LOOPS_E_BADARG; }
+    p->W = panel_cols;
+  }
   p->P = cols > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(cols), static_cast<long long>(p->W))) : 1;
   p->Hw = kernels::panel_subband_rows<T>(rows, nnz, p->P);
   if (subband_rows != 0) {  // explicit: a power of two, 64 .. 16 KB of accumulators per wavefront
@@ -1370,12 +1374,12 @@ int loops_spmv_planned_f64(const loops_spmv_plan_t* plan, const int* offsets, co
 }
 
 int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
-                                int subband_rows, void* stream, loops_panel_plan_t** out) {
-  return panel_create<float>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows);
+                                int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out) {
+  return panel_create<float>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows, panel_columns);
 }
 int loops_panel_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
-                                int subband_rows, void* stream, loops_panel_plan_t** out) {
-  return panel_create<double>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows);
+                                int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out) {
+  return panel_create<double>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows, panel_columns);
 }
 void loops_panel_plan_destroy(loops_panel_plan_t* plan) { panel_free(plan); }
 int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7) {

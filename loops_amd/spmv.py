@@ -311,15 +311,15 @@ class PanelBinnedPlan:
     -- x panels in LDS, products streamed, one wavefront per sub-band of rows adds them up in LDS.  For x far larger than
     the per-XCD L2."""
 
-    def __init__(self, csr: CSR, subband_rows: int = 0):
+    def __init__(self, csr: CSR, subband_rows: int = 0, panel_columns: int = 0):
         assert csr.values.dtype in (torch.float32, torch.float64)
         self.dtype = csr.values.dtype
         self._sfx = _suffix(csr.values)
         self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
         self._h = C.c_void_p()
         create = getattr(L.lib(), "loops_panel_plan_create_" + self._sfx)
-        L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), int(subband_rows),
-                       _stream(), C.byref(self._h)), "loops_panel_plan_create")
+        L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), int(panel_columns),
+                       int(subband_rows), _stream(), C.byref(self._h)), "loops_panel_plan_create")
         info = (C.c_int * 7)()
         L.check(L.lib().loops_panel_plan_info(self._h, info), "loops_panel_plan_info")
         self.W, self.Hw, self.num_panels, self.num_subbands, self.padded, self.num_chunks, _ = list(info)

@@ -45,8 +45,8 @@ for name in want:
     blocks = cb.num_blocks
     cb.close()
     for hw in [int(t) for t in os.environ.get("PANEL_HW", "").split(",") if t]:  # tuning aid: explicit sub-band heights
-        pv = S.PanelBinnedPlan(csr, hw)
-        print(name, "Hw", hw, "subbands", pv.num_subbands, "total %.1f us  products %.1f  reduce %.1f" % (
+        pv = S.PanelBinnedPlan(csr, hw, int(os.environ.get("PANEL_W", "0")))
+        print(name, "W", pv.W, "Hw", hw, "subbands", pv.num_subbands, "total %.1f us  products %.1f  reduce %.1f" % (
             batch_ms(lambda: pv.spmv(x, y2)) * 1e3, batch_ms(lambda: pv.spmv_stage(0, x, y2)) * 1e3, batch_ms(lambda: pv.spmv_stage(1, x, y2)) * 1e3),
             file=sys.stderr, flush=True)
         pv.close()
