@@ -281,12 +281,62 @@ panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, c
   }
 }
 
+/// acc += v on an LDS word that other lanes of the same instruction may target too: a compare-and-swap loop (ds_read +
+/// ds_cmpst_rtn until it sticks).  Measured (scripts/probe_lds_update.py, lanes per clock and CU): ds_add_f32 0.33 whatever
+/// the address pattern -- one lane every three clocks -- against 10-13 for ds_add_u32 and 4-7 for a plain read-add-write;
+/// the loop runs once per lane unless two lanes of the instruction share the word.
+template <typename type_t>
+__device__ __forceinline__ void lds_add(type_t* p, const type_t v) {
+  if constexpr (sizeof(type_t) == 4) {
+    unsigned int* u = reinterpret_cast<unsigned int*>(p);
+    unsigned int old = *u;
+    while (true) {
+      const unsigned int got = atomicCAS(u, old, __float_as_uint(__uint_as_float(old) + v));
+      if (got == old) break;
+      old = got;
+    }
+  } else {
+    unsigned long long* u = reinterpret_cast<unsigned long long*>(p);
+    unsigned long long old = *u;
+    while (true) {
+      const unsigned long long got = atomicCAS(u, old, static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(old)) + v)));
+      if (got == old) break;
+      old = got;
+    }
+  }
+}
+
+/// Four of them per lane, reads and swaps issued together (one LDS round trip each instead of four); whatever did not
+/// stick -- another lane, or this lane's own earlier item, got to the word first -- goes through the loop.
+template <typename type_t>
+__device__ __forceinline__ void lds_add4(type_t* acc, const int (&at)[4], const type_t (&v)[4]) {
+  using word_t = std::conditional_t<sizeof(type_t) == 4, unsigned int, unsigned long long>;
+  word_t* u = reinterpret_cast<word_t*>(acc);
+  word_t old[4], got[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) old[e] = u[at[e]];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    type_t f;
+    __builtin_memcpy(&f, &old[e], sizeof(type_t));
+    f += v[e];
+    word_t want;
+    __builtin_memcpy(&want, &f, sizeof(type_t));
+    got[e] = atomicCAS(u + at[e], old[e], want);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (got[e] != old[e]) lds_add(acc + at[e], v[e]);
+}
+
 /// One window of kernel B: 64 lanes x 4 consecutive items of ONE segment (rows non-decreasing; `pad_row` marks padding and
 /// lanes outside the segment).  Runs of equal rows are summed -- inside a lane, then across lanes with the segmented prefix
 /// sum -- and the lane-slot that ends a run adds the run's sum to the row's accumulator with a plain LDS read-modify-write:
 /// inside a window every row ends exactly once, so no two lanes touch the same address (LDS float atomics, the obvious
 /// alternative, retire ~0.4 lanes per clock and CU on gfx950: 5 x the time of the whole product stream).
-template <typename type_t>
+/// SHARED_ROWS: the window holds several small segments (each sorted, a row may end once in every one of them): the
+/// final update is then the compare-and-swap add above instead of the plain read-modify-write.
+template <typename type_t, bool SHARED_ROWS = false>
 __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const int dump, const type_t (&v)[4],
                                                  const unsigned int (&r)[4]) {
   type_t run[4];
@@ -313,10 +363,14 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
     at[e] = ends ? static_cast<int>(r[e]) : dump;
     add[e] = ends ? run[e] + (r[e] == r[0] ? carry_in : type_t(0)) : type_t(0);
   }
+  if constexpr (SHARED_ROWS) {
+    lds_add4(acc, at, add);
+  } else {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) old[e] = acc[at[e]];
+    for (int e = 0; e < 4; ++e) old[e] = acc[at[e]];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[at[e]] = old[e] + add[e];
+    for (int e = 0; e < 4; ++e) acc[at[e]] = old[e] + add[e];
+  }
 }
 
 /// Kernel B: one workgroup (4 wavefronts) per sub-band.  Wavefront w walks the segments of its quarter of the panels -- the
@@ -325,7 +379,12 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
 /// (dynamic) LDS; the 4 partial vectors are then added in wavefront order.  Everything a wavefront does to its accumulators
 /// is in program order: the result is reproducible.
 /// NT: the product / row streams are larger than the Infinity Cache (non-temporal loads).
-template <bool NT, typename type_t, typename store_t>
+/// SMALL: the typical segment holds a few items (matrices of very short rows), i.e. nearly every window is a packed one:
+/// those then go through the run-combining path with compare-and-swap final updates (LDS float atomics: 3 clks per ITEM,
+/// 85 us of a 134 us kernel on 8 M rows x 2 nonzeros; this way 99 us).  Otherwise packed windows are the thin remainder
+/// next to large segments and use the atomics, which cost the wavefront nothing but the issue (measured: C2 34 against 36
+/// us, host-blocked C3 stand-in 394 against 408 us).
+template <bool NT, bool SMALL, typename type_t, typename store_t>
 __global__ void __launch_bounds__(256)
 panel_reduce(const int* __restrict__ segb, const int P, const int S, const int Hw, const type_t* __restrict__ prod,
              const unsigned short* __restrict__ row16, const int rows, const store_t out) {
@@ -362,17 +421,37 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
   int pos = first, pend = seg[p_first + 1] < last ? seg[p_first + 1] : last;
   while (first < last) {
     int wb[U], we[U];
+    bool small[U], packed[U];
     bool any = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      bool whole = false;                                       // the window starts a segment
       while (pos >= pend && p + 1 < P && seg[p + 1] < last) {  // next non-empty segment of the share (wave-uniform)
         ++p;
         pos = seg[p];
         pend = seg[p + 1] < last ? seg[p + 1] : last;
+        whole = true;
       }
       wb[u] = pos;
       we[u] = pos + wave::size * 4 < pend ? pos + wave::size * 4 : pend;
       if (we[u] < wb[u]) we[u] = wb[u];
+      // A whole segment of a few items takes the following segments along while they are as small (B order is contiguous
+      // across segments; padding items are skipped by their row): a sub-band of a matrix with column locality has hundreds
+      // of segments of a few items next to its diagonal one, a matrix of very short rows nothing else.  Such a window is
+      // sorted only piecewise -- a row may end once per segment -- so its final updates are compare-and-swap adds.
+      // (Not the short TAIL of a large segment: looking ahead costs a dependent scalar load per window, 4 us of C2's 31
+      // when every segment's tail did it.)
+      small[u] = we[u] - wb[u] <= small_window;
+      packed[u] = small[u] && whole && we[u] == pend;
+      if (packed[u]) {
+        while (p + 1 < P && seg[p + 1] < last) {
+          const int ne = seg[p + 2] < last ? seg[p + 2] : last;
+          if (ne - seg[p + 1] > small_window || ne - wb[u] > wave::size * 4) break;
+          ++p;
+          pend = ne;
+          we[u] = ne;
+        }
+      }
       pos = we[u] > pos ? we[u] : pos;
       any = any || wb[u] < we[u];
     }
@@ -394,9 +473,9 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (wb[u] < we[u]) {  // (wave-uniform)
-        if (we[u] - wb[u] <= small_window) {
-          // a window of a few items (the thin remainder of a matrix with column locality: hundreds of such segments per
-          // sub-band): LDS atomics cost ~2.5 clks per LANE, the run-combining path ~200 instructions per WINDOW
+        if (small[u] && !packed[u]) {
+          // the short tail of a large segment (sorted, long runs of one row are common): LDS float atomics, ~3 clks per
+          // item whatever the addresses, against ~200 instructions per window for the run-combining path
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (live[u] && r16v[u][e] != pad_row) atomicAdd(&acc[r16v[u][e]], v[u][e]);
@@ -404,7 +483,16 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
           unsigned int r[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
-          panel_window_add<type_t>(acc, dump, v[u], r);
+          if (packed[u]) {   // several small segments in one window
+            if constexpr (SMALL) {
+              panel_window_add<type_t, true>(acc, dump, v[u], r);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (r[e] != pad_row) atomicAdd(&acc[r[e]], v[u][e]);
+            }
+          } else
+            panel_window_add<type_t, false>(acc, dump, v[u], r);
         }
       }
     }
@@ -438,6 +526,11 @@ inline int panel_subband_rows(int rows, int nnz, int P) {
   if (hw == hw_max && per_row * (hw_max / 2) >= 96.0) hw = hw_max / 2;
   while (hw > 256 && static_cast<long long>(rows) / hw < 512) hw /= 2;
   return hw;
+}
+
+/// Kernel B variant: true when the mean (panel, sub-band) segment holds fewer than 64 items (see panel_reduce).
+inline bool panel_small_segments(int nnz, int P, int S) {
+  return static_cast<long long>(nnz) < 64ll * static_cast<long long>(P > 0 ? P : 1) * static_cast<long long>(S > 0 ? S : 1);
 }
 
 /// Bytes of temporary device storage build_panel_binned needs.
@@ -576,8 +669,9 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
       }
       hipLaunchKernelGGL(kernel, dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod, m.row16, m.rows, out);
     };
-    if (nt) go(panel::panel_reduce<true, type_t, store_t>);
-    else go(panel::panel_reduce<false, type_t, store_t>);
+    const bool small = panel_small_segments(m.nnz, m.P, m.S);
+    if (nt) { if (small) go(panel::panel_reduce<true, true, type_t, store_t>); else go(panel::panel_reduce<true, false, type_t, store_t>); }
+    else { if (small) go(panel::panel_reduce<false, true, type_t, store_t>); else go(panel::panel_reduce<false, false, type_t, store_t>); }
   }
   return static_cast<int>(hipGetLastError());
 }

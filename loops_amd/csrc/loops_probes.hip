@@ -159,6 +159,12 @@ int loops_address_rate_f32(const float* table, int table_words, int reps, int pa
   return kernels::launch_address_rate(as_stream(stream), table, table_words, reps, pattern, blocks, out);
 }
 
+int loops_lds_update_rate_f32(int mode, int pattern, int reps, int blocks, float* out, void* stream) {
+  if (!out || reps < 0 || blocks <= 0) return E_BADARG;
+  const int rc = kernels::launch_lds_update(as_stream(stream), mode, pattern, reps, blocks, out);
+  return rc == -1 ? E_BADARG : rc;
+}
+
 int loops_row_gather_f32(const float* table, const int* idx, size_t count, int row_floats, int blocks, float* out,
                          void* stream) {
   if (!table || !idx || !out || blocks <= 0) return E_BADARG;

@@ -111,6 +111,56 @@ inline int launch_address_rate(hipStream_t stream, const float* table, int table
   return static_cast<int>(hipGetLastError());
 }
 
+/// LDS update rate: every lane of `blocks` x 256 applies `reps` updates to a 4096-word LDS table.
+/// MODE 0: atomicAdd(float) (ds_add_f32), 1: atomicAdd(unsigned) (ds_add_u32), 2: plain read-add-write (not atomic),
+/// 3: ds_add_rtn_f32 (returning), 4: compare-and-swap loop (ds_read + ds_cmpst_rtn_b32 until it sticks).  PATTERN 0: consecutive words per lane (no two lanes share a word or a bank within
+/// one instruction), 1: hashed words (random bank conflicts, rare same-word), 2: all 64 lanes the same word, 3: pairs of
+/// adjacent lanes share a word (sorted-rows shape).
+template <int MODE, int PATTERN>
+__global__ void __launch_bounds__(256) lds_update_kernel(int reps, float* __restrict__ out) {
+  __shared__ float table[4096];
+  for (int j = threadIdx.x; j < 4096; j += 256) table[j] = 0.f;
+  __syncthreads();
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned h = gid * 2654435761u;
+  float keep = 0.f;
+  for (int k = 0; k < reps; ++k) {
+    unsigned j;
+    if constexpr (PATTERN == 0) j = (threadIdx.x + k * 256u) & 4095u;
+    else if constexpr (PATTERN == 1) { h = h * 1664525u + 1013904223u; j = (h >> 8) & 4095u; }
+    else if constexpr (PATTERN == 2) j = (k * 17u) & 4095u;
+    else j = ((threadIdx.x >> 1) + k * 128u) & 4095u;
+    if constexpr (MODE == 0) atomicAdd(&table[j], 1.0f);
+    else if constexpr (MODE == 1) atomicAdd(reinterpret_cast<unsigned*>(&table[j]), 1u);
+    else if constexpr (MODE == 2) table[j] = table[j] + 1.0f;
+    else if constexpr (MODE == 3) keep += atomicAdd(&table[j], 1.0f);
+    else {
+      unsigned* u = reinterpret_cast<unsigned*>(&table[j]);
+      unsigned old = *u;
+      while (true) {
+        const unsigned got = atomicCAS(u, old, __float_as_uint(__uint_as_float(old) + 1.0f));
+        if (got == old) break;
+        old = got;
+      }
+    }
+  }
+  __syncthreads();
+  if (keep == 123.456f || table[threadIdx.x] == -1.f) out[gid] = keep;
+}
+
+inline int launch_lds_update(hipStream_t stream, int mode, int pattern, int reps, int blocks, float* out) {
+  const dim3 g(blocks), b(256);
+#define LOOPS_LDS_CASE(M, P) \
+  if (mode == M && pattern == P) { hipLaunchKernelGGL((lds_update_kernel<M, P>), g, b, 0, stream, reps, out); return static_cast<int>(hipGetLastError()); }
+  LOOPS_LDS_CASE(0, 0) LOOPS_LDS_CASE(0, 1) LOOPS_LDS_CASE(0, 2) LOOPS_LDS_CASE(0, 3)
+  LOOPS_LDS_CASE(1, 0) LOOPS_LDS_CASE(1, 1) LOOPS_LDS_CASE(1, 2) LOOPS_LDS_CASE(1, 3)
+  LOOPS_LDS_CASE(2, 0) LOOPS_LDS_CASE(2, 1) LOOPS_LDS_CASE(2, 2) LOOPS_LDS_CASE(2, 3)
+  LOOPS_LDS_CASE(3, 0) LOOPS_LDS_CASE(3, 1) LOOPS_LDS_CASE(3, 2) LOOPS_LDS_CASE(3, 3)
+  LOOPS_LDS_CASE(4, 0) LOOPS_LDS_CASE(4, 1) LOOPS_LDS_CASE(4, 2) LOOPS_LDS_CASE(4, 3)
+#undef LOOPS_LDS_CASE
+  return -1;
+}
+
 /// Read-only stream: every lane sums its float4s (one store per thread at the very end, only if the
 /// sum is a magic value) -- the achievable READ rate of HBM / Infinity Cache.
 __global__ void __launch_bounds__(256) stream_read_kernel(const float4* __restrict__ src, float* __restrict__ sink,

@@ -28,6 +28,7 @@ def lib() -> C.CDLL:
         P.loops_mixed_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         P.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         P.loops_row_gather_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, vp, vp]
+        P.loops_lds_update_rate_f32.argtypes = [ci, ci, ci, ci, vp, vp]
         P.loops_probe_merge_path_scratch_bytes.argtypes = [ci, ci]
         P.loops_probe_merge_path_scratch_bytes.restype = C.c_size_t
         P.loops_probe_policy_name.argtypes = [ci]
@@ -66,6 +67,10 @@ def gather(table, idx, out, mode: int = 0):
 def address_rate(table, reps: int, pattern: int, blocks: int, out):
     L.check(lib().loops_address_rate_f32(_ptr(table), table.numel(), reps, pattern, blocks, _ptr(out), _stream()),
             "loops_address_rate_f32")
+
+
+def lds_update_rate(mode: int, pattern: int, reps: int, blocks: int, out):
+    L.check(lib().loops_lds_update_rate_f32(mode, pattern, reps, blocks, _ptr(out), _stream()), "loops_lds_update_rate_f32")
 
 
 def row_gather(table, idx, row_floats: int, blocks: int, out):

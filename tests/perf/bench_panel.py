@@ -7,6 +7,17 @@ import numpy as np, torch
 from loops_amd import generate as G, spmv as S
 
 
+def build_ms(make):
+    """Wall time of one plan creation (device work included), second of two creations (the first pays allocator warm-up)."""
+    import time
+    make().close()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    plan = make()
+    torch.cuda.synchronize()
+    return plan, (time.perf_counter() - t) * 1e3
+
+
 def batch_ms(fn, iters=20, warm=3):
     for _ in range(warm):
         fn()
@@ -38,9 +49,9 @@ for name in want:
     x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
     y0, y1, y2 = (torch.empty(rows, device="cuda") for _ in range(3))
     abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
-    mp = S.MergePathPlan(csr, "512x8")
+    mp, b_csr = build_ms(lambda: S.MergePathPlan(csr, "512x8"))
     t_csr = batch_ms(lambda: S.merge_path_flat(csr, x, y0, plan=mp))
-    cb = S.ColumnBlockedPlan(csr)
+    cb, b_cb = build_ms(lambda: S.ColumnBlockedPlan(csr))
     t_cb = batch_ms(lambda: cb.spmv(x, y1))
     blocks = cb.num_blocks
     cb.close()
@@ -50,7 +61,7 @@ for name in want:
             batch_ms(lambda: pv.spmv(x, y2)) * 1e3, batch_ms(lambda: pv.spmv_stage(0, x, y2)) * 1e3, batch_ms(lambda: pv.spmv_stage(1, x, y2)) * 1e3),
             file=sys.stderr, flush=True)
         pv.close()
-    pb = S.PanelBinnedPlan(csr)
+    pb, b_pb = build_ms(lambda: S.PanelBinnedPlan(csr))
     t_pb = batch_ms(lambda: pb.spmv(x, y2))
     t_a = batch_ms(lambda: pb.spmv_stage(0, x, y2))
     t_b = batch_ms(lambda: pb.spmv_stage(1, x, y2))
@@ -63,7 +74,11 @@ for name in want:
            "frac_csr": round(abytes / t_csr / 1e6 / 8000, 4), "frac_blocked": round(abytes / t_cb / 1e6 / 8000, 4),
            "frac_panel": round(abytes / t_pb / 1e6 / 8000, 4),
            "products_GBps": round(pb.padded * 11 / t_a / 1e6, 1), "reduce_GBps": round(pb.padded * 6 / t_b / 1e6, 1),
-           "equal": bool(torch.equal(y0, y1) and torch.equal(y0, y2))}
+           "equal": bool(torch.equal(y0, y1) and torch.equal(y0, y2)),
+           # what a plan costs to build, and after how many products the copy has paid for itself against the held CSR plan
+           "build_ms": {"csr_plan": round(b_csr, 2), "column_blocked": round(b_cb, 2), "panel_binned": round(b_pb, 2)},
+           "products_to_amortise": {"column_blocked": round(b_cb / (t_csr - t_cb), 1) if t_cb < t_csr else None,
+                                    "panel_binned": round(b_pb / (t_csr - t_pb), 1) if t_pb < t_csr else None}}
     out[name] = row
     print(name, json.dumps(row), file=sys.stderr, flush=True)
     pb.close()
