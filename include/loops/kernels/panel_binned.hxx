@@ -25,7 +25,9 @@
  *                       items that never cross a segment boundary (16 + 8 bytes per lane, 8 windows in flight); inside a
  *                       window rows are sorted, so runs of equal rows are summed with the wave64 segmented prefix sum and the
  *                       run ends update the wavefront's OWN LDS accumulators with plain read-modify-writes (LDS float
- *                       atomics retire ~0.4 lanes per clock and CU on gfx950: used for windows of <= 64 items only); the 4 partial
+ *                       atomics retire 0.33 lanes per clock and CU on gfx950: used for the <= 64-item tails of segments and
+ *                       for "packed" windows -- consecutive segments of <= 64 items share one window --, and where such
+ *                       segments are the rule those get compare-and-swap final updates instead); the 4 partial
  *                       vectors are then added in wavefront order and the Hw rows of y are stored coalesced (4 B + 2 B read
  *                       per nonzero).  Reproducible: no order depends on timing.
  * HBM traffic 17 B per nonzero instead of 8 B + a gather; y needs no zero-fill; no global atomics.
