@@ -74,14 +74,7 @@ struct panel_binned_t {
     std::vector<int> ps(static_cast<std::size_t>(P) + 1);
     error::throw_if_exception(hipMemcpy(ps.data(), panel_start.data().get(), sizeof(int) * ps.size(), hipMemcpyDeviceToHost) != hipSuccess,
                               "panel_binned_t: cannot read the panel starts");
-    constexpr int CH = 65536;  // items per workgroup of the products kernel (the 64 KB x panel is then <= 10 % of its traffic)
-    std::vector<int> list;
-    for (int k = 0; k < P; ++k)
-      for (int b = ps[k]; b < ps[k + 1]; b += CH) {
-        list.push_back(k);
-        list.push_back(b);
-        list.push_back(b + CH < ps[k + 1] ? b + CH : ps[k + 1]);
-      }
+    const std::vector<int> list = kernels::panel_chunk_list(ps, P);  // kernel A's work list
     num_chunks = static_cast<int>(list.size() / 3);
     if (!list.empty()) chunks = vector_t<int>(list.begin(), list.end());
   }

@@ -42,6 +42,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <type_traits>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -637,6 +638,27 @@ int build_panel_binned_stage2(hipStream_t stream, const index_t* indices, const 
   hipLaunchKernelGGL(panel::extract_starts, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, seg_dest, seg_dest_b, out.P, out.S,
                      out.bstart, panel_start_dev);
   return static_cast<int>(hipGetLastError());
+}
+
+/// Kernel A's work list from the panel starts (A order, P + 1 entries): {panel, begin, end} triples.  A panel is cut into
+/// round(items / 65536) chunks of EQUAL size (a multiple of 4096 items = one load per lane of the widest workgroup), so no
+/// workgroup loads a 64 / 128 KB x panel for the few thousand items left over by a fixed chunk length (8 M rows x 2
+/// nonzeros: 68 K items per panel were 2 chunks, 65 536 + 2 700, and the launch two rounds of workgroups instead of one).
+inline std::vector<int> panel_chunk_list(const std::vector<int>& panel_start, int P) {
+  constexpr int CH = 65536;  // measured 32768 / 65536 / 98304 / 131072 / 262144: C2 45 / 39 / 46 / 55 / 86 us, C5 shard 214 / 190 / 188 / 189 / 189
+  std::vector<int> list;
+  for (int k = 0; k < P; ++k) {
+    const int b0 = panel_start[k], n = panel_start[k + 1] - b0;
+    if (n <= 0) continue;
+    const int pieces = n / CH + (n % CH >= CH / 2 || n < CH ? 1 : 0);
+    const int size = ((n + pieces - 1) / pieces + 4095) & ~4095;
+    for (int b = b0; b < b0 + n; b += size) {
+      list.push_back(k);
+      list.push_back(b);
+      list.push_back(b + size < b0 + n ? b + size : b0 + n);
+    }
+  }
+  return list;
 }
 
 /// y = A x over a panel-binned matrix: kernel A then kernel B.  stages: bit 0 = products, bit 1 = reduce.

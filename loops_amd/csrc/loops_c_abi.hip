@@ -763,15 +763,7 @@ int panel_create(int rows, int cols, int nnz, const int* offsets, const int* ind
   if (!err) err = static_cast<int>(hipMemcpyAsync(ps.data(), panel_start, sizeof(int) * ps.size(), hipMemcpyDeviceToHost, st));
   if (!err) err = static_cast<int>(hipStreamSynchronize(st));
   if (!err) {
-    // kernel A's work list: chunks of one panel, at most 65536 items each (the 64 KB x panel is then <= 10 % of a chunk's traffic)
-    constexpr int CH = 65536;
-    std::vector<int> chunks;
-    for (int k = 0; k < p->P; ++k)
-      for (int b = ps[k]; b < ps[k + 1]; b += CH) {
-        chunks.push_back(k);
-        chunks.push_back(b);
-        chunks.push_back(b + CH < ps[k + 1] ? b + CH : ps[k + 1]);
-      }
+    const std::vector<int> chunks = kernels::panel_chunk_list(ps, p->P);  // kernel A's work list
     p->num_chunks = static_cast<int>(chunks.size() / 3);
     e = hipMalloc(reinterpret_cast<void**>(&p->chunks), sizeof(int) * (chunks.empty() ? 3 : chunks.size()));
     if (e == hipSuccess && !chunks.empty())

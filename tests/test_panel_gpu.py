@@ -99,6 +99,46 @@ def test_many_panels_and_subbands_bit_exact(dtype):
     plan.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_small_segments_throughout(dtype):
+    """Very short rows over many panels: the mean (panel, sub-band) segment holds far fewer than 64 items, so kernel B runs its
+    SMALL variant -- several segments per window, compare-and-swap final updates (a row may end in several segments of one
+    window, and two lanes may target one accumulator in the same instruction).  Bit-exact vs the oracle on exactly summable
+    inputs, identical bits from run to run with real values, the fan-out twin, hub rows among the short ones."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows, cols = 300_007, 1_000_003
+    deg = np.full(rows, 2, np.int64)
+    deg[::5] = 0
+    deg[3::1001] = 700                      # hub rows: ~20 items in every panel of their sub-band
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    nnz = int(off[-1])
+    xh = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    csr = _dev(off, idx, val.astype(dtype), rows, cols)
+    plan = S.PanelBinnedPlan(csr)
+    assert nnz < 64 * plan.num_panels * plan.num_subbands         # what selects the variant (kernels::panel_small_segments)
+    _check_layout(plan, off, idx, val.astype(dtype))
+    x = torch.from_numpy(xh.astype(dtype)).cuda()
+    y = plan.spmv(x)
+    assert np.array_equal(y.cpu().numpy(), ref.astype(dtype))
+    peers = [torch.full((rows,), -1.0, dtype=y.dtype, device="cuda") for _ in range(2)]
+    y2 = torch.empty_like(y)
+    plan.spmv_fanout(x, y2, peers)
+    assert torch.equal(y2, y) and all(torch.equal(p, y) for p in peers)
+    xr = torch.from_numpy(G.realistic_x(cols).astype(dtype)).cuda()
+    first = plan.spmv(xr).clone()
+    for _ in range(5):
+        assert torch.equal(plan.spmv(xr), first)
+    refr = np.add.reduceat(val.astype(np.float64) * xr.cpu().numpy().astype(np.float64)[idx], np.minimum(off[:-1], nnz - 1).astype(np.int64))
+    refr[np.diff(off) == 0] = 0
+    l1 = np.add.reduceat(np.abs(val.astype(np.float64) * xr.cpu().numpy().astype(np.float64)[idx]), np.minimum(off[:-1], nnz - 1).astype(np.int64))
+    l1[np.diff(off) == 0] = 0
+    tol = 2e-6 if dtype == np.float32 else 1e-14
+    assert np.all(np.abs(first.cpu().numpy().astype(np.float64) - refr) <= tol * l1 + 1e-300)
+    plan.close()
+
+
 def test_empty_and_degenerate_shapes():
     from loops_amd import spmv as S
     for rows, cols in ((0, 5), (5, 0), (6, 4), (1, 1)):
