@@ -376,25 +376,24 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
   }
 }
 
-/// Kernel B: one workgroup (4 wavefronts) per sub-band.  Wavefront w walks the segments of its quarter of the panels -- the
-/// sub-band's products are one contiguous run of the B order, `segb` (S * P + 1 ints) says where every segment starts -- U
-/// segments in flight, one window (64 lanes x 4 items) of each per step, and adds them into its OWN Hw accumulators in
-/// (dynamic) LDS; the 4 partial vectors are then added in wavefront order.  Everything a wavefront does to its accumulators
-/// is in program order: the result is reproducible.
+/// Kernel B: one workgroup of WAVES wavefronts per sub-band.  The sub-band's products are one contiguous run of the B order
+/// (`segb`, S * P + 1 ints, says where every segment starts); wavefront w takes the w-th share of the run's ITEMS, walks it
+/// in windows of 64 lanes x 4 items, U windows in flight, and adds them into its OWN Hw accumulators in (dynamic) LDS; the
+/// WAVES partial vectors are then added in wavefront order.  Everything a wavefront does to its accumulators is in program
+/// order: the result is reproducible.
 /// NT: the product / row streams are larger than the Infinity Cache (non-temporal loads).
 /// SMALL: the typical segment holds a few items (matrices of very short rows), i.e. nearly every window is a packed one:
 /// those then go through the run-combining path with compare-and-swap final updates (LDS float atomics: 3 clks per ITEM,
 /// 85 us of a 134 us kernel on 8 M rows x 2 nonzeros; this way 99 us).  Otherwise packed windows are the thin remainder
 /// next to large segments and use the atomics, which cost the wavefront nothing but the issue (measured: C2 34 against 36
 /// us, host-blocked C3 stand-in 394 against 408 us).
-template <bool NT, bool SMALL, typename type_t, typename store_t>
-__global__ void __launch_bounds__(256)
+template <bool NT, bool SMALL, int WAVES, typename type_t, typename store_t>
+__global__ void __launch_bounds__(WAVES * wave::size)
 panel_reduce(const int* __restrict__ segb, const int P, const int S, const int Hw, const type_t* __restrict__ prod,
              const unsigned short* __restrict__ row16, const int rows, const store_t out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char panel_lds[];
   constexpr int U = 8;      // windows in flight per wavefront
   constexpr int small_window = 64;  // items: below this a window goes through LDS atomics instead of run-combining
-  constexpr int WAVES = 256 / wave::size;
   using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
   const int lane = wave::lane();
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / wave::size);
@@ -502,7 +501,7 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
   }
   __syncthreads();
   const long long row0 = static_cast<long long>(s) * Hw;
-  for (int j = threadIdx.x; j < Hw && row0 + j < rows; j += 256) {
+  for (int j = threadIdx.x; j < Hw && row0 + j < rows; j += WAVES * wave::size) {
     type_t sum = all[j];
 #pragma unroll
     for (int k = 1; k < WAVES; ++k) sum += all[static_cast<std::size_t>(k) * stride + j];
@@ -683,7 +682,12 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
     }
   }
   if (stages & 2) {
-    const std::size_t lds = static_cast<std::size_t>(256 / wave::size) * (m.Hw + wave::size) * sizeof(type_t);
+    const bool small = panel_small_segments(m.nnz, m.P, m.S);
+    // One wavefront per sub-band where segments are small throughout (few items per row: zeroing and summing four partial
+    // vectors then costs more LDS traffic than the items: 8 M rows x 2 nonzeros 99 -> 81 us); four otherwise (measured 4 / 2
+    // / 1 wavefronts: C2 34 / 40 / 64 us, C5 shard 126 / 175 / 299 us).
+    const int waves = small ? 1 : 4;
+    const std::size_t lds = static_cast<std::size_t>(waves) * (m.Hw + wave::size) * sizeof(type_t);
     auto go = [&](auto kernel) {
       // (66.5 KB at Hw = 16 KB / sizeof(T): above the 64 KB a kernel may use without asking)
       static bool raised = false;  // once per instantiation
@@ -691,11 +695,10 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
         raised = true;
       }
-      hipLaunchKernelGGL(kernel, dim3(m.S), dim3(256), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod, m.row16, m.rows, out);
+      hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod, m.row16, m.rows, out);
     };
-    const bool small = panel_small_segments(m.nnz, m.P, m.S);
-    if (nt) { if (small) go(panel::panel_reduce<true, true, type_t, store_t>); else go(panel::panel_reduce<true, false, type_t, store_t>); }
-    else { if (small) go(panel::panel_reduce<false, true, type_t, store_t>); else go(panel::panel_reduce<false, false, type_t, store_t>); }
+    if (nt) { if (small) go(panel::panel_reduce<true, true, 1, type_t, store_t>); else go(panel::panel_reduce<true, false, 4, type_t, store_t>); }
+    else { if (small) go(panel::panel_reduce<false, true, 1, type_t, store_t>); else go(panel::panel_reduce<false, false, 4, type_t, store_t>); }
   }
   return static_cast<int>(hipGetLastError());
 }
