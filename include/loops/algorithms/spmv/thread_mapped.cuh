@@ -2,7 +2,9 @@
  * @file thread_mapped.cuh
  * @brief `algorithms::spmv::thread_mapped(csr, x, y, stream)`: row per thread through
  * `schedule::setup<thread_mapped>` (reference include/loops/algorithms/spmv/thread_mapped.cuh:27-91).
- * Blocks on the stream before returning, like the reference wrapper.
+ * Blocks on the stream before returning, like the reference wrapper.  The kernel keeps the schedule's row-to-thread map and
+ * walks a row 16 / 4 atoms at a time (kernels::thread_mapped_batched_spmv): the same bits as the reference's loop, which
+ * remains available through loops_spmv_csr_schedule_api_f32 / kernels::launch_thread_mapped(..., reference_shape = true).
  */
 #pragma once
 

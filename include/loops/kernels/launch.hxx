@@ -266,16 +266,23 @@ int launch_group_mapped_fused(hipStream_t stream, int rows, int nnz, const offse
   return launch_status();
 }
 
+/// `reference_shape`: the plain loop over `config.atoms(row)` (the reference's kernel, algorithms/spmv/thread_mapped.cuh:27-44)
+/// instead of the batched one (same schedule, same bits, 5-12 x faster on this GPU: see thread_mapped_batched_spmv).
 template <typename index_t, typename offset_t, typename T>
 int launch_thread_mapped(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz,
-                         const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y) {
+                         const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
+                         bool reference_shape = false) {
   if (rows == 0) return 0;
   constexpr std::size_t block = algorithms::spmv::launch_t<T>::block_size;
   using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, offset_t>;
   setup_t config(const_cast<offset_t*>(offsets), rows, nnz);
-  launch::non_cooperative(stream, thread_mapped_spmv<setup_t, index_t, offset_t, T>,
-                          dim3(static_cast<unsigned>(math::ceil_div(rows, block))), dim3(block), config, rows, cols,
-                          nnz, offsets, indices, values, x, y);
+  const dim3 grid(static_cast<unsigned>(math::ceil_div(rows, block)));
+  if (reference_shape)
+    launch::non_cooperative(stream, thread_mapped_spmv<setup_t, index_t, offset_t, T>, grid, dim3(block), config, rows, cols, nnz,
+                            offsets, indices, values, x, y);
+  else
+    launch::non_cooperative(stream, thread_mapped_batched_spmv<setup_t, index_t, offset_t, T>, grid, dim3(block), config, offsets,
+                            indices, values, x, y);
   return launch_status();
 }
 

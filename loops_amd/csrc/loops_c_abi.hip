@@ -287,7 +287,7 @@ int spmv_schedule_api(int schedule, int cfg, int rows, int cols, int nnz, const 
   if (rows == 0) return 0;
   const std::size_t R = rows, C = cols, N = nnz;
   switch (schedule) {
-    case LOOPS_THREAD_MAPPED: return kernels::launch_thread_mapped(stream, R, C, N, off, idx, val, x, y);
+    case LOOPS_THREAD_MAPPED: return kernels::launch_thread_mapped(stream, R, C, N, off, idx, val, x, y, /*reference shape*/ true);
     case LOOPS_ORIGINAL: return kernels::launch_original(stream, R, C, N, off, idx, val, x, y);
     case LOOPS_GROUP_MAPPED: return kernels::launch_group_mapped_atomic(stream, R, C, N, off, idx, val, x, y);
     case LOOPS_WORK_ORIENTED: return kernels::launch_work_oriented_atomic(stream, R, C, N, off, idx, val, x, y);
@@ -322,7 +322,8 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
       if (!err) err = spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
       return err;
     }
-    case LOOPS_THREAD_MAPPED:
+    case LOOPS_THREAD_MAPPED:  // the schedule as given (a thread owns whole rows), the row's atoms 16 / 4 at a time
+      return kernels::launch_thread_mapped(stream, std::size_t(rows), std::size_t(cols), std::size_t(nnz), off, idx, val, x, y);
     case LOOPS_ORIGINAL:
       return spmv_schedule_api<T>(schedule, 0, rows, cols, nnz, off, idx, val, x, y, stream);
     case LOOPS_WORK_ORIENTED: {
