@@ -302,6 +302,7 @@ int loops_spmv_panel_f32(const loops_panel_plan_t* plan, const float* x, float* 
 int loops_spmv_panel_f64(const loops_panel_plan_t* plan, const double* x, double* y, void* stream);
 /* one kernel at a time for timing: stage 0 = products, 1 = sub-band reduce */
 int loops_spmv_panel_stage_f32(const loops_panel_plan_t* plan, int stage, const float* x, float* y, void* stream);
+int loops_spmv_panel_stage_f64(const loops_panel_plan_t* plan, int stage, const double* x, double* y, void* stream);
 int loops_spmv_panel_fanout_f32(const loops_panel_plan_t* plan, const float* x, float* y, int num_peers, float* const* h_peer_y,
                                 void* stream);
 int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x, double* y, int num_peers, double* const* h_peer_y,

@@ -1414,6 +1414,10 @@ int loops_spmv_panel_stage_f32(const loops_panel_plan_t* plan, int stage, const 
   if (stage < 0 || stage > 1) return LOOPS_E_BADARG;
   return panel_spmv<float>(plan, 1 << stage, x, y, as_stream(stream));
 }
+int loops_spmv_panel_stage_f64(const loops_panel_plan_t* plan, int stage, const double* x, double* y, void* stream) {
+  if (stage < 0 || stage > 1) return LOOPS_E_BADARG;
+  return panel_spmv<double>(plan, 1 << stage, x, y, as_stream(stream));
+}
 int loops_spmv_panel_fanout_f32(const loops_panel_plan_t* plan, const float* x, float* y, int num_peers, float* const* h_peer_y,
                                 void* stream) {
   if (!plan || plan->vbytes != 4 || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;

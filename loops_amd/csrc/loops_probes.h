@@ -38,7 +38,8 @@ int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, i
 int loops_address_rate_f32(const float* table, int table_words, int reps, int pattern, int blocks, float* out,
                            void* stream);
 /* LDS update rate: `blocks` x 256 lanes each apply `reps` updates to a 4096-word LDS table.  mode 0 ds_add_f32, 1 ds_add_u32,
- * 2 plain read-add-write (not atomic), 3 ds_add_rtn_f32, 4 compare-and-swap loop; pattern 0 consecutive words (conflict-free), 1 hashed, 2 all lanes
+ * 2 plain read-add-write (not atomic), 3 ds_add_rtn_f32, 4 compare-and-swap loop; 10 / 11 / 12: ds_add_f64 / read-add-write /
+ * compare-and-swap loop on 8-byte words; pattern 0 consecutive words (conflict-free), 1 hashed, 2 all lanes
  * one word, 3 adjacent lane pairs share a word.  `out`: blocks * 256 floats.  What bounds panel_reduce's small windows. */
 int loops_lds_update_rate_f32(int mode, int pattern, int reps, int blocks, float* out, void* stream);
 /* Row-gather probe (the SpMM's B access pattern in isolation): sub-groups of row_floats / 4 lanes

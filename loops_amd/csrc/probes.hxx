@@ -148,6 +148,37 @@ __global__ void __launch_bounds__(256) lds_update_kernel(int reps, float* __rest
   if (keep == 123.456f || table[threadIdx.x] == -1.f) out[gid] = keep;
 }
 
+/// The same for 8-byte words (a 2048-word table): MODE 0 atomicAdd(double) (ds_add_f64), 1 plain read-add-write, 2
+/// compare-and-swap loop (ds_cmpst_rtn_b64).
+template <int MODE, int PATTERN>
+__global__ void __launch_bounds__(256) lds_update64_kernel(int reps, float* __restrict__ out) {
+  __shared__ double table[2048];
+  for (int j = threadIdx.x; j < 2048; j += 256) table[j] = 0.0;
+  __syncthreads();
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned h = gid * 2654435761u;
+  for (int k = 0; k < reps; ++k) {
+    unsigned j;
+    if constexpr (PATTERN == 0) j = (threadIdx.x + k * 256u) & 2047u;
+    else if constexpr (PATTERN == 1) { h = h * 1664525u + 1013904223u; j = (h >> 8) & 2047u; }
+    else if constexpr (PATTERN == 2) j = (k * 17u) & 2047u;
+    else j = ((threadIdx.x >> 1) + k * 128u) & 2047u;
+    if constexpr (MODE == 0) atomicAdd(&table[j], 1.0);
+    else if constexpr (MODE == 1) table[j] = table[j] + 1.0;
+    else {
+      unsigned long long* u = reinterpret_cast<unsigned long long*>(&table[j]);
+      unsigned long long old = *u;
+      while (true) {
+        const unsigned long long got = atomicCAS(u, old, static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(old)) + 1.0)));
+        if (got == old) break;
+        old = got;
+      }
+    }
+  }
+  __syncthreads();
+  if (table[threadIdx.x] == -1.0) out[gid] = 1.f;
+}
+
 inline int launch_lds_update(hipStream_t stream, int mode, int pattern, int reps, int blocks, float* out) {
   const dim3 g(blocks), b(256);
 #define LOOPS_LDS_CASE(M, P) \
@@ -158,6 +189,12 @@ inline int launch_lds_update(hipStream_t stream, int mode, int pattern, int reps
   LOOPS_LDS_CASE(3, 0) LOOPS_LDS_CASE(3, 1) LOOPS_LDS_CASE(3, 2) LOOPS_LDS_CASE(3, 3)
   LOOPS_LDS_CASE(4, 0) LOOPS_LDS_CASE(4, 1) LOOPS_LDS_CASE(4, 2) LOOPS_LDS_CASE(4, 3)
 #undef LOOPS_LDS_CASE
+#define LOOPS_LDS_CASE64(M, P) \
+  if (mode == 10 + M && pattern == P) { hipLaunchKernelGGL((lds_update64_kernel<M, P>), g, b, 0, stream, reps, out); return static_cast<int>(hipGetLastError()); }
+  LOOPS_LDS_CASE64(0, 0) LOOPS_LDS_CASE64(0, 1) LOOPS_LDS_CASE64(0, 2) LOOPS_LDS_CASE64(0, 3)
+  LOOPS_LDS_CASE64(1, 0) LOOPS_LDS_CASE64(1, 1) LOOPS_LDS_CASE64(1, 2) LOOPS_LDS_CASE64(1, 3)
+  LOOPS_LDS_CASE64(2, 0) LOOPS_LDS_CASE64(2, 1) LOOPS_LDS_CASE64(2, 2) LOOPS_LDS_CASE64(2, 3)
+#undef LOOPS_LDS_CASE64
   return -1;
 }
 

@@ -356,7 +356,7 @@ class PanelBinnedPlan:
         return y
 
     def spmv_stage(self, stage: int, x, y):
-        L.check(L.lib().loops_spmv_panel_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_panel_stage_f32")
+        L.check(getattr(L.lib(), "loops_spmv_panel_stage_" + self._sfx)(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_panel_stage")
         return y
 
     def spmv_fanout(self, x, y, peers):

@@ -20,7 +20,7 @@ def ev(fn, iters=10):
 reps = 4096
 for blocks in (256 * 2, 256 * 8):   # 8 and 32 wavefronts per CU
     out = torch.zeros(blocks * 256, device="cuda")
-    for mode, mname in ((0, "ds_add_f32"), (1, "ds_add_u32"), (2, "read-add-write"), (3, "ds_add_rtn_f32"), (4, "cas loop")):
+    for mode, mname in ((0, "ds_add_f32"), (1, "ds_add_u32"), (2, "read-add-write"), (3, "ds_add_rtn_f32"), (4, "cas loop"), (10, "ds_add_f64"), (11, "read-add-write 64"), (12, "cas loop 64")):
         row = []
         for pat, pname in ((0, "conflict-free"), (1, "hashed"), (2, "one word"), (3, "lane pairs")):
             ms = ev(lambda: P.lds_update_rate(mode, pat, reps, blocks, out))

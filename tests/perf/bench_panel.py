@@ -38,6 +38,7 @@ CASES = {
     "c3_band65536": (7_414_866, 7_414_866, 194_109_311, 65536),
     "short_rows_8M": (1 << 23, 1 << 23, 1 << 24, None),
 }
+F64 = "--f64" in sys.argv   # the same cases with 8-byte values
 want = [a for a in sys.argv[1:] if a in CASES] or ["c2", "c5_shard", "c3_uniform", "c3_host_blocked"]
 out = {}
 for name in want:
@@ -45,10 +46,12 @@ for name in want:
     deg = G.powerlaw_degrees(rows, nnz, cap=min(1 << 14, cols)) if name != "short_rows_8M" else np.full(rows, 2, np.int64)
     hosts = G.host_blocks(cols) if window == G.HOST_BLOCKED else None
     off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=hosts)
-    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    vb = 8 if F64 else 4
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val.astype(np.float64) if F64 else val)
     x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
-    y0, y1, y2 = (torch.empty(rows, device="cuda") for _ in range(3))
-    abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
+    x = x.double() if F64 else x
+    y0, y1, y2 = (torch.empty(rows, device="cuda", dtype=x.dtype) for _ in range(3))
+    abytes = nnz * (4 + vb) + (rows + 1) * 4 + rows * vb + cols * vb
     mp, b_csr = build_ms(lambda: S.MergePathPlan(csr, "512x8"))
     t_csr = batch_ms(lambda: S.merge_path_flat(csr, x, y0, plan=mp))
     cb, b_cb = build_ms(lambda: S.ColumnBlockedPlan(csr))
@@ -66,14 +69,14 @@ for name in want:
     t_a = batch_ms(lambda: pb.spmv_stage(0, x, y2))
     t_b = batch_ms(lambda: pb.spmv_stage(1, x, y2))
     pb.spmv(x, y2)
-    row = {"rows": rows, "cols": cols, "nnz": nnz, "x_MB": cols * 4 >> 20, "algorithmic_bytes": abytes,
+    row = {"rows": rows, "cols": cols, "nnz": nnz, "dtype": "f64" if F64 else "f32", "x_MB": cols * vb >> 20, "algorithmic_bytes": abytes,
            "csr_512x8_ms": round(t_csr, 4), "column_blocked_ms": round(t_cb, 4), "column_blocks": blocks,
            "panel_binned_ms": round(t_pb, 4), "panel_products_ms": round(t_a, 4), "panel_reduce_ms": round(t_b, 4),
            "panel": {"W": pb.W, "Hw": pb.Hw, "panels": pb.num_panels, "subbands": pb.num_subbands, "padding_items": pb.padded - nnz,
                      "chunks": pb.num_chunks, "items_per_segment": round(nnz / (pb.num_panels * pb.num_subbands), 1)},
            "frac_csr": round(abytes / t_csr / 1e6 / 8000, 4), "frac_blocked": round(abytes / t_cb / 1e6 / 8000, 4),
            "frac_panel": round(abytes / t_pb / 1e6 / 8000, 4),
-           "products_GBps": round(pb.padded * 11 / t_a / 1e6, 1), "reduce_GBps": round(pb.padded * 6 / t_b / 1e6, 1),
+           "products_GBps": round(pb.padded * (3 + 2 * vb) / t_a / 1e6, 1), "reduce_GBps": round(pb.padded * (2 + vb) / t_b / 1e6, 1),
            "equal": bool(torch.equal(y0, y1) and torch.equal(y0, y2)),
            # what a plan costs to build, and after how many products the copy has paid for itself against the held CSR plan
            "build_ms": {"csr_plan": round(b_csr, 2), "column_blocked": round(b_cb, 2), "panel_binned": round(b_pb, 2)},
