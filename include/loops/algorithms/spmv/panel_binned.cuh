@@ -31,7 +31,7 @@ struct panel_binned_t {
   int W, Hw, P, S, padded = 0, num_chunks = 0;
   vector_t<type_t> values, products;
   vector_t<unsigned short> col16, row16;
-  vector_t<int> dst4, perm, segb, bstart, chunks;
+  vector_t<int> dst4, perm, segb, bstart, chunks, wins, wstart;
 
   /// @param subband_rows 0 = automatic (kernels::panel_subband_rows), or a power of two in [64, 16384 / sizeof(type_t)]
   explicit panel_binned_t(csr_t<index_t, offset_t, type_t>& csr, int subband_rows = 0, xpu::stream_t stream = 0)
@@ -66,9 +66,11 @@ struct panel_binned_t {
     dst4 = vector_t<int>(n / 4 + 1);
     segb = vector_t<int>(static_cast<std::size_t>(segments) + 1);
     bstart = vector_t<int>(static_cast<std::size_t>(S) + 1);
+    wstart = vector_t<int>(static_cast<std::size_t>(S) + 1);
+    wins = vector_t<int>(2 * kernels::panel_window_capacity(padded, segments));
     chunks = vector_t<int>(3);
     error::throw_if_exception(kernels::build_panel_binned_stage2<index_t, type_t>(stream, csr.indices.data().get(), csr.values.data().get(),
-                                                                                  view(), temp.data().get(), panel_start.data().get()) != 0,
+                                                                                  view(), temp.data().get(), temp_bytes, panel_start.data().get()) != 0,
                               "panel_binned_t: build (placement) failed");
     (void)xpu::stream_synchronize(stream);
     std::vector<int> ps(static_cast<std::size_t>(P) + 1);
@@ -83,7 +85,7 @@ struct panel_binned_t {
     return kernels::panel_binned_view<type_t>{static_cast<int>(rows), static_cast<int>(cols), static_cast<int>(nnzs), W, Hw, P, S, padded,
                                               values.data().get(), col16.data().get(), dst4.data().get(), row16.data().get(),
                                               perm.data().get(), segb.data().get(), bstart.data().get(), chunks.data().get(), num_chunks,
-                                              products.data().get()};
+                                              products.data().get(), wins.data().get(), wstart.data().get()};
   }
 
   /// y = A x; asynchronous on `stream`.

@@ -70,7 +70,20 @@ struct panel_binned_view {
   int* chunks;                ///< [3 * num_chunks] {panel, begin, end} work list of kernel A (A-order positions)
   int num_chunks;
   type_t* prod;               ///< [padded] B order: products scratch (kernel A -> kernel B)
+  int* wins;                  ///< [2 * panel_window_capacity] kernel B's windows: {first item, items | packed << 16} (B order)
+  int* wstart;                ///< [S + 1] sub-band s owns windows [wstart[s], wstart[s + 1])
 };
+
+/// Upper bound of the number of kernel-B windows: full windows of 256 items plus at most one remainder per segment.
+inline std::size_t panel_window_capacity(int padded, long long segments) {
+  return static_cast<std::size_t>(padded / 256) + static_cast<std::size_t>(segments) + 1;
+}
+
+/// Segments of at most this many items share windows ("packed"): 64 for 4-byte values, whose packed windows cost an LDS
+/// float atomic (0.33 lanes per clock and CU) or a compare-and-swap per item; 128 for 8-byte values (ds_add_f64: 3-8 lanes
+/// per clock and CU; C5 shard in f64: kernel B 378 -> 211 us; 256 loses on C2, whose hub rows then meet in one word).
+template <typename type_t>
+constexpr int panel_pack_items() { return sizeof(type_t) == 4 ? 64 : 128; }
 
 /// Panel widths kernel A is compiled for: 64 KB of x per workgroup (512 threads, two workgroups per CU) and 128 KB (1024
 /// threads, one workgroup per CU).  `value` = the narrow one.
@@ -185,6 +198,44 @@ extract_starts(const int* __restrict__ seg_dest, const int* __restrict__ seg_des
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t <= S) bstart[t] = seg_dest_b[static_cast<long long>(t) * P];
   if (t <= P) panel_start[t] = seg_dest[static_cast<long long>(t) * S];
+}
+
+/// Kernel B's work list, built once: the windows of sub-band s (one thread per sub-band walks its P segments).  A window is
+/// at most 256 consecutive items of the B order: either a piece of ONE segment (rows sorted: run-combining path) or
+/// "packed" -- consecutive segments / segment tails of at most `pack` items each (sorted only piecewise).  FILL = false
+/// counts (wstart[s] = number of windows), FILL = true writes them at wstart[s] (after the exclusive scan).
+/// Why a table: the walk needs one dependent wave-uniform load per segment, and a sub-band of a matrix with column locality
+/// has hundreds of segments of a few items -- done inside kernel B it was most of that kernel's time on such matrices.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+make_windows(const int* __restrict__ segb, const int P, const int S, const int pack, int* __restrict__ wstart, int* __restrict__ wins) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int* seg = segb + static_cast<long long>(s) * P;
+  int* out = FILL ? wins + 2ll * wstart[s] : nullptr;
+  int count = 0, ob = 0, oe = 0;                        // [ob, oe): the open packed window
+  auto emit = [&](int b, int e, int packed) {
+    if constexpr (FILL) { out[2 * count] = b; out[2 * count + 1] = (e - b) | (packed << 16); }
+    ++count;
+  };
+  int e = seg[0];
+  for (int p = 0; p < P; ++p) {
+    int b = e;
+    e = seg[p + 1];
+    if (e - b > pack) {                                 // a large segment: sorted windows, its short tail opens a packed one
+      if (oe > ob) emit(ob, oe, 1);
+      ob = oe = 0;
+      while (e - b > 256) { emit(b, b + 256, 0); b += 256; }
+      if (e - b > pack) { emit(b, e, 0); continue; }
+    }
+    if (e == b) continue;
+    if (oe > ob && e - ob <= 256) { oe = e; continue; }  // joins the open window (B order is contiguous across segments)
+    if (oe > ob) emit(ob, oe, 1);
+    ob = b;
+    oe = e;
+  }
+  if (oe > ob) emit(ob, oe, 1);
+  if constexpr (!FILL) wstart[s] = count;
 }
 
 template <typename type_t>
@@ -389,11 +440,10 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
 /// us, host-blocked C3 stand-in 394 against 408 us).
 template <bool NT, bool SMALL, int WAVES, typename type_t, typename store_t>
 __global__ void __launch_bounds__(WAVES * wave::size)
-panel_reduce(const int* __restrict__ segb, const int P, const int S, const int Hw, const type_t* __restrict__ prod,
+panel_reduce(const int* __restrict__ wstart, const int* __restrict__ wins, const int Hw, const type_t* __restrict__ prod,
              const unsigned short* __restrict__ row16, const int rows, const store_t out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char panel_lds[];
   constexpr int U = 8;      // windows in flight per wavefront
-  constexpr int small_window = 64;  // items: below this a window goes through LDS atomics instead of run-combining
   using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
   const int lane = wave::lane();
   const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / wave::size);
@@ -403,61 +453,24 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
   const int dump = Hw + lane;
   const int s = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
   for (int j = lane; j < stride; j += wave::size) acc[j] = type_t(0);
-  // This wavefront's share: a quarter of the sub-band's ITEMS (not of its panels: with column locality a few panels hold
-  // nearly everything), cut at a multiple of 4.  A run of equal rows cut by the boundary ends up in two accumulators: fine.
-  const int* seg = segb + static_cast<long long>(s) * P;   // seg[p] .. seg[p + 1] = segment (s, p); seg[P] = next sub-band's first
-  const int b0 = seg[0], b1 = seg[P];
-  const int groups = (b1 - b0) >> 2;
-  const int first = b0 + (static_cast<int>(static_cast<long long>(groups) * w / WAVES) << 2);
-  const int last = b0 + (static_cast<int>(static_cast<long long>(groups) * (w + 1) / WAVES) << 2);
-  int p_first = 0;                                           // last p with seg[p] <= first (wave-uniform search)
-  for (int count = P; count > 1;) {
-    const int half = count >> 1;
-    if (seg[p_first + half] <= first) { p_first += half; count -= half; }
-    else count = half;
-  }
-  // The share is consumed as a sequence of WINDOWS -- 64 lanes x 4 items, never across a segment boundary -- handed out by a
-  // wave-uniform iterator, U windows per step whatever the segments look like (one huge diagonal segment next to hundreds
-  // of tiny ones on matrices with column locality: a step that followed U SEGMENTS had one window in flight there).
-  int p = p_first;
-  int pos = first, pend = seg[p_first + 1] < last ? seg[p_first + 1] : last;
-  while (first < last) {
+  // This wavefront's share: a contiguous WAVES-th of the sub-band's windows (make_windows built them: at most 256 items each,
+  // pieces of one segment or packed small segments).  A run of equal rows cut between two wavefronts ends up in two
+  // accumulators: fine.  Window descriptors are wave-uniform loads, U independent ones per step.
+  const int w_lo = wstart[s], w_n = wstart[s + 1] - w_lo;
+  const int my0 = w_lo + static_cast<int>(static_cast<long long>(w_n) * w / WAVES);
+  const int my1 = w_lo + static_cast<int>(static_cast<long long>(w_n) * (w + 1) / WAVES);
+  const int first = my0 < my1 ? wins[2 * my0] : 0;          // an in-bounds item for lanes that have nothing to load
+  for (int base = my0; base < my1; base += U) {
     int wb[U], we[U];
-    bool small[U], packed[U];
-    bool any = false;
+    bool packed[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      bool whole = false;                                       // the window starts a segment
-      while (pos >= pend && p + 1 < P && seg[p + 1] < last) {  // next non-empty segment of the share (wave-uniform)
-        ++p;
-        pos = seg[p];
-        pend = seg[p + 1] < last ? seg[p + 1] : last;
-        whole = true;
-      }
-      wb[u] = pos;
-      we[u] = pos + wave::size * 4 < pend ? pos + wave::size * 4 : pend;
-      if (we[u] < wb[u]) we[u] = wb[u];
-      // A whole segment of a few items takes the following segments along while they are as small (B order is contiguous
-      // across segments; padding items are skipped by their row): a sub-band of a matrix with column locality has hundreds
-      // of segments of a few items next to its diagonal one, a matrix of very short rows nothing else.  Such a window is
-      // sorted only piecewise -- a row may end once per segment -- so its final updates are compare-and-swap adds.
-      // (Not the short TAIL of a large segment: looking ahead costs a dependent scalar load per window, 4 us of C2's 31
-      // when every segment's tail did it.)
-      small[u] = we[u] - wb[u] <= small_window;
-      packed[u] = small[u] && whole && we[u] == pend;
-      if (packed[u]) {
-        while (p + 1 < P && seg[p + 1] < last) {
-          const int ne = seg[p + 2] < last ? seg[p + 2] : last;
-          if (ne - seg[p + 1] > small_window || ne - wb[u] > wave::size * 4) break;
-          ++p;
-          pend = ne;
-          we[u] = ne;
-        }
-      }
-      pos = we[u] > pos ? we[u] : pos;
-      any = any || wb[u] < we[u];
+      const int k = base + u < my1 ? base + u : my0;          // (the surplus slots of the last step re-read a descriptor
+      const int b = wins[2 * k], d = wins[2 * k + 1];         //  and are given no items)
+      wb[u] = b;
+      we[u] = base + u < my1 ? b + (d & 0xFFFF) : b;
+      packed[u] = (d >> 16) != 0;
     }
-    if (!any) break;
     // branch-free loads: every vector of the U windows is requested before the first is waited for (a lane outside its
     // window re-reads the window's first vector -- in bounds -- and contributes padding)
     type_t v[U][4];
@@ -475,26 +488,19 @@ panel_reduce(const int* __restrict__ segb, const int P, const int S, const int H
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (wb[u] < we[u]) {  // (wave-uniform)
-        if (small[u] && !packed[u]) {
-          // the short tail of a large segment (sorted, long runs of one row are common): LDS float atomics, ~3 clks per
-          // item whatever the addresses, against ~200 instructions per window for the run-combining path
+        unsigned int r[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (live[u] && r16v[u][e] != pad_row) atomicAdd(&acc[r16v[u][e]], v[u][e]);
+        for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
+        if (packed[u]) {   // small segments / segment tails sharing the window: sorted only piecewise
+          if constexpr (SMALL) {
+            panel_window_add<type_t, true>(acc, dump, v[u], r);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r[e] != pad_row) atomicAdd(&acc[r[e]], v[u][e]);
+          }
         } else {
-          unsigned int r[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
-          if (packed[u]) {   // several small segments in one window
-            if constexpr (SMALL) {
-              panel_window_add<type_t, true>(acc, dump, v[u], r);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (r[e] != pad_row) atomicAdd(&acc[r[e]], v[u][e]);
-            }
-          } else
-            panel_window_add<type_t, false>(acc, dump, v[u], r);
+          panel_window_add<type_t, false>(acc, dump, v[u], r);
         }
       }
     }
@@ -606,7 +612,7 @@ int build_panel_binned_stage1(hipStream_t stream, const offset_t* offsets, const
 /// (`panel_start_dev`: P + 1 ints, A order).  `out.val / col16 / row16 / perm / dst4` must hold out.padded (/ 4) items.
 template <typename index_t, typename type_t>
 int build_panel_binned_stage2(hipStream_t stream, const index_t* indices, const type_t* values, const panel_binned_view<type_t>& out,
-                              void* temp, int* panel_start_dev) {
+                              void* temp, std::size_t temp_bytes, int* panel_start_dev) {
   const int nnz = out.nnz;
   const long long segments = static_cast<long long>(out.P) * out.S;
   const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
@@ -633,6 +639,18 @@ int build_panel_binned_stage2(hipStream_t stream, const index_t* indices, const 
                        out.row16, out.perm);
   e = hipMemcpyAsync(out.segb, seg_dest_b, sizeof(int) * static_cast<std::size_t>(segments + 1), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return static_cast<int>(e);
+  // kernel B's windows: count per sub-band, scan, fill
+  e = hipMemsetAsync(out.wstart, 0, sizeof(int) * (static_cast<std::size_t>(out.S) + 1), stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  const dim3 wgrid(math::ceil_div(out.S, 256));
+  hipLaunchKernelGGL(panel::make_windows<false>, wgrid, dim3(256), 0, stream, seg_dest_b, out.P, out.S, panel_pack_items<type_t>(), out.wstart,
+                     static_cast<int*>(nullptr));
+  void* cub_temp = base + 2 * key_bytes + row_bytes + 6 * seg_bytes;
+  std::size_t cub_bytes = temp_bytes - (2 * key_bytes + row_bytes + 6 * seg_bytes);
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, out.wstart, out.wstart, out.S + 1, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(panel::make_windows<true>, wgrid, dim3(256), 0, stream, seg_dest_b, out.P, out.S, panel_pack_items<type_t>(), out.wstart,
+                     out.wins);
   const int m = (out.S > out.P ? out.S : out.P) + 1;
   hipLaunchKernelGGL(panel::extract_starts, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, seg_dest, seg_dest_b, out.P, out.S,
                      out.bstart, panel_start_dev);
@@ -682,7 +700,7 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
     }
   }
   if (stages & 2) {
-    const bool small = panel_small_segments(m.nnz, m.P, m.S);
+    const bool small = sizeof(type_t) == 4 && panel_small_segments(m.nnz, m.P, m.S);  // (8-byte values: ds_add_f64 is fast, see panel_pack_items)
     // One wavefront per sub-band where segments are small throughout (few items per row: zeroing and summing four partial
     // vectors then costs more LDS traffic than the items: 8 M rows x 2 nonzeros 99 -> 81 us); four otherwise (measured 4 / 2
     // / 1 wavefronts: C2 34 / 40 / 64 us, C5 shard 126 / 175 / 299 us).
@@ -695,7 +713,7 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
         raised = true;
       }
-      hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.segb, m.P, m.S, m.Hw, m.prod, m.row16, m.rows, out);
+      hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.wstart, m.wins, m.Hw, m.prod, m.row16, m.rows, out);
     };
     if (nt) { if (small) go(panel::panel_reduce<true, true, 1, type_t, store_t>); else go(panel::panel_reduce<true, false, 4, type_t, store_t>); }
     else { if (small) go(panel::panel_reduce<false, true, 1, type_t, store_t>); else go(panel::panel_reduce<false, false, 4, type_t, store_t>); }

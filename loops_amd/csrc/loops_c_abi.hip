@@ -694,7 +694,7 @@ struct loops_panel_plan {
   int W, Hw, P, S, padded, num_chunks;
   void *val, *prod;
   unsigned short *col16, *row16;
-  int *perm, *dst4, *segb, *bstart, *chunks;
+  int *perm, *dst4, *segb, *bstart, *chunks, *wins, *wstart;
 };
 
 namespace {
@@ -703,6 +703,7 @@ void panel_free(loops_panel_plan* p) {
   if (!p) return;
   (void)hipFree(p->val); (void)hipFree(p->prod); (void)hipFree(p->col16); (void)hipFree(p->row16);
   (void)hipFree(p->perm); (void)hipFree(p->dst4); (void)hipFree(p->segb); (void)hipFree(p->bstart); (void)hipFree(p->chunks);
+  (void)hipFree(p->wins); (void)hipFree(p->wstart);
   delete p;
 }
 
@@ -710,7 +711,7 @@ template <typename T>
 kernels::panel_binned_view<T> panel_view(const loops_panel_plan* p) {
   return kernels::panel_binned_view<T>{p->rows, p->cols, p->nnz, p->W, p->Hw, p->P, p->S, p->padded, static_cast<T*>(p->val),
                                        p->col16, p->dst4, p->row16, p->perm, p->segb, p->bstart, p->chunks, p->num_chunks,
-                                       static_cast<T*>(p->prod)};
+                                       static_cast<T*>(p->prod), p->wins, p->wstart};
 }
 
 template <typename T>
@@ -757,9 +758,11 @@ int panel_create(int rows, int cols, int nnz, const int* offsets, const int* ind
     alloc(&p->dst4, sizeof(int) * (n / 4 + 1));
     alloc(&p->segb, sizeof(int) * (static_cast<size_t>(segments) + 1));
     alloc(&p->bstart, sizeof(int) * (static_cast<size_t>(p->S) + 1));
+    alloc(&p->wstart, sizeof(int) * (static_cast<size_t>(p->S) + 1));
+    alloc(&p->wins, sizeof(int) * 2 * kernels::panel_window_capacity(p->padded, segments));
     err = static_cast<int>(e);
   }
-  if (!err) err = kernels::build_panel_binned_stage2<int, T>(st, indices, values, panel_view<T>(p), temp, panel_start);
+  if (!err) err = kernels::build_panel_binned_stage2<int, T>(st, indices, values, panel_view<T>(p), temp, temp_bytes, panel_start);
   std::vector<int> ps(static_cast<size_t>(p->P) + 1, 0);
   if (!err) err = static_cast<int>(hipMemcpyAsync(ps.data(), panel_start, sizeof(int) * ps.size(), hipMemcpyDeviceToHost, st));
   if (!err) err = static_cast<int>(hipStreamSynchronize(st));
