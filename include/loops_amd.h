@@ -296,6 +296,11 @@ void loops_panel_plan_destroy(loops_panel_plan_t* plan);
 int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7);
 int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsigned short* col16, int* dst4, unsigned short* row16,
                             int* perm, int* subband_start);
+/* Kernel B's work list (synchronous copies): window_start[subbands + 1]; windows[2 * window_start[subbands]] = {first item,
+ * items | packed << 16} in (sub-band, panel) order (NULL: only the starts, to size the second call); segment_start
+ * [subbands * panels + 1] (may be NULL).  A window holds at most 256 items: a piece of ONE segment (rows sorted), or -- packed
+ * -- consecutive segments / segment tails of at most 64 (f64: 128) items each. */
+int loops_panel_plan_windows(const loops_panel_plan_t* plan, int* window_start, int* windows, int* segment_start);
 int loops_panel_plan_refresh_values_f32(loops_panel_plan_t* plan, const float* values, void* stream);
 int loops_panel_plan_refresh_values_f64(loops_panel_plan_t* plan, const double* values, void* stream);
 int loops_spmv_panel_f32(const loops_panel_plan_t* plan, const float* x, float* y, void* stream);

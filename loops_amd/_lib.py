@@ -47,7 +47,7 @@ SYMBOLS = [
     "loops_spmv_plan_create_f32", "loops_spmv_plan_create_f64", "loops_spmv_plan_destroy", "loops_spmv_plan_info",
     "loops_spmv_plan_refresh_values_f32", "loops_spmv_plan_refresh_values_f64", "loops_spmv_planned_f32", "loops_spmv_planned_f64",
     "loops_panel_plan_create_f32", "loops_panel_plan_create_f64", "loops_panel_plan_destroy", "loops_panel_plan_info",
-    "loops_panel_plan_arrays", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
+    "loops_panel_plan_arrays", "loops_panel_plan_windows", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
 
@@ -202,6 +202,7 @@ def lib() -> C.CDLL:
         L.loops_panel_plan_destroy.restype = None
         L.loops_panel_plan_info.argtypes = [vp, vp]
         L.loops_panel_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.loops_panel_plan_windows.argtypes = [vp, vp, vp, vp]
         L.loops_spmv_panel_stage_f32.argtypes = [vp, ci, vp, vp, vp]
         L.loops_spmv_panel_stage_f64.argtypes = [vp, ci, vp, vp, vp]
         L.loops_spmv_plan_destroy.argtypes = [vp]

@@ -1401,6 +1401,18 @@ int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsign
   copy(subband_start, plan->bstart, sizeof(int) * (static_cast<size_t>(plan->S) + 1));
   return static_cast<int>(e);
 }
+int loops_panel_plan_windows(const loops_panel_plan_t* plan, int* window_start, int* windows, int* segment_start) {
+  if (!plan || !window_start) return LOOPS_E_BADARG;
+  if (plan->rows == 0) return 0;
+  hipError_t e = hipDeviceSynchronize();
+  const size_t S = static_cast<size_t>(plan->S);
+  if (e == hipSuccess) e = hipMemcpy(window_start, plan->wstart, sizeof(int) * (S + 1), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && windows && window_start[S] > 0)
+    e = hipMemcpy(windows, plan->wins, sizeof(int) * 2 * static_cast<size_t>(window_start[S]), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && segment_start)
+    e = hipMemcpy(segment_start, plan->segb, sizeof(int) * (S * static_cast<size_t>(plan->P) + 1), hipMemcpyDeviceToHost);
+  return static_cast<int>(e);
+}
 int loops_panel_plan_refresh_values_f32(loops_panel_plan_t* plan, const float* values, void* stream) {
   return panel_refresh<float>(plan, values, as_stream(stream));
 }

@@ -339,6 +339,17 @@ class PanelBinnedPlan:
         L.check(L.lib().loops_panel_plan_arrays(self._h, p(val), p(col16), p(dst4), p(row16), p(perm), p(bstart)), "loops_panel_plan_arrays")
         return val, col16, dst4, row16, perm, bstart
 
+    def windows(self):
+        """(window_start [subbands + 1], windows [n, 2] = {first item, items | packed << 16}, segment_start [subbands * panels
+        + 1]) copied to the host: kernel B's work list (loops_panel_plan_windows)."""
+        ws = np.zeros(self.num_subbands + 1, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        L.check(L.lib().loops_panel_plan_windows(self._h, p(ws), None, None), "loops_panel_plan_windows")
+        wins = np.zeros((int(ws[-1]), 2), np.int32)
+        segb = np.zeros(self.num_subbands * self.num_panels + 1, np.int32)
+        L.check(L.lib().loops_panel_plan_windows(self._h, p(ws), p(wins) if wins.size else None, p(segb)), "loops_panel_plan_windows")
+        return ws, wins, segb
+
     def refresh_values(self, values: torch.Tensor):
         assert values.dtype == self.dtype and values.numel() == self.nnz
         L.check(getattr(L.lib(), "loops_panel_plan_refresh_values_" + self._sfx)(self._h, _ptr(values), _stream()),

@@ -51,6 +51,31 @@ def _check_layout(plan, off, idx, val):
     untouched = np.ones(plan.padded, bool)
     untouched[b] = False
     assert np.all(r16[untouched] == 0xFFFF)                                                       # padding rows are marked
+    # kernel B's work list: the windows of a sub-band tile its run of the B order exactly, <= 256 items each; a window that is
+    # not packed lies inside ONE segment (rows sorted); a packed one is made of whole small segments / the short tail of one
+    ws, wins, segb = plan.windows()
+    pack = 64 if v.dtype == np.float32 else 128
+    assert ws[0] == 0 and np.all(np.diff(ws) >= 0) and segb[0] == 0 and segb[-1] == plan.padded
+    if wins.shape[0] == 0:
+        assert plan.padded == 0
+        return
+    wb, wl, wp = wins[:, 0].astype(np.int64), (wins[:, 1] & 0xFFFF).astype(np.int64), wins[:, 1] >> 16
+    assert np.all(wl > 0) and np.all(wl <= 256) and np.all(wb % 4 == 0) and np.all(wl % 4 == 0)
+    sub = np.repeat(np.arange(S), np.diff(ws))
+    assert np.array_equal(wb[ws[:-1][np.diff(ws) > 0]], bstart[:-1][np.diff(ws) > 0])            # a sub-band's first window starts its run
+    nxt = np.where(np.r_[sub[1:] != sub[:-1], True], bstart[sub + 1], np.r_[wb[1:], 0])
+    assert np.array_equal(wb + wl, nxt)                                                         # contiguous, nothing left out
+    assert np.all(bstart[1:][np.diff(ws) == 0] == bstart[:-1][np.diff(ws) == 0])                  # no windows <=> no items
+    seg_of = np.searchsorted(segb, wb, side="right") - 1                                          # segment holding the first item
+    plain = wp == 0
+    assert np.all(wb[plain] + wl[plain] <= segb[seg_of[plain] + 1])                               # one segment
+    assert np.all(segb[seg_of[plain] + 1] - segb[seg_of[plain]] > pack)                           # ... a large one
+    last_seg = np.searchsorted(segb, wb + wl - 1, side="right") - 1
+    inner = np.flatnonzero(~plain)
+    for k in inner[:2000]:                                                                        # (spot check: a host loop)
+        sizes = np.diff(segb[seg_of[k]:last_seg[k] + 2])
+        sizes[0] = segb[seg_of[k] + 1] - wb[k]                                                    # the first piece may be a tail
+        assert np.all(sizes <= pack), (k, sizes)
 
 
 def test_battery_layout_and_product():
