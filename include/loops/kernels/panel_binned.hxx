@@ -20,16 +20,17 @@
  *                       prod[dst4[i / 4] ..] = val[i ..] * xs[col16[i ..]], 16-byte loads and stores: the products leave in
  *                       16-byte groups, consecutive groups of a segment to consecutive addresses (7 B read + 4 B written per
  *                       nonzero, no gather leaves the CU);
- *   B  panel_reduce     one WORKGROUP per sub-band of Hw rows: the sub-band's products are ONE contiguous run of the B order;
- *                       each of the 4 wavefronts takes a quarter of the run's items and walks it in windows of 64 lanes x 4
- *                       items that never cross a segment boundary (16 + 8 bytes per lane, 8 windows in flight); inside a
- *                       window rows are sorted, so runs of equal rows are summed with the wave64 segmented prefix sum and the
- *                       run ends update the wavefront's OWN LDS accumulators with plain read-modify-writes (LDS float
- *                       atomics retire 0.33 lanes per clock and CU on gfx950: used for the <= 64-item tails of segments and
- *                       for "packed" windows -- consecutive segments of <= 64 items share one window --, and where such
- *                       segments are the rule those get compare-and-swap final updates instead); the 4 partial
- *                       vectors are then added in wavefront order and the Hw rows of y are stored coalesced (4 B + 2 B read
- *                       per nonzero).  Reproducible: no order depends on timing.
+ *   B  panel_reduce     one WORKGROUP per sub-band of Hw rows: the sub-band's products are ONE contiguous run of the B order,
+ *                       cut at plan time into WINDOWS of at most 64 lanes x 4 items (make_windows: a piece of one segment,
+ *                       or -- "packed" -- consecutive segments / segment tails of <= 64 items each; 128 for 8-byte values);
+ *                       each of the 4 wavefronts takes a quarter of the windows, 8 in flight (16 + 8 bytes per lane).  Inside
+ *                       a one-segment window rows are sorted: runs of equal rows are summed with the wave64 segmented prefix
+ *                       sum and the run ends update the wavefront's OWN LDS accumulators with plain read-modify-writes.
+ *                       Packed windows use LDS atomics (ds_add_f32 retires 0.33 lanes per clock and CU on gfx950, ds_add_f64
+ *                       3-8), or -- where small segments are the rule (4-byte values) -- the run-combining path with
+ *                       compare-and-swap final updates and one wavefront per sub-band.  The partial vectors are added in
+ *                       wavefront order and the Hw rows of y are stored coalesced (4 B + 2 B read per nonzero).
+ *                       Reproducible: no order depends on timing.
  * HBM traffic 17 B per nonzero instead of 8 B + a gather; y needs no zero-fill; no global atomics.
  *
  * When it pays: x beyond the L2 and rows spread over many panels (C3- / C5-like inputs).  Sub-bands are the unit of
