@@ -39,8 +39,9 @@ struct spmv_plan_t {
   std::unique_ptr<blocked_t> blocked;
   std::unique_ptr<panel_t> panel;
 
-  /// @param allow_copy the plan may keep a column-blocked copy of `csr` (adopted when >= 5 % faster than the best CSR shape;
-  ///        without `measure`: when cols * sizeof(type_t) > 6 MB and the mean row holds >= 8 nonzeros)
+  /// @param allow_copy the plan may keep a re-ordered copy of `csr` (adopted when >= 5 % faster than the best CSR shape;
+  ///        without `measure`: when cols * sizeof(type_t) > 6 MB -- panel-binned for 4-byte values or x >= 32 MB, else
+  ///        column-blocked if the mean row holds >= 8 nonzeros)
   /// @param measure time the candidates (`repeats` products each) instead of choosing by structure alone
   explicit spmv_plan_t(csr_t<index_t, offset_t, type_t>& csr, bool allow_copy = true, bool measure = true, int repeats = 10,
                        xpu::stream_t stream = 0) {
@@ -55,11 +56,19 @@ struct spmv_plan_t {
         large->classify(stream);
         small.reset();
       }
-      if (allow_copy && work && x_bytes > (std::size_t(6) << 20) && csr.nnzs / csr.rows >= 8 && fits_blocked(csr)) {
-        blocked = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
-        layout = column_blocked_layout;
-        small.reset();
-        large.reset();
+      if (allow_copy && work && x_bytes > (std::size_t(6) << 20)) {   // (the rule of loops_spmv_plan_create_* without MEASURE)
+        const bool want_panel = sizeof(type_t) == 4 || x_bytes >= (std::size_t(32) << 20);
+        if (want_panel && fits_panel(csr)) {
+          panel = std::make_unique<panel_t>(csr, 0, stream);
+          layout = panel_binned_layout;
+        } else if (!want_panel && csr.nnzs / csr.rows >= 8 && fits_blocked(csr)) {
+          blocked = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
+          layout = column_blocked_layout;
+        }
+        if (layout != csr_layout) {
+          small.reset();
+          large.reset();
+        }
       }
       return;
     }

@@ -320,8 +320,10 @@ int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x,
  *                                  unmodified CSR; `repeats` launches each, <= 0: 10) instead of choosing by structure alone;
  *   flags & LOOPS_PLAN_ALLOW_COPY  the plan may keep a column-blocked COPY of the matrix (see "column-blocked CSR" above:
  *                                  + nnz * (8 + sizeof(T)) + K * rows * (4 + sizeof(T)) bytes) when x exceeds the per-XCD L2;
- *                                  with MEASURE it is adopted only if >= 5 % faster than the best CSR shape, without MEASURE
- *                                  when cols * sizeof(T) > 6 MB and the mean row holds >= 8 nonzeros.
+ *                                  with MEASURE it is adopted only if >= 5 % faster than the best CSR shape; without MEASURE
+ *                                  a copy is taken when cols * sizeof(T) > 6 MB: the panel-binned one (4-byte values, or x >=
+ *                                  32 MB), else the column-blocked one if the mean row holds >= 8 nonzeros.  (Structure does
+ *                                  not show column locality -- a narrow band is faster from the CSR as given: MEASURE finds out.)
  * Without ALLOW_COPY the product always runs on the caller's arrays.  Creation is synchronous.  One product in flight per plan.
  * loops_spmv_planned_*: y = A x; offsets / indices / values are the arrays the plan was created from (ignored -- may be NULL
  * -- when the plan holds the copy; after changing the VALUES of the matrix call loops_spmv_plan_refresh_values_* first).

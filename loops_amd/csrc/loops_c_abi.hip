@@ -859,13 +859,22 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
   const long long x_bytes = static_cast<long long>(cols) * static_cast<long long>(sizeof(T));
   int err = 0;
   if (!measure) {
-    // structural choice only: tile by the self-completing test; the copy when x exceeds 1.5 per-XCD L2s and rows are long
-    // enough to be cut into blocks (the regime in which the blocked layout won every measurement so far)
+    // structural choice only: tile by the self-completing test; a copy when x exceeds 1.5 per-XCD L2s -- panel-binned (the
+    // fastest layout on every such input measured with 4-byte values, and with 8-byte values from x = 32 MB), else
+    // column-blocked if rows are long enough to be cut into blocks.  Structure cannot see column LOCALITY (a narrow band
+    // runs faster from the CSR as it is): callers who cannot rule it out should pass LOOPS_PLAN_MEASURE.
     err = plan_create_auto(rows, nnz, off, st, &p->merge);
-    if (!err && may_copy && x_bytes > (6ll << 20) && nnz / (rows > 0 ? rows : 1) >= 8) {
-      err = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &p->blocked);
-      if (!err) { p->layout = LOOPS_LAYOUT_COLUMN_BLOCKED; plan_release(p->merge); p->merge = nullptr; }
-      else if (err == LOOPS_E_RANGE || err == LOOPS_E_CONFIG) err = 0;  // K * rows + nnz does not fit: stay on the CSR
+    if (!err && may_copy && x_bytes > (6ll << 20)) {
+      const bool panel = sizeof(T) == 4 || x_bytes >= (32ll << 20);
+      if (panel) {
+        err = panel_create<T>(rows, cols, nnz, off, idx, val, st, &p->panel);
+        if (!err) p->layout = LOOPS_LAYOUT_PANEL_BINNED;
+      } else if (nnz / (rows > 0 ? rows : 1) >= 8) {
+        err = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &p->blocked);
+        if (!err) p->layout = LOOPS_LAYOUT_COLUMN_BLOCKED;
+      }
+      if (!err && p->layout != LOOPS_LAYOUT_CSR) { plan_release(p->merge); p->merge = nullptr; }
+      else if (err == LOOPS_E_RANGE || err == LOOPS_E_CONFIG) err = 0;  // the copy does not fit 32-bit positions: stay on the CSR
     }
     if (err) { spmv_plan_free(p); return err; }
     *out = p;

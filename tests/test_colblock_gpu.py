@@ -127,8 +127,8 @@ def test_double_precision_plan():
 
 def test_spmv_plan_picks_tile_and_layout():
     """loops_spmv_plan_*: the plan chooses tile shape and layout per matrix.  Structural mode: a band matrix stays on the
-    unmodified CSR in 256x8 tiles (self-completing), a matrix whose x is far larger than an L2 is held column-blocked when a
-    copy is allowed and never without that flag.  Measured mode: whatever is chosen, the times of the candidates are
+    unmodified CSR in 256x8 tiles (self-completing), a matrix whose x is far larger than an L2 is held panel-binned (8-byte values below 32
+    MB of x: column-blocked) when a copy is allowed and never without that flag.  Measured mode: whatever is chosen, the times of the candidates are
     reported and the product equals the oracle's bit for bit."""
     from loops_amd import spmv as S, generate as G
     from oracle import oracle as O
@@ -158,7 +158,7 @@ def test_spmv_plan_picks_tile_and_layout():
     assert np.array_equal(p.spmv(x).cpu().numpy(), ref)
     p.close()
     p = S.SpmvPlan(csr, allow_copy=True, measure=False)
-    assert p.info["layout"] == "column_blocked" and p.info["column_blocks"] >= 2
+    assert p.info["layout"] == "panel_binned" and p.info["column_blocks"] == cols // 32768      # (4-byte values: panels)
     assert np.array_equal(p.spmv(x).cpu().numpy(), ref)
     # new values, same structure: the held copy follows after refresh_values()
     csr.values.mul_(2.0)
@@ -189,3 +189,20 @@ def test_spmv_plan_picks_tile_and_layout():
     p = S.SpmvPlan(csr64, allow_copy=True, measure=True, repeats=3)
     assert np.array_equal(p.spmv(x.double()).cpu().numpy(), O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64)))
     p.close()
+
+
+def test_spmv_plan_structural_rule_with_8_byte_values():
+    """Without LOOPS_PLAN_MEASURE a copy is chosen by structure: 8-byte values take the panel-binned copy from 32 MB of x, the
+    column-blocked one between 6 and 32 MB (where it measured faster: C2 in fp64); products equal the oracle's."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    for cols, want in ((1 << 21, "column_blocked"), (1 << 22, "panel_binned")):       # x = 16 MB / 32 MB
+        rows = 1 << 15
+        deg = G.powerlaw_degrees(rows, 1 << 20, cap=1 << 12)
+        off, idx, val = G.csr_from_degrees(deg, cols, seed=3)
+        xh = G.uniform_distribution_int(cols).astype(np.float64)
+        csr = S.CSR.from_numpy(rows, cols, off, idx, val.astype(np.float64))
+        p = S.SpmvPlan(csr, allow_copy=True, measure=False)
+        assert p.info["layout"] == want, (cols, p.info)
+        assert np.array_equal(p.spmv(torch.from_numpy(xh).cuda()).cpu().numpy(), O.spmv_f64(off, idx, val.astype(np.float64), xh))
+        p.close()
