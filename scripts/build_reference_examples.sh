@@ -29,6 +29,7 @@ build "$REF/examples/range/range.cu" "$OUT/loops.range" "" &
 # this repository's own example drivers for the paths the reference does not have
 build "$ROOT/examples/spmm/merge_path_flat.cu" "$OUT/loops.spmm.merge_path_flat" "" &
 build "$ROOT/examples/spmv/column_blocked.cu" "$OUT/loops.spmv.column_blocked" "" &
+build "$ROOT/examples/spmv/spmv_plan.cu" "$OUT/loops.spmv.spmv_plan" "" &
 wait
 # which headers these binaries were built from: tests/test_examples_gpu.py refuses stale binaries
 if [ $fail -eq 0 ]; then python3 "$ROOT/scripts/headers_digest.py" > "$OUT/HEADERS.sha256"; fi
