@@ -709,10 +709,14 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
     const std::size_t lds = static_cast<std::size_t>(waves) * (m.Hw + wave::size) * sizeof(type_t);
     auto go = [&](auto kernel) {
       // (66.5 KB at Hw = 16 KB / sizeof(T): above the 64 KB a kernel may use without asking)
-      static bool raised = false;  // once per instantiation
-      if (!raised && lds > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
-        raised = true;
+      static bool raised[64] = {};  // once per instantiation AND device (the attribute belongs to the device's copy of the kernel)
+      if (lds > 65536) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !raised[dev]) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
+          if (dev >= 0 && dev < 64) raised[dev] = true;
+        }
       }
       hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.wstart, m.wins, m.Hw, m.prod, m.row16, m.rows, out);
     };

@@ -171,6 +171,67 @@ static void test_market_loader() {
   for (std::size_t i = 0; i < c64.nnzs; ++i) CHECK(c64.values[i] == 2.5);
 }
 
+// Files large enough (> 4 MB of body) for the loader to tokenise the body on several threads: the result must be what a
+// front-to-back pass gives -- entry k of the file is entry k of the COO (mirrors right after their originals), trailing
+// text after the declared entries is ignored even if malformed, a malformed line among them or too few lines are errors.
+static void test_market_loader_parallel_body() {
+  const int n = 400000, entries = 500000;
+  auto row_of = [&](int k) { return static_cast<int>((static_cast<long long>(k) * 7919) % n); };
+  auto col_of = [&](int k) { return static_cast<int>((static_cast<long long>(k) * 104729 + 13) % n); };
+  auto body = [&](int count, bool lower) {
+    std::string text;
+    text.reserve(static_cast<std::size_t>(count) * 24);
+    for (int k = 0; k < count; ++k) {
+      int r = row_of(k), c = col_of(k);
+      if (lower && c > r) std::swap(r, c);
+      text += std::to_string(r + 1) + " " + std::to_string(c + 1) + " " + std::to_string(k % 1000) + ".5\n";
+    }
+    return text;
+  };
+  matrix_market_t<int, int, float> rd;
+  const std::string head = "%%MatrixMarket matrix coordinate real general\n% comment\n" + std::to_string(n) + " " + std::to_string(n) + " " +
+                           std::to_string(entries) + "\n";
+  const std::string general = body(entries, false);
+  CHECK(general.size() > (std::size_t(4) << 20));
+  auto coo = rd.load(write_tmp("big_general", head + general));
+  CHECK(coo.rows == static_cast<std::size_t>(n) && coo.nnzs == static_cast<std::size_t>(entries));
+  bool same = true;
+  for (int k = 0; k < entries; ++k)
+    same = same && coo.row_indices[k] == row_of(k) && coo.col_indices[k] == col_of(k) && coo.values[k] == static_cast<float>(k % 1000) + 0.5f;
+  CHECK(same);
+  // trailing lines after the declared entries are not read, malformed or not
+  coo = rd.load(write_tmp("big_trailing", head + general + "this is not an entry\n7 7 7.0\n"));
+  CHECK(coo.nnzs == static_cast<std::size_t>(entries) && coo.row_indices[entries - 1] == row_of(entries - 1));
+  // a malformed line among the declared entries (deep inside the file, i.e. in some later chunk) is an error
+  std::string broken = general;
+  const std::size_t at = broken.find('\n', broken.size() * 3 / 4) + 1;
+  broken.insert(at, "oops 3 1.0\n");
+  CHECK_THROWS(rd.load(write_tmp("big_broken", head + broken)));
+  // fewer lines than declared
+  CHECK_THROWS(rd.load(write_tmp("big_short", head + body(entries - 5, false))));
+  // a zero index deep inside
+  std::string zero = general;
+  zero.insert(zero.find('\n', zero.size() / 2) + 1, "0 5 1.0\n");
+  CHECK_THROWS(rd.load(write_tmp("big_zero", head + zero)));
+  // symmetric: every off-diagonal entry is followed by its mirror, in file order
+  const std::string shead = "%%MatrixMarket matrix coordinate real symmetric\n" + std::to_string(n) + " " + std::to_string(n) + " " +
+                            std::to_string(entries) + "\n";
+  coo = rd.load(write_tmp("big_symmetric", shead + body(entries, true)));
+  std::size_t o = 0;
+  same = true;
+  for (int k = 0; k < entries && same; ++k) {
+    int r = row_of(k), c = col_of(k);
+    if (c > r) std::swap(r, c);
+    same = o < coo.nnzs && coo.row_indices[o] == r && coo.col_indices[o] == c;
+    ++o;
+    if (r != c) {
+      same = same && o < coo.nnzs && coo.row_indices[o] == c && coo.col_indices[o] == r && coo.values[o] == coo.values[o - 1];
+      ++o;
+    }
+  }
+  CHECK(same && o == coo.nnzs);
+}
+
 template <typename csr_type>
 static std::vector<std::vector<float>> dense_of(const csr_type& m) {
   std::vector<std::vector<float>> d(m.rows, std::vector<float>(m.cols, 0.f));
@@ -288,6 +349,7 @@ int main(int argc, char** argv) {
   test_layouts();
   test_ranges_math();
   test_market_loader();
+  test_market_loader_parallel_body();
   test_containers_round_trip();
   if (argc > 1) test_c1_chesapeake(argv[1]);
   std::printf("%d checks, %d failures\n", g_checks, g_fail);
