@@ -35,7 +35,7 @@ class mapped_file_t {
     if (size_ > 0) {
       void* p = ::mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
       if (p != MAP_FAILED) {
-        ::madvise(p, size_, MADV_SEQUENTIAL);
+        ::madvise(p, size_, MADV_WILLNEED);  // (read by several threads at once: whole-file read-ahead, not one sequential stream)
         base_ = static_cast<const char*>(p);
         mapped_ = true;
       } else {  // fall back to read()
