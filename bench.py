@@ -1045,7 +1045,9 @@ def main():
     n_copy = 1 << 28  # 1 GiB in + 1 GiB out: beyond the 256 MiB Infinity Cache
     src = torch.empty(n_copy, dtype=torch.float32, device="cuda").normal_()
     dst = torch.empty_like(src)
-    copy_avg = batch_event_time(lambda: PR.stream_copy(src, dst), 20)
+    # (4 vectors per lane in flight, non-temporal loads and stores, 32 workgroups per CU: the fastest of scripts/probe_copy_rate.py
+    #  -- 5.9 TB/s where the plain one-vector loop gets 4.7)
+    copy_avg = batch_event_time(lambda: PR.stream_copy_tuned(src, dst, 4, 3, 256 * 32), 20)
     R_["copy_gbps"] = 2 * n_copy * 4 / (copy_avg * 1e-3) / 1e9
     del src, dst
     gidx = torch.from_numpy(idx[: 1 << 24]).cuda() if idx.size >= 1 << 24 else csr.indices

@@ -19,6 +19,9 @@ extern "C" {
  * also quoted against.  dst == src selects a READ-ONLY stream (per-lane sums, nothing
  * written): the achievable read rate. */
 int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream);
+/* Copy-rate tuning: `unroll` (1, 2, 4, 8) 16-byte vectors per lane in flight; flags bit 0 non-temporal loads, bit 1
+ * non-temporal stores, bit 2 one contiguous chunk per workgroup instead of grid-stride steps; `blocks` workgroups of 256. */
+int loops_stream_copy_tuned_f32(const float* src, float* dst, size_t n, int unroll, int flags, int blocks, void* stream);
 /* out[i] = table[idx[i]] with `scalar_per_64` (0, 4, 8, 16, 24, 32, 64) of every 64 gathers of a wavefront issued through the
  * scalar memory path (v_readlane -> s_load_dword -> select) and the rest as a divergent vector load: does the scalar path
  * add gather throughput on top of the vector L1's outstanding-read capacity? */

@@ -148,6 +148,12 @@ int loops_stream_copy_f32(const float* src, float* dst, size_t n, void* stream) 
   return kernels::launch_stream_copy(as_stream(stream), src, dst, n);
 }
 
+int loops_stream_copy_tuned_f32(const float* src, float* dst, size_t n, int unroll, int flags, int blocks, void* stream) {
+  if (!src || !dst || blocks <= 0) return E_BADARG;
+  const int rc = kernels::launch_stream_copy_tuned(as_stream(stream), src, dst, n, unroll, flags, blocks);
+  return rc == -1 ? E_BADARG : rc;
+}
+
 int loops_gather_f32(const float* table, const int* idx, float* out, size_t n, int mode, void* stream) {
   if (!table || !idx || !out) return E_BADARG;
   return kernels::launch_gather(as_stream(stream), table, idx, out, n, mode);

@@ -19,6 +19,53 @@ __global__ void __launch_bounds__(256) stream_copy_kernel(const float4* __restri
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
 }
 
+/// Copy-rate tuning probe: U 16-byte vectors per lane in flight (all loads of a step before its stores), plain or
+/// non-temporal loads / stores, grid-stride steps or one contiguous chunk per workgroup, `blocks` workgroups of 256.
+template <int U, bool NTL, bool NTS, bool CHUNKED>
+__global__ void __launch_bounds__(256) stream_copy_tuned_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  using f4 = float __attribute__((ext_vector_type(4)));
+  const f4* s = reinterpret_cast<const f4*>(src);
+  f4* d = reinterpret_cast<f4*>(dst);
+  size_t begin, end, step;
+  if constexpr (CHUNKED) {
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    begin = per * blockIdx.x;
+    end = begin + per < n4 ? begin + per : n4;
+    step = static_cast<size_t>(256) * U;
+  } else {
+    begin = static_cast<size_t>(blockIdx.x) * 256 * U;
+    end = n4;
+    step = static_cast<size_t>(gridDim.x) * 256 * U;
+  }
+  for (size_t i0 = begin; i0 < end; i0 += step) {
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + static_cast<size_t>(u) * 256 + threadIdx.x;
+      if (i < end) v[u] = NTL ? __builtin_nontemporal_load(s + i) : s[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + static_cast<size_t>(u) * 256 + threadIdx.x;
+      if (i < end) { if constexpr (NTS) __builtin_nontemporal_store(v[u], d + i); else d[i] = v[u]; }
+    }
+  }
+}
+
+inline int launch_stream_copy_tuned(hipStream_t stream, const float* src, float* dst, size_t n, int unroll, int flags, int blocks) {
+  const size_t n4 = n / 4;
+  const dim3 g(blocks), b(256);
+  const float4* s = reinterpret_cast<const float4*>(src);
+  float4* d = reinterpret_cast<float4*>(dst);
+#define LOOPS_COPY_CASE(UU, F) \
+  if (unroll == UU && flags == F) { hipLaunchKernelGGL((stream_copy_tuned_kernel<UU, (F & 1) != 0, (F & 2) != 0, (F & 4) != 0>), g, b, 0, stream, s, d, n4); return static_cast<int>(hipGetLastError()); }
+#define LOOPS_COPY_U(UU) LOOPS_COPY_CASE(UU, 0) LOOPS_COPY_CASE(UU, 1) LOOPS_COPY_CASE(UU, 2) LOOPS_COPY_CASE(UU, 3) LOOPS_COPY_CASE(UU, 4) LOOPS_COPY_CASE(UU, 5) LOOPS_COPY_CASE(UU, 6) LOOPS_COPY_CASE(UU, 7)
+  LOOPS_COPY_U(1) LOOPS_COPY_U(2) LOOPS_COPY_U(4) LOOPS_COPY_U(8)
+#undef LOOPS_COPY_U
+#undef LOOPS_COPY_CASE
+  return -1;
+}
+
 /// How the gathered word is requested: 0 plain, 1 non-temporal, 2 agent-scope (sc1, bypasses the
 /// CU's vector L1), 3 system-scope (sc0 sc1), 4 plain gather but non-temporal index / output streams.
 template <int MODE>

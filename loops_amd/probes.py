@@ -24,6 +24,7 @@ def lib() -> C.CDLL:
         vp, ci = C.c_void_p, C.c_int
         P.loops_stream_copy_f32.argtypes = [vp, vp, C.c_size_t, vp]
         P.loops_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
+        P.loops_stream_copy_tuned_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, ci, vp]
         P.loops_stream_read_prefetch_f32.argtypes = [vp, vp, C.c_size_t, ci, ci, ci, vp]
         P.loops_mixed_gather_f32.argtypes = [vp, vp, vp, C.c_size_t, ci, vp]
         P.loops_address_rate_f32.argtypes = [vp, ci, ci, ci, ci, vp, vp]
@@ -49,6 +50,10 @@ def _ptr(t):
 
 def stream_copy(src, dst):
     L.check(lib().loops_stream_copy_f32(_ptr(src), _ptr(dst), src.numel(), _stream()), "loops_stream_copy_f32")
+
+
+def stream_copy_tuned(src, dst, unroll: int, flags: int, blocks: int):
+    L.check(lib().loops_stream_copy_tuned_f32(_ptr(src), _ptr(dst), src.numel(), unroll, flags, blocks, _stream()), "loops_stream_copy_tuned_f32")
 
 
 def stream_read_prefetch(src, sink, distance: int, line_words: int = 32, waves_per_cu: int = 32):
