@@ -7,7 +7,7 @@
  * coalesced (neighbouring lanes read neighbouring cells of a diagonal) but 4 bytes per lane and load, one diagonal
  * in flight, and the diagonal's offset re-read by every lane.  `dia_row4_spmv`: a lane owns FOUR consecutive rows --
  * one 16-byte load per diagonal (`global_load_dwordx4`; stride and bases 16-byte aligned), the matching four x values
- * are consecutive too -- U diagonals in flight, the offsets are wave-uniform scalar loads, y leaves as one 16-byte
+ * are consecutive too -- U (= 2) diagonals in flight, the offsets are wave-uniform scalar loads, y leaves as one 16-byte
  * store.  A pure stream: bound by HBM (4 or 8 B per cell + x from L2).
  */
 #pragma once
@@ -120,7 +120,10 @@ int launch_dia_row4(hipStream_t stream, int rows, int cols, std::size_t stride, 
   if (rows == 0) return 0;
   const bool vec = stride % 4 == 0 && ((reinterpret_cast<std::uintptr_t>(values) | reinterpret_cast<std::uintptr_t>(y)) & 15u) == 0;
   const dim3 grid(math::ceil_div(math::ceil_div(rows, 4), 256)), block(256);
-  constexpr int U = sizeof(type_t) > 4 ? 4 : 8;  // 128 bytes per lane in flight
+  // Diagonals in flight per lane: 2 -- measured 2 / 4 / 8 / 16 / 32 on 2^20 rows x 33 diagonals (138 MB): 5.9 / 5.7 / 5.0 /
+  // 3.8 / 3.1 TB/s in f32 (registers, i.e. resident wavefronts, matter more than loads per lane; 2^23 rows, 1.1 GB: 5.6 / 5.3
+  // / 5.1); f64 is within 3 % for 1 / 2 / 4.
+  constexpr int U = 2;
   if (vec)
     hipLaunchKernelGGL((dia_row4_spmv<U, true, index_t, type_t>), grid, block, 0, stream, rows, cols, stride, num_diagonals,
                        diag_offsets, values, x, y);
