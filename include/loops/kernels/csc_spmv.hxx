@@ -120,5 +120,48 @@ int launch_csc_nonzero_split(hipStream_t stream, int cols, int nnz, const offset
   return static_cast<int>(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------- CSC -> CSR on the device
+// What a held CSC plan does once (loops_csc_plan_*): the scatter y[row] += ... of a CSC product is one global atomic per
+// nonzero on this chip (~16 G/s: 1.04 ms on C2 whatever the kernel), the same matrix as CSR runs in 0.1 ms -- so a caller
+// that multiplies more than once should transpose the storage once.  Keys (row << 32 | column) + the nonzero's position are
+// radix-sorted; rows are counted on the way.
+
+/// key[k] = row << 32 | column of nonzero k (column by a search over the offsets), pos[k] = k, counts[row + 1] += 1.
+template <typename index_t, typename offset_t>
+__global__ void __launch_bounds__(256)
+csc_transpose_keys(const int cols, const int nnz, const offset_t* __restrict__ col_offsets, const index_t* __restrict__ row_indices,
+                   unsigned long long* __restrict__ keys, int* __restrict__ pos, int* __restrict__ counts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  int col = 0, count = cols;   // last c with col_offsets[c] <= k
+  while (count > 1) {
+    const int half = count >> 1;
+    if (col_offsets[col + half] <= k) { col += half; count -= half; }
+    else count = half;
+  }
+  const unsigned int r = static_cast<unsigned int>(row_indices[k]);
+  keys[k] = (static_cast<unsigned long long>(r) << 32) | static_cast<unsigned int>(col);
+  pos[k] = k;
+  atomicAdd(counts + r + 1, 1);
+}
+
+/// indices[i] = column of the i-th nonzero in (row, column) order, values[i] = its value.
+template <typename index_t, typename type_t>
+__global__ void __launch_bounds__(256)
+csc_transpose_finish(const int nnz, const unsigned long long* __restrict__ keys_sorted, const int* __restrict__ perm,
+                     const type_t* __restrict__ csc_values, index_t* __restrict__ indices, type_t* __restrict__ values) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nnz) return;
+  indices[i] = static_cast<index_t>(keys_sorted[i] & 0xFFFFFFFFull);
+  values[i] = csc_values[perm[i]];
+}
+
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+gather_values(const int n, const int* __restrict__ perm, const type_t* __restrict__ from, type_t* __restrict__ to) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) to[i] = from[perm[i]];
+}
+
 }  // namespace kernels
 }  // namespace loops

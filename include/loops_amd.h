@@ -405,6 +405,26 @@ int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_off
 int loops_spmv_csc_f64(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
                        const double* values, const double* x, double* y, void* stream);
 
+/* ---- CSC plan: the storage transposed once -------------------------------------------------------------------------------
+ * A CSC product scatters into y: one global atomic per nonzero, ~16 G/s on this chip -- 1.04 ms on the C2 matrix whatever the
+ * kernel, ten times the CSR product of the same matrix.  A caller that multiplies more than once holds this plan instead: it
+ * transposes the storage to CSR on the device once (one 64-bit radix sort of (row, column) keys; rows of y then have one
+ * writer and need no zero-fill) and keeps a SpMV plan (above; same `flags` / `repeats`) over that copy.
+ * loops_csc_plan_info = loops_spmv_plan_info of the inner plan.  After changing the VALUES (same structure) call
+ * loops_csc_plan_refresh_values_* with the CSC values array.  One product in flight per plan.  No reference counterpart
+ * (algorithms/spmv/csc_thread_mapped.cuh:36-95 is the scatter). */
+typedef struct loops_csc_plan loops_csc_plan_t;
+int loops_csc_plan_create_f32(int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const float* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out);
+int loops_csc_plan_create_f64(int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const double* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out);
+void loops_csc_plan_destroy(loops_csc_plan_t* plan);
+int loops_csc_plan_info(const loops_csc_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4);
+int loops_csc_plan_refresh_values_f32(loops_csc_plan_t* plan, const float* values, void* stream);
+int loops_csc_plan_refresh_values_f64(loops_csc_plan_t* plan, const double* values, void* stream);
+int loops_spmv_csc_planned_f32(const loops_csc_plan_t* plan, const float* x, float* y, void* stream);
+int loops_spmv_csc_planned_f64(const loops_csc_plan_t* plan, const double* x, double* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

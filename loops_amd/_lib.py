@@ -48,6 +48,8 @@ SYMBOLS = [
     "loops_spmv_plan_refresh_values_f32", "loops_spmv_plan_refresh_values_f64", "loops_spmv_planned_f32", "loops_spmv_planned_f64",
     "loops_panel_plan_create_f32", "loops_panel_plan_create_f64", "loops_panel_plan_destroy", "loops_panel_plan_info",
     "loops_panel_plan_arrays", "loops_panel_plan_windows", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
+    "loops_csc_plan_create_f32", "loops_csc_plan_create_f64", "loops_csc_plan_destroy", "loops_csc_plan_info",
+    "loops_csc_plan_refresh_values_f32", "loops_csc_plan_refresh_values_f64", "loops_spmv_csc_planned_f32", "loops_spmv_csc_planned_f64",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
 
@@ -206,6 +208,9 @@ def lib() -> C.CDLL:
         L.loops_spmv_panel_stage_f32.argtypes = [vp, ci, vp, vp, vp]
         L.loops_spmv_panel_stage_f64.argtypes = [vp, ci, vp, vp, vp]
         L.loops_spmv_plan_destroy.argtypes = [vp]
+        L.loops_csc_plan_destroy.argtypes = [vp]
+        L.loops_csc_plan_destroy.restype = None
+        L.loops_csc_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), vp]
         L.loops_spmv_plan_destroy.restype = None
         L.loops_spmv_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), vp]
         L.loops_autotune_merge_path_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]

@@ -968,6 +968,90 @@ int spmv_planned(const loops_spmv_plan* p, const int* off, const int* idx, const
 
 }  // namespace
 
+// ------------------------------------------------------------------ CSC plan: transpose the storage once, then a SpMV plan
+struct loops_csc_plan {
+  int rows, cols, nnz, vbytes;
+  int *off, *idx, *perm;   // the matrix as CSR (owned) and, per CSR position, the CSC position its value comes from
+  void* val;
+  loops_spmv_plan* inner;
+};
+
+namespace {
+
+void csc_plan_free(loops_csc_plan* p) {
+  if (!p) return;
+  spmv_plan_free(p->inner);
+  (void)hipFree(p->off); (void)hipFree(p->idx); (void)hipFree(p->perm); (void)hipFree(p->val);
+  delete p;
+}
+
+template <typename T>
+int csc_plan_create(int rows, int cols, int nnz, const int* col_off, const int* row_idx, const T* val, int flags, int repeats,
+                    hipStream_t st, loops_csc_plan** out) {
+  if (!out || !col_off || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_idx || !val))) return LOOPS_E_BADARG;
+  if (static_cast<long long>(rows) + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
+  auto* p = new (std::nothrow) loops_csc_plan();
+  if (!p) return static_cast<int>(hipErrorOutOfMemory);
+  p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T));
+  const size_t n = static_cast<size_t>(nnz > 0 ? nnz : 1);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->off), sizeof(int) * (static_cast<size_t>(rows) + 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->idx), sizeof(int) * n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->perm), sizeof(int) * n);
+  if (e == hipSuccess) e = hipMalloc(&p->val, sizeof(T) * n);
+  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+  int* pos = nullptr;
+  void* cub_temp = nullptr;
+  size_t sort_bytes = 0, scan_bytes = 0;
+  int end_bit = 33;
+  while (end_bit < 64 && (static_cast<unsigned long long>(rows > 0 ? rows - 1 : 0) >> (end_bit - 32)) != 0) ++end_bit;
+  if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, pos, p->perm, nnz, 0, end_bit, st);
+  if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, p->off, p->off, rows + 1, st);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&keys_in), sizeof(unsigned long long) * n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&keys_out), sizeof(unsigned long long) * n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pos), sizeof(int) * n);
+  size_t cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+  if (e == hipSuccess) e = hipMalloc(&cub_temp, cub_bytes > 0 ? cub_bytes : 16);
+  if (e == hipSuccess) e = hipMemsetAsync(p->off, 0, sizeof(int) * (static_cast<size_t>(rows) + 1), st);
+  if (e == hipSuccess && nnz > 0) {
+    const dim3 grid(math::ceil_div(nnz, 256)), block(256);
+    hipLaunchKernelGGL((kernels::csc_transpose_keys<int, int>), grid, block, 0, st, cols, nnz, col_off, row_idx, keys_in, pos, p->off);
+    size_t bytes = cub_bytes;
+    e = hipcub::DeviceRadixSort::SortPairs(cub_temp, bytes, keys_in, keys_out, pos, p->perm, nnz, 0, end_bit, st);
+    if (e == hipSuccess) hipLaunchKernelGGL((kernels::csc_transpose_finish<int, T>), grid, block, 0, st, nnz, keys_out, p->perm, val, p->idx, static_cast<T*>(p->val));
+  }
+  if (e == hipSuccess) {
+    size_t bytes = cub_bytes;
+    e = hipcub::DeviceScan::InclusiveSum(cub_temp, bytes, p->off, p->off, rows + 1, st);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(pos); (void)hipFree(cub_temp);
+  int err = static_cast<int>(e);
+  if (!err) err = spmv_plan_create<T>(rows, cols, nnz, p->off, p->idx, static_cast<const T*>(p->val), flags, repeats, st, &p->inner);
+  if (err) { csc_plan_free(p); return err; }
+  *out = p;
+  return 0;
+}
+
+template <typename T>
+int csc_plan_spmv(const loops_csc_plan* p, const T* x, T* y, hipStream_t st) {
+  if (!p || p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
+  return spmv_planned<T>(p->inner, p->off, p->idx, static_cast<const T*>(p->val), x, y, st);
+}
+
+template <typename T>
+int csc_plan_refresh(loops_csc_plan* p, const T* values, hipStream_t st) {
+  if (!p || p->vbytes != static_cast<int>(sizeof(T)) || (p->nnz > 0 && !values)) return LOOPS_E_BADARG;
+  if (p->nnz == 0) return 0;
+  hipLaunchKernelGGL((kernels::gather_values<T>), dim3(math::ceil_div(p->nnz, 256)), dim3(256), 0, st, p->nnz, p->perm, values, static_cast<T*>(p->val));
+  int err = static_cast<int>(hipGetLastError());
+  if (!err && p->inner->panel) err = panel_refresh<T>(p->inner->panel, static_cast<const T*>(p->val), st);
+  else if (!err && p->inner->blocked) err = colblock_refresh<T>(p->inner->blocked, static_cast<const T*>(p->val), st);
+  return err;
+}
+
+}  // namespace
+
 // =============================================================================== extern "C"
 extern "C" {
 
@@ -1459,6 +1543,33 @@ int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x,
   if (err) return err;
   if (plan->rows == 0) return 0;
   return kernels::launch_panel_binned_fanout<double>(as_stream(stream), panel_view<double>(plan), x, y, peers);
+}
+
+
+int loops_csc_plan_create_f32(int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const float* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out) {
+  return csc_plan_create<float>(rows, cols, nnz, col_offsets, row_indices, values, flags, repeats, as_stream(stream), out);
+}
+int loops_csc_plan_create_f64(int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const double* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out) {
+  return csc_plan_create<double>(rows, cols, nnz, col_offsets, row_indices, values, flags, repeats, as_stream(stream), out);
+}
+void loops_csc_plan_destroy(loops_csc_plan_t* plan) { csc_plan_free(plan); }
+int loops_csc_plan_info(const loops_csc_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4) {
+  if (!plan) return LOOPS_E_BADARG;
+  return loops_spmv_plan_info(plan->inner, layout, tile_config, num_blocks, ms4);
+}
+int loops_csc_plan_refresh_values_f32(loops_csc_plan_t* plan, const float* values, void* stream) {
+  return csc_plan_refresh<float>(plan, values, as_stream(stream));
+}
+int loops_csc_plan_refresh_values_f64(loops_csc_plan_t* plan, const double* values, void* stream) {
+  return csc_plan_refresh<double>(plan, values, as_stream(stream));
+}
+int loops_spmv_csc_planned_f32(const loops_csc_plan_t* plan, const float* x, float* y, void* stream) {
+  return csc_plan_spmv<float>(plan, x, y, as_stream(stream));
+}
+int loops_spmv_csc_planned_f64(const loops_csc_plan_t* plan, const double* x, double* y, void* stream) {
+  return csc_plan_spmv<double>(plan, x, y, as_stream(stream));
 }
 
 }  // extern "C"

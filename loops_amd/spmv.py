@@ -615,6 +615,49 @@ def autotune_merge_path(csr: CSR, x, repeats: int = 5):
     return names[best.value], {names[i]: ms[i] for i in range(6) if ms[i] >= 0 and i in names}
 
 
+class CSCPlan:
+    """loops_csc_plan_*: a CSC matrix held for repeated products -- transposed to CSR on the device once (the CSC product
+    itself is one global atomic per nonzero), then a SpMV plan over that copy (``allow_copy`` / ``measure`` as in SpmvPlan)."""
+
+    def __init__(self, rows: int, cols: int, col_offsets, row_indices, values, allow_copy: bool = True, measure: bool = True,
+                 repeats: int = 10):
+        assert values.dtype in (torch.float32, torch.float64)
+        self.rows, self.cols, self.nnz, self.dtype = rows, cols, values.numel(), values.dtype
+        self._sfx = _suffix(values)
+        self._h = C.c_void_p()
+        flags = (1 if measure else 0) | (2 if allow_copy else 0)
+        L.check(getattr(L.lib(), "loops_csc_plan_create_" + self._sfx)(rows, cols, self.nnz, _ptr(col_offsets), _ptr(row_indices),
+                                                                        _ptr(values), flags, repeats, _stream(), C.byref(self._h)),
+                "loops_csc_plan_create")
+        layout, tile, blocks = C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib().loops_csc_plan_info(self._h, C.byref(layout), C.byref(tile), C.byref(blocks), None), "loops_csc_plan_info")
+        self.layout = SpmvPlan.LAYOUTS[layout.value]
+
+    def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+        if y is None:
+            y = torch.empty(self.rows, dtype=self.dtype, device=x.device)
+        assert x.dtype == self.dtype and y.dtype == self.dtype and x.numel() >= self.cols and y.numel() >= self.rows
+        assert x.is_contiguous() and y.is_contiguous()
+        L.check(getattr(L.lib(), "loops_spmv_csc_planned_" + self._sfx)(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_csc_planned")
+        return y
+
+    def refresh_values(self, values: torch.Tensor):
+        assert values.dtype == self.dtype and values.numel() == self.nnz
+        L.check(getattr(L.lib(), "loops_csc_plan_refresh_values_" + self._sfx)(self._h, _ptr(values), _stream()),
+                "loops_csc_plan_refresh_values")
+
+    def close(self):
+        if self._h:
+            L.lib().loops_csc_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def csc_spmv(rows: int, cols: int, col_offsets, row_indices, values, x, y=None, tuned: bool = True):
     """CSC SpMV (loops_spmv_csc_f32 / _f64): ``tuned`` = nonzero-split kernel (y zero-filled inside); otherwise the
     reference shape, lane per column, into a y zero-filled here."""

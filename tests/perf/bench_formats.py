@@ -48,6 +48,14 @@ row = {}
 for tuned in (True, False):
     t = ev(lambda: S.csc_spmv(rows, cols, dc["off"], dc["r"], dc["v"], x, y, tuned=tuned))
     row["tuned" if tuned else "reference-shaped"] = {"ms": round(t, 4), "equal": bool(torch.equal(y, want))}
+import time
+for copy in (False, True):   # the held CSC plan: storage transposed once; with / without a re-ordered copy
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    cp = S.CSCPlan(rows, cols, dc["off"], dc["r"], dc["v"], allow_copy=copy, measure=True)
+    torch.cuda.synchronize(); build = (time.perf_counter() - t0) * 1e3
+    t = ev(lambda: cp.spmv(x, y))
+    row["held plan" + (", copy allowed" if copy else " (CSR copy only)")] = {"ms": round(t, 4), "layout": cp.layout, "build_ms": round(build, 1), "equal": bool(torch.equal(y, want))}
+    cp.close()
 t, yr = ref_format(1, rows, cols, off, idx, val, xh)
 row["reference build"] = {"ms": None if t is None else round(t, 4), "equal": None if yr is None else bool(np.array_equal(yr, want.cpu().numpy()))}
 out["CSC, C2 matrix"] = row; print("CSC", row, file=sys.stderr, flush=True)

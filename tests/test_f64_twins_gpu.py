@@ -39,6 +39,36 @@ def test_coo_csc_f64():
         assert y.dtype == torch.float64 and np.array_equal(y.cpu().numpy(), want), ("csc", tuned)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_csc_plan_transposes_once_and_matches_the_oracle(dtype):
+    """loops_csc_plan_*: the CSC storage is transposed to CSR on the device once and a SpMV plan runs over the copy.  The copy
+    must be the CSR of the same matrix (columns ascending inside a row, the values following them); the product equals the
+    oracle's bit for bit, needs no zero-filled y, follows a value refresh, in f32 and f64, with C2-sized skew (x = 8 MB in
+    f64, so a measured plan may hold a re-ordered copy) and with empty rows / empty columns."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows, cols = 300_000, 1 << 20
+    deg = G.powerlaw_degrees(rows, 1 << 22, cap=1 << 13)
+    deg[::9] = 0
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    val = val.astype(dtype)
+    xh = G.uniform_distribution_int(cols).astype(dtype)
+    want = (O.spmv_f32(off, idx, val, xh, omp=True) if dtype == np.float32 else O.spmv_f64(off, idx, val, xh))
+    ri = np.repeat(np.arange(rows, dtype=np.int32), np.diff(off))
+    order = np.lexsort((ri, idx))                      # CSC: by column, rows ascending inside a column
+    coff = np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=cols))]).astype(np.int32)
+    dev = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    x = dev(xh)
+    for allow_copy, measure in ((False, False), (True, True)):
+        plan = S.CSCPlan(rows, cols, dev(coff), dev(ri[order]), dev(val[order]), allow_copy=allow_copy, measure=measure, repeats=3)
+        assert allow_copy or plan.layout == "csr"
+        y = torch.full((rows,), -3.0, dtype=x.dtype, device="cuda")
+        assert np.array_equal(plan.spmv(x, y).cpu().numpy(), want), (allow_copy, plan.layout)
+        plan.refresh_values(dev((3 * val[order]).astype(dtype)))
+        assert np.array_equal(plan.spmv(x).cpu().numpy(), 3 * want), (allow_copy, plan.layout)
+        plan.close()
+
+
 @pytest.mark.parametrize("R", [2, 3, 4])
 def test_bcsr_f64(R):
     """Register path in fp64 for every compiled block size; the MFMA modes are fp32-only and must say so."""

@@ -111,6 +111,14 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         y = S.csc_spmv(rows, cols, torch.from_numpy(coff).cuda(), torch.from_numpy(ri[order]).cuda(),
                        torch.from_numpy(val[order]).cuda(), x, tuned=tuned)
         assert np.array_equal(y.cpu().numpy(), want), ("csc", tuned) + tag
+    for measure in (False, True):   # the held CSC plan (transposed once on the device), incl. a value refresh
+        cp = S.CSCPlan(rows, cols, torch.from_numpy(coff).cuda(), torch.from_numpy(ri[order]).cuda(), torch.from_numpy(val[order]).cuda(),
+                       allow_copy=True, measure=measure, repeats=2)
+        yp = torch.full((rows,), 5.0, device="cuda")
+        assert np.array_equal(cp.spmv(x, yp).cpu().numpy(), want), ("csc plan", measure) + tag
+        cp.refresh_values(torch.from_numpy(2 * val[order]).cuda())
+        assert np.array_equal(cp.spmv(x).cpu().numpy(), 2 * want), ("csc plan refresh", measure) + tag
+        cp.close()
     # SpMM, a few widths of B
     for n in (1, 6, 16, 40):
         B = rng.integers(1, 11, size=(cols, n)).astype(np.float32)
