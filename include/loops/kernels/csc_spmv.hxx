@@ -145,6 +145,19 @@ csc_transpose_keys(const int cols, const int nnz, const offset_t* __restrict__ c
   atomicAdd(counts + r + 1, 1);
 }
 
+/// The same keys from COO triplets (any order): key[k] = row << 32 | column.
+template <typename index_t>
+__global__ void __launch_bounds__(256)
+coo_transpose_keys(const int nnz, const index_t* __restrict__ row_indices, const index_t* __restrict__ col_indices,
+                   unsigned long long* __restrict__ keys, int* __restrict__ pos, int* __restrict__ counts) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nnz) return;
+  const unsigned int r = static_cast<unsigned int>(row_indices[k]);
+  keys[k] = (static_cast<unsigned long long>(r) << 32) | static_cast<unsigned int>(col_indices[k]);
+  pos[k] = k;
+  atomicAdd(counts + r + 1, 1);
+}
+
 /// indices[i] = column of the i-th nonzero in (row, column) order, values[i] = its value.
 template <typename index_t, typename type_t>
 __global__ void __launch_bounds__(256)

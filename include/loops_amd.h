@@ -418,6 +418,12 @@ int loops_csc_plan_create_f32(int rows, int cols, int nnz, const int* col_offset
                               int flags, int repeats, void* stream, loops_csc_plan_t** out);
 int loops_csc_plan_create_f64(int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const double* values,
                               int flags, int repeats, void* stream, loops_csc_plan_t** out);
+/* The same handle from COO triplets in ANY order (duplicates are added up in their original order): the tuned COO kernel
+ * (loops_spmv_coo_*) needs row-sorted triplets to be fast and atomics otherwise; this sorts once.  Everything else as above. */
+int loops_coo_plan_create_f32(int rows, int cols, int nnz, const int* row_indices, const int* col_indices, const float* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out);
+int loops_coo_plan_create_f64(int rows, int cols, int nnz, const int* row_indices, const int* col_indices, const double* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out);
 void loops_csc_plan_destroy(loops_csc_plan_t* plan);
 int loops_csc_plan_info(const loops_csc_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4);
 int loops_csc_plan_refresh_values_f32(loops_csc_plan_t* plan, const float* values, void* stream);

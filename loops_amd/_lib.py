@@ -48,7 +48,7 @@ SYMBOLS = [
     "loops_spmv_plan_refresh_values_f32", "loops_spmv_plan_refresh_values_f64", "loops_spmv_planned_f32", "loops_spmv_planned_f64",
     "loops_panel_plan_create_f32", "loops_panel_plan_create_f64", "loops_panel_plan_destroy", "loops_panel_plan_info",
     "loops_panel_plan_arrays", "loops_panel_plan_windows", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
-    "loops_csc_plan_create_f32", "loops_csc_plan_create_f64", "loops_csc_plan_destroy", "loops_csc_plan_info",
+    "loops_csc_plan_create_f32", "loops_csc_plan_create_f64", "loops_coo_plan_create_f32", "loops_coo_plan_create_f64", "loops_csc_plan_destroy", "loops_csc_plan_info",
     "loops_csc_plan_refresh_values_f32", "loops_csc_plan_refresh_values_f64", "loops_spmv_csc_planned_f32", "loops_spmv_csc_planned_f64",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]

@@ -985,10 +985,11 @@ void csc_plan_free(loops_csc_plan* p) {
   delete p;
 }
 
+/// `col_off` != nullptr: CSC (column offsets + row indices); else COO triplets (row_idx, col_idx), any order.
 template <typename T>
 int csc_plan_create(int rows, int cols, int nnz, const int* col_off, const int* row_idx, const T* val, int flags, int repeats,
-                    hipStream_t st, loops_csc_plan** out) {
-  if (!out || !col_off || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_idx || !val))) return LOOPS_E_BADARG;
+                    hipStream_t st, loops_csc_plan** out, const int* col_idx = nullptr) {
+  if (!out || (!col_off && nnz > 0 && !col_idx) || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!row_idx || !val))) return LOOPS_E_BADARG;
   if (static_cast<long long>(rows) + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
   auto* p = new (std::nothrow) loops_csc_plan();
   if (!p) return static_cast<int>(hipErrorOutOfMemory);
@@ -1014,7 +1015,8 @@ int csc_plan_create(int rows, int cols, int nnz, const int* col_off, const int* 
   if (e == hipSuccess) e = hipMemsetAsync(p->off, 0, sizeof(int) * (static_cast<size_t>(rows) + 1), st);
   if (e == hipSuccess && nnz > 0) {
     const dim3 grid(math::ceil_div(nnz, 256)), block(256);
-    hipLaunchKernelGGL((kernels::csc_transpose_keys<int, int>), grid, block, 0, st, cols, nnz, col_off, row_idx, keys_in, pos, p->off);
+    if (col_off) hipLaunchKernelGGL((kernels::csc_transpose_keys<int, int>), grid, block, 0, st, cols, nnz, col_off, row_idx, keys_in, pos, p->off);
+    else hipLaunchKernelGGL((kernels::coo_transpose_keys<int>), grid, block, 0, st, nnz, row_idx, col_idx, keys_in, pos, p->off);
     size_t bytes = cub_bytes;
     e = hipcub::DeviceRadixSort::SortPairs(cub_temp, bytes, keys_in, keys_out, pos, p->perm, nnz, 0, end_bit, st);
     if (e == hipSuccess) hipLaunchKernelGGL((kernels::csc_transpose_finish<int, T>), grid, block, 0, st, nnz, keys_out, p->perm, val, p->idx, static_cast<T*>(p->val));
@@ -1553,6 +1555,14 @@ int loops_csc_plan_create_f32(int rows, int cols, int nnz, const int* col_offset
 int loops_csc_plan_create_f64(int rows, int cols, int nnz, const int* col_offsets, const int* row_indices, const double* values,
                               int flags, int repeats, void* stream, loops_csc_plan_t** out) {
   return csc_plan_create<double>(rows, cols, nnz, col_offsets, row_indices, values, flags, repeats, as_stream(stream), out);
+}
+int loops_coo_plan_create_f32(int rows, int cols, int nnz, const int* row_indices, const int* col_indices, const float* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out) {
+  return csc_plan_create<float>(rows, cols, nnz, nullptr, row_indices, values, flags, repeats, as_stream(stream), out, col_indices);
+}
+int loops_coo_plan_create_f64(int rows, int cols, int nnz, const int* row_indices, const int* col_indices, const double* values,
+                              int flags, int repeats, void* stream, loops_csc_plan_t** out) {
+  return csc_plan_create<double>(rows, cols, nnz, nullptr, row_indices, values, flags, repeats, as_stream(stream), out, col_indices);
 }
 void loops_csc_plan_destroy(loops_csc_plan_t* plan) { csc_plan_free(plan); }
 int loops_csc_plan_info(const loops_csc_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4) {

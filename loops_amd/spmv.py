@@ -618,6 +618,7 @@ def autotune_merge_path(csr: CSR, x, repeats: int = 5):
 class CSCPlan:
     """loops_csc_plan_*: a CSC matrix held for repeated products -- transposed to CSR on the device once (the CSC product
     itself is one global atomic per nonzero), then a SpMV plan over that copy (``allow_copy`` / ``measure`` as in SpmvPlan)."""
+    _coo = False
 
     def __init__(self, rows: int, cols: int, col_offsets, row_indices, values, allow_copy: bool = True, measure: bool = True,
                  repeats: int = 10):
@@ -626,9 +627,9 @@ class CSCPlan:
         self._sfx = _suffix(values)
         self._h = C.c_void_p()
         flags = (1 if measure else 0) | (2 if allow_copy else 0)
-        L.check(getattr(L.lib(), "loops_csc_plan_create_" + self._sfx)(rows, cols, self.nnz, _ptr(col_offsets), _ptr(row_indices),
-                                                                        _ptr(values), flags, repeats, _stream(), C.byref(self._h)),
-                "loops_csc_plan_create")
+        create = getattr(L.lib(), ("loops_coo_plan_create_" if self._coo else "loops_csc_plan_create_") + self._sfx)
+        L.check(create(rows, cols, self.nnz, _ptr(col_offsets), _ptr(row_indices), _ptr(values), flags, repeats, _stream(),
+                       C.byref(self._h)), "loops_csc_plan_create")
         layout, tile, blocks = C.c_int(), C.c_int(), C.c_int()
         L.check(L.lib().loops_csc_plan_info(self._h, C.byref(layout), C.byref(tile), C.byref(blocks), None), "loops_csc_plan_info")
         self.layout = SpmvPlan.LAYOUTS[layout.value]
@@ -656,6 +657,16 @@ class CSCPlan:
             self.close()
         except Exception:
             pass
+
+
+class COOPlan(CSCPlan):
+    """loops_coo_plan_*: COO triplets in any order, sorted into a CSR copy on the device once; then as CSCPlan."""
+    _coo = True
+
+    def __init__(self, rows: int, cols: int, row_indices, col_indices, values, allow_copy: bool = True, measure: bool = True,
+                 repeats: int = 10):
+        # (the C entry takes (row_indices, col_indices): the base class passes its 4th and 5th argument in that order)
+        super().__init__(rows, cols, row_indices, col_indices, values, allow_copy, measure, repeats)
 
 
 def csc_spmv(rows: int, cols: int, col_offsets, row_indices, values, x, y=None, tuned: bool = True):

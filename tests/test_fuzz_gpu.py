@@ -119,6 +119,12 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         cp.refresh_values(torch.from_numpy(2 * val[order]).cuda())
         assert np.array_equal(cp.spmv(x).cpu().numpy(), 2 * want), ("csc plan refresh", measure) + tag
         cp.close()
+    # COO plan: shuffled triplets sorted once on the device
+    shuffle = rng.permutation(idx.size)
+    kp = S.COOPlan(rows, cols, torch.from_numpy(ri[shuffle]).cuda(), torch.from_numpy(idx[shuffle]).cuda(), torch.from_numpy(val[shuffle]).cuda(),
+                   allow_copy=False, measure=False)
+    assert np.array_equal(kp.spmv(x).cpu().numpy(), want), ("coo plan",) + tag
+    kp.close()
     # SpMM, a few widths of B
     for n in (1, 6, 16, 40):
         B = rng.integers(1, 11, size=(cols, n)).astype(np.float32)
