@@ -47,6 +47,16 @@ struct coo_t {
     detail::offsets_to_indices(row_offsets, row_indices);
   }
 
+  /// Expand a CSC matrix (one column id per nonzero; column-major order).  With `csr_t(coo)` -- which sorts row-major -- this
+  /// is the CSC -> CSR path of the header API (no counterpart in the reference, whose conversions stop at csc_t(csr)):
+  /// `csr_t<...> csr(coo_t<...>(csc));` then any CSR schedule or `spmv_plan_t`, instead of the scatter of csc_thread_mapped.
+  template <auto rhs_space, typename offset_t>
+  coo_t(const csc_t<index_t, offset_t, value_t, rhs_space>& csc)
+      : rows(csc.rows), cols(csc.cols), nnzs(csc.nnzs), row_indices(csc.indices), col_indices(csc.nnzs), values(csc.values) {
+    vector_t<offset_t, space> col_offsets = csc.offsets;
+    detail::offsets_to_indices(col_offsets, col_indices);
+  }
+
   /// Row-major order (ties by column).
   void sort_by_row() { detail::order_by<index_t, value_t, space>(row_indices, col_indices, values); }
   /// Column-major order (ties by row).

@@ -113,6 +113,14 @@ static void run_battery() {
         vector_t<int, H> o2(again.offsets); bool same = true; for (std::size_t i = 0; i <= h.rows; ++i) same = same && o2[i] == h.offsets[i]; CHECK(same); }
       { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_thread_mapped(csc, x, y); check_y("csc_thread_mapped", m, y, ref); }
       { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_nonzero_mapped(csc, x, y); check_y("csc_nonzero_mapped", m, y, ref); }
+      {  // CSC -> COO -> CSR on the device (coo_t(csc), csr_t(coo)), then the headline schedule: the transposed-once path
+        csc_t<int, int, T> csc(csr);
+        coo_t<int, T> coo(csc);
+        csr_t<int, int, T> back(coo);
+        auto y = fresh();
+        algorithms::spmv::merge_path_flat(back, x, y);
+        check_y("merge_path_flat over csr_t(coo_t(csc))", m, y, ref);
+      }
       { ell_t<int, T> ell(csr); auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_row_mapped(ell, x, y); check_y("ell_row_mapped", m, y, ref); }
       { ell_t<int, T> ell(csr); auto y = fresh(); algorithms::spmv::ell_thread_mapped(ell, x, y); check_y("ell_thread_mapped", m, y, ref);
         auto y2 = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_merge_path(ell, x, y2); check_y("ell_merge_path", m, y2, ref);  // fused engine: y not pre-zeroed
