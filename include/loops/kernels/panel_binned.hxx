@@ -264,16 +264,6 @@ panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, c
   const int p = chunks[3 * c], begin = chunks[3 * c + 1], end = chunks[3 * c + 2];
   const long long base = static_cast<long long>(p) * W;
   const int n = cols - base < W ? static_cast<int>(cols - base) : W;
-  for (int j = tid * VW; j < n; j += TPB * VW) {
-    if (j + VW <= n) {
-      const vec_t v = *reinterpret_cast<const vec_ld_t*>(x + base + j);
-#pragma unroll
-      for (int e = 0; e < VW; ++e) xs[j + e] = v[e];
-    } else {
-      for (int e = 0; j + e < n; ++e) xs[j + e] = x[base + j + e];
-    }
-  }
-  __syncthreads();
   // 4 items per lane and vector: 16 B of values (f32; 2 x 16 B for f64), 8 B of columns, 4 B of destination; U vectors per
   // step.  Software-pipelined: the loads of step k + 1 are issued BEFORE the stores of step k (gfx9 counts loads and
   // stores in one in-order counter, vmcnt).  Measured equal to the straight loop (C5 shard 202 vs 206 us): the kernel moves
@@ -320,10 +310,21 @@ panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, c
       }
     }
   };
-  if (begin >= end) return;
+  if (begin >= end) return;  // (workgroup-uniform)
   batch_t a, b;
   int i0 = begin;  // (wave-uniform loop control)
-  load(a, i0);
+  load(a, i0);     // the first step's stream loads are in flight while the x panel is fetched (one workgroup per CU: nothing
+                   // else would cover that round trip; C2: one chunk per CU, so it is paid once per product)
+  for (int j = tid * VW; j < n; j += TPB * VW) {
+    if (j + VW <= n) {
+      const vec_t v = *reinterpret_cast<const vec_ld_t*>(x + base + j);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) xs[j + e] = v[e];
+    } else {
+      for (int e = 0; j + e < n; ++e) xs[j + e] = x[base + j + e];
+    }
+  }
+  __syncthreads();
   for (;;) {
     if (i0 + STEP < end) load(b, i0 + STEP);
     consume(a, i0);
