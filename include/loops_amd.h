@@ -274,8 +274,8 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
  * inside the sub-band + a products scratch.  y = A x runs as two streaming kernels: products with the x panel held in LDS
  * (the x value of a nonzero is an LDS read, not a memory gather), stored in 16-byte groups so that every sub-band's products
  * form one contiguous run; then one workgroup per sub-band adds its run into LDS-resident accumulators (one set per
- * wavefront, combined in wavefront order) and stores its rows of y.  17 bytes of HBM traffic per nonzero and no scattered
- * read; y needs no zero-fill; reproducible (no floating-point atomics on global memory; LDS adds in program order).
+ * wavefront, combined in wavefront order; its work list -- windows of <= 256 items -- is built with the plan) and stores its
+ * rows of y.  17 bytes of HBM traffic per nonzero (4-byte values) and no scattered read; y needs no zero-fill; reproducible (no floating-point atomics on global memory; LDS adds in program order).
  * Creation is synchronous (device radix sort + scans, O(nnz)); LOOPS_E_RANGE when panels x sub-bands exceed 2^26 or
  * nnz + padding reaches 2^31.  info7 = {W, Hw, panels, sub-bands, items incl. padding, kernel-A chunks, sizeof(T)}.
  * loops_panel_plan_arrays: HOST copies (any pointer may be NULL) for inspection and tests: values / col16 / perm [padded]
@@ -286,7 +286,7 @@ typedef struct loops_panel_plan loops_panel_plan_t;
 /* subband_rows: 0 = automatic (the power of two that brings a (panel, sub-band) segment to ~192 nonzeros, within 256 rows ..
  * 16 KB of accumulators per wavefront, at least 512 sub-bands when the matrix has the rows for it), or an explicit power of
  * two in [64, 16384 / sizeof(T)] (LOOPS_E_BADARG otherwise). */
-/* panel_columns: 0 = automatic (64 KB of x per panel, 128 KB when the segments would otherwise stay below ~160 nonzeros), or
+/* panel_columns: 0 = automatic (128 KB of x per panel whenever the matrix spans at least four 64 KB panels, 64 KB otherwise), or
  * explicitly 65536 / sizeof(T) or 131072 / sizeof(T) (LOOPS_E_BADARG otherwise). */
 int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
                                 int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out);
