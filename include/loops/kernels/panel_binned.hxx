@@ -702,6 +702,10 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
     }
   }
   if (stages & 2) {
+    // kernel B's own streams (products + rows): non-temporal only when THEY exceed the Infinity Cache -- on C2 (101 MB) the
+    // products kernel A just wrote are still cached and plain loads are 2 us faster per product; beyond it (C5 shard: 407 MB)
+    // plain loads evict what kernel A streams next (256 -> 291 us)
+    const bool nt_b = static_cast<double>(m.padded) * (sizeof(type_t) + 2.0) > 200e6;
     const bool small = sizeof(type_t) == 4 && panel_small_segments(m.nnz, m.P, m.S);  // (8-byte values: ds_add_f64 is fast, see panel_pack_items)
     // One wavefront per sub-band where segments are small throughout (few items per row: zeroing and summing four partial
     // vectors then costs more LDS traffic than the items: 8 M rows x 2 nonzeros 99 -> 81 us); four otherwise (measured 4 / 2
@@ -721,7 +725,7 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
       }
       hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.wstart, m.wins, m.Hw, m.prod, m.row16, m.rows, out);
     };
-    if (nt) { if (small) go(panel::panel_reduce<true, true, 1, type_t, store_t>); else go(panel::panel_reduce<true, false, 4, type_t, store_t>); }
+    if (nt_b) { if (small) go(panel::panel_reduce<true, true, 1, type_t, store_t>); else go(panel::panel_reduce<true, false, 4, type_t, store_t>); }
     else { if (small) go(panel::panel_reduce<false, true, 1, type_t, store_t>); else go(panel::panel_reduce<false, false, 4, type_t, store_t>); }
   }
   return static_cast<int>(hipGetLastError());
