@@ -681,14 +681,17 @@ inline std::vector<int> panel_chunk_list(const std::vector<int>& panel_start, in
 }
 
 /// y = A x over a panel-binned matrix: kernel A then kernel B.  stages: bit 0 = products, bit 1 = reduce.
-/// Streams larger than the Infinity Cache are read non-temporally (they are read once per product); smaller ones with plain
-/// loads (the products kernel A wrote are then still cached when kernel B reads them).
+/// Streams are read non-temporally unless the product's whole working set fits the Infinity Cache (see `nt` below).
 template <typename type_t, typename store_t>
 int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& m, const type_t* x, const store_t out, int stages = 3) {
   if (m.rows == 0) return 0;
   constexpr int W = panel_width<type_t>::value, W2 = panel_width<type_t>::wide;
   if (m.W != W && m.W != W2) return static_cast<int>(hipErrorInvalidValue);
-  const bool nt = static_cast<double>(m.padded) * (2.0 * sizeof(type_t) + 4.0) > 200e6;
+  // Non-temporal streams unless the WHOLE working set of a product -- values, columns, destinations, rows, products: 13 B per
+  // item with 4-byte values, plus x and y -- fits the 256 MB Infinity Cache and so survives from one product to the next (C2, 219 MB: plain
+  // loads 64.7 -> 58.2 us per product, kernel A 37.4 -> 31.6); beyond it plain loads only evict each other's streams (C5
+  // shard, kernel B plain: 256 -> 291 us).
+  const bool nt = static_cast<double>(m.padded) * (2.0 * sizeof(type_t) + 5.0) + (static_cast<double>(m.rows) + m.cols) * sizeof(type_t) > 240e6;
   if ((stages & 1) && m.num_chunks > 0) {
     auto go = [&](auto kernel, int threads) {
       hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(threads), 0, stream, m.chunks, m.val, m.col16, m.dst4, x, m.cols, m.prod);
@@ -702,10 +705,7 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
     }
   }
   if (stages & 2) {
-    // kernel B's own streams (products + rows): non-temporal only when THEY exceed the Infinity Cache -- on C2 (101 MB) the
-    // products kernel A just wrote are still cached and plain loads are 2 us faster per product; beyond it (C5 shard: 407 MB)
-    // plain loads evict what kernel A streams next (256 -> 291 us)
-    const bool nt_b = static_cast<double>(m.padded) * (sizeof(type_t) + 2.0) > 200e6;
+    const bool nt_b = nt;
     const bool small = sizeof(type_t) == 4 && panel_small_segments(m.nnz, m.P, m.S);  // (8-byte values: ds_add_f64 is fast, see panel_pack_items)
     // One wavefront per sub-band where segments are small throughout (few items per row: zeroing and summing four partial
     // vectors then costs more LDS traffic than the items: 8 M rows x 2 nonzeros 99 -> 81 us); four otherwise (measured 4 / 2
