@@ -33,14 +33,14 @@ struct panel_binned_t {
   vector_t<unsigned short> col16, row16;
   vector_t<int> dst4, perm, segb, bstart, chunks, wins, wstart;
 
-  /// @param subband_rows 0 = automatic (kernels::panel_subband_rows), or a power of two in [64, 16384 / sizeof(type_t)]
+  /// @param subband_rows 0 = automatic (kernels::panel_subband_rows), or a power of two in [64, kernels::panel_subband_rows_max<type_t>()]
   explicit panel_binned_t(csr_t<index_t, offset_t, type_t>& csr, int subband_rows = 0, xpu::stream_t stream = 0)
       : rows(csr.rows), cols(csr.cols), nnzs(csr.nnzs) {
     W = kernels::panel_columns<type_t>(static_cast<int>(rows), static_cast<int>(cols), static_cast<int>(nnzs));
     P = cols ? static_cast<int>((cols + W - 1) / W) : 1;
     Hw = subband_rows ? subband_rows : kernels::panel_subband_rows<type_t>(static_cast<int>(rows), static_cast<int>(nnzs), P);
-    error::throw_if_exception(Hw < 64 || Hw > 16384 / static_cast<int>(sizeof(type_t)) || (Hw & (Hw - 1)),
-                              "panel_binned_t: subband_rows must be a power of two in [64, 16384 / sizeof(type_t)]");
+    error::throw_if_exception(Hw < 64 || Hw > kernels::panel_subband_rows_max<type_t>() || (Hw & (Hw - 1)),
+                              "panel_binned_t: subband_rows must be a power of two in [64, panel_subband_rows_max<type_t>()]");
     S = rows ? static_cast<int>((rows + Hw - 1) / Hw) : 1;
     const long long segments = static_cast<long long>(P) * S;
     error::throw_if_exception(segments > (1ll << 26) || static_cast<long long>(nnzs) + 3 * segments >= (1ll << 31) - 4096,

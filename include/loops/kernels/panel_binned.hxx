@@ -42,6 +42,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -337,62 +338,12 @@ panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, c
   }
 }
 
-/// acc += v on an LDS word that other lanes of the same instruction may target too: a compare-and-swap loop (ds_read +
-/// ds_cmpst_rtn until it sticks).  Measured (scripts/probe_lds_update.py, lanes per clock and CU): ds_add_f32 0.33 whatever
-/// the address pattern -- one lane every three clocks -- against 10-13 for ds_add_u32 and 4-7 for a plain read-add-write;
-/// the loop runs once per lane unless two lanes of the instruction share the word.
-template <typename type_t>
-__device__ __forceinline__ void lds_add(type_t* p, const type_t v) {
-  if constexpr (sizeof(type_t) == 4) {
-    unsigned int* u = reinterpret_cast<unsigned int*>(p);
-    unsigned int old = *u;
-    while (true) {
-      const unsigned int got = atomicCAS(u, old, __float_as_uint(__uint_as_float(old) + v));
-      if (got == old) break;
-      old = got;
-    }
-  } else {
-    unsigned long long* u = reinterpret_cast<unsigned long long*>(p);
-    unsigned long long old = *u;
-    while (true) {
-      const unsigned long long got = atomicCAS(u, old, static_cast<unsigned long long>(__double_as_longlong(__longlong_as_double(static_cast<long long>(old)) + v)));
-      if (got == old) break;
-      old = got;
-    }
-  }
-}
-
-/// Four of them per lane, reads and swaps issued together (one LDS round trip each instead of four); whatever did not
-/// stick -- another lane, or this lane's own earlier item, got to the word first -- goes through the loop.
-template <typename type_t>
-__device__ __forceinline__ void lds_add4(type_t* acc, const int (&at)[4], const type_t (&v)[4]) {
-  using word_t = std::conditional_t<sizeof(type_t) == 4, unsigned int, unsigned long long>;
-  word_t* u = reinterpret_cast<word_t*>(acc);
-  word_t old[4], got[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) old[e] = u[at[e]];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    type_t f;
-    __builtin_memcpy(&f, &old[e], sizeof(type_t));
-    f += v[e];
-    word_t want;
-    __builtin_memcpy(&want, &f, sizeof(type_t));
-    got[e] = atomicCAS(u + at[e], old[e], want);
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (got[e] != old[e]) lds_add(acc + at[e], v[e]);
-}
-
 /// One window of kernel B: 64 lanes x 4 consecutive items of ONE segment (rows non-decreasing; `pad_row` marks padding and
 /// lanes outside the segment).  Runs of equal rows are summed -- inside a lane, then across lanes with the segmented prefix
 /// sum -- and the lane-slot that ends a run adds the run's sum to the row's accumulator with a plain LDS read-modify-write:
 /// inside a window every row ends exactly once, so no two lanes touch the same address (LDS float atomics, the obvious
 /// alternative, retire ~0.4 lanes per clock and CU on gfx950: 5 x the time of the whole product stream).
-/// SHARED_ROWS: the window holds several small segments (each sorted, a row may end once in every one of them): the
-/// final update is then the compare-and-swap add above instead of the plain read-modify-write.
-template <typename type_t, bool SHARED_ROWS = false>
+template <typename type_t>
 __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const int dump, const type_t (&v)[4],
                                                  const unsigned int (&r)[4]) {
   type_t run[4];
@@ -419,14 +370,10 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
     at[e] = ends ? static_cast<int>(r[e]) : dump;
     add[e] = ends ? run[e] + (r[e] == r[0] ? carry_in : type_t(0)) : type_t(0);
   }
-  if constexpr (SHARED_ROWS) {
-    lds_add4(acc, at, add);
-  } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) old[e] = acc[at[e]];
+  for (int e = 0; e < 4; ++e) old[e] = acc[at[e]];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[at[e]] = old[e] + add[e];
-  }
+  for (int e = 0; e < 4; ++e) acc[at[e]] = old[e] + add[e];
 }
 
 /// Kernel B: one workgroup of WAVES wavefronts per sub-band.  The sub-band's products are one contiguous run of the B order
@@ -435,12 +382,10 @@ __device__ __forceinline__ void panel_window_add(type_t* __restrict__ acc, const
 /// WAVES partial vectors are then added in wavefront order.  Everything a wavefront does to its accumulators is in program
 /// order: the result is reproducible.
 /// NT: the product / row streams are larger than the Infinity Cache (non-temporal loads).
-/// SMALL: the typical segment holds a few items (matrices of very short rows), i.e. nearly every window is a packed one:
-/// those then go through the run-combining path with compare-and-swap final updates (LDS float atomics: 3 clks per ITEM,
-/// 85 us of a 134 us kernel on 8 M rows x 2 nonzeros; this way 99 us).  Otherwise packed windows are the thin remainder
-/// next to large segments and use the atomics, which cost the wavefront nothing but the issue (measured: C2 34 against 36
-/// us, host-blocked C3 stand-in 394 against 408 us).
-template <bool NT, bool SMALL, int WAVES, typename type_t, typename store_t>
+/// Packed windows (small segments sharing a window: sorted only piecewise) add item by item with LDS atomics.
+/// Since round 4 this is the kernel of 8-BYTE values only (ds_add_f64 is fast, and private accumulators keep an f64 result
+/// reproducible to the last bit); 4-byte values go through panel_reduce_wide below.
+template <bool NT, int WAVES, typename type_t, typename store_t>
 __global__ void __launch_bounds__(WAVES * wave::size)
 panel_reduce(const int* __restrict__ wstart, const int* __restrict__ wins, const int Hw, const type_t* __restrict__ prod,
              const unsigned short* __restrict__ row16, const int rows, const store_t out) {
@@ -494,15 +439,11 @@ panel_reduce(const int* __restrict__ wstart, const int* __restrict__ wins, const
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
         if (packed[u]) {   // small segments / segment tails sharing the window: sorted only piecewise
-          if constexpr (SMALL) {
-            panel_window_add<type_t, true>(acc, dump, v[u], r);
-          } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (r[e] != pad_row) atomicAdd(&acc[r[e]], v[u][e]);
-          }
+          for (int e = 0; e < 4; ++e)
+            if (r[e] != pad_row) atomicAdd(&acc[r[e]], v[u][e]);
         } else {
-          panel_window_add<type_t, false>(acc, dump, v[u], r);
+          panel_window_add<type_t>(acc, dump, v[u], r);
         }
       }
     }
@@ -517,30 +458,103 @@ panel_reduce(const int* __restrict__ wstart, const int* __restrict__ wins, const
   }
 }
 
+/// Kernel B, second generation ("wide"): one workgroup of WAVES wavefronts per sub-band, ONE set of Hw accumulators per
+/// workgroup held as fp64 words in LDS.  The sub-band's products are one contiguous run of the B order; it is walked in
+/// windows of 64 lanes x 4 consecutive items straight from `bstart` -- no window table, no distinction between large and
+/// small segments: wavefront w takes windows w, w + WAVES, ..., U of them in flight.  A lane's 4 items belong to one segment
+/// (segments are padded to multiples of 4), so they are row-sorted; runs of equal ADJACENT rows are summed in fp64 -- inside
+/// the lane, then across lanes with the wave64 segmented prefix sum -- and every run end adds its sum to the row's
+/// accumulator with ds_add_f64 (3-8 lanes per clock and CU on gfx950, where ds_add_f32 retires 0.33): a row that ends more
+/// than once in a window (segment boundaries) or in several wavefronts at a time is the atomic unit's business.
+/// Accuracy: products are fp32 (one rounding each), everything after them is fp64, y is rounded once at the store -- the
+/// north star's 1e-6 holds on rows of any length.  Sums of fp32 products in fp64 are EXACT while a row's products span
+/// fewer than 53 - 24 - log2(n) binary orders of magnitude, so the result does not depend on the order the wavefronts'
+/// atomics arrive in (nor on W / Hw) for such rows; beyond that two runs may differ in the last bit of an fp32 y.
+/// LDS: Hw * 8 bytes per workgroup instead of WAVES * Hw * sizeof(type_t): sub-bands (and with them kernel A's store runs)
+/// can be 2-4 x taller at the same occupancy.
+template <bool NT, int WAVES, int U, typename type_t, typename store_t>
+__global__ void __launch_bounds__(WAVES * wave::size)
+panel_reduce_wide(const int* __restrict__ bstart, const int Hw, const type_t* __restrict__ prod,
+                  const unsigned short* __restrict__ row16, const int rows, const store_t out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char panel_lds[];
+  using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+  double* acc = reinterpret_cast<double*>(panel_lds);
+  const int lane = wave::lane();
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / wave::size);
+  const int s = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int b0 = bstart[s], b1 = bstart[s + 1];
+  for (int j = threadIdx.x; j < Hw; j += WAVES * wave::size) acc[j] = 0.0;
+  __syncthreads();
+  constexpr int WIN = wave::size * 4;
+  const int nw = (b1 - b0 + WIN - 1) / WIN;
+  for (int k = w; k < nw; k += WAVES * U) {
+    type_t v[U][4];
+    u16x4 r16v[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {   // branch-free: every vector of the U windows is requested before the first wait
+      const long long i = static_cast<long long>(b0) + static_cast<long long>(k + u * WAVES) * WIN + lane * 4;
+      live[u] = i < b1;
+      const int at = live[u] ? static_cast<int>(i) : b0;
+      detail::load4<type_t, NT>(prod + at, v[u]);
+      if constexpr (NT) r16v[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(row16 + at));
+      else r16v[u] = *reinterpret_cast<const u16x4*>(row16 + at);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k + u * WAVES < nw) {  // (wave-uniform)
+        unsigned int r[4];
+        double run[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
+        run[0] = static_cast<double>(v[u][0]);
+#pragma unroll
+        for (int e = 1; e < 4; ++e) run[e] = r[e] == r[e - 1] ? run[e - 1] + static_cast<double>(v[u][e]) : static_cast<double>(v[u][e]);
+        const bool closed = r[3] != r[0];
+        const unsigned int prev_last = wave::shift_up1(r[3], 0xFFFFFFFEu);
+        const unsigned int next_first = wave::shift_down1(r[0], 0xFFFFFFFDu);
+        const bool continues = r[0] == prev_last;
+        double tail = run[3];
+        bool head = closed || !continues;
+        wave::segmented_inclusive_sum(tail, head);
+        const double prev_tail = wave::shift_up1(tail, 0.0);  // (cross-lane read first, select afterwards)
+        const double carry_in = continues ? prev_tail : 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned int next = e < 3 ? r[e + 1] : next_first;
+          if (r[e] != next && r[e] != pad_row) atomicAdd(&acc[r[e]], run[e] + (r[e] == r[0] ? carry_in : 0.0));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const long long row0 = static_cast<long long>(s) * Hw;
+  for (int j = threadIdx.x; j < Hw && row0 + j < rows; j += WAVES * wave::size) out(static_cast<int>(row0 + j), static_cast<type_t>(acc[j]));
+}
+
 }  // namespace panel
 
+/// Accumulator rows a workgroup of kernel B may own: 4-byte values -> panel_reduce_wide, Hw fp64 words per WORKGROUP (32 KB at
+/// 4096 rows: four 8-wavefront workgroups per CU); 8-byte values -> panel_reduce, Hw words per WAVEFRONT (4 x 16 KB at 2048).
+template <typename type_t>
+constexpr int panel_subband_rows_max() { return sizeof(type_t) == 4 ? 4096 : 2048; }
+
 /// Sub-band height (rows per workgroup of kernel B): what matters is the size of a (panel, sub-band) segment, nnz Hw / (rows P)
-/// items -- kernel B handles them in windows of 256 and kernel A stores their products as one run: Hw = the power of two
-/// that brings a segment to ~192 items, at least 256 rows; at most HALF of the 16 KB of accumulators a wavefront may have
-/// (4 instead of 2 workgroups per CU) unless segments would then hold fewer than 96 items; halved while fewer than 512
-/// sub-bands would be left.  Measured with 128 KB panels (tests/perf/bench_panel.py, PANEL_W / PANEL_HW): C2 84 / 73 / 84 / 90
-/// / 104 us for Hw = 256 / 512 / 1024 / 2048 / 4096 (128 .. 2048 items per segment), C5 shard 700 / 583 / 444 / 272 / 295 us
-/// (16 .. 256 items), C3 uniform stand-in 1631 / 1277 / 740 / 730 / 765 us.
+/// items -- kernel A stores a segment's products as one run: Hw = the power of two that brings a segment to ~192 items, at
+/// least 256 rows, at most panel_subband_rows_max (8-byte values: half of it -- 4 instead of 2 workgroups per CU -- unless
+/// segments would then hold fewer than 96 items); halved while fewer than 512 sub-bands would be left.
+/// Measured, 4-byte values, round 4 (tests/perf/exp_panel_reduce.py, 128 KB panels, kernel A + B): C2 52.7 / 55.3 / 57.4 us for
+/// Hw = 512 / 1024 / 2048; C5 shard 231.6 / 224.4 / 247.9 us for 2048 / 4096 / 8192.
 template <typename type_t>
 inline int panel_subband_rows(int rows, int nnz, int P) {
-  const int hw_max = 16384 / static_cast<int>(sizeof(type_t));
+  const int hw_max = panel_subband_rows_max<type_t>();
   const double per_row = rows > 0 && P > 0 ? static_cast<double>(nnz) / (static_cast<double>(rows) * static_cast<double>(P)) : 0.0;
   const double want = per_row > 0 ? 192.0 / per_row : 256.0;
   int hw = 256;
   while (hw < hw_max && hw < want) hw *= 2;
-  if (hw == hw_max && per_row * (hw_max / 2) >= 96.0) hw = hw_max / 2;
+  if (sizeof(type_t) == 8 && hw == hw_max && per_row * (hw_max / 2) >= 96.0) hw = hw_max / 2;
   while (hw > 256 && static_cast<long long>(rows) / hw < 512) hw /= 2;
   return hw;
-}
-
-/// Kernel B variant: true when the mean (panel, sub-band) segment holds fewer than 64 items (see panel_reduce).
-inline bool panel_small_segments(int nnz, int P, int S) {
-  return static_cast<long long>(nnz) < 64ll * static_cast<long long>(P > 0 ? P : 1) * static_cast<long long>(S > 0 ? S : 1);
 }
 
 /// Bytes of temporary device storage build_panel_binned needs.
@@ -680,6 +694,12 @@ inline std::vector<int> panel_chunk_list(const std::vector<int>& panel_start, in
   return list;
 }
 
+/// EXPERIMENT switch: LOOPS_PANEL_REDUCE=1 sends 8-byte values through the wide kernel B too (0 / unset: the windowed one).
+inline int panel_reduce_variant() {
+  static const int v = [] { const char* e = std::getenv("LOOPS_PANEL_REDUCE"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
 /// y = A x over a panel-binned matrix: kernel A then kernel B.  stages: bit 0 = products, bit 1 = reduce.
 /// Streams are read non-temporally unless the product's whole working set fits the Infinity Cache (see `nt` below).
 template <typename type_t, typename store_t>
@@ -705,28 +725,29 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
     }
   }
   if (stages & 2) {
-    const bool nt_b = nt;
-    const bool small = sizeof(type_t) == 4 && panel_small_segments(m.nnz, m.P, m.S);  // (8-byte values: ds_add_f64 is fast, see panel_pack_items)
-    // One wavefront per sub-band where segments are small throughout (few items per row: zeroing and summing four partial
-    // vectors then costs more LDS traffic than the items: 8 M rows x 2 nonzeros 99 -> 81 us); four otherwise (measured 4 / 2
-    // / 1 wavefronts: C2 34 / 40 / 64 us, C5 shard 126 / 175 / 299 us).
-    const int waves = small ? 1 : 4;
+    const int variant = panel_reduce_variant();
+    if (sizeof(type_t) == 4 || variant != 0) {  // one set of fp64 accumulators per workgroup, 8 wavefronts, 2 windows in flight each
+      const std::size_t lds = static_cast<std::size_t>(m.Hw) * sizeof(double);
+      auto go = [&](auto kernel, int waves) {
+        if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.bstart, m.Hw, m.prod, m.row16, m.rows, out);
+      };
+      // measured WAVES x U = 4x4 / 8x4 / 8x2 / 16x4 (tests/perf/exp_panel_reduce.py): C2 (Hw 512) 24.8 / 21.4 / 21.4 / 22.2 us,
+      // C5 shard (Hw 4096) 99.2 / 83.1 / 79.4 / 79.0 us
+      if (nt) go(panel::panel_reduce_wide<true, 8, 2, type_t, store_t>, 8);
+      else go(panel::panel_reduce_wide<false, 8, 2, type_t, store_t>, 8);
+      return static_cast<int>(hipGetLastError());
+    }
+    constexpr int waves = 4;  // (measured 4 / 2 / 1 wavefronts, round 3: C2 34 / 40 / 64 us, C5 shard 126 / 175 / 299 us)
     const std::size_t lds = static_cast<std::size_t>(waves) * (m.Hw + wave::size) * sizeof(type_t);
     auto go = [&](auto kernel) {
-      // (66.5 KB at Hw = 16 KB / sizeof(T): above the 64 KB a kernel may use without asking)
-      static bool raised[64] = {};  // once per instantiation AND device (the attribute belongs to the device's copy of the kernel)
-      if (lds > 65536) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev < 0 || dev >= 64 || !raised[dev]) {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
-          if (dev >= 0 && dev < 64) raised[dev] = true;
-        }
-      }
+      // (66.5 KB at Hw = 16 KB / sizeof(T): above the 64 KB a kernel may use without asking; the attribute belongs to the
+      // device's copy of THIS kernel, so it is set at every such launch -- it is cheap -- rather than remembered per lambda)
+      if (lds > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (16384 + 64 * 8));
       hipLaunchKernelGGL(kernel, dim3(m.S), dim3(waves * wave::size), lds, stream, m.wstart, m.wins, m.Hw, m.prod, m.row16, m.rows, out);
     };
-    if (nt_b) { if (small) go(panel::panel_reduce<true, true, 1, type_t, store_t>); else go(panel::panel_reduce<true, false, 4, type_t, store_t>); }
-    else { if (small) go(panel::panel_reduce<false, true, 1, type_t, store_t>); else go(panel::panel_reduce<false, false, 4, type_t, store_t>); }
+    if (nt) go(panel::panel_reduce<true, 4, type_t, store_t>); else go(panel::panel_reduce<false, 4, type_t, store_t>);
   }
   return static_cast<int>(hipGetLastError());
 }

@@ -285,7 +285,7 @@ int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, 
 typedef struct loops_panel_plan loops_panel_plan_t;
 /* subband_rows: 0 = automatic (the power of two that brings a (panel, sub-band) segment to ~192 nonzeros, within 256 rows ..
  * 16 KB of accumulators per wavefront, at least 512 sub-bands when the matrix has the rows for it), or an explicit power of
- * two in [64, 16384 / sizeof(T)] (LOOPS_E_BADARG otherwise). */
+ * two in [64, 4096] for 4-byte values, [64, 2048] for 8-byte values (LOOPS_E_BADARG otherwise). */
 /* panel_columns: 0 = automatic (128 KB of x per panel whenever the matrix spans at least four 64 KB panels, 64 KB otherwise), or
  * explicitly 65536 / sizeof(T) or 131072 / sizeof(T) (LOOPS_E_BADARG otherwise). */
 int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,

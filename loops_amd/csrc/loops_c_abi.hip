@@ -728,8 +728,9 @@ int panel_create(int rows, int cols, int nnz, const int* offsets, const int* ind
   }
   p->P = cols > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(cols), static_cast<long long>(p->W))) : 1;
   p->Hw = kernels::panel_subband_rows<T>(rows, nnz, p->P);
-  if (subband_rows != 0) {  // explicit: a power of two, 64 .. 16 KB of accumulators per wavefront
-    if (subband_rows < 64 || subband_rows > 16384 / static_cast<int>(sizeof(T)) || (subband_rows & (subband_rows - 1))) { delete p; return LOOPS_E_BADARG; }
+  if (subband_rows != 0) {  // explicit: a power of two, 64 .. panel_subband_rows_max
+    const int cap = kernels::panel_reduce_variant() ? 4096 : kernels::panel_subband_rows_max<T>();
+    if (subband_rows < 64 || subband_rows > cap || (subband_rows & (subband_rows - 1))) { delete p; return LOOPS_E_BADARG; }
     p->Hw = subband_rows;
   }
   p->S = rows > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(rows), static_cast<long long>(p->Hw))) : 1;
