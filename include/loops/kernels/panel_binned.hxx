@@ -50,6 +50,10 @@
 #include <hipcub/hipcub.hpp>
 
 #include <loops/kernels/merge_path_spmv.hxx>
+
+#ifndef LOOPS_PANEL_COMPACT_U
+#define LOOPS_PANEL_COMPACT_U 4  // vectors of 4 items per lane and step of the compact kernel A (tuning knob of variant builds)
+#endif
 #include <loops/util/math.hxx>
 #include <loops/util/wave.hxx>
 
@@ -61,17 +65,20 @@ template <typename type_t>
 struct panel_binned_view {
   int rows, cols, nnz;
   int W, Hw, P, S;            ///< columns per panel, rows per sub-band, number of panels / sub-bands
-  int padded;                 ///< items incl. padding (multiple of 4), the same in both orders
+  int padded;                 ///< A order: items incl. padding (multiple of 4)
+  int padded_b;               ///< B order: slots incl. padding (multiple of 4); == padded unless `compact`
+  int compact;                ///< 1: kernel A pre-sums runs of equal (row, panel) and the B order holds one slot per RUN
+  int awin;                   ///< compact: items of one wavefront step of kernel A (64 lanes x 4): no run crosses a multiple of it
   type_t* val;                ///< [padded] A order
-  unsigned short* col16;      ///< [padded] A order: column inside the panel
-  int* dst4;                  ///< [padded / 4] A order: B-order position of the group's first item
-  unsigned short* row16;      ///< [padded] B order: row inside the sub-band; 0xFFFF = padding
+  unsigned short* col16;      ///< [padded] A order: column inside the panel (compact: | 0x8000 on the item that ENDS a run)
+  int* dst4;                  ///< [padded / 4] A order: B-order slot of the group's first output (compact: bit 31 = the group holds padding)
+  unsigned short* row16;      ///< [padded_b] B order: row inside the sub-band; 0xFFFF = padding
   int* perm;                  ///< [padded] A order: CSR position of the item (-1 = padding): value refresh
   int* segb;                  ///< [S * P + 1] B order: segment (s, p) = items [segb[s * P + p], segb[s * P + p + 1])
   int* bstart;                ///< [S + 1] B order: sub-band s owns items [bstart[s], bstart[s + 1]) (= segb[s * P])
   int* chunks;                ///< [3 * num_chunks] {panel, begin, end} work list of kernel A (A-order positions)
   int num_chunks;
-  type_t* prod;               ///< [padded] B order: products scratch (kernel A -> kernel B)
+  type_t* prod;               ///< [padded_b] B order: products / run sums scratch (kernel A -> kernel B)
   int* wins;                  ///< [2 * panel_window_capacity] kernel B's windows: {first item, items | packed << 16} (B order)
   int* wstart;                ///< [S + 1] sub-band s owns windows [wstart[s], wstart[s + 1])
 };
@@ -115,8 +122,8 @@ constexpr unsigned short pad_row = 0xFFFFu;
 template <int IPT, typename index_t, typename offset_t>
 __global__ void __launch_bounds__(256)
 make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indices, const int rows, const int nnz,
-          const int W, const int Hw, const int S, unsigned long long* __restrict__ keys, int* __restrict__ row_of,
-          int* __restrict__ counts) {
+          const int W, const int Hw, const int S, const int cols, unsigned long long* __restrict__ keys, int* __restrict__ row_of,
+          int* __restrict__ counts, int* __restrict__ bad) {
   const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
   if (base_ll >= nnz) return;
   const int base = static_cast<int>(base_ll);
@@ -139,7 +146,12 @@ make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indi
     const int i = base + j;
     if (i >= nnz) break;
     while (i >= row_end) row_end = offsets[++row + 1];  // skip empty rows
-    const unsigned int p = static_cast<unsigned int>(indices[i]) / static_cast<unsigned int>(W);
+    unsigned int col = static_cast<unsigned int>(indices[i]);
+    if (col >= static_cast<unsigned int>(cols)) {  // (also a negative index) flagged, then clamped so that nothing is written out of bounds
+      *bad = 1;
+      col = 0;
+    }
+    const unsigned int p = col / static_cast<unsigned int>(W);
     const unsigned int seg = p * static_cast<unsigned int>(S) + static_cast<unsigned int>(row) / static_cast<unsigned int>(Hw);
     keys[i] = (static_cast<unsigned long long>(seg) << 32) | static_cast<unsigned int>(i);
     row_of[i] = row;
@@ -170,27 +182,79 @@ transpose_counts(const int* __restrict__ padded, const int P, const int S, int* 
   paddedT[t] = padded[static_cast<long long>(p) * S + s];
 }
 
+/// Compact layout: items of one wavefront step of kernel A (64 lanes x 4 consecutive items): a run of equal rows never
+/// crosses a multiple of a_window, so the pre-summing needs no carry between wavefronts.
+constexpr int a_window = wave::size * 4;
+constexpr unsigned short run_end_bit = 0x8000u;  // of col16: "this item ENDS a run" (panels of at most 32768 columns)
+/// ends[j] = 1 when sorted item j is the LAST of its run -- the next item lies in another segment or another row, or j is the
+/// last item of its window of kernel A (a_window items; A positions are counted from the panel's start: chunks begin at
+/// multiples of 4096 items of it) -- else 0; ends[nnz] = 0.  The exclusive scan of `ends` numbers the runs.
+__global__ void __launch_bounds__(256)
+mark_run_ends(const unsigned long long* __restrict__ sorted, const int* __restrict__ seg_start, const int* __restrict__ seg_dest,
+              const int* __restrict__ row_of, const int nnz, const int S, int* __restrict__ ends) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > nnz) return;
+  if (j == nnz) { ends[j] = 0; return; }
+  const unsigned long long key = sorted[j];
+  const int g = static_cast<int>(key >> 32), i = static_cast<int>(key & 0xffffffffull);
+  bool last = j + 1 == nnz;
+  if (!last) {
+    const unsigned long long nk = sorted[j + 1];
+    last = static_cast<int>(nk >> 32) != g || row_of[static_cast<int>(nk & 0xffffffffull)] != row_of[i];
+  }
+  if (!last) {
+    const int p = g / S;
+    const int a = seg_dest[g] + (j - seg_start[g]) - seg_dest[static_cast<long long>(p) * S];
+    last = (a & (a_window - 1)) == a_window - 1;
+  }
+  ends[j] = last ? 1 : 0;
+}
+
+/// padded_b[g] = the runs of segment g rounded up to a multiple of 4 (g < n), padded_b[n] = 0.
+__global__ void __launch_bounds__(256)
+pad_run_counts(const int* __restrict__ seg_start, const int* __restrict__ run_index, const int n, int* __restrict__ padded_b) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= n) padded_b[g] = g < n ? (run_index[seg_start[g + 1]] - run_index[seg_start[g]] + 3) & ~3 : 0;
+}
+
 /// Sorted position j -> its position in both orders; fills val / col16 / perm / dst4 (A order) and row16 (B order).
-template <typename index_t, typename type_t>
+/// COMPACT: the B order holds one slot per run (`ends` / `run_index` of mark_run_ends): col16 carries the run-end flag in
+/// bit 15, dst4 the slot of the group's first run end and, in bit 31, "this group holds padding" (the items behind the
+/// group's last run end are padding then: a segment's last real item always ends a run).
+template <bool COMPACT, typename index_t, typename type_t>
 __global__ void __launch_bounds__(256)
 place(const unsigned long long* __restrict__ sorted, const int* __restrict__ seg_start, const int* __restrict__ seg_dest,
-      const int* __restrict__ seg_dest_b, const int* __restrict__ row_of, const index_t* __restrict__ indices,
-      const type_t* __restrict__ values, const int nnz, const int W, const int Hw, const int P, const int S,
-      type_t* __restrict__ val, unsigned short* __restrict__ col16, int* __restrict__ dst4, unsigned short* __restrict__ row16,
-      int* __restrict__ perm) {
+      const int* __restrict__ seg_dest_b, const int* __restrict__ row_of, const int* __restrict__ ends,
+      const int* __restrict__ run_index, const index_t* __restrict__ indices, const type_t* __restrict__ values, const int nnz,
+      const int W, const int Hw, const int P, const int S, type_t* __restrict__ val, unsigned short* __restrict__ col16,
+      int* __restrict__ dst4, unsigned short* __restrict__ row16, int* __restrict__ perm) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nnz) return;
   const unsigned long long key = sorted[j];
   const int g = static_cast<int>(key >> 32), i = static_cast<int>(key & 0xffffffffull);
-  const int within = j - seg_start[g];
+  const int first = seg_start[g];
+  const int within = j - first;
   const int p = g / S, s = g - p * S;
   const int a = seg_dest[g] + within;
-  const int b = seg_dest_b[static_cast<long long>(s) * P + p] + within;
+  const int bseg = seg_dest_b[static_cast<long long>(s) * P + p];
   val[a] = values[i];
-  col16[a] = static_cast<unsigned short>(static_cast<int>(indices[i]) - p * W);
   perm[a] = i;
-  row16[b] = static_cast<unsigned short>(row_of[i] - s * Hw);
-  if ((within & 3) == 0) dst4[a >> 2] = b;  // (the real items of a segment are a prefix of it: every group starts with one)
+  const unsigned int col = static_cast<unsigned int>(static_cast<int>(indices[i]) - p * W);
+  const unsigned short row = static_cast<unsigned short>(row_of[i] - s * Hw);
+  if constexpr (COMPACT) {
+    const int end = ends[j];
+    const int slot = bseg + (run_index[j] - run_index[first]);  // of the run item j belongs to
+    col16[a] = static_cast<unsigned short>(col | (end ? run_end_bit : 0u));
+    if (end) row16[slot] = row;
+    if ((within & 3) == 0) {
+      const bool has_padding = within + 4 > seg_start[g + 1] - first;
+      dst4[a >> 2] = slot | (has_padding ? static_cast<int>(0x80000000u) : 0);
+    }
+  } else {
+    col16[a] = static_cast<unsigned short>(col);
+    row16[bseg + within] = row;
+    if ((within & 3) == 0) dst4[a >> 2] = bseg + within;  // (the real items of a segment are a prefix of it: every group starts with one)
+  }
 }
 
 /// bstart[s] = seg_dest_b[s * P] (s <= S: bstart[S] = total); panel_start[p] = seg_dest[p * S] (p <= P).
@@ -250,33 +314,62 @@ refresh_values(const int* __restrict__ perm, const type_t* __restrict__ values, 
   }
 }
 
-/// Kernel A: products of one chunk of one panel, x panel in LDS.
-template <int TPB, int W, int U, bool NT, typename type_t>
-__global__ void __launch_bounds__(TPB)
-panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, const unsigned short* __restrict__ col16,
-               const int* __restrict__ dst4, const type_t* __restrict__ x, const int cols, type_t* __restrict__ prod) {
-  __shared__ type_t xs[W];
+/// x[base .. base + n) -> xs (16-byte loads, every thread of the workgroup); the caller synchronises.
+template <int TPB, typename type_t>
+__device__ __forceinline__ void load_x_panel(type_t* __restrict__ xs, const type_t* __restrict__ x, const long long base, const int n,
+                                             const int tid) {
   constexpr int VW = 16 / static_cast<int>(sizeof(type_t));  // elements per 16-byte vector
   using vec_t = type_t __attribute__((ext_vector_type(VW)));
   using vec_ld_t = type_t __attribute__((ext_vector_type(VW), aligned(sizeof(type_t))));
+  for (int j = tid * VW; j < n; j += TPB * VW) {
+    if (j + VW <= n) {
+      const vec_t v = *reinterpret_cast<const vec_ld_t*>(x + base + j);
+#pragma unroll
+      for (int e = 0; e < VW; ++e) xs[j + e] = v[e];
+    } else {
+      for (int e = 0; j + e < n; ++e) xs[j + e] = x[base + j + e];
+    }
+  }
+}
+
+/// 16 bytes of a group's products to `to`.
+template <typename type_t>
+__device__ __forceinline__ void store4(type_t* __restrict__ to, const type_t a, const type_t b, const type_t c, const type_t d) {
+  if constexpr (sizeof(type_t) == 4) {
+    using o4 = type_t __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<o4*>(to) = o4{a, b, c, d};
+  } else {
+    using o2 = type_t __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<o2*>(to) = o2{a, b};
+    *reinterpret_cast<o2*>(to + 2) = o2{c, d};
+  }
+}
+
+/// Kernel A: products of the chunks [g C / G, (g + 1) C / G) of workgroup g of G -- one chunk per workgroup by default (G = C;
+/// see panel_products_grid) -- x panel in LDS, (re)loaded only when the panel changes:
+///   prod[dst4[i / 4] ..] = val[i ..] * xs[col16[i ..]], one 16-byte store per group of 4 items.
+/// 4 items per lane and vector: 16 B of values (f32; 2 x 16 B for f64), 8 B of columns, 4 B of destination; U vectors per
+/// step.  Software-pipelined: the loads of step k + 1 are issued BEFORE the stores of step k (gfx9 counts loads and
+/// stores in one in-order counter, vmcnt).  Loads are branch-free (a lane behind the chunk's end re-reads the chunk's first
+/// vector and stores nothing).  Measured at the chip's copy rate (C5 shard: 870 MB in 0.2 ms).
+template <int TPB, int W, int U, bool NT, typename type_t>
+__global__ void __launch_bounds__(TPB)
+panel_products(const int* __restrict__ chunks, const int num_chunks, const type_t* __restrict__ val,
+               const unsigned short* __restrict__ col16, const int* __restrict__ dst4, const type_t* __restrict__ x, const int cols,
+               type_t* __restrict__ prod) {
+  __shared__ type_t xs[W];
   using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
   const int tid = threadIdx.x;
-  const int c = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
-  const int p = chunks[3 * c], begin = chunks[3 * c + 1], end = chunks[3 * c + 2];
-  const long long base = static_cast<long long>(p) * W;
-  const int n = cols - base < W ? static_cast<int>(cols - base) : W;
-  // 4 items per lane and vector: 16 B of values (f32; 2 x 16 B for f64), 8 B of columns, 4 B of destination; U vectors per
-  // step.  Software-pipelined: the loads of step k + 1 are issued BEFORE the stores of step k (gfx9 counts loads and
-  // stores in one in-order counter, vmcnt).  Measured equal to the straight loop (C5 shard 202 vs 206 us): the kernel moves
-  // 870 MB -- 591 MB read + 278 MB written, profiles/r03_panel_pmc_summary.json -- in 0.2 ms = 4.35 TB/s, the rate of this
-  // chip's streaming copy (4.5 TB/s on 1 GiB); what is left is bytes, not scheduling.  Loads are branch-free (a lane behind
-  // the chunk's end re-reads the chunk's first vector and stores nothing).
+  const int g = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int c_lo = static_cast<int>(static_cast<long long>(num_chunks) * g / static_cast<int>(gridDim.x));
+  const int c_hi = static_cast<int>(static_cast<long long>(num_chunks) * (g + 1) / static_cast<int>(gridDim.x));
   constexpr int STEP = TPB * 4 * U;
   struct batch_t {
     type_t v[U][4];
     u16x4 c[U];
     int dst[U];
   };
+  int begin = 0, end = 0;  // the current chunk (workgroup-uniform)
   auto load = [&](batch_t& t, const int i0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -298,43 +391,161 @@ panel_products(const int* __restrict__ chunks, const type_t* __restrict__ val, c
       type_t out[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) out[e] = t.v[u][e] * xs[t.c[u][e]];
-      if (i0 + (u * TPB + tid) * 4 < end) {
-        type_t* to = prod + t.dst[u];
-        if constexpr (sizeof(type_t) == 4) {
-          using o4 = type_t __attribute__((ext_vector_type(4)));
-          *reinterpret_cast<o4*>(to) = o4{out[0], out[1], out[2], out[3]};
+      if (i0 + (u * TPB + tid) * 4 < end) store4(prod + t.dst[u], out[0], out[1], out[2], out[3]);
+    }
+  };
+  int panel_in_lds = -1;
+  batch_t a, b;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int p = chunks[3 * c];
+    begin = chunks[3 * c + 1];
+    end = chunks[3 * c + 2];
+    if (begin >= end) continue;  // (workgroup-uniform)
+    int i0 = begin;  // (wave-uniform loop control)
+    load(a, i0);     // the chunk's first stream loads are in flight while the x panel is fetched
+    if (p != panel_in_lds) {
+      const long long base = static_cast<long long>(p) * W;
+      if (panel_in_lds >= 0) __syncthreads();  // every wavefront is done with the previous panel
+      load_x_panel<TPB>(xs, x, base, cols - base < W ? static_cast<int>(cols - base) : W, tid);
+      __syncthreads();
+      panel_in_lds = p;
+    }
+    for (;;) {
+      if (i0 + STEP < end) load(b, i0 + STEP);
+      consume(a, i0);
+      i0 += STEP;
+      if (i0 >= end) break;
+      if (i0 + STEP < end) load(a, i0 + STEP);
+      consume(b, i0);
+      i0 += STEP;
+      if (i0 >= end) break;
+    }
+  }
+}
+
+/// Kernel A of the COMPACT layout: the same stream, but runs of equal (row, panel) -- cut at plan time so that none crosses
+/// a wavefront step (a_window = 64 lanes x 4 items) -- are summed before they leave the CU: inside the lane, then across
+/// lanes with the wave64 segmented prefix sum, and the item that ENDS a run (bit 15 of its col16) stores the run's sum to
+/// the run's slot of the B order (dst4 of the lane's group + the run ends before it in the group).  On a matrix with column
+/// locality (a row's nonzeros in one or two panels: web graphs, FEM bands) a row's 20-30 products shrink to 1-2 slots: 4 B
+/// written and 6 B read back per RUN instead of per nonzero.  Items behind the last run end of a group flagged "holds
+/// padding" (bit 31 of dst4) are padding and contribute nothing, whatever x holds.
+/// Summation order: fixed by the layout (lane-sequential, then the scan's tree) -- reproducible.
+/// Where the time goes (band C3 stand-in, 1.41 GB read + 0.08 GB written; diagnostic builds): the streams alone 262 us
+/// (5.4 TB/s), + the LDS gathers and sums 323, + the stores 351-362.  Three formulations of the sums and stores were measured
+/// within 4 % of each other (4 items per lane with per-lane `if`s around the stores: this one, the fastest; 8 items per
+/// lane, run-end flags in the dst4 word, buffer stores that drop lanes by an out-of-range offset, mask arithmetic instead
+/// of selects: 362-365): 26 vector instructions per item either way, the SIMDs 26 % busy -- what is left is that a
+/// wavefront's loads are not in flight while it sums (16 wavefronts per CU: the 128 KB x panel).
+template <int TPB, int W, int U, bool NT, typename type_t>
+__global__ void __launch_bounds__(TPB)
+panel_products_compact(const int* __restrict__ chunks, const int num_chunks, const type_t* __restrict__ val,
+                       const unsigned short* __restrict__ col16, const int* __restrict__ dst4, const type_t* __restrict__ x,
+                       const int cols, type_t* __restrict__ prod) {
+  __shared__ type_t xs[W];
+  static_assert(W <= 32768, "panel_products_compact: bit 15 of col16 is the run-end flag");
+  using u16x4 = unsigned short __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  const int g = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int c_lo = static_cast<int>(static_cast<long long>(num_chunks) * g / static_cast<int>(gridDim.x));
+  const int c_hi = static_cast<int>(static_cast<long long>(num_chunks) * (g + 1) / static_cast<int>(gridDim.x));
+  constexpr int STEP = TPB * 4 * U;
+  struct batch_t {
+    type_t v[U][4];
+    u16x4 c[U];
+    int dst[U];
+  };
+  int begin = 0, end = 0;  // the current chunk (workgroup-uniform)
+  auto load = [&](batch_t& t, const int i0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int i = i0 + (u * TPB + tid) * 4;
+      i = i < end ? i : begin;
+      detail::load4<type_t, NT>(val + i, t.v[u]);
+      if constexpr (NT) {
+        t.c[u] = __builtin_nontemporal_load(reinterpret_cast<const u16x4*>(col16 + i));
+        t.dst[u] = __builtin_nontemporal_load(dst4 + (i >> 2));
+      } else {
+        t.c[u] = *reinterpret_cast<const u16x4*>(col16 + i);
+        t.dst[u] = dst4[i >> 2];
+      }
+    }
+  };
+  auto consume = [&](const batch_t& t, const int i0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = i0 + (u * TPB + tid) * 4 < end;
+      bool f[4];  // (a dead lane re-read the chunk's first group: all its items "end" and store nothing)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f[e] = !live || (t.c[u][e] & run_end_bit) != 0;
+      const bool has_padding = live && t.dst[u] < 0;
+      type_t pr[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bool ends_behind = f[e];                             // a run end at or behind item e: e is a real item
+#pragma unroll
+        for (int k = e + 1; k < 4; ++k) ends_behind = ends_behind || f[k];
+        const type_t xv = xs[t.c[u][e] & (run_end_bit - 1)];
+        pr[e] = has_padding && !ends_behind ? type_t(0) : t.v[u][e] * xv;
+      }
+      type_t run[4];
+      run[0] = pr[0];
+#pragma unroll
+      for (int e = 1; e < 4; ++e) run[e] = f[e - 1] ? pr[e] : run[e - 1] + pr[e];
+      // across lanes: the lane's first run continues the previous lane's last unless that one ended on its item 3
+      // (lane 0: the window's first item starts a run by construction)
+      const int prev_end = wave::shift_up1(f[3] ? 1 : 0, 1);
+      const bool continues = prev_end == 0;
+      type_t tail = run[3];
+      bool head = f[0] || f[1] || f[2] || !continues;
+      wave::segmented_inclusive_sum(tail, head);
+      const type_t prev_tail = wave::shift_up1(tail, type_t(0));  // (cross-lane read first, select afterwards)
+      const type_t carry_in = continues ? prev_tail : type_t(0);
+      if (live) {
+        type_t* to = prod + (t.dst[u] & 0x7FFFFFFF);
+        if (f[0] && f[1] && f[2] && f[3] && !has_padding) {  // four runs of one item (no locality here): one 16-byte store
+          store4(to, run[0] + carry_in, run[1], run[2], run[3]);
         } else {
-          using o2 = type_t __attribute__((ext_vector_type(2)));
-          *reinterpret_cast<o2*>(to) = o2{out[0], out[1]};
-          *reinterpret_cast<o2*>(to + 2) = o2{out[2], out[3]};
+          int slot = 0;
+          bool open = true;                                  // no run end in the lane before item e: the carry belongs to its run
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (f[e]) {
+              to[slot] = run[e] + (open ? carry_in : type_t(0));
+              ++slot;
+              open = false;
+            }
+          }
         }
       }
     }
   };
-  if (begin >= end) return;  // (workgroup-uniform)
+  int panel_in_lds = -1;
   batch_t a, b;
-  int i0 = begin;  // (wave-uniform loop control)
-  load(a, i0);     // the first step's stream loads are in flight while the x panel is fetched (one workgroup per CU: nothing
-                   // else would cover that round trip; C2: one chunk per CU, so it is paid once per product)
-  for (int j = tid * VW; j < n; j += TPB * VW) {
-    if (j + VW <= n) {
-      const vec_t v = *reinterpret_cast<const vec_ld_t*>(x + base + j);
-#pragma unroll
-      for (int e = 0; e < VW; ++e) xs[j + e] = v[e];
-    } else {
-      for (int e = 0; j + e < n; ++e) xs[j + e] = x[base + j + e];
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int p = chunks[3 * c];
+    begin = chunks[3 * c + 1];
+    end = chunks[3 * c + 2];
+    if (begin >= end) continue;  // (workgroup-uniform)
+    int i0 = begin;  // (wave-uniform loop control)
+    load(a, i0);     // the chunk's first stream loads are in flight while the x panel is fetched
+    if (p != panel_in_lds) {
+      const long long base = static_cast<long long>(p) * W;
+      if (panel_in_lds >= 0) __syncthreads();  // every wavefront is done with the previous panel
+      load_x_panel<TPB>(xs, x, base, cols - base < W ? static_cast<int>(cols - base) : W, tid);
+      __syncthreads();
+      panel_in_lds = p;
     }
-  }
-  __syncthreads();
-  for (;;) {
-    if (i0 + STEP < end) load(b, i0 + STEP);
-    consume(a, i0);
-    i0 += STEP;
-    if (i0 >= end) break;
-    if (i0 + STEP < end) load(a, i0 + STEP);
-    consume(b, i0);
-    i0 += STEP;
-    if (i0 >= end) break;
+    for (;;) {
+      if (i0 + STEP < end) load(b, i0 + STEP);
+      consume(a, i0);
+      i0 += STEP;
+      if (i0 >= end) break;
+      if (i0 + STEP < end) load(a, i0 + STEP);
+      consume(b, i0);
+      i0 += STEP;
+      if (i0 >= end) break;
+    }
   }
 }
 
@@ -557,128 +768,18 @@ inline int panel_subband_rows(int rows, int nnz, int P) {
   return hw;
 }
 
-/// Bytes of temporary device storage build_panel_binned needs.
-inline std::size_t panel_binned_temp_bytes(int nnz, long long segments) {
-  std::size_t sort_bytes = 0, scan_bytes = 0;
-  unsigned long long* k = nullptr;
-  int* c = nullptr;
-  (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, k, k, nnz, 32, 64);
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c, c, static_cast<int>(segments + 1));
-  const std::size_t a = (sort_bytes + 255) & ~std::size_t(255), b = (scan_bytes + 255) & ~std::size_t(255);
-  const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
-  const std::size_t row_bytes = (static_cast<std::size_t>(nnz) * 4 + 255) & ~std::size_t(255);
-  const std::size_t seg_bytes = (static_cast<std::size_t>(segments + 1) * 4 + 255) & ~std::size_t(255);
-  return 2 * key_bytes + row_bytes + 6 * seg_bytes + (a > b ? a : b);
-}
-
-/// Device-side part of the build (asynchronous on `stream`): everything but the chunk list, which the caller derives
-/// from `panel_start_host` after synchronising.  `seg_dest` (segments + 1 ints inside `temp`) is returned through
-/// `padded_total_dev` = pointer to the device int holding the padded item count (seg_dest[segments]).
-/// Stage 1 (sizes): counts, scans -> *padded_total_dev.  The caller reads it, allocates val / col16 / row16 / perm / prod,
-/// and calls stage 2 (placement).  Both stages share `temp`.
-template <typename index_t, typename offset_t>
-int build_panel_binned_stage1(hipStream_t stream, const offset_t* offsets, const index_t* indices, int rows, int nnz, int W,
-                              int Hw, int P, int S, void* temp, std::size_t temp_bytes, const int** padded_total_dev) {
-  const long long segments = static_cast<long long>(P) * S;
-  const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
-  const std::size_t row_bytes = (static_cast<std::size_t>(nnz) * 4 + 255) & ~std::size_t(255);
-  const std::size_t seg_bytes = (static_cast<std::size_t>(segments + 1) * 4 + 255) & ~std::size_t(255);
-  char* base = static_cast<char*>(temp);
-  auto* keys_in = reinterpret_cast<unsigned long long*>(base);
-  auto* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
-  int* row_of = reinterpret_cast<int*>(base + 2 * key_bytes);
-  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);
-  const std::size_t seg_ints = seg_bytes / 4;
-  int* seg_start = counts + seg_ints;        // unpadded start of segment g in the sorted keys
-  int* padded = counts + 2 * seg_ints;       // padded size of segment g
-  int* seg_dest = counts + 3 * seg_ints;     // A-order start of segment g = p * S + s
-  int* padded_t = counts + 4 * seg_ints;     // padded sizes in B order (s * P + p)
-  int* seg_dest_b = counts + 5 * seg_ints;   // B-order start of segment (s, p)
-  void* cub_temp = base + 2 * key_bytes + row_bytes + 6 * seg_bytes;
-  const std::size_t cub_avail = temp_bytes - (2 * key_bytes + row_bytes + 6 * seg_bytes);
-  std::size_t cub_bytes = cub_avail;
-  hipError_t e = hipMemsetAsync(counts, 0, seg_bytes, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  constexpr int KEYS_PER_LANE = 8;
-  if (nnz > 0) {
-    hipLaunchKernelGGL((panel::make_keys<KEYS_PER_LANE, index_t, offset_t>), dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), dim3(256), 0,
-                       stream, offsets, indices, rows, nnz, W, Hw, S, keys_in, row_of, counts);
-    int end_bit = 33;
-    while (end_bit < 64 && (static_cast<unsigned long long>(segments) >> (end_bit - 32)) != 0) ++end_bit;
-    e = hipcub::DeviceRadixSort::SortKeys(cub_temp, cub_bytes, keys_in, keys_out, nnz, 32, end_bit, stream);
-    if (e != hipSuccess) return static_cast<int>(e);
-  }
-  const int nseg = static_cast<int>(segments);
-  hipLaunchKernelGGL(panel::pad_counts, dim3(math::ceil_div(nseg + 1, 256)), dim3(256), 0, stream, counts, nseg, padded);
-  hipLaunchKernelGGL(panel::transpose_counts, dim3(math::ceil_div(nseg + 1, 256)), dim3(256), 0, stream, padded, P, S, padded_t);
-  cub_bytes = cub_avail;
-  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, counts, seg_start, nseg + 1, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  cub_bytes = cub_avail;
-  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, padded, seg_dest, nseg + 1, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  cub_bytes = cub_avail;
-  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, padded_t, seg_dest_b, nseg + 1, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  *padded_total_dev = seg_dest + nseg;
-  return static_cast<int>(hipGetLastError());
-}
-
-/// Stage 2: place every nonzero in both orders, extract the sub-band starts (out.bstart) and the panel starts
-/// (`panel_start_dev`: P + 1 ints, A order).  `out.val / col16 / row16 / perm / dst4` must hold out.padded (/ 4) items.
-template <typename index_t, typename type_t>
-int build_panel_binned_stage2(hipStream_t stream, const index_t* indices, const type_t* values, const panel_binned_view<type_t>& out,
-                              void* temp, std::size_t temp_bytes, int* panel_start_dev) {
-  const int nnz = out.nnz;
-  const long long segments = static_cast<long long>(out.P) * out.S;
-  const std::size_t key_bytes = (static_cast<std::size_t>(nnz) * 8 + 255) & ~std::size_t(255);
-  const std::size_t row_bytes = (static_cast<std::size_t>(nnz) * 4 + 255) & ~std::size_t(255);
-  const std::size_t seg_bytes = (static_cast<std::size_t>(segments + 1) * 4 + 255) & ~std::size_t(255);
-  char* base = static_cast<char*>(temp);
-  auto* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
-  int* row_of = reinterpret_cast<int*>(base + 2 * key_bytes);
-  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);
-  const std::size_t seg_ints = seg_bytes / 4;
-  int* seg_start = counts + seg_ints;
-  int* seg_dest = counts + 3 * seg_ints;
-  int* seg_dest_b = counts + 5 * seg_ints;
-  const std::size_t n = static_cast<std::size_t>(out.padded);
-  hipError_t e = hipMemsetAsync(out.val, 0, sizeof(type_t) * n, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(out.col16, 0, sizeof(unsigned short) * n, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(out.row16, 0xFF, sizeof(unsigned short) * n, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(out.perm, 0xFF, sizeof(int) * n, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(out.dst4, 0, sizeof(int) * (n / 4 + 1), stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  if (nnz > 0)
-    hipLaunchKernelGGL((panel::place<index_t, type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, seg_start,
-                       seg_dest, seg_dest_b, row_of, indices, values, nnz, out.W, out.Hw, out.P, out.S, out.val, out.col16, out.dst4,
-                       out.row16, out.perm);
-  e = hipMemcpyAsync(out.segb, seg_dest_b, sizeof(int) * static_cast<std::size_t>(segments + 1), hipMemcpyDeviceToDevice, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  // kernel B's windows: count per sub-band, scan, fill
-  e = hipMemsetAsync(out.wstart, 0, sizeof(int) * (static_cast<std::size_t>(out.S) + 1), stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  const dim3 wgrid(math::ceil_div(out.S, 256));
-  hipLaunchKernelGGL(panel::make_windows<false>, wgrid, dim3(256), 0, stream, seg_dest_b, out.P, out.S, panel_pack_items<type_t>(), out.wstart,
-                     static_cast<int*>(nullptr));
-  void* cub_temp = base + 2 * key_bytes + row_bytes + 6 * seg_bytes;
-  std::size_t cub_bytes = temp_bytes - (2 * key_bytes + row_bytes + 6 * seg_bytes);
-  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, out.wstart, out.wstart, out.S + 1, stream);
-  if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(panel::make_windows<true>, wgrid, dim3(256), 0, stream, seg_dest_b, out.P, out.S, panel_pack_items<type_t>(), out.wstart,
-                     out.wins);
-  const int m = (out.S > out.P ? out.S : out.P) + 1;
-  hipLaunchKernelGGL(panel::extract_starts, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, seg_dest, seg_dest_b, out.P, out.S,
-                     out.bstart, panel_start_dev);
-  return static_cast<int>(hipGetLastError());
-}
-
 /// Kernel A's work list from the panel starts (A order, P + 1 entries): {panel, begin, end} triples.  A panel is cut into
-/// round(items / 65536) chunks of EQUAL size (a multiple of 4096 items = one load per lane of the widest workgroup), so no
+/// round(items / CH) chunks of EQUAL size (a multiple of 4096 items = one load per lane of the widest workgroup), so no
 /// workgroup loads a 64 / 128 KB x panel for the few thousand items left over by a fixed chunk length (8 M rows x 2
 /// nonzeros: 68 K items per panel were 2 chunks, 65 536 + 2 700, and the launch two rounds of workgroups instead of one).
+/// CH = 65 536 items, 131 072 once that still leaves two chunks per compute unit (a chunk starts with the fetch of its x
+/// panel and ends with a drained pipeline: fewer, longer chunks where there are plenty).  Measured CH = 32 768 / 65 536 /
+/// 131 072 / 262 144: C2 45 / 39 / 55 / 86 us (round 3), C5 shard 214 / 181 / 176 / 177, band C3 stand-in (compact) - / 352 /
+/// 333 / 332, host-blocked - / 392 / 391 / 423.  LOOPS_PANEL_CHUNK overrides (tuning).
 inline std::vector<int> panel_chunk_list(const std::vector<int>& panel_start, int P) {
-  constexpr int CH = 65536;  // measured 32768 / 65536 / 98304 / 131072 / 262144: C2 45 / 39 / 46 / 55 / 86 us, C5 shard 214 / 190 / 188 / 189 / 189
+  static const int forced = [] { const char* e = std::getenv("LOOPS_PANEL_CHUNK"); return e ? std::atoi(e) : 0; }();
+  const long long total = P > 0 ? static_cast<long long>(panel_start[P]) - panel_start[0] : 0;
+  const int CH = forced > 0 ? forced : (total >= 512ll * 131072 ? 131072 : 65536);
   std::vector<int> list;
   for (int k = 0; k < P; ++k) {
     const int b0 = panel_start[k], n = panel_start[k + 1] - b0;
@@ -700,6 +801,230 @@ inline int panel_reduce_variant() {
   return v;
 }
 
+/// Return codes of panel_binned_create beyond hipError_t values (the C ABI's LOOPS_E_BADARG / LOOPS_E_RANGE, include/loops_amd.h).
+constexpr int panel_e_badarg = -1, panel_e_range = -2;
+
+/// The device arrays of one panel-binned matrix, OWNED (hipMalloc / hipFree); what loops_panel_plan_* and
+/// algorithms::spmv::panel_binned_t hold.  Type-erased over the value type (`vbytes`).
+struct panel_binned_storage {
+  int rows = 0, cols = 0, nnz = 0, vbytes = 0;
+  int W = 0, Hw = 0, P = 0, S = 0, padded = 0, padded_b = 0, num_chunks = 0, compact = 0, awin = 0;
+  long long runs = 0;          ///< runs of equal (row, panel) inside kernel A's windows: what a compact B order holds
+  void *val = nullptr, *prod = nullptr;
+  unsigned short *col16 = nullptr, *row16 = nullptr;
+  int *perm = nullptr, *dst4 = nullptr, *segb = nullptr, *bstart = nullptr, *chunks = nullptr, *wins = nullptr, *wstart = nullptr;
+
+  panel_binned_storage() = default;
+  panel_binned_storage(const panel_binned_storage&) = delete;
+  panel_binned_storage& operator=(const panel_binned_storage&) = delete;
+  ~panel_binned_storage() { release(); }
+  void release() {
+    (void)hipFree(val); (void)hipFree(prod); (void)hipFree(col16); (void)hipFree(row16); (void)hipFree(perm); (void)hipFree(dst4);
+    (void)hipFree(segb); (void)hipFree(bstart); (void)hipFree(chunks); (void)hipFree(wins); (void)hipFree(wstart);
+    val = prod = nullptr; col16 = row16 = nullptr; perm = dst4 = segb = bstart = chunks = wins = wstart = nullptr;
+  }
+  template <typename type_t>
+  panel_binned_view<type_t> view() const {
+    return panel_binned_view<type_t>{rows, cols, nnz, W, Hw, P, S, padded, padded_b, compact, awin, static_cast<type_t*>(val), col16, dst4, row16,
+                                     perm, segb, bstart, chunks, num_chunks, static_cast<type_t*>(prod), wins, wstart};
+  }
+};
+
+/// When the compact layout is adopted without being asked for: the B order shrinks to at most this fraction of the nonzeros.
+/// Each run costs kernel A a 4-byte store where a group of 4 single-item runs costs one 16-byte store, and the scan.  Measured
+/// (tests/perf/exp_panel_reduce.py, compact against plain, kernel A + B): C2 (runs / nnz 0.50: hub rows fill their panels) 45.0
+/// against 53.1 us, C3 stand-ins host-blocked (0.18) 434 against 742, band (0.10) 378 against 667, uniform (0.68) 671 against
+/// 747, C5 shard (0.75) 238 against 234, 8 M rows x 2 (1.0) 80 against 69.
+constexpr double panel_compact_threshold = 0.70;
+
+/// Builds the panel-binned copy of a CSR on the device (O(nnz): one radix sort of 8-byte keys, scans, one placement pass;
+/// three host synchronisations: the A-order size and the run count, the B-order size, the panel starts).
+/// subband_rows / panel_cols: 0 = automatic.  compact: -1 = automatic (panel_compact_threshold), 0 = never, 1 = always.
+/// Returns 0, a hipError_t, panel_e_badarg (also: a column index outside [0, cols)) or panel_e_range.
+template <typename index_t, typename offset_t, typename type_t>
+int panel_binned_create(hipStream_t stream, int rows, int cols, int nnz, const offset_t* offsets, const index_t* indices,
+                        const type_t* values, int subband_rows, int panel_cols, int compact, panel_binned_storage& out) {
+  static_assert(sizeof(index_t) == 4 && sizeof(offset_t) == 4, "panel_binned_create: 32-bit indices and offsets");
+  if (!offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values)) || compact < -1 || compact > 1) return panel_e_badarg;
+  out.release();
+  out.rows = rows; out.cols = cols; out.nnz = nnz; out.vbytes = static_cast<int>(sizeof(type_t));
+  out.W = panel_columns<type_t>(rows, cols, nnz);
+  if (panel_cols != 0) {  // explicit: one of the two compiled widths
+    if (panel_cols != panel_width<type_t>::value && panel_cols != panel_width<type_t>::wide) return panel_e_badarg;
+    out.W = panel_cols;
+  }
+  out.P = cols > 0 ? static_cast<int>((static_cast<long long>(cols) + out.W - 1) / out.W) : 1;
+  out.Hw = panel_subband_rows<type_t>(rows, nnz, out.P);
+  if (subband_rows != 0) {  // explicit: a power of two, 64 .. panel_subband_rows_max
+    const int cap = panel_reduce_variant() ? 4096 : panel_subband_rows_max<type_t>();
+    if (subband_rows < 64 || subband_rows > cap || (subband_rows & (subband_rows - 1))) return panel_e_badarg;
+    out.Hw = subband_rows;
+  }
+  out.S = rows > 0 ? static_cast<int>((static_cast<long long>(rows) + out.Hw - 1) / out.Hw) : 1;
+  out.padded = out.padded_b = out.num_chunks = out.compact = 0;
+  out.runs = 0;
+  const int P = out.P, S = out.S;
+  const long long segments = static_cast<long long>(P) * S;
+  // every segment may carry up to 3 padding items
+  if (segments > (1ll << 26) || static_cast<long long>(nnz) + 3 * segments >= (1ll << 31) - 4096) return panel_e_range;
+  if (rows == 0) return 0;
+  const int nseg = static_cast<int>(segments);
+
+  // temporary storage: sort keys in / out (the `in` half is reused for the run-end flags and their scan once the sort is
+  // done), the row of every nonzero, seven per-segment tables, hipcub scratch
+  auto up = [](std::size_t v) { return (v + 255) & ~std::size_t(255); };
+  std::size_t sort_bytes = 0, scan_bytes = 0;
+  {
+    unsigned long long* k = nullptr;
+    int* ci = nullptr;
+    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, k, k, nnz, 32, 64);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, ci, ci, (nnz > nseg ? nnz : nseg) + 1);
+  }
+  const std::size_t cub_bytes_total = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+  const std::size_t key_bytes = up((static_cast<std::size_t>(nnz) + 1) * 8), row_bytes = up(static_cast<std::size_t>(nnz) * 4);
+  const std::size_t seg_bytes = up((static_cast<std::size_t>(nseg) + 1) * 4);
+  const std::size_t temp_bytes = 2 * key_bytes + row_bytes + 7 * seg_bytes + 256 + cub_bytes_total;
+  char* base = nullptr;
+  int* panel_start = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), temp_bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&panel_start), sizeof(int) * (static_cast<std::size_t>(P) + 1));
+  struct guard_t {
+    char*& a; int*& b;
+    ~guard_t() { (void)hipFree(a); (void)hipFree(b); }
+  } guard{base, panel_start};
+  if (e != hipSuccess) return static_cast<int>(e);
+  auto* keys_in = reinterpret_cast<unsigned long long*>(base);
+  auto* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
+  int* ends = reinterpret_cast<int*>(base);                                   // (over keys_in, after the sort) [nnz + 1]
+  int* run_index = ends + (nnz + 1);                                          // [nnz + 1]: 2 x 4 x (nnz + 1) <= key_bytes
+  int* row_of = reinterpret_cast<int*>(base + 2 * key_bytes);
+  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);
+  const std::size_t seg_ints = seg_bytes / 4;
+  int* seg_start = counts + seg_ints;        // unpadded start of segment g in the sorted keys
+  int* padded_a = counts + 2 * seg_ints;     // padded size of segment g = p * S + s
+  int* seg_dest = counts + 3 * seg_ints;     // A-order start of segment g
+  int* padded_b = counts + 4 * seg_ints;     // B-order size of segment g (its padded item or run count)
+  int* padded_t = counts + 5 * seg_ints;     // the same transposed to s * P + p
+  int* seg_dest_b = counts + 6 * seg_ints;   // B-order start of segment (s, p)
+  int* bad = counts + 7 * seg_ints;
+  void* cub_temp = base + 2 * key_bytes + row_bytes + 7 * seg_bytes + 256;
+  std::size_t cub_bytes = cub_bytes_total;
+  auto scan = [&](const int* in, int* outp, int n) {
+    cub_bytes = cub_bytes_total;
+    return hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, in, outp, n, stream);
+  };
+  const dim3 seg_grid(math::ceil_div(nseg + 1, 256));
+
+  // ---- stage 1: segments of the A order, run ends
+  e = hipMemsetAsync(counts, 0, seg_bytes, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  constexpr int KEYS_PER_LANE = 8;
+  if (nnz > 0) {
+    hipLaunchKernelGGL((panel::make_keys<KEYS_PER_LANE, index_t, offset_t>), dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), dim3(256), 0,
+                       stream, offsets, indices, rows, nnz, out.W, out.Hw, S, cols, keys_in, row_of, counts, bad);
+    int end_bit = 33;
+    while (end_bit < 64 && (static_cast<unsigned long long>(segments) >> (end_bit - 32)) != 0) ++end_bit;
+    cub_bytes = cub_bytes_total;
+    e = hipcub::DeviceRadixSort::SortKeys(cub_temp, cub_bytes, keys_in, keys_out, nnz, 32, end_bit, stream);
+    if (e != hipSuccess) return static_cast<int>(e);
+  }
+  hipLaunchKernelGGL(panel::pad_counts, seg_grid, dim3(256), 0, stream, counts, nseg, padded_a);
+  e = scan(counts, seg_start, nseg + 1);
+  if (e == hipSuccess) e = scan(padded_a, seg_dest, nseg + 1);
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL(panel::mark_run_ends, dim3(math::ceil_div(nnz + 1, 256)), dim3(256), 0, stream, keys_out, seg_start, seg_dest, row_of, nnz, S, ends);
+  e = scan(ends, run_index, nnz + 1);
+  if (e != hipSuccess) return static_cast<int>(e);
+  int h_sizes[3] = {0, 0, 0};  // padded A items, runs, bad index seen
+  e = hipMemcpyAsync(&h_sizes[0], seg_dest + nseg, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_sizes[1], run_index + nnz, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_sizes[2], bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  if (h_sizes[2] != 0) return panel_e_badarg;
+  out.padded = h_sizes[0];
+  out.runs = h_sizes[1];
+  // (the run-end flag lives in bit 15 of col16: panels of at most 32768 columns -- both compiled widths of both value types)
+  out.compact = compact == 1 || (compact == -1 && static_cast<double>(out.runs) <= panel_compact_threshold * static_cast<double>(nnz)) ? 1 : 0;
+  if (out.W > 32768) out.compact = 0;
+  out.awin = panel::a_window;
+
+  // ---- stage 2: segments of the B order
+  if (out.compact) hipLaunchKernelGGL(panel::pad_run_counts, seg_grid, dim3(256), 0, stream, seg_start, run_index, nseg, padded_b);
+  const int* sizes_b = out.compact ? padded_b : padded_a;
+  hipLaunchKernelGGL(panel::transpose_counts, seg_grid, dim3(256), 0, stream, sizes_b, P, S, padded_t);
+  e = scan(padded_t, seg_dest_b, nseg + 1);
+  if (e == hipSuccess) e = hipMemcpyAsync(&out.padded_b, seg_dest_b + nseg, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+
+  // ---- stage 3: allocation and placement
+  const std::size_t na = static_cast<std::size_t>(out.padded > 0 ? out.padded : 4), nb = static_cast<std::size_t>(out.padded_b > 0 ? out.padded_b : 4);
+  auto alloc = [&](auto** ptr, std::size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes); };
+  alloc(&out.val, sizeof(type_t) * na);
+  alloc(&out.prod, sizeof(type_t) * nb);
+  alloc(&out.col16, sizeof(unsigned short) * na);
+  alloc(&out.row16, sizeof(unsigned short) * nb);
+  alloc(&out.perm, sizeof(int) * na);
+  alloc(&out.dst4, sizeof(int) * (na / 4 + 1));
+  alloc(&out.segb, sizeof(int) * (static_cast<std::size_t>(nseg) + 1));
+  alloc(&out.bstart, sizeof(int) * (static_cast<std::size_t>(S) + 1));
+  alloc(&out.wstart, sizeof(int) * (static_cast<std::size_t>(S) + 1));
+  alloc(&out.wins, sizeof(int) * 2 * panel_window_capacity(out.padded_b, segments));
+  if (e == hipSuccess) e = hipMemsetAsync(out.val, 0, sizeof(type_t) * na, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.col16, 0, sizeof(unsigned short) * na, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.row16, 0xFF, sizeof(unsigned short) * nb, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.perm, 0xFF, sizeof(int) * na, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.dst4, 0, sizeof(int) * (na / 4 + 1), stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out.prod, 0, sizeof(type_t) * nb, stream);  // (compact: kernel A never writes the padding slots)
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  if (nnz > 0) {
+    auto* v = static_cast<type_t*>(out.val);
+    const dim3 grid(math::ceil_div(nnz, 256));
+    if (out.compact)
+      hipLaunchKernelGGL((panel::place<true, index_t, type_t>), grid, dim3(256), 0, stream, keys_out, seg_start, seg_dest, seg_dest_b, row_of,
+                         ends, run_index, indices, values, nnz, out.W, out.Hw, P, S, v, out.col16, out.dst4, out.row16, out.perm);
+    else
+      hipLaunchKernelGGL((panel::place<false, index_t, type_t>), grid, dim3(256), 0, stream, keys_out, seg_start, seg_dest, seg_dest_b, row_of,
+                         ends, run_index, indices, values, nnz, out.W, out.Hw, P, S, v, out.col16, out.dst4, out.row16, out.perm);
+  }
+  e = hipMemcpyAsync(out.segb, seg_dest_b, sizeof(int) * (static_cast<std::size_t>(nseg) + 1), hipMemcpyDeviceToDevice, stream);
+  // the windowed kernel B's work list: count per sub-band, scan, fill
+  if (e == hipSuccess) e = hipMemsetAsync(out.wstart, 0, sizeof(int) * (static_cast<std::size_t>(S) + 1), stream);
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  const dim3 wgrid(math::ceil_div(S, 256));
+  hipLaunchKernelGGL(panel::make_windows<false>, wgrid, dim3(256), 0, stream, seg_dest_b, P, S, panel_pack_items<type_t>(), out.wstart,
+                     static_cast<int*>(nullptr));
+  e = scan(out.wstart, out.wstart, S + 1);
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  hipLaunchKernelGGL(panel::make_windows<true>, wgrid, dim3(256), 0, stream, seg_dest_b, P, S, panel_pack_items<type_t>(), out.wstart, out.wins);
+  const int m = (S > P ? S : P) + 1;
+  hipLaunchKernelGGL(panel::extract_starts, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, seg_dest, seg_dest_b, P, S, out.bstart, panel_start);
+  std::vector<int> ps(static_cast<std::size_t>(P) + 1, 0);
+  e = hipMemcpyAsync(ps.data(), panel_start, sizeof(int) * ps.size(), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) {
+    const std::vector<int> list = panel_chunk_list(ps, P);  // kernel A's work list
+    out.num_chunks = static_cast<int>(list.size() / 3);
+    e = hipMalloc(reinterpret_cast<void**>(&out.chunks), sizeof(int) * (list.empty() ? 3 : list.size()));
+    if (e == hipSuccess && !list.empty()) e = hipMemcpy(out.chunks, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  return 0;
+}
+
+/// Workgroups of kernel A: 0 = one per chunk (the default); LOOPS_PANEL_GRID=<n> makes n workgroups walk contiguous shares
+/// of the chunk list, keeping the x panel in LDS while the panel stays the same.  Measured (round 4, 256 / 512 / 1024
+/// workgroups against one per chunk): host-blocked C3 stand-in 414 / 426 / 423 against 392 us, uniform 621 / 612 / 598 against
+/// 567, C5 shard 189 / 181 / 186 against 186, C2 equal -- the panel fetch per chunk is not what kernel A waits for, and static
+/// shares lose the balancing of the hardware dispatcher.
+inline int panel_products_grid() {
+  static const int v = [] { const char* e = std::getenv("LOOPS_PANEL_GRID"); return e ? std::atoi(e) : 0; }();
+  return v;
+}
+
 /// y = A x over a panel-binned matrix: kernel A then kernel B.  stages: bit 0 = products, bit 1 = reduce.
 /// Streams are read non-temporally unless the product's whole working set fits the Infinity Cache (see `nt` below).
 template <typename type_t, typename store_t>
@@ -707,16 +1032,29 @@ int launch_panel_binned_to(hipStream_t stream, const panel_binned_view<type_t>& 
   if (m.rows == 0) return 0;
   constexpr int W = panel_width<type_t>::value, W2 = panel_width<type_t>::wide;
   if (m.W != W && m.W != W2) return static_cast<int>(hipErrorInvalidValue);
-  // Non-temporal streams unless the WHOLE working set of a product -- values, columns, destinations, rows, products: 13 B per
-  // item with 4-byte values, plus x and y -- fits the 256 MB Infinity Cache and so survives from one product to the next (C2, 219 MB: plain
-  // loads 64.7 -> 58.2 us per product, kernel A 37.4 -> 31.6); beyond it plain loads only evict each other's streams (C5
-  // shard, kernel B plain: 256 -> 291 us).
-  const bool nt = static_cast<double>(m.padded) * (2.0 * sizeof(type_t) + 5.0) + (static_cast<double>(m.rows) + m.cols) * sizeof(type_t) > 240e6;
+  // Non-temporal streams unless the WHOLE working set of a product -- values, columns, destinations (7 B per item with 4-byte
+  // values), products and rows (6 B per slot), plus x and y -- fits the 256 MB Infinity Cache and so survives from one product
+  // to the next (C2, 219 MB: plain loads 64.7 -> 58.2 us per product, kernel A 37.4 -> 31.6); beyond it plain loads only
+  // evict each other's streams (C5 shard, kernel B plain: 256 -> 291 us).
+  const bool nt = static_cast<double>(m.padded) * (sizeof(type_t) + 3.0) + static_cast<double>(m.padded_b) * (sizeof(type_t) + 2.0) +
+                      (static_cast<double>(m.rows) + m.cols) * sizeof(type_t) > 240e6;
   if ((stages & 1) && m.num_chunks > 0) {
+    const int want = panel_products_grid();
+    const int grid = want > 0 && want < m.num_chunks ? want : m.num_chunks;  // one workgroup per chunk unless asked otherwise
     auto go = [&](auto kernel, int threads) {
-      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(threads), 0, stream, m.chunks, m.val, m.col16, m.dst4, x, m.cols, m.prod);
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), 0, stream, m.chunks, m.num_chunks, m.val, m.col16, m.dst4, x, m.cols, m.prod);
     };
-    if (m.W == W) {
+    if (m.compact) {
+      if (m.awin != panel::a_window) return static_cast<int>(hipErrorInvalidValue);
+      constexpr int UC = LOOPS_PANEL_COMPACT_U;
+      if (m.W == W) {
+        if (nt) go(panel::panel_products_compact<512, W, UC, true, type_t>, 512);
+        else go(panel::panel_products_compact<512, W, UC, false, type_t>, 512);
+      } else {
+        if (nt) go(panel::panel_products_compact<1024, W2, UC, true, type_t>, 1024);
+        else go(panel::panel_products_compact<1024, W2, UC, false, type_t>, 1024);
+      }
+    } else if (m.W == W) {
       if (nt) go(panel::panel_products<512, W, 4, true, type_t>, 512);
       else go(panel::panel_products<512, W, 4, false, type_t>, 512);
     } else {

@@ -292,6 +292,19 @@ int loops_panel_plan_create_f32(int rows, int cols, int nnz, const int* offsets,
                                 int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out);
 int loops_panel_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
                                 int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out);
+/* The same with the B order chosen explicitly.  compact: -1 = automatic (what loops_panel_plan_create_* does), 0 = one slot
+ * per nonzero, 1 = COMPACT: kernel A sums runs of equal (row, panel) -- cut so that none crosses a 256-item wavefront step --
+ * before they leave the CU, and the B order holds one slot per run (matrices with column locality: a row's 20-30 products
+ * become 1-2 slots; adopted automatically when the runs are at most 0.7 of the nonzeros).  Then col16 carries the run-end
+ * flag in bit 15, dst4 the slot of the group's first run end and in bit 31 "the group holds padding", and row16 / the
+ * products scratch have loops_panel_plan_layout's info4[2] slots.
+ * loops_panel_plan_layout: info4 = {compact, runs, B-order slots incl. padding, items per wavefront step of kernel A (the
+ * window no run crosses)}. */
+int loops_panel_plan_create_layout_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                                       int panel_columns, int subband_rows, int compact, void* stream, loops_panel_plan_t** out);
+int loops_panel_plan_create_layout_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                                       int panel_columns, int subband_rows, int compact, void* stream, loops_panel_plan_t** out);
+int loops_panel_plan_layout(const loops_panel_plan_t* plan, long long* info4);
 void loops_panel_plan_destroy(loops_panel_plan_t* plan);
 int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7);
 int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsigned short* col16, int* dst4, unsigned short* row16,

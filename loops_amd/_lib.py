@@ -50,6 +50,7 @@ SYMBOLS = [
     "loops_panel_plan_arrays", "loops_panel_plan_windows", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
     "loops_csc_plan_create_f32", "loops_csc_plan_create_f64", "loops_coo_plan_create_f32", "loops_coo_plan_create_f64", "loops_csc_plan_destroy", "loops_csc_plan_info",
     "loops_csc_plan_refresh_values_f32", "loops_csc_plan_refresh_values_f64", "loops_spmv_csc_planned_f32", "loops_spmv_csc_planned_f64",
+    "loops_panel_plan_create_layout_f32", "loops_panel_plan_create_layout_f64", "loops_panel_plan_layout",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
 
@@ -197,12 +198,14 @@ def lib() -> C.CDLL:
             getattr(L, "loops_spmv_planned_" + sfx).argtypes = [vp, vp, vp, vp, vp, vp, vp]
         for sfx in ("f32", "f64"):
             getattr(L, "loops_panel_plan_create_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
+            getattr(L, "loops_panel_plan_create_layout_" + sfx).argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, ci, vp, C.POINTER(vp)]
             getattr(L, "loops_panel_plan_refresh_values_" + sfx).argtypes = [vp, vp, vp]
             getattr(L, "loops_spmv_panel_" + sfx).argtypes = [vp, vp, vp, vp]
             getattr(L, "loops_spmv_panel_fanout_" + sfx).argtypes = [vp, vp, vp, ci, vp, vp]
         L.loops_panel_plan_destroy.argtypes = [vp]
         L.loops_panel_plan_destroy.restype = None
         L.loops_panel_plan_info.argtypes = [vp, vp]
+        L.loops_panel_plan_layout.argtypes = [vp, vp]
         L.loops_panel_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.loops_panel_plan_windows.argtypes = [vp, vp, vp, vp]
         L.loops_spmv_panel_stage_f32.argtypes = [vp, ci, vp, vp, vp]

@@ -689,95 +689,24 @@ int colblock_fanout(const loops_colblock_plan* plan, const T* x, T* y, int num_p
 }  // namespace
 
 // ------------------------------------------------------------------------------------ panel-binned layout
-struct loops_panel_plan {
-  int rows, cols, nnz, vbytes;
-  int W, Hw, P, S, padded, num_chunks;
-  void *val, *prod;
-  unsigned short *col16, *row16;
-  int *perm, *dst4, *segb, *bstart, *chunks, *wins, *wstart;
-};
+static_assert(kernels::panel_e_badarg == LOOPS_E_BADARG && kernels::panel_e_range == LOOPS_E_RANGE, "panel_binned_create speaks the C ABI's error codes");
+struct loops_panel_plan : kernels::panel_binned_storage {};  // (the builder and the owned arrays: include/loops/kernels/panel_binned.hxx)
 
 namespace {
 
-void panel_free(loops_panel_plan* p) {
-  if (!p) return;
-  (void)hipFree(p->val); (void)hipFree(p->prod); (void)hipFree(p->col16); (void)hipFree(p->row16);
-  (void)hipFree(p->perm); (void)hipFree(p->dst4); (void)hipFree(p->segb); (void)hipFree(p->bstart); (void)hipFree(p->chunks);
-  (void)hipFree(p->wins); (void)hipFree(p->wstart);
-  delete p;
-}
+void panel_free(loops_panel_plan* p) { delete p; }
 
 template <typename T>
-kernels::panel_binned_view<T> panel_view(const loops_panel_plan* p) {
-  return kernels::panel_binned_view<T>{p->rows, p->cols, p->nnz, p->W, p->Hw, p->P, p->S, p->padded, static_cast<T*>(p->val),
-                                       p->col16, p->dst4, p->row16, p->perm, p->segb, p->bstart, p->chunks, p->num_chunks,
-                                       static_cast<T*>(p->prod), p->wins, p->wstart};
-}
+kernels::panel_binned_view<T> panel_view(const loops_panel_plan* p) { return p->view<T>(); }
 
 template <typename T>
 int panel_create(int rows, int cols, int nnz, const int* offsets, const int* indices, const T* values, hipStream_t st,
-                 loops_panel_plan** out, int subband_rows = 0, int panel_cols = 0) {
-  if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
+                 loops_panel_plan** out, int subband_rows = 0, int panel_cols = 0, int compact = -1) {
+  if (!out) return LOOPS_E_BADARG;
   auto* p = new (std::nothrow) loops_panel_plan();
   if (!p) return static_cast<int>(hipErrorOutOfMemory);
-  p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T));
-  p->W = kernels::panel_columns<T>(rows, cols, nnz);
-  if (panel_cols != 0) {  // explicit: one of the two compiled widths
-    if (panel_cols != kernels::panel_width<T>::value && panel_cols != kernels::panel_width<T>::wide) { delete p; return LOOPS_E_BADARG; }
-    p->W = panel_cols;
-  }
-  p->P = cols > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(cols), static_cast<long long>(p->W))) : 1;
-  p->Hw = kernels::panel_subband_rows<T>(rows, nnz, p->P);
-  if (subband_rows != 0) {  // explicit: a power of two, 64 .. panel_subband_rows_max
-    const int cap = kernels::panel_reduce_variant() ? 4096 : kernels::panel_subband_rows_max<T>();
-    if (subband_rows < 64 || subband_rows > cap || (subband_rows & (subband_rows - 1))) { delete p; return LOOPS_E_BADARG; }
-    p->Hw = subband_rows;
-  }
-  p->S = rows > 0 ? static_cast<int>(math::ceil_div(static_cast<long long>(rows), static_cast<long long>(p->Hw))) : 1;
-  const long long segments = static_cast<long long>(p->P) * p->S;
-  // every segment may carry up to 3 padding items
-  if (segments > (1ll << 26) || static_cast<long long>(nnz) + 3 * segments >= (1ll << 31) - 4096) { delete p; return LOOPS_E_RANGE; }
-  if (rows == 0) { *out = p; return 0; }
-  void* temp = nullptr;
-  int* panel_start = nullptr;
-  const size_t temp_bytes = kernels::panel_binned_temp_bytes(nnz, segments);
-  hipError_t e = hipMalloc(&temp, temp_bytes);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&panel_start), sizeof(int) * (static_cast<size_t>(p->P) + 1));
-  int err = static_cast<int>(e);
-  const int* padded_dev = nullptr;
-  if (!err) err = kernels::build_panel_binned_stage1(st, offsets, indices, rows, nnz, p->W, p->Hw, p->P, p->S, temp, temp_bytes, &padded_dev);
-  if (!err) err = static_cast<int>(hipMemcpyAsync(&p->padded, padded_dev, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (!err) err = static_cast<int>(hipStreamSynchronize(st));
-  if (!err) {
-    const size_t n = static_cast<size_t>(p->padded > 0 ? p->padded : 4);
-    auto alloc = [&](auto** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes); };
-    alloc(&p->val, sizeof(T) * n);
-    alloc(&p->prod, sizeof(T) * n);
-    alloc(&p->col16, sizeof(unsigned short) * n);
-    alloc(&p->row16, sizeof(unsigned short) * n);
-    alloc(&p->perm, sizeof(int) * n);
-    alloc(&p->dst4, sizeof(int) * (n / 4 + 1));
-    alloc(&p->segb, sizeof(int) * (static_cast<size_t>(segments) + 1));
-    alloc(&p->bstart, sizeof(int) * (static_cast<size_t>(p->S) + 1));
-    alloc(&p->wstart, sizeof(int) * (static_cast<size_t>(p->S) + 1));
-    alloc(&p->wins, sizeof(int) * 2 * kernels::panel_window_capacity(p->padded, segments));
-    err = static_cast<int>(e);
-  }
-  if (!err) err = kernels::build_panel_binned_stage2<int, T>(st, indices, values, panel_view<T>(p), temp, temp_bytes, panel_start);
-  std::vector<int> ps(static_cast<size_t>(p->P) + 1, 0);
-  if (!err) err = static_cast<int>(hipMemcpyAsync(ps.data(), panel_start, sizeof(int) * ps.size(), hipMemcpyDeviceToHost, st));
-  if (!err) err = static_cast<int>(hipStreamSynchronize(st));
-  if (!err) {
-    const std::vector<int> chunks = kernels::panel_chunk_list(ps, p->P);  // kernel A's work list
-    p->num_chunks = static_cast<int>(chunks.size() / 3);
-    e = hipMalloc(reinterpret_cast<void**>(&p->chunks), sizeof(int) * (chunks.empty() ? 3 : chunks.size()));
-    if (e == hipSuccess && !chunks.empty())
-      e = hipMemcpy(p->chunks, chunks.data(), sizeof(int) * chunks.size(), hipMemcpyHostToDevice);
-    err = static_cast<int>(e);
-  }
-  (void)hipFree(temp);
-  (void)hipFree(panel_start);
-  if (err) { panel_free(p); return err; }
+  const int err = kernels::panel_binned_create<int, int, T>(st, rows, cols, nnz, offsets, indices, values, subband_rows, panel_cols, compact, *p);
+  if (err) { delete p; return err; }  // (panel_e_badarg / panel_e_range are LOOPS_E_BADARG / LOOPS_E_RANGE)
   *out = p;
   return 0;
 }
@@ -1473,6 +1402,19 @@ int loops_panel_plan_create_f64(int rows, int cols, int nnz, const int* offsets,
                                 int panel_columns, int subband_rows, void* stream, loops_panel_plan_t** out) {
   return panel_create<double>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows, panel_columns);
 }
+int loops_panel_plan_create_layout_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                                       int panel_columns, int subband_rows, int compact, void* stream, loops_panel_plan_t** out) {
+  return panel_create<float>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows, panel_columns, compact);
+}
+int loops_panel_plan_create_layout_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                                       int panel_columns, int subband_rows, int compact, void* stream, loops_panel_plan_t** out) {
+  return panel_create<double>(rows, cols, nnz, offsets, indices, values, as_stream(stream), out, subband_rows, panel_columns, compact);
+}
+int loops_panel_plan_layout(const loops_panel_plan_t* plan, long long* info4) {
+  if (!plan || !info4) return LOOPS_E_BADARG;
+  info4[0] = plan->compact; info4[1] = plan->runs; info4[2] = plan->padded_b; info4[3] = plan->awin;
+  return 0;
+}
 void loops_panel_plan_destroy(loops_panel_plan_t* plan) { panel_free(plan); }
 int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7) {
   if (!plan || !info7) return LOOPS_E_BADARG;
@@ -1491,7 +1433,7 @@ int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsign
   };
   copy(values, plan->val, static_cast<size_t>(plan->vbytes) * n);
   copy(col16, plan->col16, sizeof(unsigned short) * n);
-  copy(row16, plan->row16, sizeof(unsigned short) * n);
+  copy(row16, plan->row16, sizeof(unsigned short) * static_cast<size_t>(plan->padded_b));
   copy(perm, plan->perm, sizeof(int) * n);
   copy(dst4, plan->dst4, sizeof(int) * (n / 4));
   copy(subband_start, plan->bstart, sizeof(int) * (static_cast<size_t>(plan->S) + 1));

@@ -311,18 +311,24 @@ class PanelBinnedPlan:
     -- x panels in LDS, products streamed, one wavefront per sub-band of rows adds them up in LDS.  For x far larger than
     the per-XCD L2."""
 
-    def __init__(self, csr: CSR, subband_rows: int = 0, panel_columns: int = 0):
+    def __init__(self, csr: CSR, subband_rows: int = 0, panel_columns: int = 0, compact: int | None = None):
+        """``compact``: None = automatic, False = one B-order slot per nonzero, True = kernel A pre-sums runs of equal
+        (row, panel) and the B order holds one slot per run (loops_panel_plan_create_layout_*)."""
         assert csr.values.dtype in (torch.float32, torch.float64)
         self.dtype = csr.values.dtype
         self._sfx = _suffix(csr.values)
         self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
         self._h = C.c_void_p()
-        create = getattr(L.lib(), "loops_panel_plan_create_" + self._sfx)
+        create = getattr(L.lib(), "loops_panel_plan_create_layout_" + self._sfx)
         L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), int(panel_columns),
-                       int(subband_rows), _stream(), C.byref(self._h)), "loops_panel_plan_create")
+                       int(subband_rows), -1 if compact is None else int(bool(compact)), _stream(), C.byref(self._h)),
+                "loops_panel_plan_create_layout")
         info = (C.c_int * 7)()
         L.check(L.lib().loops_panel_plan_info(self._h, info), "loops_panel_plan_info")
         self.W, self.Hw, self.num_panels, self.num_subbands, self.padded, self.num_chunks, _ = list(info)
+        lay = (C.c_longlong * 4)()
+        L.check(L.lib().loops_panel_plan_layout(self._h, lay), "loops_panel_plan_layout")
+        self.compact, self.runs, self.padded_b, self.a_window = bool(lay[0]), int(lay[1]), int(lay[2]), int(lay[3])
 
     @property
     def handle(self):
@@ -330,9 +336,10 @@ class PanelBinnedPlan:
 
     def arrays(self):
         """(values, col16, dst4, row16, perm, subband_start) copied to the host: values / col16 / perm [padded] and dst4
-        [padded / 4] in (panel, sub-band) order, row16 [padded] in (sub-band, panel) order."""
+        [padded / 4] in (panel, sub-band) order, row16 [padded_b] in (sub-band, panel) order (compact: one slot per run, col16
+        bit 15 = run end, dst4 bit 31 = the group holds padding)."""
         val = np.zeros(self.padded, np.float32 if self.dtype == torch.float32 else np.float64)
-        col16, row16 = np.zeros(self.padded, np.uint16), np.zeros(self.padded, np.uint16)
+        col16, row16 = np.zeros(self.padded, np.uint16), np.zeros(self.padded_b, np.uint16)
         perm, dst4 = np.zeros(self.padded, np.int32), np.zeros(self.padded // 4, np.int32)
         bstart = np.zeros(self.num_subbands + 1, np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731

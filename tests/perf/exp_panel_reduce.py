@@ -6,7 +6,8 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S
-from bench_panel import CASES, batch_ms
+import bench_panel_cases
+from bench_panel_cases import CASES, batch_ms
 
 want = [a for a in sys.argv[1:] if a in CASES] or ["c2", "c5_shard"]
 hws = [int(t) for t in os.environ.get("PANEL_HW", "0").split(",") if t]
@@ -33,7 +34,8 @@ for name in want:
     xrd = torch.from_numpy(xr).cuda()
     for hw in hws:
         try:
-            pv = S.PanelBinnedPlan(csr, hw, int(os.environ.get("PANEL_W", "0")))
+            cm = os.environ.get("PANEL_COMPACT", "")
+            pv = S.PanelBinnedPlan(csr, hw, int(os.environ.get("PANEL_W", "0")), compact=None if cm == "" else bool(int(cm)))
         except Exception as e:  # noqa: BLE001
             print(name, "variant", variant, "Hw", hw, "FAILED", e, flush=True)
             continue
@@ -48,7 +50,7 @@ for name in want:
         rel = np.abs(yr - ref)[nz] / np.abs(ref[nz])
         again = all(bool(torch.equal(pv.spmv(xrd), torch.from_numpy(yr.astype(np.float32)).cuda())) for _ in range(3))
         pv.refresh_values(csr.values)
-        print(json.dumps({"case": name, "variant": variant, "W": pv.W, "Hw": pv.Hw, "subbands": pv.num_subbands, "total_us": round(t, 1),
+        print(json.dumps({"case": name, "variant": variant, "W": pv.W, "Hw": pv.Hw, "subbands": pv.num_subbands, "compact": pv.compact, "runs_over_nnz": round(pv.runs / nnz, 4), "total_us": round(t, 1),
                           "products_us": round(ta, 1), "reduce_us": round(tb, 1), "equal": equal, "max_rel_err": float(rel.max()),
                           "reproducible": again}), flush=True)
         pv.close()

@@ -41,3 +41,32 @@ def test_disarm_and_rearm():
              "w.arm('a', 1.0)\nw.disarm()\ntime.sleep(2.5)\n"
              "w.arm('b', 60.0)\ntime.sleep(1.0)\nw.disarm()\nprint('reached')\n")
     assert r.returncode == 0 and r.stdout.strip() == "reached"
+
+
+def test_self_launch_builds_the_driver_command_and_passes_the_status_through(tmp_path):
+    """bench.self_launch (what `python bench.py --gpus N` does when no launcher set WORLD_SIZE): the command is the one the
+    driver would have used -- torch.distributed.run, one node, N processes, 127.0.0.1 rendezvous, the same arguments -- and
+    the launcher's exit status is returned.  No GPU: subprocess.call is replaced by a recorder."""
+    r = _run("import subprocess\n"
+             "seen = {}\n"
+             "def fake(cmd, env=None):\n"
+             "    seen['cmd'] = cmd; seen['legacy'] = env.get('HSA_ENABLE_IPC_MODE_LEGACY'); return 7\n"
+             "subprocess.call = fake\n"
+             "sys.argv = ['bench.py', '--gpus', '4', '--steps', '9', '--warmup', '3']\n"
+             "rc = bench.self_launch(4)\n"
+             "print(json.dumps({'rc': rc, 'cmd': seen['cmd'], 'legacy': seen['legacy']}))\n")
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = d["cmd"]
+    assert d["rc"] == 7 and d["legacy"] == "0"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "9", "--warmup", "3"] and cmd[-7].endswith("bench.py")
+
+
+def test_a_launcher_in_the_environment_is_respected():
+    """With WORLD_SIZE set (the driver's torchrun command) bench.py must NOT start ranks of its own; a mismatch between
+    --gpus and WORLD_SIZE is still an error."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120,
+                       cwd=ROOT, env=dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and "no launcher in the environment" not in r.stderr

@@ -20,13 +20,16 @@ def _dev(off, idx, val, rows, cols):
 
 def _check_layout(plan, off, idx, val):
     """The layout contract, from the host copies: every nonzero exactly once in (panel, sub-band, CSR) order; groups of 4 never
-    straddle segments; dst4 maps every group to where the same items sit in (sub-band, panel, CSR) order; padding is inert."""
+    straddle segments; dst4 maps every group to where the same items sit in (sub-band, panel, CSR) order; padding is inert.
+    Compact plans: col16 bit 15 marks the item that ends a run of equal (row, panel) inside a 256-item window of kernel A,
+    the B order holds one slot per run, dst4 bit 31 marks groups that hold padding."""
     v, c16, dst4, r16, perm, bstart = plan.arrays()
     rows, nnz = off.size - 1, idx.size
     W, Hw, P, S = plan.W, plan.Hw, plan.num_panels, plan.num_subbands
     if rows == 0:
         return
-    assert plan.padded % 4 == 0 and bstart[0] == 0 and bstart[-1] == plan.padded and np.all(np.diff(bstart) >= 0) and np.all(bstart % 4 == 0)
+    assert plan.padded % 4 == 0 and plan.padded_b % 4 == 0 and (plan.compact or plan.padded_b == plan.padded)
+    assert bstart[0] == 0 and bstart[-1] == plan.padded_b and np.all(np.diff(bstart) >= 0) and np.all(bstart % 4 == 0)
     real = perm >= 0
     assert real.sum() == nnz and np.array_equal(np.sort(perm[real]), np.arange(nnz))            # every nonzero exactly once
     assert np.all(v[~real] == 0)                                                                 # padding multiplies to 0
@@ -35,29 +38,57 @@ def _check_layout(plan, off, idx, val):
     i = perm[a]
     assert np.array_equal(v[a], val[i])
     p, s = idx[i] // W, row_of[i] // Hw
-    assert np.array_equal(c16[a].astype(np.int64), idx[i] - p * W)
+    assert np.array_equal((c16[a] & (0x7FFF if plan.compact else 0xFFFF)).astype(np.int64), idx[i] - p * W)
     g = p.astype(np.int64) * S + s
     assert np.all(np.diff(g) >= 0) and np.array_equal(np.lexsort((i, g)), np.arange(i.size))     # (panel, sub-band), then CSR order
     grp = a // 4
     same_group = grp[1:] == grp[:-1]
     assert np.all(g[1:][same_group] == g[:-1][same_group])                                        # a group of 4 holds ONE segment
-    b = dst4[grp] + (a % 4)                                                                       # where the item's product goes
-    assert np.unique(b).size == b.size and b.max(initial=-1) < plan.padded
-    assert np.array_equal(r16[b].astype(np.int64), row_of[i] - s * Hw)
-    assert np.all((b >= bstart[s]) & (b < bstart[s + 1]))                                         # inside its sub-band's run
+    if not plan.compact:
+        b = dst4[grp] + (a % 4)                                                                   # where the item's product goes
+        rows_b, seg_s, seg_p, order_key = row_of[i] - s * Hw, s, p, i
+    else:
+        # run ends: the next real item lies in another segment or row, or the item closes a window of kernel A (64 lanes x 4
+        # items; A positions counted from the panel's first item)
+        win = plan.a_window
+        assert win == 256
+        pstart = np.full(P + 1, plan.padded, np.int64)
+        np.minimum.at(pstart, p, a)
+        win_last = ((a - pstart[p]) % win) == win - 1
+        nxt_differs = np.r_[(g[1:] != g[:-1]) | (row_of[i][1:] != row_of[i][:-1]), True]
+        ends = nxt_differs | win_last
+        assert np.array_equal((c16[a] >> 15).astype(bool), ends)
+        assert np.all(c16[~real] == 0)
+        assert int(ends.sum()) == plan.runs
+        has_pad = np.zeros(plan.padded // 4, bool)
+        has_pad[np.flatnonzero(~real) // 4] = True
+        assert np.array_equal(dst4[:plan.padded // 4] < 0, has_pad)
+        first_slot = dst4[:plan.padded // 4] & 0x7FFFFFFF
+        # slot of the run an item belongs to = its group's first slot + the run ends before it inside the group
+        ends_before = np.cumsum(ends) - ends                                                      # exclusive, over the real items
+        grp_first = np.r_[True, grp[1:] != grp[:-1]]
+        base = np.maximum.accumulate(np.where(grp_first, ends_before, 0))
+        slot = first_slot[grp] + (ends_before - base)
+        b = slot[ends]
+        rows_b, seg_s, seg_p, order_key = (row_of[i] - s * Hw)[ends], s[ends], p[ends], i[ends]
+        # every item of a run maps to the run's slot: slots are non-decreasing inside a segment and step by one at run ends
+        assert np.all(np.diff(slot)[(g[1:] == g[:-1])] == ends[:-1][(g[1:] == g[:-1])])
+    assert np.unique(b).size == b.size and b.max(initial=-1) < plan.padded_b
+    assert np.array_equal(r16[b].astype(np.int64), rows_b)
+    assert np.all((b >= bstart[seg_s]) & (b < bstart[seg_s + 1]))                                 # inside its sub-band's run
     order_b = np.argsort(b, kind="stable")
-    gb = s[order_b].astype(np.int64) * P + p[order_b]
-    assert np.all(np.diff(gb) >= 0) and np.array_equal(np.lexsort((i[order_b], gb)), np.arange(i.size))  # (sub-band, panel), CSR order
-    untouched = np.ones(plan.padded, bool)
+    gb = seg_s[order_b].astype(np.int64) * P + seg_p[order_b]
+    assert np.all(np.diff(gb) >= 0) and np.array_equal(np.lexsort((order_key[order_b], gb)), np.arange(b.size))  # (sub-band, panel), CSR order
+    untouched = np.ones(plan.padded_b, bool)
     untouched[b] = False
     assert np.all(r16[untouched] == 0xFFFF)                                                       # padding rows are marked
     # kernel B's work list: the windows of a sub-band tile its run of the B order exactly, <= 256 items each; a window that is
     # not packed lies inside ONE segment (rows sorted); a packed one is made of whole small segments / the short tail of one
     ws, wins, segb = plan.windows()
     pack = 64 if v.dtype == np.float32 else 128
-    assert ws[0] == 0 and np.all(np.diff(ws) >= 0) and segb[0] == 0 and segb[-1] == plan.padded
+    assert ws[0] == 0 and np.all(np.diff(ws) >= 0) and segb[0] == 0 and segb[-1] == plan.padded_b
     if wins.shape[0] == 0:
-        assert plan.padded == 0
+        assert plan.padded_b == 0
         return
     wb, wl, wp = wins[:, 0].astype(np.int64), (wins[:, 1] & 0xFFFF).astype(np.int64), wins[:, 1] >> 16
     assert np.all(wl > 0) and np.all(wl <= 256) and np.all(wb % 4 == 0) and np.all(wl % 4 == 0)
@@ -83,15 +114,17 @@ def test_battery_layout_and_product():
     g = load_golden("battery.npz")
     for name, (r, c, off, idx, val) in battery().items():
         csr = _dev(off, idx, val, r, c)
-        plan = S.PanelBinnedPlan(csr)
-        _check_layout(plan, off, idx, val)
-        for tag in ("int", "real"):
-            x = torch.from_numpy(g[f"{name}.x_{tag}"]).cuda()
-            y = torch.full((r,), 7.0, device="cuda")          # y must not need a zero-fill
-            plan.spmv(x, y)
-            ref, l1 = g[f"{name}.y_{tag}"], g[f"{name}.l1_{tag}"]
-            assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= 2e-6 * l1 + 1e-30), (name, tag)
-        plan.close()
+        for compact in (None, False, True):
+            plan = S.PanelBinnedPlan(csr, compact=compact)
+            assert compact is None or plan.compact == compact or r == 0
+            _check_layout(plan, off, idx, val)
+            for tag in ("int", "real"):
+                x = torch.from_numpy(g[f"{name}.x_{tag}"]).cuda()
+                y = torch.full((r,), 7.0, device="cuda")          # y must not need a zero-fill
+                plan.spmv(x, y)
+                ref, l1 = g[f"{name}.y_{tag}"], g[f"{name}.l1_{tag}"]
+                assert np.all(np.abs(y.cpu().numpy().astype(np.float64) - ref) <= 1e-6 * l1 + 1e-30), (name, tag, compact)
+            plan.close()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -126,10 +159,10 @@ def test_many_panels_and_subbands_bit_exact(dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_small_segments_throughout(dtype):
-    """Very short rows over many panels: the mean (panel, sub-band) segment holds far fewer than 64 items, so kernel B runs its
-    SMALL variant -- several segments per window, compare-and-swap final updates (a row may end in several segments of one
-    window, and two lanes may target one accumulator in the same instruction).  Bit-exact vs the oracle on exactly summable
-    inputs, identical bits from run to run with real values, the fan-out twin, hub rows among the short ones."""
+    """Very short rows over many panels: the mean (panel, sub-band) segment holds far fewer than 64 items -- several segments
+    per window of kernel B, so a row may end in several segments of one window and two lanes may target one accumulator in
+    the same instruction (the LDS atomics' business).  Bit-exact vs the oracle on exactly summable inputs, identical bits
+    from run to run with real values, the fan-out twin, hub rows among the short ones."""
     from loops_amd import spmv as S, generate as G
     from oracle import oracle as O
     rows, cols = 300_007, 1_000_003
@@ -142,7 +175,7 @@ def test_small_segments_throughout(dtype):
     ref = O.spmv_f32(off, idx, val, xh, omp=True)
     csr = _dev(off, idx, val.astype(dtype), rows, cols)
     plan = S.PanelBinnedPlan(csr)
-    assert nnz < 64 * plan.num_panels * plan.num_subbands         # what selects the variant (kernels::panel_small_segments)
+    assert nnz < 64 * plan.num_panels * plan.num_subbands         # small segments throughout
     _check_layout(plan, off, idx, val.astype(dtype))
     x = torch.from_numpy(xh.astype(dtype)).cuda()
     y = plan.spmv(x)
@@ -260,3 +293,68 @@ def test_full_size_realistic_values_hold_1e6_on_every_row(case):
     print("max relative error vs f64 accumulation:", case, worst, "longest row", int(n.max()))
     assert all(w <= 1e-6 for w in worst.values()), worst
     assert np.all(y.cpu().numpy()[~live] == 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("structure", ["band", "host_blocked"])
+def test_compact_layout_on_matrices_with_column_locality(structure, dtype):
+    """Column locality (a band around the diagonal; crawl-ordered "hosts"): most of a row's nonzeros share a panel, the plan
+    adopts the COMPACT layout by itself (runs <= 0.7 nnz), kernel A pre-sums the runs -- rows longer than a 256-item window
+    (run cut at the window), rows spread over several panels, empty rows, a ragged tail.  Bit-exact vs the oracle on exactly
+    summable inputs, the same bits as the uncompacted plan, the fan-out twin, a value refresh, identical bits from run to
+    run and 1e-6 of the f64 sum with realistic values."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows, cols = 250_003, 400_009
+    deg = G.powerlaw_degrees(rows, 1 << 22, cap=1 << 12)
+    deg[::11] = 0
+    if structure == "band":
+        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, 40_000)
+    else:
+        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, G.HOST_BLOCKED, hosts=G.host_blocks(cols))
+    nnz = int(off[-1])
+    xh = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xh, omp=True)
+    csr = _dev(off, idx, val.astype(dtype), rows, cols)
+    x = torch.from_numpy(xh.astype(dtype)).cuda()
+    plan = S.PanelBinnedPlan(csr)
+    assert plan.compact and plan.runs <= 0.70 * nnz and plan.padded_b < plan.padded
+    assert int(deg.max()) > plan.a_window                               # some run is cut at a window of kernel A
+    _check_layout(plan, off, idx, val.astype(dtype))
+    y = plan.spmv(x)
+    assert np.array_equal(y.cpu().numpy(), ref.astype(dtype))
+    flat = S.PanelBinnedPlan(csr, compact=False)
+    assert not flat.compact and torch.equal(flat.spmv(x), y)
+    flat.close()
+    peers = [torch.full((rows,), -1.0, dtype=y.dtype, device="cuda") for _ in range(2)]
+    y2 = torch.empty_like(y)
+    plan.spmv_fanout(x, y2, peers)
+    assert torch.equal(y2, y) and all(torch.equal(p, y) for p in peers)
+    # realistic values through a refresh of the held copy
+    rng = np.random.default_rng(3)
+    val_r = (rng.random(nnz) + 0.5).astype(dtype)
+    xr = G.realistic_x(cols).astype(dtype)
+    csr.values.copy_(torch.from_numpy(val_r))
+    plan.refresh_values(csr.values)
+    xd = torch.from_numpy(xr).cuda()
+    first = plan.spmv(xd).clone()
+    for _ in range(3):
+        assert torch.equal(plan.spmv(xd), first)
+    live = np.diff(off) > 0
+    yd = np.zeros(rows)
+    yd[live] = np.add.reduceat(val_r.astype(np.float64) * xr.astype(np.float64)[idx], off[:-1].astype(np.int64)[live])
+    rel = np.abs(first.cpu().numpy().astype(np.float64) - yd)[live] / np.abs(yd[live])
+    assert rel.max() <= (1e-6 if dtype == np.float32 else 1e-14), rel.max()
+    assert np.all(first.cpu().numpy()[~live] == 0)
+    plan.close()
+
+
+def test_out_of_range_column_index_is_refused():
+    """A column index outside [0, cols) must not be binned (it would address another panel's keys): LOOPS_E_BADARG."""
+    from loops_amd import spmv as S, _lib as L
+    off = np.array([0, 2, 3], np.int32)
+    for bad in (7, -1):
+        idx = np.array([0, bad, 1], np.int32)
+        csr = _dev(off, idx, np.ones(3, np.float32), 2, 5)
+        with pytest.raises(L.LoopsError, match="BADARG"):
+            S.PanelBinnedPlan(csr)

@@ -411,6 +411,31 @@ def test_bench_two_ranks_functional():
         assert d["config"]["parity_vs_oracle_bit_exact"] is True and exchange in d["config"]["step_includes"]
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2 ...` the way the driver starts N = 1 -- no torchrun, no WORLD_SIZE in the environment: bench.py
+    re-executes itself under torch.distributed.run (bench.self_launch), rank 0's one JSON line comes through on stdout and the
+    exit status is the job's.  Two ranks share cuda:0 over gloo here, as in the test above."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--backend", "gloo",
+           "--single-device", "--c5-log2-rows", "17", "--c5-log2-nnz", "21", "--no-one-gpu-reference"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "no launcher in the environment" in r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["config"]["parity_vs_oracle_bit_exact"] is True
+    regions = d["config"]["timed_regions_ms_per_step"]
+    assert len(regions) >= 5 and abs(d["ms_per_step"] - float(np.median(regions))) < 1e-4
+    # a rank that dies takes the job down with a non-zero status (an unknown exchange name fails on every rank)
+    r = subprocess.run(cmd + ["--exchange", "no-such-exchange"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_launch_box_autotuner():
     """Every compiled tile shape is timed on the matrix; the winner is one of them and y is A x."""
     from loops_amd import spmv as S, generate as G, _lib
