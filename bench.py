@@ -892,6 +892,27 @@ def main():
                 exchange_dropped[name] = bad
             chunked.pop(name, None)
         wd.disarm()
+        if args.backend == "nccl":
+            # the same grouped point-to-point exchange issued by the library itself (loops_allgatherv_f32 on a communicator of
+            # its own, include/loops/multi_gpu/allgatherv.hxx): no Python op list, no work objects per call.  RCCL only (two
+            # ranks of the gloo functional test share one device, which RCCL refuses).
+            wd.arm("exchange candidate native-p2p", 300)
+            why = None
+            try:
+                exchanges["native-p2p"] = P.NativeAllgatherv(y_full, shard)
+            except Exception as e:  # noqa: BLE001
+                why = f"{type(e).__name__}: {e}"
+            ok, bad = agreed(why is None, why)
+            if ok:
+                gather_mode["mode"] = "native-p2p"
+                if reproduces("native-p2p"):
+                    exchange_probe["native-p2p"] = probe_ms()
+            else:
+                exchange_dropped["native-p2p"] = bad
+                exchanges.pop("native-p2p", None)
+                if rank == 0:
+                    print(f"[rank 0] exchange candidate native-p2p dropped: {bad}", file=sys.stderr)
+            wd.disarm()
         if args.no_fused_stores:
             exchange_dropped["fused-stores"] = {"all ranks": "--no-fused-stores"}
         else:

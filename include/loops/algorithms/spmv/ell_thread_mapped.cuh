@@ -34,9 +34,21 @@ __global__ void __ell_thread_mapped(setup_t config, const index_t* indices, cons
   }
 }
 
+/// The drop-in entry (reference ell_thread_mapped.cuh:53: y overwritten, the call returns after the stream has drained):
+/// since round 4 it launches the row-split kernel (loops/kernels/ell_spmv.hxx: G lanes per row read it as contiguous
+/// 16-byte pieces and reduce across lanes; C2-shaped ELL 0.405 -> 0.094 ms).  The reference's lane-per-row kernel stays as
+/// `__ell_thread_mapped` behind ell_thread_mapped_schedule_api.
 template <typename index_t, typename type_t>
 void ell_thread_mapped(ell_t<index_t, type_t>& ell, vector_t<type_t>& x, vector_t<type_t>& y,
                        xpu::stream_t stream = 0) {
+  kernels::launch_ell_row_split(stream, ell.rows, ell.pitch, ell.indices.data().get(), ell.values.data().get(),
+                                x.data().get(), y.data().get());
+  (void)xpu::stream_synchronize(stream);
+}
+
+template <typename index_t, typename type_t>
+void ell_thread_mapped_schedule_api(ell_t<index_t, type_t>& ell, vector_t<type_t>& x, vector_t<type_t>& y,
+                                    xpu::stream_t stream = 0) {
   using layout_t = layout::ell<index_t, index_t>;
   using setup_t = schedule::setup<schedule::algorithms_t::thread_mapped, 1, 1, index_t, index_t, std::size_t,
                                   std::size_t, layout_t>;
@@ -49,13 +61,10 @@ void ell_thread_mapped(ell_t<index_t, type_t>& ell, vector_t<type_t>& x, vector_
   (void)xpu::stream_synchronize(stream);
 }
 
-/// Tuned ELL SpMV: G lanes per row read it as contiguous 16-byte pieces and reduce across lanes
-/// (loops/kernels/ell_spmv.hxx); same contract as ell_thread_mapped (y overwritten).
+/// The name the row-split kernel had before ell_thread_mapped was routed to it (kept for callers of rounds 1-3).
 template <typename index_t, typename type_t>
 void ell_row_mapped(ell_t<index_t, type_t>& ell, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
-  kernels::launch_ell_row_split(stream, ell.rows, ell.pitch, ell.indices.data().get(), ell.values.data().get(),
-                                x.data().get(), y.data().get());
-  (void)xpu::stream_synchronize(stream);
+  ell_thread_mapped(ell, x, y, stream);
 }
 
 }  // namespace spmv

@@ -14,6 +14,7 @@
  */
 #pragma once
 
+#include <exception>
 #include <memory>
 
 #include <loops/algorithms/spmv/column_blocked.cuh>
@@ -58,12 +59,20 @@ struct spmv_plan_t {
       }
       if (allow_copy && work && x_bytes > (std::size_t(6) << 20)) {   // (the rule of loops_spmv_plan_create_* without MEASURE)
         const bool want_panel = sizeof(type_t) == 4 || x_bytes >= (std::size_t(32) << 20);
-        if (want_panel && fits_panel(csr)) {
-          panel = std::make_unique<panel_t>(csr, 0, stream);
-          layout = panel_binned_layout;
-        } else if (!want_panel && csr.nnzs / csr.rows >= 8 && fits_blocked(csr)) {
-          blocked = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
-          layout = column_blocked_layout;
+        // (the copy is OPTIONAL: a build that fails -- no memory for it -- leaves the plan on the CSR, as the measured path does)
+        try {
+          if (want_panel && fits_panel(csr)) {
+            panel = std::make_unique<panel_t>(csr, 0, stream);
+            layout = panel_binned_layout;
+          } else if (!want_panel && csr.nnzs / csr.rows >= 8 && fits_blocked(csr)) {
+            blocked = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
+            layout = column_blocked_layout;
+          }
+        } catch (const std::exception&) {
+          (void)hipGetLastError();  // clear the sticky error of the failed allocation
+          panel.reset();
+          blocked.reset();
+          layout = csr_layout;
         }
         if (layout != csr_layout) {
           small.reset();

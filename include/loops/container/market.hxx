@@ -14,8 +14,10 @@
 #pragma once
 
 #include <cstddef>
+#include <exception>
 #include <limits>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -78,6 +80,7 @@ struct matrix_market_t {
       std::vector<index_t> r, c;
       std::vector<type_t> v;
       std::string error;        // the first malformed line of the chunk: entry number r.size() of it
+      bool failed = false;      // a worker threw (out of memory): `error` says what
       std::size_t used = 0;     // entries that count (the first dims[2] of the file)
       std::size_t out = 0;      // ... plus mirrored ones
       std::size_t out_at = 0;
@@ -128,14 +131,41 @@ struct matrix_market_t {
         ch.v.push_back(static_cast<type_t>(w));
       }
     };
-    auto on_all = [&](auto&& work) {   // work(chunk index) on every chunk, one thread each
-      if (pieces == 1) { work(std::size_t(0)); return; }
+    // work(chunk index) on every chunk, one thread each.  Exception-safe: whatever a worker throws (bad_alloc in a reserve /
+    // push_back) is recorded in its chunk and rethrown as exception_t by the caller's checks; a thread that cannot be started
+    // (system_error) makes this thread do the chunk itself; every started thread is joined before the function returns.
+    auto on_all = [&](auto&& work) {
+      auto guarded = [&work, &chunks](std::size_t k) {
+        try {
+          work(k);
+        } catch (const std::exception& e) {
+          chunks[k].error = std::string("matrix-market: ") + e.what();
+          chunks[k].failed = true;
+        } catch (...) {
+          chunks[k].error = "matrix-market: unknown failure while reading the body";
+          chunks[k].failed = true;
+        }
+      };
+      if (pieces == 1) { guarded(std::size_t(0)); return; }
       std::vector<std::thread> pool;
       pool.reserve(pieces);
-      for (std::size_t k = 0; k < pieces; ++k) pool.emplace_back([&work, k] { work(k); });
-      for (auto& t : pool) t.join();
+      struct join_all {
+        std::vector<std::thread>& p;
+        ~join_all() { for (auto& t : p) if (t.joinable()) t.join(); }
+      } joiner{pool};
+      for (std::size_t k = 0; k < pieces; ++k) {
+        try {
+          pool.emplace_back([&guarded, k] { guarded(k); });
+        } catch (const std::system_error&) {
+          guarded(k);
+        }
+      }
+    };
+    auto rethrow = [&chunks] {
+      for (auto& ch : chunks) error::throw_if_exception(ch.failed, ch.error);
     };
     on_all([&](std::size_t k) { parse(chunks[k], dims[2] / pieces + dims[2] / (8 * pieces) + 16); });
+    rethrow();
     std::size_t total = 0;
     for (auto& ch : chunks) {
       const std::size_t need = dims[2] - total;

@@ -127,10 +127,12 @@ int launch_csc_nonzero_split(hipStream_t stream, int cols, int nnz, const offset
 // radix-sorted; rows are counted on the way.
 
 /// key[k] = row << 32 | column of nonzero k (column by a search over the offsets), pos[k] = k, counts[row + 1] += 1.
+/// A row index outside [0, rows) sets *bad and is counted nowhere (the caller refuses the input after the pass).
 template <typename index_t, typename offset_t>
 __global__ void __launch_bounds__(256)
-csc_transpose_keys(const int cols, const int nnz, const offset_t* __restrict__ col_offsets, const index_t* __restrict__ row_indices,
-                   unsigned long long* __restrict__ keys, int* __restrict__ pos, int* __restrict__ counts) {
+csc_transpose_keys(const int rows, const int cols, const int nnz, const offset_t* __restrict__ col_offsets,
+                   const index_t* __restrict__ row_indices, unsigned long long* __restrict__ keys, int* __restrict__ pos,
+                   int* __restrict__ counts, int* __restrict__ bad) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
   int col = 0, count = cols;   // last c with col_offsets[c] <= k
@@ -139,23 +141,28 @@ csc_transpose_keys(const int cols, const int nnz, const offset_t* __restrict__ c
     if (col_offsets[col + half] <= k) { col += half; count -= half; }
     else count = half;
   }
-  const unsigned int r = static_cast<unsigned int>(row_indices[k]);
+  unsigned int r = static_cast<unsigned int>(row_indices[k]);
+  const bool ok = r < static_cast<unsigned int>(rows);
+  if (!ok) { *bad = 1; r = 0; }
   keys[k] = (static_cast<unsigned long long>(r) << 32) | static_cast<unsigned int>(col);
   pos[k] = k;
-  atomicAdd(counts + r + 1, 1);
+  if (ok) atomicAdd(counts + r + 1, 1);
 }
 
-/// The same keys from COO triplets (any order): key[k] = row << 32 | column.
+/// The same keys from COO triplets (any order): key[k] = row << 32 | column; a row or column index out of range sets *bad.
 template <typename index_t>
 __global__ void __launch_bounds__(256)
-coo_transpose_keys(const int nnz, const index_t* __restrict__ row_indices, const index_t* __restrict__ col_indices,
-                   unsigned long long* __restrict__ keys, int* __restrict__ pos, int* __restrict__ counts) {
+coo_transpose_keys(const int rows, const int cols, const int nnz, const index_t* __restrict__ row_indices,
+                   const index_t* __restrict__ col_indices, unsigned long long* __restrict__ keys, int* __restrict__ pos,
+                   int* __restrict__ counts, int* __restrict__ bad) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nnz) return;
-  const unsigned int r = static_cast<unsigned int>(row_indices[k]);
-  keys[k] = (static_cast<unsigned long long>(r) << 32) | static_cast<unsigned int>(col_indices[k]);
+  unsigned int r = static_cast<unsigned int>(row_indices[k]), c = static_cast<unsigned int>(col_indices[k]);
+  const bool ok = r < static_cast<unsigned int>(rows) && c < static_cast<unsigned int>(cols);
+  if (!ok) { *bad = 1; r = 0; c = 0; }
+  keys[k] = (static_cast<unsigned long long>(r) << 32) | c;
   pos[k] = k;
-  atomicAdd(counts + r + 1, 1);
+  if (ok) atomicAdd(counts + r + 1, 1);
 }
 
 /// indices[i] = column of the i-th nonzero in (row, column) order, values[i] = its value.

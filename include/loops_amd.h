@@ -444,6 +444,28 @@ int loops_csc_plan_refresh_values_f64(loops_csc_plan_t* plan, const double* valu
 int loops_spmv_csc_planned_f32(const loops_csc_plan_t* plan, const float* x, float* y, void* stream);
 int loops_spmv_csc_planned_f64(const loops_csc_plan_t* plan, const double* x, double* y, void* stream);
 
+/* ---- multi-GPU: row-range partition + allgatherv over RCCL (include/loops/multi_gpu/) --------------------------------------
+ * The reference is single-GPU; this is the leg BASELINE.json's C5 adds.  y = A x is independent per row: the CSR is cut into
+ * `parts` contiguous row ranges balanced by rows + nonzeros (the merge-path diagonal split the kernels use per workgroup,
+ * reference include/loops/util/search.hxx:35-60, applied per GPU), x is replicated, and the slices of y are exchanged by one
+ * group of RCCL point-to-point operations (every xGMI link once, all at the same time).
+ * loops_row_ranges: HOST function over HOST offsets (rows + 1 entries); bounds has parts + 1 entries; LOOPS_E_RANGE when
+ * rows + nnz reaches 2^31.
+ * loops_comm_*: a communicator of this library's own (ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy of the RCCL the
+ * process has loaded -- resolved at run time, no link-time dependency): rank 0 obtains the 128-byte id, the caller ships it to
+ * the other ranks (any transport), every rank calls loops_comm_init.  A caller that already owns an ncclComm_t passes that
+ * instead (same RCCL instance).  LOOPS_E_CONFIG: no RCCL entry points found in the process or on the library path; other
+ * non-zero codes are ncclResult_t values (loops_comm_error_string).
+ * loops_allgatherv_*: on entry rank r has written y_full[bounds[r] .. bounds[r + 1]); after the call (stream-ordered) y_full
+ * is complete on every rank.  `bounds` is a HOST array.  Unmeasured on multi-GPU hardware so far. */
+int loops_row_ranges(int rows, const int* offsets, int parts, long long* bounds);
+int loops_comm_unique_id(void* id128);
+int loops_comm_init(int world, int rank, const void* id128, void** comm);
+int loops_comm_destroy(void* comm);
+const char* loops_comm_error_string(int code);
+int loops_allgatherv_f32(void* comm, int rank, int world, float* y_full, const long long* bounds, void* stream);
+int loops_allgatherv_f64(void* comm, int rank, int world, double* y_full, const long long* bounds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ SYMBOLS = [
     "loops_csc_plan_create_f32", "loops_csc_plan_create_f64", "loops_coo_plan_create_f32", "loops_coo_plan_create_f64", "loops_csc_plan_destroy", "loops_csc_plan_info",
     "loops_csc_plan_refresh_values_f32", "loops_csc_plan_refresh_values_f64", "loops_spmv_csc_planned_f32", "loops_spmv_csc_planned_f64",
     "loops_panel_plan_create_layout_f32", "loops_panel_plan_create_layout_f64", "loops_panel_plan_layout",
+    "loops_row_ranges", "loops_comm_unique_id", "loops_comm_init", "loops_comm_destroy", "loops_comm_error_string",
+    "loops_allgatherv_f32", "loops_allgatherv_f64",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
 
@@ -206,6 +208,14 @@ def lib() -> C.CDLL:
         L.loops_panel_plan_destroy.restype = None
         L.loops_panel_plan_info.argtypes = [vp, vp]
         L.loops_panel_plan_layout.argtypes = [vp, vp]
+        L.loops_row_ranges.argtypes = [ci, vp, ci, vp]
+        L.loops_comm_unique_id.argtypes = [vp]
+        L.loops_comm_init.argtypes = [ci, ci, vp, C.POINTER(vp)]
+        L.loops_comm_destroy.argtypes = [vp]
+        L.loops_comm_error_string.argtypes = [ci]
+        L.loops_comm_error_string.restype = C.c_char_p
+        L.loops_allgatherv_f32.argtypes = [vp, ci, ci, vp, vp, vp]
+        L.loops_allgatherv_f64.argtypes = [vp, ci, ci, vp, vp, vp]
         L.loops_panel_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.loops_panel_plan_windows.argtypes = [vp, vp, vp, vp]
         L.loops_spmv_panel_stage_f32.argtypes = [vp, ci, vp, vp, vp]

@@ -13,6 +13,8 @@
 #include <new>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
 
 #include <loops/schedule.hxx>
@@ -22,6 +24,7 @@
 #include <loops/kernels/launch.hxx>
 #include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/panel_binned.hxx>
+#include <loops/multi_gpu/partition.hxx>
 #include <loops/kernels/coo_spmv.hxx>
 #include <loops/kernels/ell_spmv.hxx>
 #include <loops/kernels/dia_spmv.hxx>
@@ -805,6 +808,10 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
       }
       if (!err && p->layout != LOOPS_LAYOUT_CSR) { plan_release(p->merge); p->merge = nullptr; }
       else if (err == LOOPS_E_RANGE || err == LOOPS_E_CONFIG) err = 0;  // the copy does not fit 32-bit positions: stay on the CSR
+      else if (err == static_cast<int>(hipErrorOutOfMemory)) {            // no memory for the OPTIONAL copy: stay on the CSR, as
+        (void)hipGetLastError();                                          // the measured path does (clear the sticky error)
+        err = 0;
+      }
     }
     if (err) { spmv_plan_free(p); return err; }
     *out = p;
@@ -942,11 +949,14 @@ int csc_plan_create(int rows, int cols, int nnz, const int* col_off, const int* 
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&pos), sizeof(int) * n);
   size_t cub_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
   if (e == hipSuccess) e = hipMalloc(&cub_temp, cub_bytes > 0 ? cub_bytes : 16);
+  int* bad = nullptr;   // set by the key kernels when an index lies outside the matrix
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&bad), sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), st);
   if (e == hipSuccess) e = hipMemsetAsync(p->off, 0, sizeof(int) * (static_cast<size_t>(rows) + 1), st);
   if (e == hipSuccess && nnz > 0) {
     const dim3 grid(math::ceil_div(nnz, 256)), block(256);
-    if (col_off) hipLaunchKernelGGL((kernels::csc_transpose_keys<int, int>), grid, block, 0, st, cols, nnz, col_off, row_idx, keys_in, pos, p->off);
-    else hipLaunchKernelGGL((kernels::coo_transpose_keys<int>), grid, block, 0, st, nnz, row_idx, col_idx, keys_in, pos, p->off);
+    if (col_off) hipLaunchKernelGGL((kernels::csc_transpose_keys<int, int>), grid, block, 0, st, rows, cols, nnz, col_off, row_idx, keys_in, pos, p->off, bad);
+    else hipLaunchKernelGGL((kernels::coo_transpose_keys<int>), grid, block, 0, st, rows, cols, nnz, row_idx, col_idx, keys_in, pos, p->off, bad);
     size_t bytes = cub_bytes;
     e = hipcub::DeviceRadixSort::SortPairs(cub_temp, bytes, keys_in, keys_out, pos, p->perm, nnz, 0, end_bit, st);
     if (e == hipSuccess) hipLaunchKernelGGL((kernels::csc_transpose_finish<int, T>), grid, block, 0, st, nnz, keys_out, p->perm, val, p->idx, static_cast<T*>(p->val));
@@ -956,9 +966,12 @@ int csc_plan_create(int rows, int cols, int nnz, const int* col_off, const int* 
     e = hipcub::DeviceScan::InclusiveSum(cub_temp, bytes, p->off, p->off, rows + 1, st);
   }
   if (e == hipSuccess) e = hipGetLastError();
+  int h_bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(pos); (void)hipFree(cub_temp);
+  (void)hipFree(keys_in); (void)hipFree(keys_out); (void)hipFree(pos); (void)hipFree(cub_temp); (void)hipFree(bad);
   int err = static_cast<int>(e);
+  if (!err && h_bad) err = LOOPS_E_BADARG;  // a row (or COO column) index outside the matrix
   if (!err) err = spmv_plan_create<T>(rows, cols, nnz, p->off, p->idx, static_cast<const T*>(p->val), flags, repeats, st, &p->inner);
   if (err) { csc_plan_free(p); return err; }
   *out = p;
@@ -1525,4 +1538,116 @@ int loops_spmv_csc_planned_f64(const loops_csc_plan_t* plan, const double* x, do
   return csc_plan_spmv<double>(plan, x, y, as_stream(stream));
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------ multi-GPU: partition + RCCL allgatherv
+// The RCCL entry points are resolved at run time (no link-time dependency, and -- in a Python process -- the RCCL instance
+// PyTorch has already loaded is the one used): first the process's global symbols, then a library that is already mapped
+// under the name librccl.so / librccl.so.1 (RTLD_NOLOAD), then the library path.
+namespace {
+struct rccl_api {
+  using result_t = int;  // ncclResult_t
+  result_t (*GetUniqueId)(void*) = nullptr;
+  // ncclUniqueId is a 128-byte struct passed BY VALUE: the same calling convention as this stand-in
+  struct unique_id { char internal[128]; };
+  result_t (*CommInitRank)(void**, int, unique_id, int) = nullptr;
+  result_t (*CommDestroy)(void*) = nullptr;
+  result_t (*GroupStart)() = nullptr;
+  result_t (*GroupEnd)() = nullptr;
+  result_t (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  result_t (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(result_t) = nullptr;
+  bool ok = false;
+};
+
+const rccl_api& rccl() {
+  static const rccl_api api = [] {
+    rccl_api a;
+    void* handles[4] = {RTLD_DEFAULT, nullptr, nullptr, nullptr};
+    if (!dlsym(RTLD_DEFAULT, "ncclSend")) {
+      int n = 0;
+      for (const char* name : {"librccl.so", "librccl.so.1"})
+        if (void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD)) { handles[n++] = h; break; }
+      if (n == 0)
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+          if (void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) { handles[n++] = h; break; }
+      if (n == 0) return a;
+    }
+    void* h = handles[0];
+    auto sym = [&](const char* name) { return dlsym(h, name); };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv;
+    return a;
+  }();
+  return api;
+}
+
+// ncclDataType_t (rccl.h:466-467): ncclFloat32 = 7, ncclFloat64 = 8
+template <typename T> constexpr int nccl_dtype() { return sizeof(T) == 4 ? 7 : 8; }
+
+// The same group of sends / receives as multi_gpu::allgatherv (include/loops/multi_gpu/allgatherv.hxx), through the resolved
+// entry points.
+template <typename T>
+int allgatherv_rt(void* comm, int rank, int world, T* y_full, const long long* bounds, hipStream_t st) {
+  if (world <= 1) return 0;
+  if (!comm || !y_full || !bounds || rank < 0 || rank >= world) return LOOPS_E_BADARG;
+  const rccl_api& r = rccl();
+  if (!r.ok) return LOOPS_E_CONFIG;
+  const size_t mine = static_cast<size_t>(bounds[rank + 1] - bounds[rank]);
+  int rc = r.GroupStart();
+  for (int peer = 0; peer < world && rc == 0; ++peer) {
+    if (peer == rank) continue;
+    const size_t theirs = static_cast<size_t>(bounds[peer + 1] - bounds[peer]);
+    if (mine) rc = r.Send(y_full + bounds[rank], mine, nccl_dtype<T>(), peer, comm, st);
+    if (theirs && rc == 0) rc = r.Recv(y_full + bounds[peer], theirs, nccl_dtype<T>(), peer, comm, st);
+  }
+  const int e = r.GroupEnd();
+  return rc ? rc : e;
+}
+}  // namespace
+
+extern "C" {
+int loops_row_ranges(int rows, const int* offsets, int parts, long long* bounds) {
+  if (rows < 0 || !offsets || parts < 1 || !bounds) return LOOPS_E_BADARG;
+  if (static_cast<long long>(rows) + offsets[rows] >= (1ll << 31)) return LOOPS_E_RANGE;
+  return multi_gpu::row_ranges(offsets, static_cast<size_t>(rows), parts, bounds) ? 0 : LOOPS_E_BADARG;
+}
+int loops_comm_unique_id(void* id128) {
+  if (!id128) return LOOPS_E_BADARG;
+  const rccl_api& r = rccl();
+  return r.ok ? r.GetUniqueId(id128) : LOOPS_E_CONFIG;
+}
+int loops_comm_init(int world, int rank, const void* id128, void** comm) {
+  if (!id128 || !comm || world < 1 || rank < 0 || rank >= world) return LOOPS_E_BADARG;
+  const rccl_api& r = rccl();
+  if (!r.ok) return LOOPS_E_CONFIG;
+  rccl_api::unique_id id;
+  __builtin_memcpy(&id, id128, sizeof(id));
+  return r.CommInitRank(comm, world, id, rank);
+}
+int loops_comm_destroy(void* comm) {
+  if (!comm) return 0;
+  const rccl_api& r = rccl();
+  return r.ok ? r.CommDestroy(comm) : LOOPS_E_CONFIG;
+}
+const char* loops_comm_error_string(int code) {
+  if (code == LOOPS_E_BADARG) return "LOOPS_E_BADARG";
+  if (code == LOOPS_E_RANGE) return "LOOPS_E_RANGE";
+  if (code == LOOPS_E_CONFIG) return "LOOPS_E_CONFIG: no RCCL entry points in this process or on the library path";
+  const rccl_api& r = rccl();
+  return r.ok && r.GetErrorString ? r.GetErrorString(code) : "unknown";
+}
+int loops_allgatherv_f32(void* comm, int rank, int world, float* y_full, const long long* bounds, void* stream) {
+  return allgatherv_rt<float>(comm, rank, world, y_full, bounds, as_stream(stream));
+}
+int loops_allgatherv_f64(void* comm, int rank, int world, double* y_full, const long long* bounds, void* stream) {
+  return allgatherv_rt<double>(comm, rank, world, y_full, bounds, as_stream(stream));
+}
 }  // extern "C"

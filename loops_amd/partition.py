@@ -41,7 +41,23 @@ def merge_path_split(offsets: np.ndarray, diagonal: int) -> tuple[int, int]:
 
 def row_ranges(offsets: np.ndarray, parts: int) -> np.ndarray:
     """parts + 1 row boundaries: range p = [b[p], b[p+1]) holds ~ (rows + nnz) / parts merge items.
-    A boundary that falls inside a row moves to that row's start (rows are never split)."""
+    A boundary that falls inside a row moves to that row's start (rows are never split).
+    Computed by the library (loops_row_ranges: include/loops/multi_gpu/partition.hxx, the kernels' own
+    `search::_binary_search`) whenever the offsets fit its 32-bit arithmetic; `row_ranges_numpy` is the specification
+    it is tested against and the path of larger inputs."""
+    rows = offsets.size - 1
+    if rows + int(offsets[-1]) < (1 << 31) and parts >= 1:
+        from . import _lib as L
+        import ctypes as C
+        off32 = np.ascontiguousarray(offsets, np.int32)
+        b = np.zeros(parts + 1, np.int64)
+        L.check(L.lib().loops_row_ranges(rows, off32.ctypes.data_as(C.c_void_p), parts, b.ctypes.data_as(C.c_void_p)), "loops_row_ranges")
+        return b
+    return row_ranges_numpy(offsets, parts)
+
+
+def row_ranges_numpy(offsets: np.ndarray, parts: int) -> np.ndarray:
+    """The specification of `row_ranges` in numpy / Python integers (any size)."""
     rows = offsets.size - 1
     total = rows + int(offsets[-1])
     b = np.zeros(parts + 1, np.int64)
@@ -317,3 +333,65 @@ class FusedFanout:
                 self._token = torch.zeros(1, dtype=torch.float32, device=self.y_full.device)
             dist.all_reduce(self._token, group=self.group)
         return self.y_full
+
+
+class NativeComm:
+    """A communicator of the library's own (loops_comm_*: ncclGetUniqueId / ncclCommInitRank of the RCCL instance this
+    process has loaded, resolved at run time) next to the torch.distributed process group: rank 0 obtains the 128-byte id,
+    the group broadcasts it (any backend), every rank joins.  What a C++ caller does with its own ncclComm_t
+    (include/loops/multi_gpu/allgatherv.hxx), reachable from Python.  Collective."""
+
+    def __init__(self, rank: int, world: int, group=None):
+        import ctypes as C
+        from . import _lib as L
+        self.rank, self.world = rank, world
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            L.check(L.lib().loops_comm_unique_id(ident), "loops_comm_unique_id")
+        if world > 1:
+            box = [bytes(ident.raw) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            ident = (C.c_char * 128).from_buffer_copy(box[0])
+        self._h = C.c_void_p()
+        code = L.lib().loops_comm_init(world, rank, ident, C.byref(self._h))
+        if code != 0:
+            raise L.LoopsError(f"loops_comm_init failed: {L.lib().loops_comm_error_string(code).decode()}")
+
+    def allgatherv(self, y_full: torch.Tensor, bounds: np.ndarray) -> torch.Tensor:
+        """In place, asynchronous on torch's current stream: rank r has written y_full[bounds[r]:bounds[r + 1]]."""
+        import ctypes as C
+        from . import _lib as L
+        assert y_full.is_cuda and y_full.is_contiguous() and y_full.dtype in (torch.float32, torch.float64)
+        b = np.ascontiguousarray(bounds, np.int64)
+        assert b.size == self.world + 1 and int(b[-1]) <= y_full.numel()
+        fn = L.lib().loops_allgatherv_f32 if y_full.dtype == torch.float32 else L.lib().loops_allgatherv_f64
+        code = fn(self._h, self.rank, self.world, C.c_void_p(y_full.data_ptr()), b.ctypes.data_as(C.c_void_p),
+                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if code != 0:
+            raise L.LoopsError(f"loops_allgatherv failed: {L.lib().loops_comm_error_string(code).decode()}")
+        return y_full
+
+    def close(self):
+        if getattr(self, "_h", None):
+            from . import _lib as L
+            L.lib().loops_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class NativeAllgatherv:
+    """`Allgatherv` with the exchange issued by the library (loops_allgatherv_*: one ncclGroupStart / Send / Recv / GroupEnd
+    on its own communicator, on torch's current stream) instead of torch.distributed.batch_isend_irecv: no Python op list,
+    no per-call work objects.  Exchange mode "native-p2p" of bench.py."""
+
+    def __init__(self, y_full: torch.Tensor, shard: Shard, group=None):
+        self.y_full, self.shard = y_full, shard
+        self.comm = NativeComm(shard.rank, shard.world, group)
+
+    def run(self) -> torch.Tensor:
+        return self.comm.allgatherv(self.y_full, self.shard.bounds)

@@ -108,11 +108,13 @@ static void run_battery() {
     { auto y = fresh(); algorithms::spmv::flat_partitioned<4>(csr, x, y); check_y("flat_partitioned<4>", m, y, ref); }
     if (h.rows && h.nnzs) {
       { coo_t<int, T> coo(csr); auto y = fresh(); algorithms::spmv::coo_run_mapped(coo, x, y); check_y("coo_run_mapped", m, y, ref); }
+      { coo_t<int, T> coo(csr); auto y = fresh(); algorithms::spmv::coo_thread_mapped_schedule_api(coo, x, y); check_y("coo_thread_mapped_schedule_api", m, y, ref); }
       { coo_t<int, T> coo(csr); auto y = fresh(); algorithms::spmv::coo_thread_mapped(coo, x, y); check_y("coo_thread_mapped", m, y, ref);
         csr_t<int, int, T> again(coo);  // device-side COO -> CSR (radix sort + lower_bound)
         vector_t<int, H> o2(again.offsets); bool same = true; for (std::size_t i = 0; i <= h.rows; ++i) same = same && o2[i] == h.offsets[i]; CHECK(same); }
       { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_thread_mapped(csc, x, y); check_y("csc_thread_mapped", m, y, ref); }
       { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_nonzero_mapped(csc, x, y); check_y("csc_nonzero_mapped", m, y, ref); }
+      { csc_t<int, int, T> csc(csr); auto y = fresh(); algorithms::spmv::csc_thread_mapped_schedule_api(csc, x, y); check_y("csc_thread_mapped_schedule_api", m, y, ref); }
       {  // CSC -> COO -> CSR on the device (coo_t(csc), csr_t(coo)), then the headline schedule: the transposed-once path
         csc_t<int, int, T> csc(csr);
         coo_t<int, T> coo(csc);
@@ -122,11 +124,13 @@ static void run_battery() {
         check_y("merge_path_flat over csr_t(coo_t(csc))", m, y, ref);
       }
       { ell_t<int, T> ell(csr); auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_row_mapped(ell, x, y); check_y("ell_row_mapped", m, y, ref); }
+      { ell_t<int, T> ell(csr); auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_thread_mapped_schedule_api(ell, x, y); check_y("ell_thread_mapped_schedule_api", m, y, ref); }
       { ell_t<int, T> ell(csr); auto y = fresh(); algorithms::spmv::ell_thread_mapped(ell, x, y); check_y("ell_thread_mapped", m, y, ref);
         auto y2 = vector_t<T>(h.rows, T(7)); algorithms::spmv::ell_merge_path(ell, x, y2); check_y("ell_merge_path", m, y2, ref);  // fused engine: y not pre-zeroed
         auto y3 = fresh(); algorithms::spmv::ell_merge_path_atomic(ell, x, y3); check_y("ell_merge_path_atomic", m, y3, ref); }
       if (h.cols <= 64) { dia_t<int, int, T> dia(csr); auto y = fresh(); algorithms::spmv::dia_thread_mapped(dia, x, y); check_y("dia_thread_mapped", m, y, ref);
-        auto y2 = vector_t<T>(h.rows, T(7)); algorithms::spmv::dia_row_mapped(dia, x, y2); check_y("dia_row_mapped", m, y2, ref); }
+        auto y2 = vector_t<T>(h.rows, T(7)); algorithms::spmv::dia_row_mapped(dia, x, y2); check_y("dia_row_mapped", m, y2, ref);
+        auto y3 = vector_t<T>(h.rows, T(7)); algorithms::spmv::dia_thread_mapped_schedule_api(dia, x, y3); check_y("dia_thread_mapped_schedule_api", m, y3, ref); }
       auto bcsr_case = [&](auto b, const char* what) {
         vector_t<T, H> xp(b.num_block_cols * b.kBlockCols, T(0));
         for (std::size_t i = 0; i < h.cols; ++i) xp[i] = xh[i];
@@ -290,14 +294,23 @@ static void misc() {
       for (std::size_t i = 0; i < g0.size(); ++i) same = same && std::fabs(g0[i] - g1[i]) <= 1e-9 + 1e-12 * std::fabs(g0[i]);
       CHECK(same);
     }
-  // tuned SpMM == reference-shaped SpMM (every battery matrix, several widths of B, f32 + f64)
+  // the drop-in spmm::thread_mapped (merge-path SpMM since round 4) == the reference-shaped per-thread loop kept behind
+  // thread_mapped_schedule_api == spmm::merge_path_flat (every battery matrix, several widths of B, f32 + f64)
   for (auto& dense : battery())
     for (int n : {1, 4, 10, 32, 70}) {
       hcsr_t<float> hf = from_dense<float>(dense);
       csr_t<int, int, float> a(hf);
       matrix_t<float> Bn(hf.cols, n), C0(hf.rows, n), C1(hf.rows, n);
       generate::random::uniform_distribution(Bn.m_data.begin(), Bn.m_data.end(), 1, 10, 5u);
-      algorithms::spmm::thread_mapped(a, Bn, C0);
+      algorithms::spmm::thread_mapped_schedule_api(a, Bn, C0);
+      {
+        matrix_t<float> C2(hf.rows, n);
+        algorithms::spmm::thread_mapped(a, Bn, C2);
+        vector_t<float, H> c0(C0.m_data), c2(C2.m_data);
+        bool same = true;
+        for (std::size_t i = 0; i < c0.size(); ++i) same = same && std::fabs(c0[i] - c2[i]) <= 1e-3f + 1e-5f * std::fabs(c0[i]);
+        CHECK(same);
+      }
       auto timer = algorithms::spmm::merge_path_flat(a, Bn, C1);
       CHECK(timer.milliseconds() >= 0.f);
       vector_t<float, H> c0(C0.m_data), c1(C1.m_data);
@@ -308,8 +321,8 @@ static void misc() {
       csr_t<int, int, double> ad(hd);
       matrix_t<double> Bd(hd.cols, n), D0(hd.rows, n), D1(hd.rows, n);
       generate::random::uniform_distribution(Bd.m_data.begin(), Bd.m_data.end(), 1, 10, 5u);
-      algorithms::spmm::thread_mapped(ad, Bd, D0);
-      algorithms::spmm::merge_path_flat(ad, Bd, D1);
+      algorithms::spmm::thread_mapped_schedule_api(ad, Bd, D0);
+      algorithms::spmm::thread_mapped(ad, Bd, D1);
       vector_t<double, H> d0(D0.m_data), d1(D1.m_data);
       same = true;
       for (std::size_t i = 0; i < d0.size(); ++i) same = same && std::fabs(d0[i] - d1[i]) <= 1e-9 + 1e-12 * std::fabs(d0[i]);

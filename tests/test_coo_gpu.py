@@ -55,3 +55,24 @@ def test_powerlaw_bit_exact_and_unaligned(shift):
         assert np.array_equal(y.astype(np.float64), want), (shift, tuned)
     if not shift:
         assert np.array_equal(y, O.spmv_f32(off, idx, val, xh))
+
+
+def test_plans_refuse_indices_outside_the_matrix():
+    """loops_csc_plan_create_* / loops_coo_plan_create_*: a row index (COO: or a column index) outside the matrix must not be
+    counted into a neighbouring row's offset or the temporaries: LOOPS_E_BADARG, nothing corrupted (a good plan still works)."""
+    from loops_amd import spmv as S, _lib as L
+    rows, cols = 4, 5
+    good_r = torch.tensor([0, 1, 3, 3], dtype=torch.int32, device="cuda")
+    good_c = torch.tensor([0, 4, 2, 3], dtype=torch.int32, device="cuda")
+    vals = torch.ones(4, device="cuda")
+    for bad_r, bad_c in (([0, 4, 3, 3], [0, 4, 2, 3]), ([0, -1, 3, 3], [0, 4, 2, 3]), ([0, 1, 3, 3], [0, 5, 2, 3])):
+        with pytest.raises(L.LoopsError, match="BADARG"):
+            S.COOPlan(rows, cols, torch.tensor(bad_r, dtype=torch.int32, device="cuda"),
+                      torch.tensor(bad_c, dtype=torch.int32, device="cuda"), vals, measure=False)
+    col_off = torch.tensor([0, 1, 1, 2, 3, 4], dtype=torch.int32, device="cuda")
+    with pytest.raises(L.LoopsError, match="BADARG"):
+        S.CSCPlan(rows, cols, col_off, torch.tensor([0, 9, 3, 1], dtype=torch.int32, device="cuda"), vals, measure=False)
+    plan = S.COOPlan(rows, cols, good_r, good_c, vals, measure=False)
+    y = plan.spmv(torch.arange(1, cols + 1, dtype=torch.float32, device="cuda"))
+    assert y.cpu().tolist() == [1.0, 5.0, 0.0, 7.0]
+    plan.close()

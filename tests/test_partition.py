@@ -138,3 +138,60 @@ def test_column_block_bounds_respect_owners_and_budget():
             s = k // world
             if world * s * 2 <= max(max_blocks, world):                          # stopped early only because pieces are small enough
                 assert int(np.diff(owners).max()) * 4 // s <= (2 << 20)
+
+
+def test_native_row_ranges_match_the_numpy_specification():
+    """loops_row_ranges (include/loops/multi_gpu/partition.hxx through the C ABI: the kernels' own search on N - 1 diagonals,
+    a host function -- no GPU needed) against the numpy / Python-integer specification: battery matrices, power-law degrees,
+    empty rows at both ends, more parts than rows, one part; the ranges tile the rows and are balanced by rows + nnz."""
+    import ctypes as C
+    from loops_amd import generate as G, partition as P, _lib as L
+    from conftest import battery
+    cases = [np.asarray(off, np.int64) for (_, _, off, _, _) in battery().values()]
+    for rows, nnz, cap in ((1 << 13, 1 << 17, 1 << 11), (100_003, 1 << 20, 1 << 14), (5, 40, 10)):
+        deg = G.powerlaw_degrees(rows, nnz, cap=cap)
+        cases.append(np.concatenate([[0], np.cumsum(deg)]))
+    z = np.zeros(1000, np.int64)
+    z[400:600] = 7
+    cases.append(np.concatenate([[0], np.cumsum(z)]))                    # empty rows at both ends
+    for off in cases:
+        rows = off.size - 1
+        for parts in (1, 2, 3, 8, 17):
+            want = P.row_ranges_numpy(off, parts)
+            got = P.row_ranges(off, parts)
+            assert np.array_equal(got, want), (rows, parts)
+            assert got[0] == 0 and got[-1] == rows and np.all(np.diff(got) >= 0)
+            if rows and parts > 1:                                       # balanced: no range exceeds its share by more than one row's items
+                items = np.diff(got) + np.diff(off[got])
+                longest = int(np.diff(off).max(initial=0)) + 1
+                assert items.max() <= -(-(rows + int(off[-1])) // parts) + longest
+    # argument errors come back as codes, not crashes
+    off32 = np.array([0, 1, 2], np.int32)
+    b = np.zeros(3, np.int64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert L.lib().loops_row_ranges(2, p(off32), 0, p(b)) == -1
+    assert L.lib().loops_row_ranges(-1, p(off32), 2, p(b)) == -1
+    assert L.lib().loops_row_ranges(2, None, 2, p(b)) == -1
+    big = np.array([0, (1 << 31) - 2], np.int32)
+    assert L.lib().loops_row_ranges(1, p(big), 2, p(b)) == 0 and L.lib().loops_row_ranges(2, p(np.array([0, 1 << 30, (1 << 31) - 1], np.int32)), 2, p(b)) == -2
+
+
+@pytest.mark.gpu
+def test_native_communicator_world_size_one():
+    """loops_comm_* / loops_allgatherv_* on the one GPU a test box has: the RCCL entry points resolve inside this process (the
+    instance PyTorch loaded), a communicator of one rank initialises, the allgatherv of a one-rank partition leaves y alone and
+    returns success on torch's stream.  Two ranks cannot share a device under RCCL: the N > 1 flow is covered with gloo
+    (test_allgatherv_gloo) and by bench.py's probe, which lists "native-p2p" only where it worked on every rank."""
+    import torch
+    from loops_amd import partition as P
+    torch.cuda.set_device(0)
+    comm = P.NativeComm(0, 1)
+    y = torch.arange(1000, dtype=torch.float32, device="cuda")
+    want = y.clone()
+    comm.allgatherv(y, np.array([0, 1000], np.int64))
+    torch.cuda.synchronize()
+    assert torch.equal(y, want)
+    yd = torch.arange(10, dtype=torch.float64, device="cuda")
+    comm.allgatherv(yd, np.array([0, 10], np.int64))
+    comm.close()
+    comm.close()   # idempotent
