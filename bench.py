@@ -759,8 +759,8 @@ def main():
                        "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
                                        (f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)" if shard_kind == "blocked" else
-                                        f"panel-binned, {blocked.num_panels} panels of {blocked.W} columns x {blocked.num_subbands} sub-bands of {blocked.Hw} rows "
-                                        f"(x per GPU {cols * 4 >> 20} MB)"),
+                                        f"panel-binned{' (compact)' if blocked.compact else ''}, {blocked.num_panels} panels of {blocked.W} columns x "
+                                        f"{blocked.num_subbands} sub-bands of {blocked.Hw} rows (x per GPU {cols * 4 >> 20} MB)"),
                        "shard_layout_probe_ms": layout_probe,
                        "step_includes": step_includes,
                        "ms_per_step_with_prepass": None if R_["ms_with_prepass"] is None else round(R_["ms_with_prepass"], 5),
@@ -1058,11 +1058,13 @@ def main():
         torch.cuda.synchronize()
         ab = algorithmic_bytes(csr.rows, cols, csr.nnzs)
         R_["panel_info"] = {"panels": pb.num_panels, "panel_columns": pb.W, "subbands": pb.num_subbands, "subband_rows": pb.Hw,
+                            "compact": pb.compact, "runs_over_nnz": round(pb.runs / max(csr.nnzs, 1), 4),
                             "ms_per_step": round(ms_p, 5), "products_ms": round(ms_pa, 5), "reduce_ms": round(ms_pb, 5),
                             "GFLOPs": round(2.0 * nnz / (ms_p * 1e-3) / 1e9, 2), "frac": round(ab / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                             "equal_to_csr_result": bool(torch.equal(yp, y_loc)),
-                            "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/panel_binned.hxx): 17 B of streamed traffic per "
-                                    "nonzero instead of 8 B + a gather; not the headline"}
+                            "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/panel_binned.hxx): 7 B read per nonzero + "
+                                    "10 B per run of equal (row, panel) -- 17 B per nonzero when nothing is pre-summed -- instead of 8 B + a gather; "
+                                    "fp64 accumulators in LDS; not the headline"}
         pb.close()
 
     # for context at N = 1: the SAME kernel on a matrix of the same size whose columns are local (16 per row inside a
