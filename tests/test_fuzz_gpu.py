@@ -64,10 +64,14 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
         for sch in ("work_oriented", "group_mapped"):
             assert np.array_equal(cb.spmv_schedule(sch, x).cpu().numpy(), want), ("blocked", K, sch) + tag
     # panel-binned copy (automatic and smallest sub-bands) and the measured SpMV plan that may pick it
+    # (both forms of the B order: one slot per nonzero, and -- compact -- one per run of equal (row, panel) pre-summed by kernel A;
+    # with <= 9000 columns everything is one panel, so a row is one run cut only at kernel A's 256-item windows)
     for hw in (0, 64):
-        pb = S.PanelBinnedPlan(csr, hw)
-        assert np.array_equal(pb.spmv(x).cpu().numpy(), want), ("panel", hw) + tag
-        pb.close()
+        for compact in (None, False, True):
+            pb = S.PanelBinnedPlan(csr, hw, compact=compact)
+            y = torch.full((rows,), 5.0, device="cuda")
+            assert np.array_equal(pb.spmv(x, y).cpu().numpy(), want), ("panel", hw, compact, pb.compact) + tag
+            pb.close()
     sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=1)
     assert np.array_equal(sp.spmv(x).cpu().numpy(), want), ("spmv_plan", sp.info["layout"]) + tag
     sp.close()
