@@ -117,13 +117,16 @@ namespace panel {
 
 constexpr unsigned short pad_row = 0xFFFFu;
 
-/// key[i] = (segment of nonzero i) << 32 | i, row_of[i], counts[segment] += 1.  Lane per IPT consecutive nonzeros:
-/// one search for the row of the first, then a walk along the offsets (as colblock::make_keys).
+/// key[i] = (segment of nonzero i) << 32 | i and rc[i] = (row inside the sub-band) << 16 | (column inside the panel): everything
+/// the later passes need of a nonzero besides its value, so that they gather ONE word per item.  Lane per IPT consecutive
+/// nonzeros: one search for the row of the first, then a walk along the offsets (as colblock::make_keys).  No counting here:
+/// the per-segment counts come from the SORTED keys (segment_starts) -- one global atomic per item was 0.9 of this kernel's
+/// 0.92 ms on C2 (scattered atomics into L2 retire at ~18 G/s).
 template <int IPT, typename index_t, typename offset_t>
 __global__ void __launch_bounds__(256)
 make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indices, const int rows, const int nnz,
-          const int W, const int Hw, const int S, const int cols, unsigned long long* __restrict__ keys, int* __restrict__ row_of,
-          int* __restrict__ counts, int* __restrict__ bad) {
+          const int W, const int Hw, const int S, const int cols, unsigned long long* __restrict__ keys, unsigned int* __restrict__ rc,
+          int* __restrict__ bad) {
   const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
   if (base_ll >= nnz) return;
   const int base = static_cast<int>(base_ll);
@@ -139,8 +142,6 @@ make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indi
     }
   }
   offset_t row_end = offsets[row + 1];
-  unsigned int run_seg = 0xffffffffu;
-  int run_len = 0;
 #pragma unroll
   for (int j = 0; j < IPT; ++j) {
     const int i = base + j;
@@ -151,24 +152,37 @@ make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indi
       *bad = 1;
       col = 0;
     }
-    const unsigned int p = col / static_cast<unsigned int>(W);
-    const unsigned int seg = p * static_cast<unsigned int>(S) + static_cast<unsigned int>(row) / static_cast<unsigned int>(Hw);
+    const unsigned int p = col / static_cast<unsigned int>(W), sb = static_cast<unsigned int>(row) / static_cast<unsigned int>(Hw);
+    const unsigned int seg = p * static_cast<unsigned int>(S) + sb;
     keys[i] = (static_cast<unsigned long long>(seg) << 32) | static_cast<unsigned int>(i);
-    row_of[i] = row;
-    if (seg != run_seg) {
-      if (run_len) atomicAdd(counts + run_seg, run_len);
-      run_seg = seg;
-      run_len = 0;
-    }
-    ++run_len;
+    rc[i] = ((static_cast<unsigned int>(row) - sb * static_cast<unsigned int>(Hw)) << 16) | (col - p * static_cast<unsigned int>(W));
   }
-  if (run_len) atomicAdd(counts + run_seg, run_len);
 }
 
-/// padded[g] = counts[g] rounded up to a multiple of 4 (g < n), padded[n] = 0.
-__global__ void __launch_bounds__(256) pad_counts(const int* __restrict__ counts, const int n, int* __restrict__ padded) {
+/// seg_start[g] = the first sorted position whose segment is >= g (g <= n: seg_start[n] = nnz): the segments' extents read off
+/// the sorted keys by n + 1 independent binary searches.
+__global__ void __launch_bounds__(256)
+segment_starts(const unsigned long long* __restrict__ sorted, const int nnz, const int n, int* __restrict__ seg_start) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g <= n) padded[g] = g < n ? (counts[g] + 3) & ~3 : 0;
+  if (g > n) return;
+  const unsigned long long want = static_cast<unsigned long long>(g) << 32;
+  int lo = 0, count = nnz;
+  while (count > 0) {
+    const int half = count >> 1;
+    if (sorted[lo + half] < want) {
+      lo += half + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  seg_start[g] = lo;
+}
+
+/// padded[g] = the items of segment g (seg_start[g + 1] - seg_start[g]) rounded up to a multiple of 4 (g < n), padded[n] = 0.
+__global__ void __launch_bounds__(256) pad_segment_sizes(const int* __restrict__ seg_start, const int n, int* __restrict__ padded) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= n) padded[g] = g < n ? (seg_start[g + 1] - seg_start[g] + 3) & ~3 : 0;
 }
 
 /// paddedT[s * P + p] = padded[p * S + s]; paddedT[S * P] = 0 (the segments in B order).
@@ -191,7 +205,7 @@ constexpr unsigned short run_end_bit = 0x8000u;  // of col16: "this item ENDS a 
 /// multiples of 4096 items of it) -- else 0; ends[nnz] = 0.  The exclusive scan of `ends` numbers the runs.
 __global__ void __launch_bounds__(256)
 mark_run_ends(const unsigned long long* __restrict__ sorted, const int* __restrict__ seg_start, const int* __restrict__ seg_dest,
-              const int* __restrict__ row_of, const int nnz, const int S, int* __restrict__ ends) {
+              const unsigned int* __restrict__ rc, const int nnz, const int S, int* __restrict__ ends) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j > nnz) return;
   if (j == nnz) { ends[j] = 0; return; }
@@ -200,7 +214,8 @@ mark_run_ends(const unsigned long long* __restrict__ sorted, const int* __restri
   bool last = j + 1 == nnz;
   if (!last) {
     const unsigned long long nk = sorted[j + 1];
-    last = static_cast<int>(nk >> 32) != g || row_of[static_cast<int>(nk & 0xffffffffull)] != row_of[i];
+    // (inside one segment the row inside the sub-band identifies the row)
+    last = static_cast<int>(nk >> 32) != g || (rc[static_cast<int>(nk & 0xffffffffull)] >> 16) != (rc[i] >> 16);
   }
   if (!last) {
     const int p = g / S;
@@ -221,13 +236,13 @@ pad_run_counts(const int* __restrict__ seg_start, const int* __restrict__ run_in
 /// COMPACT: the B order holds one slot per run (`ends` / `run_index` of mark_run_ends): col16 carries the run-end flag in
 /// bit 15, dst4 the slot of the group's first run end and, in bit 31, "this group holds padding" (the items behind the
 /// group's last run end are padding then: a segment's last real item always ends a run).
-template <bool COMPACT, typename index_t, typename type_t>
+template <bool COMPACT, typename type_t>
 __global__ void __launch_bounds__(256)
 place(const unsigned long long* __restrict__ sorted, const int* __restrict__ seg_start, const int* __restrict__ seg_dest,
-      const int* __restrict__ seg_dest_b, const int* __restrict__ row_of, const int* __restrict__ ends,
-      const int* __restrict__ run_index, const index_t* __restrict__ indices, const type_t* __restrict__ values, const int nnz,
-      const int W, const int Hw, const int P, const int S, type_t* __restrict__ val, unsigned short* __restrict__ col16,
-      int* __restrict__ dst4, unsigned short* __restrict__ row16, int* __restrict__ perm) {
+      const int* __restrict__ seg_dest_b, const unsigned int* __restrict__ rc, const int* __restrict__ ends,
+      const int* __restrict__ run_index, const type_t* __restrict__ values, const int nnz, const int P, const int S,
+      type_t* __restrict__ val, unsigned short* __restrict__ col16, int* __restrict__ dst4, unsigned short* __restrict__ row16,
+      int* __restrict__ perm) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nnz) return;
   const unsigned long long key = sorted[j];
@@ -239,8 +254,9 @@ place(const unsigned long long* __restrict__ sorted, const int* __restrict__ seg
   const int bseg = seg_dest_b[static_cast<long long>(s) * P + p];
   val[a] = values[i];
   perm[a] = i;
-  const unsigned int col = static_cast<unsigned int>(static_cast<int>(indices[i]) - p * W);
-  const unsigned short row = static_cast<unsigned short>(row_of[i] - s * Hw);
+  const unsigned int packed = rc[i];
+  const unsigned int col = packed & 0xFFFFu;
+  const unsigned short row = static_cast<unsigned short>(packed >> 16);
   if constexpr (COMPACT) {
     const int end = ends[j];
     const int slot = bseg + (run_index[j] - run_index[first]);  // of the run item j belongs to
@@ -673,12 +689,16 @@ panel_reduce(const int* __restrict__ wstart, const int* __restrict__ wins, const
 /// workgroup held as fp64 words in LDS.  The sub-band's products are one contiguous run of the B order; it is walked in
 /// windows of 64 lanes x 4 consecutive items straight from `bstart` -- no window table, no distinction between large and
 /// small segments: wavefront w takes windows w, w + WAVES, ..., U of them in flight.  A lane's 4 items belong to one segment
-/// (segments are padded to multiples of 4), so they are row-sorted; runs of equal ADJACENT rows are summed in fp64 -- inside
-/// the lane, then across lanes with the wave64 segmented prefix sum -- and every run end adds its sum to the row's
-/// accumulator with ds_add_f64 (3-8 lanes per clock and CU on gfx950, where ds_add_f32 retires 0.33): a row that ends more
-/// than once in a window (segment boundaries) or in several wavefronts at a time is the atomic unit's business.
-/// Accuracy: products are fp32 (one rounding each), everything after them is fp64, y is rounded once at the store -- the
-/// north star's 1e-6 holds on rows of any length.  Sums of fp32 products in fp64 are EXACT while a row's products span
+/// (segments are padded to multiples of 4), so they are row-sorted; runs of equal ADJACENT rows are summed inside the window
+/// -- in the lane, then across lanes with the wave64 segmented prefix sum, in the value type: a 256-slot partial carries at
+/// most 3 + 6 roundings -- and every run end adds its sum to the row's accumulator with ds_add_f64 (3-8 lanes per clock and CU
+/// on gfx950, where ds_add_f32 retires 0.33): a row that ends more than once in a window (segment boundaries) or in several
+/// wavefronts at a time is the atomic unit's business.  A window without two adjacent equal rows (the rule when kernel A has
+/// pre-summed the runs) skips sums and scan altogether.  (The fp64 scan of the first version was 42 of the window's 130
+/// vector instructions and the kernel 78 % issue-bound on a C5 shard: profiles/r04_panel_pmc_c5_shard.json.)
+/// Accuracy: products are fp32 (one rounding each), a window's partial is within 5.4e-7 of its L1 mass at worst (measured:
+/// 1-2e-7), everything across windows, panels and wavefronts is fp64, y is rounded once at the store -- the north star's
+/// 1e-6 holds on rows of any length.  Sums of fp32 numbers in fp64 are EXACT while a row's partials span
 /// fewer than 53 - 24 - log2(n) binary orders of magnitude, so the result does not depend on the order the wavefronts'
 /// atomics arrive in (nor on W / Hw) for such rows; beyond that two runs may differ in the last bit of an fp32 y.
 /// LDS: Hw * 8 bytes per workgroup instead of WAVES * Hw * sizeof(type_t): sub-bands (and with them kernel A's store runs)
@@ -715,25 +735,37 @@ panel_reduce_wide(const int* __restrict__ bstart, const int Hw, const type_t* __
     for (int u = 0; u < U; ++u) {
       if (k + u * WAVES < nw) {  // (wave-uniform)
         unsigned int r[4];
-        double run[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = live[u] ? static_cast<unsigned int>(r16v[u][e]) : static_cast<unsigned int>(pad_row);
-        run[0] = static_cast<double>(v[u][0]);
+        const unsigned int next_first = wave::shift_down1(r[0], 0xFFFFFFFDu);
+        // No two ADJACENT slots of the window share a row (the rule in a compact B order, where kernel A has already summed
+        // the runs): every slot is its own run -- no sums, no scan, four atomics.  (wave-uniform)
+        const bool joins = (r[0] == r[1] && r[1] != pad_row) || (r[1] == r[2] && r[2] != pad_row) || (r[2] == r[3] && r[3] != pad_row) ||
+                           (r[3] == next_first && r[3] != pad_row);  // (padding ends a segment: equal pad marks join nothing)
+        if (__builtin_amdgcn_ballot_w64(joins) == 0) {
 #pragma unroll
-        for (int e = 1; e < 4; ++e) run[e] = r[e] == r[e - 1] ? run[e - 1] + static_cast<double>(v[u][e]) : static_cast<double>(v[u][e]);
+          for (int e = 0; e < 4; ++e)
+            if (r[e] != pad_row) atomicAdd(&acc[r[e]], static_cast<double>(v[u][e]));
+          continue;
+        }
+        // Runs of equal adjacent rows: summed in the VALUE type inside the window (lane-sequential, then the scan's tree: at most
+        // 3 + 6 roundings of a 256-slot partial, 5.4e-7 of its L1 mass at worst with 4-byte values), widened to fp64 at the atomic.
+        type_t run[4];
+        run[0] = v[u][0];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) run[e] = r[e] == r[e - 1] ? run[e - 1] + v[u][e] : v[u][e];
         const bool closed = r[3] != r[0];
         const unsigned int prev_last = wave::shift_up1(r[3], 0xFFFFFFFEu);
-        const unsigned int next_first = wave::shift_down1(r[0], 0xFFFFFFFDu);
         const bool continues = r[0] == prev_last;
-        double tail = run[3];
+        type_t tail = run[3];
         bool head = closed || !continues;
         wave::segmented_inclusive_sum(tail, head);
-        const double prev_tail = wave::shift_up1(tail, 0.0);  // (cross-lane read first, select afterwards)
-        const double carry_in = continues ? prev_tail : 0.0;
+        const type_t prev_tail = wave::shift_up1(tail, type_t(0));  // (cross-lane read first, select afterwards)
+        const type_t carry_in = continues ? prev_tail : type_t(0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const unsigned int next = e < 3 ? r[e + 1] : next_first;
-          if (r[e] != next && r[e] != pad_row) atomicAdd(&acc[r[e]], run[e] + (r[e] == r[0] ? carry_in : 0.0));
+          if (r[e] != next && r[e] != pad_row) atomicAdd(&acc[r[e]], static_cast<double>(run[e] + (r[e] == r[0] ? carry_in : type_t(0))));
         }
       }
     }
@@ -837,7 +869,8 @@ struct panel_binned_storage {
 /// 747, C5 shard (0.75) 238 against 234, 8 M rows x 2 (1.0) 80 against 69.
 constexpr double panel_compact_threshold = 0.70;
 
-/// Builds the panel-binned copy of a CSR on the device (O(nnz): one radix sort of 8-byte keys, scans, one placement pass;
+/// Builds the panel-binned copy of a CSR on the device (O(nnz): one radix sort of 8-byte keys, n + 1 binary searches for the
+/// segments' extents, scans, one placement pass that gathers two words per nonzero;
 /// three host synchronisations: the A-order size and the run count, the B-order size, the panel starts).
 /// subband_rows / panel_cols: 0 = automatic.  compact: -1 = automatic (panel_compact_threshold), 0 = never, 1 = always.
 /// Returns 0, a hipError_t, panel_e_badarg (also: a column index outside [0, cols)) or panel_e_range.
@@ -897,8 +930,8 @@ int panel_binned_create(hipStream_t stream, int rows, int cols, int nnz, const o
   auto* keys_out = reinterpret_cast<unsigned long long*>(base + key_bytes);
   int* ends = reinterpret_cast<int*>(base);                                   // (over keys_in, after the sort) [nnz + 1]
   int* run_index = ends + (nnz + 1);                                          // [nnz + 1]: 2 x 4 x (nnz + 1) <= key_bytes
-  int* row_of = reinterpret_cast<int*>(base + 2 * key_bytes);
-  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);
+  auto* rc = reinterpret_cast<unsigned int*>(base + 2 * key_bytes);   // (row inside the sub-band) << 16 | column inside the panel
+  int* counts = reinterpret_cast<int*>(base + 2 * key_bytes + row_bytes);  // (first of the seven per-segment tables; unused slot 0)
   const std::size_t seg_ints = seg_bytes / 4;
   int* seg_start = counts + seg_ints;        // unpadded start of segment g in the sorted keys
   int* padded_a = counts + 2 * seg_ints;     // padded size of segment g = p * S + s
@@ -916,24 +949,24 @@ int panel_binned_create(hipStream_t stream, int rows, int cols, int nnz, const o
   const dim3 seg_grid(math::ceil_div(nseg + 1, 256));
 
   // ---- stage 1: segments of the A order, run ends
-  e = hipMemsetAsync(counts, 0, seg_bytes, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
+  e = hipMemsetAsync(bad, 0, sizeof(int), stream);
   if (e != hipSuccess) return static_cast<int>(e);
   constexpr int KEYS_PER_LANE = 8;
   if (nnz > 0) {
     hipLaunchKernelGGL((panel::make_keys<KEYS_PER_LANE, index_t, offset_t>), dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), dim3(256), 0,
-                       stream, offsets, indices, rows, nnz, out.W, out.Hw, S, cols, keys_in, row_of, counts, bad);
+                       stream, offsets, indices, rows, nnz, out.W, out.Hw, S, cols, keys_in, rc, bad);
     int end_bit = 33;
     while (end_bit < 64 && (static_cast<unsigned long long>(segments) >> (end_bit - 32)) != 0) ++end_bit;
     cub_bytes = cub_bytes_total;
     e = hipcub::DeviceRadixSort::SortKeys(cub_temp, cub_bytes, keys_in, keys_out, nnz, 32, end_bit, stream);
     if (e != hipSuccess) return static_cast<int>(e);
   }
-  hipLaunchKernelGGL(panel::pad_counts, seg_grid, dim3(256), 0, stream, counts, nseg, padded_a);
-  e = scan(counts, seg_start, nseg + 1);
-  if (e == hipSuccess) e = scan(padded_a, seg_dest, nseg + 1);
+  // the segments' extents from the sorted keys (nnz == 0: keys_out is not read, every start is 0)
+  hipLaunchKernelGGL(panel::segment_starts, seg_grid, dim3(256), 0, stream, keys_out, nnz, nseg, seg_start);
+  hipLaunchKernelGGL(panel::pad_segment_sizes, seg_grid, dim3(256), 0, stream, seg_start, nseg, padded_a);
+  e = scan(padded_a, seg_dest, nseg + 1);
   if (e != hipSuccess) return static_cast<int>(e);
-  hipLaunchKernelGGL(panel::mark_run_ends, dim3(math::ceil_div(nnz + 1, 256)), dim3(256), 0, stream, keys_out, seg_start, seg_dest, row_of, nnz, S, ends);
+  hipLaunchKernelGGL(panel::mark_run_ends, dim3(math::ceil_div(nnz + 1, 256)), dim3(256), 0, stream, keys_out, seg_start, seg_dest, rc, nnz, S, ends);
   e = scan(ends, run_index, nnz + 1);
   if (e != hipSuccess) return static_cast<int>(e);
   int h_sizes[3] = {0, 0, 0};  // padded A items, runs, bad index seen
@@ -983,11 +1016,11 @@ int panel_binned_create(hipStream_t stream, int rows, int cols, int nnz, const o
     auto* v = static_cast<type_t*>(out.val);
     const dim3 grid(math::ceil_div(nnz, 256));
     if (out.compact)
-      hipLaunchKernelGGL((panel::place<true, index_t, type_t>), grid, dim3(256), 0, stream, keys_out, seg_start, seg_dest, seg_dest_b, row_of,
-                         ends, run_index, indices, values, nnz, out.W, out.Hw, P, S, v, out.col16, out.dst4, out.row16, out.perm);
+      hipLaunchKernelGGL((panel::place<true, type_t>), grid, dim3(256), 0, stream, keys_out, seg_start, seg_dest, seg_dest_b, rc,
+                         ends, run_index, values, nnz, P, S, v, out.col16, out.dst4, out.row16, out.perm);
     else
-      hipLaunchKernelGGL((panel::place<false, index_t, type_t>), grid, dim3(256), 0, stream, keys_out, seg_start, seg_dest, seg_dest_b, row_of,
-                         ends, run_index, indices, values, nnz, out.W, out.Hw, P, S, v, out.col16, out.dst4, out.row16, out.perm);
+      hipLaunchKernelGGL((panel::place<false, type_t>), grid, dim3(256), 0, stream, keys_out, seg_start, seg_dest, seg_dest_b, rc,
+                         ends, run_index, values, nnz, P, S, v, out.col16, out.dst4, out.row16, out.perm);
   }
   e = hipMemcpyAsync(out.segb, seg_dest_b, sizeof(int) * (static_cast<std::size_t>(nseg) + 1), hipMemcpyDeviceToDevice, stream);
   // the windowed kernel B's work list: count per sub-band, scan, fill
