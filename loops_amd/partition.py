@@ -346,12 +346,17 @@ class NativeComm:
         from . import _lib as L
         self.rank, self.world = rank, world
         ident = (C.c_char * 128)()
-        if rank == 0:
-            L.check(L.lib().loops_comm_unique_id(ident), "loops_comm_unique_id")
+        code = L.lib().loops_comm_unique_id(ident) if rank == 0 else 0
         if world > 1:
-            box = [bytes(ident.raw) if rank == 0 else None]
+            # (every rank reaches the broadcast whatever happened on rank 0: a failure there travels as None instead of leaving
+            # the others waiting)
+            box = [bytes(ident.raw) if rank == 0 and code == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:
+                raise L.LoopsError("loops_comm_unique_id failed on rank 0" + (f": {L.lib().loops_comm_error_string(code).decode()}" if rank == 0 else ""))
             ident = (C.c_char * 128).from_buffer_copy(box[0])
+        elif code != 0:
+            raise L.LoopsError(f"loops_comm_unique_id failed: {L.lib().loops_comm_error_string(code).decode()}")
         self._h = C.c_void_p()
         code = L.lib().loops_comm_init(world, rank, ident, C.byref(self._h))
         if code != 0:
