@@ -50,6 +50,14 @@ def algorithmic_bytes(rows, cols, nnz, vbytes=4):
 
 
 KERNEL_SOURCES = ("include/loops/kernels/merge_path_spmv.hxx", "include/loops/util/wave.hxx")
+VARIANT_PHASED = 8  # include/loops_amd.h LOOPS_VARIANT_PHASED: the default kernel with phased x gathers (same CSR, same bits)
+
+
+def headline_kernel(args):
+    """Name prefix (incl. the tile shape's template arguments) of the dominant kernel of the N = 1 run in rocprofv3's tables."""
+    tpb, ipt = args.tile.split("x")
+    base = "merge_path_spmv_fused_phased" if args.variant == VARIANT_PHASED else "merge_path_spmv_fused"
+    return f"{base}<{tpb}, {ipt},"
 
 
 def kernel_sources_digest():
@@ -66,13 +74,14 @@ def pmc_summary(args):
     scripts/pmc_c2.sh: separate --pmc runs) -- only when the configuration is the profiled one AND the summary was collected
     at the kernel sources as they are now (`_kernel_sources_sha256`, written by scripts/pmc_summarize.py); otherwise
     (None, None, why)."""
-    if args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 or args.variant != 0 \
+    if args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 or args.variant not in (0, VARIANT_PHASED) \
             or args.layout in ("blocked", "panel"):
         return None, None, "configuration differs from the profiled one (C2, N = 1, unmodified CSR)"
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_c2_pmc_summary_{args.tile}.json")), reverse=True)
+    tag = args.tile + ("_phased" if args.variant == VARIANT_PHASED else "")
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_c2_pmc_summary_{tag}.json")), reverse=True)
     if not paths:
-        return None, None, f"no committed counter summary for tile {args.tile}"
+        return None, None, f"no committed counter summary for tile {tag}"
     d = json.load(open(paths[0]))
     rel = os.path.relpath(paths[0], ROOT)
     if d.get("_kernel_sources_sha256") != kernel_sources_digest():
@@ -90,7 +99,7 @@ def pmc_traffic(args):
     if d is None:
         return None, None, why
     for k, v in d.items():
-        if "merge_path_spmv_fused" not in k or "stacked" in k or not isinstance(v, dict):
+        if headline_kernel(args) not in k or not isinstance(v, dict):
             continue
         wr = v.get("WRITE_SIZE", {}).get("mean")
         if "TCC_EA0_RDREQ_sum" in v and wr is not None:
@@ -108,7 +117,7 @@ def pmc_bound(args):
     if d is None:
         return None
     for k, v in d.items():
-        if "merge_path_spmv_fused" in k and "stacked" not in k and isinstance(v, dict) and "TCP_TCC_READ_REQ_LATENCY_sum" in v:
+        if headline_kernel(args) in k and isinstance(v, dict) and "TCP_TCC_READ_REQ_LATENCY_sum" in v:
             m = {c: x["mean"] for c, x in v.items()}
             cyc = m["GRBM_GUI_ACTIVE"] / 8
             return {"l2_requests_per_launch": int(m["TCC_REQ_sum"]), "l2_hit_rate": round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4),
@@ -427,19 +436,29 @@ def main():
     layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "auto")
     if args.tile == "auto" and layout != "csr":
         args.tile = "512x8"  # column-blocked plans are built for 512 x 8 tiles (COLBLOCK_TILE): nothing to tune on the CSR shard
-    if args.tile == "auto":  # measured launch box: every compiled tile shape timed on this shard, outside the timed region
-        best, tile_probe = S.autotune_merge_path(csr, x, repeats=30)
-        if world > 1:  # one shape for the whole job: the one with the smallest worst-rank time
-            names = sorted(tile_probe)
+    if "+" in args.tile:  # "512x8+phased": the phased-gather twin of that shape
+        args.tile, tag = args.tile.split("+", 1)
+        assert tag == "phased", f"--tile {args.tile}+{tag}: unknown kernel variant"
+        args.variant = VARIANT_PHASED
+    if args.tile == "auto":  # measured launch box: every compiled tile shape AND kernel variant (the phased-gather twins:
+        # same CSR, same bits, another order of the x gathers) timed on this shard, outside the timed region
+        best, _, tile_probe = S.autotune_merge_path_variants(csr, x, repeats=30)
+        if world > 1:  # one kernel for the whole job: the one with the smallest worst-rank time (a candidate some rank did
+            names = sorted(tile_probe)  # not time -- a self-completing shard has no phased twin -- is out for everybody)
+            every = [None] * world
+            dist.all_gather_object(every, names)
+            names = sorted(set.intersection(*map(set, every)))
             t = torch.tensor([tile_probe[n] for n in names], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            best = names[int(torch.argmin(t))]
             tile_probe = {n: float(v) for n, v in zip(names, t.tolist())}
-        # the library's default shape unless another one is measurably (> 1 %) faster: shapes within the run-to-run
+        best = min(tile_probe, key=tile_probe.get)
+        # the library's default kernel unless another one is measurably (> 1 %) faster: candidates within the run-to-run
         # noise of the probe must not flip the kernel (and its profile) between runs
         if "512x8" in tile_probe and tile_probe["512x8"] <= 1.01 * tile_probe[best]:
             best = "512x8"
-        args.tile = best
+        args.tile = best.split("+")[0]
+        if best.endswith("+phased"):
+            args.variant = VARIANT_PHASED
         tile_probe = {k: round(v, 5) for k, v in tile_probe.items()}
     plan = S.MergePathPlan(csr, args.tile)
     blocked = None      # the shard's re-ordered copy, if any: a ColumnBlockedPlan or a PanelBinnedPlan
@@ -704,7 +723,8 @@ def main():
             achieved = abytes / (k_main * 1e-3) / 1e9
             traffic, traffic_src, traffic_note = pmc_traffic(args)
             counters = pmc_bound(args)
-            roofline = {"bound": "hbm", "kernel": {"csr": "loops::kernels::merge_path_spmv_fused", "blocked": "loops::kernels::merge_path_spmv_fused_stacked",
+            roofline = {"bound": "hbm", "kernel": {"csr": "loops::kernels::merge_path_spmv_fused" + ("_phased" if args.variant == VARIANT_PHASED else ""),
+                                                    "blocked": "loops::kernels::merge_path_spmv_fused_stacked",
                                                     "panel": "loops::kernels::panel::panel_products + panel_reduce"}[shard_kind],
                         "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -734,7 +754,8 @@ def main():
                 roofline["panel_reduce_avg_launch_ms" if shard_kind == "panel" else "block_reduce_avg_launch_ms"] = round(K_["reduce_avg"], 5)
         mode = gather_mode["mode"] if watchdog is None else safe["mode"]
         one_gpu, spmv_only_ms = R_["one_gpu"], K_["spmv_only_ms"]
-        step_includes = {"csr": "fused merge-tile kernel + carry-out fix-up", "blocked": "fused merge-tile kernel + carry-out fix-up + block reduce",
+        step_includes = {"csr": "fused merge-tile kernel" + (" (phased x gathers: 8 passes by column range, clock-aligned across workgroups)"
+                                                            if args.variant == VARIANT_PHASED else "") + " + carry-out fix-up", "blocked": "fused merge-tile kernel + carry-out fix-up + block reduce",
                          "panel": "panel products (x panels in LDS) + sub-band reduce"}[shard_kind]
         if world > 1:
             step_includes += f" + allgatherv(y) [{mode}"

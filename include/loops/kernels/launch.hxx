@@ -118,6 +118,45 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   return launch_status();
 }
 
+/// Number of column parts of the phased-gather kernels, and the shift that maps a column of a `cols`-wide matrix to its
+/// part: min(col >> shift, parts - 1) -- parts of 2^shift columns, the last one takes what is left.
+constexpr int phased_parts = 8;
+inline unsigned int phased_shift(int cols, int parts = phased_parts) {
+  int bits = 0;
+  while (bits < 31 && (static_cast<long long>(cols) - 1) >> bits) ++bits;  // bits needed for cols - 1
+  int lg = 0;
+  while ((1 << (lg + 1)) <= parts) ++lg;
+  return static_cast<unsigned int>(bits > lg ? bits - lg : 0);
+}
+
+/// Fused merge-path SpMV with PHASED x gathers (merge_path_spmv_fused_phased; + fix-up).  Only the two-kernel form on
+/// 16-byte aligned arrays has a phased twin: a self-completing plan (no long rows), a single tile or unaligned arrays run the
+/// plain kernel -- same result either way.
+template <int TPB, int IPT, typename index_t, typename offset_t, typename T>
+int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& plan, int rows, int cols, int nnz,
+                                   const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
+                                   int stages = 3, bool planned = false) {
+  const int m = plan.num_merge_tiles;
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  if (m <= 1 || !aligned || (plan.self_complete && plan.head_start))
+    return launch_merge_path_fused<TPB, IPT, true, 0, index_t, offset_t, T, true>(stream, plan, rows, nnz, offsets, indices, values, x, y,
+                                                                                 stages, false, planned);
+  T* carry_val = static_cast<T*>(plan.carry_val);
+  const unsigned int shift = phased_shift(cols);
+  if (stages & 1) {
+    if (planned)
+      hipLaunchKernelGGL((merge_path_spmv_fused_phased_planned<TPB, IPT, phased_parts, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
+                         stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val, shift);
+    else
+      hipLaunchKernelGGL((merge_path_spmv_fused_phased<TPB, IPT, phased_parts, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0, stream,
+                         plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val, shift);
+  }
+  if (stages & 2)
+    hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,
+                       carry_val, m, rows, y);
+  return launch_status();
+}
+
 /// Fused merge-path SpMV (+ fix-up) whose finished rows also go to `peers.count` peer-mapped vectors: the allgatherv(y)
 /// of a row-range sharded multi-GPU SpMV issued from the epilogue.  Always the two-kernel form (the
 /// fix-up re-writes completed rows on every destination).

@@ -53,8 +53,12 @@ SYMBOLS = [
     "loops_panel_plan_create_layout_f32", "loops_panel_plan_create_layout_f64", "loops_panel_plan_layout",
     "loops_row_ranges", "loops_comm_unique_id", "loops_comm_init", "loops_comm_destroy", "loops_comm_error_string",
     "loops_allgatherv_f32", "loops_allgatherv_f64",
+    "loops_autotune_merge_path_variants_f32", "loops_spmv_plan_variant",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
+
+
+VARIANT_PHASED = 8  # include/loops_amd.h LOOPS_VARIANT_PHASED: the default merge-path kernel with phased x gathers
 
 
 class LoopsError(RuntimeError):
@@ -227,6 +231,8 @@ def lib() -> C.CDLL:
         L.loops_spmv_plan_destroy.restype = None
         L.loops_spmv_plan_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), vp]
         L.loops_autotune_merge_path_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]
+        L.loops_autotune_merge_path_variants_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), C.POINTER(ci), vp]
+        L.loops_spmv_plan_variant.argtypes = [vp, C.POINTER(ci), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 

@@ -239,9 +239,21 @@ int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, co
 
 template <typename T>
 int spmv_merge_path(const loops_merge_plan* p, int variant, int rows, int nnz, const int* off, const int* idx,
-                    const T* val, const T* x, T* y, hipStream_t stream, int stages = 3, bool planned = false) {
+                    const T* val, const T* x, T* y, hipStream_t stream, int stages = 3, bool planned = false, int cols = 0) {
   const int m = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(p->tpb) * p->ipt));
   if (rows != p->rows || nnz != p->nnz) return LOOPS_E_BADARG;
+  if (variant == LOOPS_VARIANT_PHASED) {
+    // the default kernel with PHASED x gathers (kernels::merge_path_spmv_fused_phased): compiled for the two shapes it pays on
+    if (cols <= 0) return LOOPS_E_BADARG;
+    kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, m, p->self_complete != 0, p->head_start};
+    switch (p->cfg) {
+      case LOOPS_TILE_512x8:
+        return kernels::launch_merge_path_fused_phased<512, 8, int, int, T>(stream, view, rows, cols, nnz, off, idx, val, x, y, stages, planned);
+      case LOOPS_TILE_256x16:
+        return kernels::launch_merge_path_fused_phased<256, 16, int, int, T>(stream, view, rows, cols, nnz, off, idx, val, x, y, stages, planned);
+      default: return LOOPS_E_CONFIG;
+    }
+  }
   // variant 0 = the default kernel (bit-mask split, padded LDS products, temporal loads).  Tuning aids, all with
   // the per-thread halving search of the first implementation: 4 = otherwise as 0; bit 0 = non-temporal
   // streaming loads, bit 1 = unpadded LDS product array (1, 2, 3)
@@ -743,6 +755,8 @@ struct loops_spmv_plan {
   loops_merge_plan* merge;      // held for LOOPS_LAYOUT_CSR
   loops_colblock_plan* blocked; // held for LOOPS_LAYOUT_COLUMN_BLOCKED
   loops_panel_plan* panel;      // held for LOOPS_LAYOUT_PANEL_BINNED
+  int merge_variant;            // LOOPS_LAYOUT_CSR: 0 = the default kernel, LOOPS_VARIANT_PHASED = phased x gathers
+  float ms_phased;              // measured ms per product of the best phased candidate; -1 = not timed
   float ms[4];                  // measured ms per product: CSR 256 x 8, CSR 512 x 8, column-blocked, panel-binned; -1 = not timed
 };
 
@@ -786,6 +800,8 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
   if (!p) return static_cast<int>(hipErrorOutOfMemory);
   p->rows = rows; p->cols = cols; p->nnz = nnz; p->vbytes = static_cast<int>(sizeof(T)); p->flags = flags;
   p->layout = LOOPS_LAYOUT_CSR;
+  p->merge_variant = 0;
+  p->ms_phased = -1.f;
   p->ms[0] = p->ms[1] = p->ms[2] = p->ms[3] = -1.f;
   const bool measure = (flags & LOOPS_PLAN_MEASURE) != 0 && rows > 0 && nnz > 0;
   const bool may_copy = (flags & LOOPS_PLAN_ALLOW_COPY) != 0 && rows > 0 && nnz > 0;
@@ -841,6 +857,31 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
     else plan_release(m);
   }
   p->merge = best;
+  // The same CSR with PHASED x gathers (kernels::merge_path_spmv_fused_phased: no copy, same bits): a candidate where it can
+  // pay at all -- long rows (two-kernel plans) and an x between a quarter of and four times one XCD's L2 -- adopted when it is
+  // measurably (> 2 %) faster than the best plain shape.
+  if (!err && best && !best->self_complete && best->num_tiles > 1 && x_bytes >= (1ll << 20) && x_bytes <= (16ll << 20)) {
+    const int pshapes[2] = {LOOPS_TILE_512x8, LOOPS_TILE_256x16};
+    for (int i = 0; !err && i < 2; ++i) {
+      loops_merge_plan* m = nullptr;
+      err = plan_alloc(rows, nnz, pshapes[i], &m);
+      if (!err) err = plan_compute(m, off, st);
+      if (!err) err = plan_classify(m, off, st);
+      float ms = 0.f;
+      if (!err && !m->self_complete)
+        err = time_ms(st, repeats, &ms, [&]() { return spmv_merge_path<T>(m, LOOPS_VARIANT_PHASED, rows, nnz, off, idx, val, x, y, st, 3, true, cols); });
+      if (err) { plan_release(m); break; }
+      if (ms > 0.f && (p->ms_phased < 0.f || ms < p->ms_phased)) p->ms_phased = ms;
+      if (ms > 0.f && ms < 0.98f * best_ms) {
+        plan_release(p->merge);
+        p->merge = best = m;
+        best_ms = ms;
+        p->merge_variant = LOOPS_VARIANT_PHASED;
+      } else {
+        plan_release(m);
+      }
+    }
+  }
   if (!err && may_copy && x_bytes >= (2ll << 20)) {
     loops_colblock_plan* cb = nullptr;
     int cerr = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &cb);
@@ -900,7 +941,7 @@ int spmv_planned(const loops_spmv_plan* p, const int* off, const int* idx, const
   if (p->layout == LOOPS_LAYOUT_PANEL_BINNED) return panel_spmv<T>(p->panel, 3, x, y, st);
   int err = check_csr(p->rows, p->cols, p->nnz, off, idx, val, x, y);
   if (err) return err;
-  return spmv_merge_path<T>(p->merge, 0, p->rows, p->nnz, off, idx, val, x, y, st, 3, /*planned=*/true);
+  return spmv_merge_path<T>(p->merge, p->merge_variant, p->rows, p->nnz, off, idx, val, x, y, st, 3, /*planned=*/true, p->cols);
 }
 
 }  // namespace
@@ -1072,7 +1113,7 @@ int loops_spmv_merge_path_f32(const loops_merge_plan_t* plan, int variant, int r
   if (!plan) return LOOPS_E_BADARG;
   int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
   if (err) return err;
-  return spmv_merge_path<float>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream));
+  return spmv_merge_path<float>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream), 3, false, cols);
 }
 int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
                               const int* offsets, const int* indices, const double* values, const double* x,
@@ -1080,7 +1121,7 @@ int loops_spmv_merge_path_f64(const loops_merge_plan_t* plan, int variant, int r
   if (!plan) return LOOPS_E_BADARG;
   int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
   if (err) return err;
-  return spmv_merge_path<double>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream));
+  return spmv_merge_path<double>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream), 3, false, cols);
 }
 
 int loops_enable_peer_access(int peer_device) {
@@ -1128,7 +1169,7 @@ int loops_spmv_merge_path_stage_f32(const loops_merge_plan_t* plan, int variant,
   int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
   if (err) return err;
   return spmv_merge_path<float>(plan, variant, rows, nnz, offsets, indices, values, x, y, as_stream(stream),
-                                1 << stage);
+                                1 << stage, false, cols);
 }
 
 int loops_spmv_csr_schedule_api_f32(int schedule, int tile_config, int rows, int cols, int nnz, const int* offsets,
@@ -1323,43 +1364,73 @@ int loops_spmv_dia_f64(int mode, int rows, int cols, int num_diagonals, size_t s
   return spmv_dia<double>(mode, rows, cols, num_diagonals, stride, diag_offsets, values, x, y, as_stream(stream));
 }
 
-int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
-                                  const float* values, const float* x, float* y, int repeats, void* stream,
-                                  int* best_tile_config, float* ms_per_config /* 6 entries, may be NULL */) {
-  if (!best_tile_config) return LOOPS_E_BADARG;
+namespace {
+// The launch-box autotuner: every compiled tile shape (and, with `phased`, the phased-gather twin of the shapes that have
+// one) timed on this matrix; ms[cfg] = plain kernel, ms[6 + cfg] = phased (-1 = not timed).
+int autotune_merge_path(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                        const float* x, float* y, int repeats, hipStream_t st, bool phased, int* best_cfg, int* best_variant,
+                        float* ms_out /* 12 entries or NULL */) {
   int err = check_csr(rows, cols, nnz, offsets, indices, values, x, y);
   if (err) return err;
   if (repeats < 1) repeats = 5;
-  hipStream_t st = as_stream(stream);
   hipEvent_t e0, e1;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return static_cast<int>(hipGetLastError());
+  if (hipEventCreate(&e0) != hipSuccess) return static_cast<int>(hipGetLastError());
+  if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return static_cast<int>(hipGetLastError()); }
   static const int candidates[] = {LOOPS_TILE_256x8, LOOPS_TILE_256x7, LOOPS_TILE_128x7, LOOPS_TILE_512x8, LOOPS_TILE_256x16};
   float best = 0.f;
-  *best_tile_config = LOOPS_TILE_DEFAULT;
-  if (ms_per_config) for (int i = 0; i < 6; ++i) ms_per_config[i] = -1.f;
+  *best_cfg = LOOPS_TILE_DEFAULT;
+  *best_variant = 0;
+  if (ms_out) for (int i = 0; i < 12; ++i) ms_out[i] = -1.f;
   for (int cfg : candidates) {
     loops_merge_plan* p = nullptr;
     err = plan_alloc(rows, nnz, cfg, &p);
     if (!err) err = plan_compute(p, offsets, st);
     if (!err) err = plan_classify(p, offsets, st);  // time what a held plan of this shape would run
-    for (int it = 0; !err && it < 2; ++it) err = spmv_merge_path<float>(p, 0, rows, nnz, offsets, indices, values, x, y, st);
-    float ms = 0.f;
-    if (!err) {
-      (void)hipEventRecord(e0, st);
-      for (int it = 0; !err && it < repeats; ++it) err = spmv_merge_path<float>(p, 0, rows, nnz, offsets, indices, values, x, y, st);
-      (void)hipEventRecord(e1, st);
-      if (!err) err = static_cast<int>(hipEventSynchronize(e1));
-      if (!err) err = static_cast<int>(hipEventElapsedTime(&ms, e0, e1));
-      ms /= static_cast<float>(repeats);
+    const bool twin = phased && !err && !p->self_complete && p->num_tiles > 1 && (cfg == LOOPS_TILE_512x8 || cfg == LOOPS_TILE_256x16);
+    for (int variant : {0, LOOPS_VARIANT_PHASED}) {
+      if (err || (variant != 0 && !twin)) continue;
+      for (int it = 0; !err && it < 2; ++it) err = spmv_merge_path<float>(p, variant, rows, nnz, offsets, indices, values, x, y, st, 3, false, cols);
+      float ms = 0.f;
+      if (!err) {
+        (void)hipEventRecord(e0, st);
+        for (int it = 0; !err && it < repeats; ++it)
+          err = spmv_merge_path<float>(p, variant, rows, nnz, offsets, indices, values, x, y, st, 3, false, cols);
+        (void)hipEventRecord(e1, st);
+        if (!err) err = static_cast<int>(hipEventSynchronize(e1));
+        if (!err) err = static_cast<int>(hipEventElapsedTime(&ms, e0, e1));
+        ms /= static_cast<float>(repeats);
+      }
+      if (err) break;
+      if (ms_out) ms_out[(variant ? 6 : 0) + cfg] = ms;
+      if (best == 0.f || ms < best) { best = ms; *best_cfg = cfg; *best_variant = variant; }
     }
-    if (p) { (void)hipFree(p->wide_carry); (void)hipFree(p->base); delete p; }
+    plan_release(p);
     if (err) break;
-    if (ms_per_config) ms_per_config[cfg] = ms;
-    if (best == 0.f || ms < best) { best = ms; *best_tile_config = cfg; }
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   return err;
+}
+}  // namespace
+
+int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                                  const float* values, const float* x, float* y, int repeats, void* stream,
+                                  int* best_tile_config, float* ms_per_config /* 6 entries, may be NULL */) {
+  if (!best_tile_config) return LOOPS_E_BADARG;
+  float ms[12];
+  int variant = 0;
+  const int err = autotune_merge_path(rows, cols, nnz, offsets, indices, values, x, y, repeats, as_stream(stream), false,
+                                      best_tile_config, &variant, ms);
+  if (ms_per_config) for (int i = 0; i < 6; ++i) ms_per_config[i] = ms[i];
+  return err;
+}
+
+int loops_autotune_merge_path_variants_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
+                                           const float* values, const float* x, float* y, int repeats, void* stream,
+                                           int* best_tile_config, int* best_variant, float* ms_per_config /* 12 entries, may be NULL */) {
+  if (!best_tile_config || !best_variant) return LOOPS_E_BADARG;
+  return autotune_merge_path(rows, cols, nnz, offsets, indices, values, x, y, repeats, as_stream(stream), true, best_tile_config,
+                             best_variant, ms_per_config);
 }
 
 int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
@@ -1386,6 +1457,12 @@ int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_c
   if (tile_config) *tile_config = plan->merge ? plan->merge->cfg : COLBLOCK_TILE;
   if (num_blocks) *num_blocks = plan->blocked ? plan->blocked->K : plan->panel ? plan->panel->P : 0;
   if (ms4) for (int i = 0; i < 4; ++i) ms4[i] = plan->ms[i];
+  return 0;
+}
+int loops_spmv_plan_variant(const loops_spmv_plan_t* plan, int* variant, float* ms_phased) {
+  if (!plan) return LOOPS_E_BADARG;
+  if (variant) *variant = plan->layout == LOOPS_LAYOUT_CSR ? plan->merge_variant : 0;
+  if (ms_phased) *ms_phased = plan->ms_phased;
   return 0;
 }
 int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream) {

@@ -418,10 +418,15 @@ class SpmvPlan:
         names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
         self.layout, self.tile, self.num_blocks = self.LAYOUTS[layout.value], names[tile.value], blocks.value
         self.measured_ms = {k: (round(float(v), 5) if v >= 0 else None) for k, v in zip(("csr_256x8", "csr_512x8", "column_blocked", "panel_binned"), ms)}
+        variant, ms_phased = C.c_int(), C.c_float()
+        L.check(L.lib().loops_spmv_plan_variant(self._h, C.byref(variant), C.byref(ms_phased)), "loops_spmv_plan_variant")
+        self.variant = variant.value  # CSR layout: 0 or L.VARIANT_PHASED (phased x gathers)
+        self.measured_ms["csr_phased"] = round(float(ms_phased.value), 5) if ms_phased.value >= 0 else None
 
     @property
     def info(self):
-        return {"layout": self.layout, "tile": self.tile, "column_blocks": self.num_blocks, "measured_ms": self.measured_ms}
+        return {"layout": self.layout, "tile": self.tile + ("+phased" if self.variant == L.VARIANT_PHASED else ""),
+                "column_blocks": self.num_blocks, "measured_ms": self.measured_ms}
 
     def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
         c = self.csr
@@ -620,6 +625,22 @@ def autotune_merge_path(csr: CSR, x, repeats: int = 5):
             "loops_autotune_merge_path_f32")
     names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
     return names[best.value], {names[i]: ms[i] for i in range(6) if ms[i] >= 0 and i in names}
+
+
+def autotune_merge_path_variants(csr: CSR, x, repeats: int = 5):
+    """The same over tile shapes AND kernel variants (loops_autotune_merge_path_variants_f32): the phased-gather twin of the
+    shapes that have one is timed too.  Returns (best tile name, best variant, {name: ms}) with phased entries named
+    "<tile>+phased"."""
+    y = torch.empty(csr.rows, dtype=torch.float32, device=x.device)
+    best, variant = C.c_int(), C.c_int()
+    ms = (C.c_float * 12)()
+    L.check(L.lib().loops_autotune_merge_path_variants_f32(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+                                                           _ptr(csr.values), _ptr(x), _ptr(y), repeats, _stream(), C.byref(best),
+                                                           C.byref(variant), ms), "loops_autotune_merge_path_variants_f32")
+    names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
+    table = {names[i]: ms[i] for i in range(6) if ms[i] >= 0 and i in names}
+    table.update({names[i] + "+phased": ms[6 + i] for i in range(6) if ms[6 + i] >= 0 and i in names})
+    return names[best.value], variant.value, table
 
 
 class CSCPlan:

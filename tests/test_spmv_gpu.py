@@ -738,3 +738,98 @@ def test_c4_full_size_bcsr_bit_exact():
         y = torch.full((nbr * 4,), -1.0, device="cuda")
         S.bcsr_thread_mapped(b, x, y, mfma=mode)
         assert np.array_equal(y.cpu().numpy(), want), mode
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Phased x gathers (LOOPS_VARIANT_PHASED, kernels::merge_path_spmv_fused_phased): the same loads in another order -- the result
+# must equal the default kernel's BIT FOR BIT on any input, not only on exactly summable ones.
+@pytest.mark.parametrize("tile", ["512x8", "256x16"])
+@pytest.mark.parametrize("cols", [1 << 13, 8191, 5000, 100003, 9, 1])
+def test_phased_gathers_equal_the_default_kernel_bit_for_bit(tile, cols):
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    rows, nnz = 1 << 13, 1 << 17
+    # (tiny column counts: short rows only -- a self-completing plan, where the entry falls back to the one-kernel form)
+    deg = G.powerlaw_degrees(rows, nnz, cap=min(1 << 12, cols)) if cols >= 4096 else np.full(rows, min(cols, 4), np.int64)
+    off, idx, val = G.powerlaw_csr(rows, cols, int(deg.sum()), degrees=deg, exact=False)  # realistic values: order matters
+    csr = _dev(off, idx, val, rows, cols)
+    plan = S.MergePathPlan(csr, tile)
+    assert plan.num_tiles > 1
+    x = torch.from_numpy(G.realistic_x(cols)).cuda()
+    y0 = S.merge_path_flat(csr, x, plan=plan, variant=0)
+    y8 = S.merge_path_flat(csr, x, plan=plan, variant=_lib.VARIANT_PHASED)
+    assert torch.equal(y0, y8), (tile, cols)
+    # and against the oracle on exactly summable values
+    off, idx, val = G.powerlaw_csr(rows, cols, int(deg.sum()), degrees=deg)
+    xi = G.uniform_distribution_int(cols)
+    csr = _dev(off, idx, val, rows, cols)
+    y = S.merge_path_flat(csr, torch.from_numpy(xi).cuda(), plan=S.MergePathPlan(csr, tile), variant=_lib.VARIANT_PHASED)
+    assert np.array_equal(y.cpu().numpy(), O.spmv_f32(off, idx, val, xi)), (tile, cols)
+    # unaligned views (a shard's slice): the phased entry falls back to the plain kernel, same result
+    pad_i = torch.zeros(idx.size + 1, dtype=torch.int32, device="cuda")
+    pad_v = torch.zeros(val.size + 1, dtype=torch.float32, device="cuda")
+    pad_i[1:] = torch.from_numpy(idx).cuda()
+    pad_v[1:] = torch.from_numpy(val).cuda()
+    un = S.CSR(rows, cols, torch.from_numpy(off).cuda(), pad_i[1:], pad_v[1:])
+    assert torch.equal(S.merge_path_flat(un, torch.from_numpy(xi).cuda(), plan=S.MergePathPlan(un, tile), variant=_lib.VARIANT_PHASED), y)
+
+
+def test_phased_gathers_f64_self_completing_plans_and_unsupported_shapes():
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    rows = cols = 1 << 13
+    deg = G.powerlaw_degrees(rows, 1 << 17, cap=1 << 12)
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 17, degrees=deg)
+    xi = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, xi)
+    csr64 = S.CSR.from_numpy(rows, cols, off, idx, val.astype(np.float64))
+    x64 = torch.from_numpy(xi.astype(np.float64)).cuda()
+    for tile in ("512x8", "256x16"):
+        y = S.merge_path_flat(csr64, x64, plan=S.MergePathPlan(csr64, tile), variant=_lib.VARIANT_PHASED)
+        assert np.array_equal(y.cpu().numpy(), ref.astype(np.float64)), tile
+    # shapes without a phased twin are refused, not silently run as something else
+    csr = _dev(off, idx, val, rows, cols)
+    with pytest.raises(_lib.LoopsError):
+        S.merge_path_flat(csr, torch.from_numpy(xi).cuda(), plan=S.MergePathPlan(csr, "256x8"), variant=_lib.VARIANT_PHASED)
+    # a self-completing plan (short rows only) has nothing to phase: the entry runs the one-kernel form
+    off, idx, val = G.csr_from_degrees(np.full(rows, 16, np.int64), cols, 1, 0, True, 64)
+    band = _dev(off, idx, val, rows, cols)
+    plan = S.MergePathPlan(band, "512x8")
+    assert plan.self_complete
+    y = S.merge_path_flat(band, torch.from_numpy(xi).cuda(), plan=plan, variant=_lib.VARIANT_PHASED)
+    assert np.array_equal(y.cpu().numpy(), O.spmv_f32(off, idx, val, xi))
+
+
+def test_full_size_c2_phased_gathers_bit_exact_and_chosen_by_measurement():
+    """BASELINE config C2 at full size through the phased-gather kernel: the oracle's bits on exactly summable inputs, the
+    default kernel's bits on realistic ones, and the two ways a caller gets it -- the variant autotuner and a measured SpMV
+    plan WITHOUT a copy -- report / adopt it only by measurement."""
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    rows = cols = 1 << 20
+    deg = G.powerlaw_degrees(rows, 1 << 24)
+    off, idx, val = G.powerlaw_csr(rows, cols, 1 << 24, degrees=deg)
+    x = G.uniform_distribution_int(cols)
+    ref = O.spmv_f32(off, idx, val, x, omp=True)
+    csr = _dev(off, idx, val, rows, cols)
+    xd = torch.from_numpy(x).cuda()
+    for tile in ("512x8", "256x16"):
+        plan = S.MergePathPlan(csr, tile)
+        y = S.merge_path_flat(csr, xd, plan=plan, variant=_lib.VARIANT_PHASED)
+        assert np.array_equal(y.cpu().numpy(), ref), tile
+        y2 = S.merge_path_flat(csr, xd, plan=plan, variant=_lib.VARIANT_PHASED)
+        assert torch.equal(y, y2)  # run to run
+    best, variant, table = S.autotune_merge_path_variants(csr, xd, repeats=10)
+    assert {"512x8", "256x16", "512x8+phased", "256x16+phased", "256x8"} <= set(table) and "256x8+phased" not in table
+    assert variant in (0, _lib.VARIANT_PHASED) and table[best + ("+phased" if variant else "")] == min(table.values())
+    sp = S.SpmvPlan(csr, allow_copy=False, measure=True, repeats=10)
+    assert sp.layout == "csr" and sp.measured_ms["csr_phased"] is not None
+    assert np.array_equal(sp.spmv(xd).cpu().numpy(), ref)
+    if sp.variant == _lib.VARIANT_PHASED:  # adopted only when measured > 2 % faster than the best plain shape
+        assert sp.measured_ms["csr_phased"] < 0.98 * min(v for k, v in sp.measured_ms.items() if k.startswith("csr_") and k != "csr_phased" and v)
+    sp.close()
+    off_r, idx_r, val_r = G.powerlaw_csr(rows, cols, 1 << 24, degrees=deg, exact=False)
+    csr_r = _dev(off_r, idx_r, val_r, rows, cols)
+    xr = torch.from_numpy(G.realistic_x(cols)).cuda()
+    plan = S.MergePathPlan(csr_r, "512x8")
+    assert torch.equal(S.merge_path_flat(csr_r, xr, plan=plan, variant=0), S.merge_path_flat(csr_r, xr, plan=plan, variant=_lib.VARIANT_PHASED))
