@@ -55,6 +55,23 @@ void merge_path_flat_async_with(const merge_path_plan_of_t<TPB, IPT, index_t, of
       csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get(), 3, false, planned);
 }
 
+/// The same product through the PHASED-gather kernel (kernels::merge_path_spmv_fused_phased: a tile's x gathers in 8 passes by
+/// column range, clock-aligned across workgroups -- for columns scattered over an x of about one XCD's L2; same bits as the
+/// plain kernel; shapes 512 x 8 and 256 x 16 only).  Pick it by measurement (spmv_plan_t does).  No reference counterpart.
+template <std::size_t TPB, std::size_t IPT, typename index_t, typename offset_t, typename type_t>
+void merge_path_flat_phased_async_with(const merge_path_plan_of_t<TPB, IPT, index_t, offset_t>& plan,
+                                       csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y,
+                                       xpu::stream_t stream = 0, bool planned = false) {
+  static_assert((TPB == 512 && IPT == 8) || (TPB == 256 && IPT == 16), "phased gathers: 512 x 8 or 256 x 16 merge tiles");
+  error::throw_if_exception(static_cast<unsigned long long>(csr.rows) + static_cast<unsigned long long>(csr.nnzs) >= (1ull << 31) - 4096,
+                            "merge_path_flat: rows + nnz must stay below 2^31 (the merge-path search arithmetic is int, as in util/search.hxx:46-47)");
+  kernels::merge_plan_view view{plan.data(), plan.carry_rows(), plan.template carry_values<type_t>(),
+                                static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
+  kernels::launch_merge_path_fused_phased<static_cast<int>(TPB), static_cast<int>(IPT)>(
+      stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.cols), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get(), 3, planned);
+}
+
 /// SpMV with a prebuilt plan (the merge_path launch box: 512 x 8 / 512 x 4); asynchronous on `stream`.
 template <typename index_t, typename offset_t, typename type_t>
 void merge_path_flat_async(const merge_path_plan_t<index_t, offset_t, type_t>& plan,

@@ -7,7 +7,7 @@
  * header-API twin of loops_spmv_plan_* (include/loops_amd.h).  The reference fixes the tile shape per architecture at
  * compile time (algorithms/spmv/launch_box.hxx:56-90) and always runs the CSR as given; no counterpart there.
  *
- *   algorithms::spmv::spmv_plan_t<int, int, float> plan(csr);            // measures 256 x 8, 512 x 8 and the blocked copy
+ *   algorithms::spmv::spmv_plan_t<int, int, float> plan(csr);            // measures 256 x 8, 512 x 8 (+ its phased-gather twin) and the copies
  *   for (...) plan.spmv_async(csr, x, y, stream);                         // y = csr * x with whatever won
  *
  * One product in flight per plan (it owns one set of carry-out / partial-result buffers).
@@ -32,9 +32,12 @@ struct spmv_plan_t {
   using large_t = merge_path_plan_t<index_t, offset_t, type_t>;        // 512 x 8 (512 x 4)
   using blocked_t = column_blocked_t<index_t, offset_t, type_t>;
   using panel_t = panel_binned_t<index_t, offset_t, type_t>;
+  static constexpr std::size_t large_block = merge_path_launch_t<type_t>::block_size, large_items = merge_path_launch_t<type_t>::items_per_thread;
 
   layout_kind layout = csr_layout;
+  bool phased = false;  ///< csr_layout over `large`: the product runs the phased-gather kernel (merge_path_flat_phased_async_with)
   float ms_small = -1.f, ms_large = -1.f, ms_blocked = -1.f, ms_panel = -1.f;  ///< measured ms per product (-1: not timed)
+  float ms_phased = -1.f;
   std::unique_ptr<small_t> small;
   std::unique_ptr<large_t> large;
   std::unique_ptr<blocked_t> blocked;
@@ -95,6 +98,17 @@ struct spmv_plan_t {
     float best = keep_small ? ms_small : ms_large;
     if (keep_small) large.reset();
     else small.reset();
+    // the same CSR with PHASED x gathers (no copy, same bits): a candidate where it can pay at all -- long rows (two-kernel
+    // plans) over an x between a quarter of and four times one XCD's L2 -- adopted when > 2 % faster (as loops_spmv_plan_create_*)
+    if constexpr (large_block == 512 && large_items == 8) {
+      if (large && !large->self_complete() && large->merge_tiles() > 1 && x_bytes >= (std::size_t(1) << 20) && x_bytes <= (std::size_t(16) << 20)) {
+        ms_phased = time_ms(repeats, stream, [&] { merge_path_flat_phased_async_with<512, 8>(*large, csr, x, y, stream, true); });
+        if (ms_phased < 0.98f * best) {
+          phased = true;
+          best = ms_phased;
+        }
+      }
+    }
     if (allow_copy && x_bytes >= (std::size_t(2) << 20) && fits_blocked(csr)) {
       auto cb = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
       ms_blocked = time_ms(repeats, stream, [&] { cb->spmv_async(x, y, stream); });
@@ -125,7 +139,9 @@ struct spmv_plan_t {
     else if (blocked) blocked->spmv_async(x, y, stream);
     else if (small)
       merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream, true);
-    else
+    else if (phased) {
+      if constexpr (large_block == 512 && large_items == 8) merge_path_flat_phased_async_with<512, 8>(*large, csr, x, y, stream, true);
+    } else
       merge_path_flat_async_with<merge_path_launch_t<type_t>::block_size, merge_path_launch_t<type_t>::items_per_thread>(*large, csr, x, y, stream, true);
   }
 

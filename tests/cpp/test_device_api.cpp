@@ -294,6 +294,59 @@ static void misc() {
       for (std::size_t i = 0; i < g0.size(); ++i) same = same && std::fabs(g0[i] - g1[i]) <= 1e-9 + 1e-12 * std::fabs(g0[i]);
       CHECK(same);
     }
+  // phased x gathers (merge_path_flat_phased_async_with; spmv_plan_t's candidate for long rows over an x of 1-16 MB): the
+  // plain kernel's bits on real values, for a power-of-two and an odd column count, f32 and f64
+  for (std::size_t cols : {std::size_t(1) << 19, std::size_t(300007)}) {
+    const std::size_t rows = 1 << 12;
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> u(0.5, 1.5);
+    std::vector<int> off(rows + 1, 0), idx;
+    std::vector<double> val;
+    for (std::size_t r = 0; r < rows; ++r) {
+      const std::size_t deg = r % 97 == 0 ? 9000 : 3 + r % 29;      // rows of 9 000 nonzeros span several 4 096-item tiles
+      const std::size_t step = cols / deg;
+      for (std::size_t k = 0; k < deg; ++k) { idx.push_back(static_cast<int>(k * step + rng() % step)); val.push_back(u(rng)); }
+      off[r + 1] = static_cast<int>(idx.size());
+    }
+    hcsr_t<float> hf(rows, cols, idx.size());
+    hcsr_t<double> hd(rows, cols, idx.size());
+    for (std::size_t r = 0; r <= rows; ++r) hf.offsets[r] = hd.offsets[r] = off[r];
+    for (std::size_t k = 0; k < idx.size(); ++k) { hf.indices[k] = hd.indices[k] = idx[k]; hf.values[k] = static_cast<float>(val[k]); hd.values[k] = val[k]; }
+    csr_t<int, int, float> a(hf);
+    csr_t<int, int, double> ad(hd);
+    vector_t<float, H> hx(cols);
+    vector_t<double, H> hxd(cols);
+    for (std::size_t c = 0; c < cols; ++c) { hxd[c] = u(rng); hx[c] = static_cast<float>(hxd[c]); }
+    vector_t<float> x(hx), y0(rows, -1.f), y1(rows, -2.f), y2(rows, -3.f);
+    vector_t<double> xd(hxd), z0(rows, -1.0), z1(rows, -2.0);
+    using plan_t = algorithms::spmv::merge_path_plan_of_t<512, 8, int, int>;
+    const plan_t::layout_t lay(a.offsets.data().get(), static_cast<int>(rows), static_cast<int>(idx.size()));
+    plan_t plan(lay, 0, plan_t::prepass_always);
+    plan.classify(0);
+    CHECK(!plan.self_complete() && plan.merge_tiles() > 1);
+    algorithms::spmv::merge_path_flat_async_with<512, 8>(plan, a, x, y0);
+    algorithms::spmv::merge_path_flat_phased_async_with<512, 8>(plan, a, x, y1);
+    algorithms::spmv::merge_path_flat_async_with<512, 8>(plan, ad, xd, z0);
+    algorithms::spmv::merge_path_flat_phased_async_with<512, 8>(plan, ad, xd, z1);
+    algorithms::spmv::spmv_plan_t<int, int, float> sp(a, /*allow_copy=*/false, /*measure=*/true, 3);
+    CHECK(sp.layout == algorithms::spmv::spmv_plan_t<int, int, float>::csr_layout && sp.ms_phased > 0.f);
+    sp.spmv(a, x, y2);
+    (void)xpu::stream_synchronize(0);
+    vector_t<float, H> h0(y0), h1(y1), h2(y2);
+    vector_t<double, H> g0(z0), g1(z1);
+    const auto href = reference::spmv(hf, hx);
+    bool equal = true, equal_d = true, close = true, plan_ok = true;
+    for (std::size_t i = 0; i < rows; ++i) {
+      equal = equal && h0[i] == h1[i];
+      equal_d = equal_d && g0[i] == g1[i];
+      plan_ok = plan_ok && std::fabs(h2[i] - h0[i]) <= 1e-5f * std::fabs(h0[i]);
+      close = close && std::fabs(h1[i] - href[i]) <= 1e-4f * std::fabs(href[i]);
+    }
+    CHECK(equal);
+    CHECK(equal_d);
+    CHECK(plan_ok);
+    CHECK(close);
+  }
   // the drop-in spmm::thread_mapped (merge-path SpMM since round 4) == the reference-shaped per-thread loop kept behind
   // thread_mapped_schedule_api == spmm::merge_path_flat (every battery matrix, several widths of B, f32 + f64)
   for (auto& dense : battery())
