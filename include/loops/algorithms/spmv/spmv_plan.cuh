@@ -96,12 +96,11 @@ struct spmv_plan_t {
     // (a shape must be measurably -- > 1 % -- faster to displace the structural choice)
     const bool keep_small = ms_small < 0.99f * ms_large || (short_rows && ms_small <= 1.01f * ms_large);
     float best = keep_small ? ms_small : ms_large;
-    if (keep_small) large.reset();
-    else small.reset();
     // the same CSR with PHASED x gathers (no copy, same bits): a candidate where it can pay at all -- long rows (two-kernel
-    // plans) over an x between a quarter of and four times one XCD's L2 -- adopted when > 2 % faster (as loops_spmv_plan_create_*)
+    // plans) over an x of at least a quarter of one XCD's L2 -- adopted when > 2 % faster than the best plain shape (as
+    // loops_spmv_plan_create_*)
     if constexpr (large_block == 512 && large_items == 8) {
-      if (large && !large->self_complete() && large->merge_tiles() > 1 && x_bytes >= (std::size_t(1) << 20) && x_bytes <= (std::size_t(16) << 20)) {
+      if (!large->self_complete() && large->merge_tiles() > 1 && x_bytes >= (std::size_t(1) << 20)) {
         ms_phased = time_ms(repeats, stream, [&] { merge_path_flat_phased_async_with<512, 8>(*large, csr, x, y, stream, true); });
         if (ms_phased < 0.98f * best) {
           phased = true;
@@ -109,12 +108,15 @@ struct spmv_plan_t {
         }
       }
     }
+    if (keep_small && !phased) large.reset();
+    else small.reset();
     if (allow_copy && x_bytes >= (std::size_t(2) << 20) && fits_blocked(csr)) {
       auto cb = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
       ms_blocked = time_ms(repeats, stream, [&] { cb->spmv_async(x, y, stream); });
       if (ms_blocked < 0.95f * best) {
         blocked = std::move(cb);
         layout = column_blocked_layout;
+        phased = false;
         small.reset();
         large.reset();
       }
@@ -126,6 +128,7 @@ struct spmv_plan_t {
       if (ms_panel < 0.95f * incumbent && ms_panel < 0.95f * best) {
         panel = std::move(pb);
         layout = panel_binned_layout;
+        phased = false;
         small.reset();
         large.reset();
         blocked.reset();

@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <type_traits>
 
 #include <hip/hip_runtime.h>
@@ -118,15 +119,33 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
   return launch_status();
 }
 
-/// Number of column parts of the phased-gather kernels, and the shift that maps a column of a `cols`-wide matrix to its
-/// part: min(col >> shift, parts - 1) -- parts of 2^shift columns, the last one takes what is left.
-constexpr int phased_parts = 8;
-inline unsigned int phased_shift(int cols, int parts = phased_parts) {
+/// How the phased-gather kernels are run on a matrix of `cols` columns of `elem_bytes`-byte values: the number of column
+/// parts M -- 8 up to |x| = 6 MB, 16 up to 24 MB, 32 beyond: parts of 0.5-2 MB -- the shift that maps a column to its part,
+/// min(col >> shift, M - 1), and the period the first part of a tile is chosen by: about the time a pass takes, 3.75 us with 8
+/// parts, 1.87 us with 16 or 32.  Measured optima over |x| = 4 ... 64 MB, flat within +- 25 %
+/// (profiles/r04_phased_gather_experiments.txt, sections 2, 7 and 8).  LOOPS_PHASED_PARTS / LOOPS_PHASED_TICKS (environment, read
+/// once) override M and the period in 10 ns ticks: measurement aids (scripts/sweep_phased.sh).
+struct phased_config {
+  int parts;
+  detail::phase_args args;
+};
+inline phased_config phased_config_for(long long cols, int elem_bytes) {
+  static const int env_parts = [] { const char* e = std::getenv("LOOPS_PHASED_PARTS"); return e ? std::atoi(e) : 0; }();
+  static const int env_ticks = [] { const char* e = std::getenv("LOOPS_PHASED_TICKS"); return e ? std::atoi(e) : 0; }();
+  const double x_mb = static_cast<double>(cols > 0 ? cols : 1) * elem_bytes / (1024.0 * 1024.0);
+  int parts = x_mb <= 6.0 ? 8 : x_mb <= 24.0 ? 16 : 32;
+  if (env_parts == 8 || env_parts == 16 || env_parts == 32) parts = env_parts;
+  double ticks = parts == 8 ? 375.0 : 187.0;             // 10 ns ticks per pass
+  if (env_ticks > 0) ticks = env_ticks;
   int bits = 0;
-  while (bits < 31 && (static_cast<long long>(cols) - 1) >> bits) ++bits;  // bits needed for cols - 1
+  while (bits < 31 && ((cols > 0 ? cols : 1) - 1) >> bits) ++bits;  // bits needed for cols - 1
   int lg = 0;
   while ((1 << (lg + 1)) <= parts) ++lg;
-  return static_cast<unsigned int>(bits > lg ? bits - lg : 0);
+  phased_config c;
+  c.parts = parts;
+  c.args.shift = static_cast<unsigned int>(bits > lg ? bits - lg : 0);
+  c.args.inv_ticks = static_cast<unsigned int>(4294967296.0 / (ticks < 2.0 ? 2.0 : ticks));
+  return c;
 }
 
 /// Fused merge-path SpMV with PHASED x gathers (merge_path_spmv_fused_phased; + fix-up).  Only the two-kernel form on
@@ -142,14 +161,22 @@ int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& pl
     return launch_merge_path_fused<TPB, IPT, true, 0, index_t, offset_t, T, true>(stream, plan, rows, nnz, offsets, indices, values, x, y,
                                                                                  stages, false, planned);
   T* carry_val = static_cast<T*>(plan.carry_val);
-  const unsigned int shift = phased_shift(cols);
+  const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
   if (stages & 1) {
-    if (planned)
-      hipLaunchKernelGGL((merge_path_spmv_fused_phased_planned<TPB, IPT, phased_parts, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0,
-                         stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val, shift);
+    auto go = [&](auto plain, auto from_plan) {
+      if (planned)
+        hipLaunchKernelGGL(from_plan, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
+                           plan.carry_row, carry_val, cfg.args);
+      else
+        hipLaunchKernelGGL(plain, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
+                           plan.carry_row, carry_val, cfg.args);
+    };
+    if (cfg.parts == 8)
+      go(merge_path_spmv_fused_phased<TPB, IPT, 8, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 8, true, index_t, offset_t, T>);
+    else if (cfg.parts == 16)
+      go(merge_path_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 16, true, index_t, offset_t, T>);
     else
-      hipLaunchKernelGGL((merge_path_spmv_fused_phased<TPB, IPT, phased_parts, true, index_t, offset_t, T>), dim3(m), dim3(TPB), 0, stream,
-                         plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row, carry_val, shift);
+      go(merge_path_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 32, true, index_t, offset_t, T>);
   }
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,

@@ -77,14 +77,19 @@ constexpr int val_aux(int p) { return (p >> 5) & 31; }
 constexpr int x_aux(int p) { return (p >> 10) & 31; }
 constexpr unsigned int rsrc_flags = 0x00020000u;  // gfx9 raw buffer: DATA_FORMAT = 32 bit, no swizzle, no TID
 /// policy::phased(M): plain loads, the x gathers of a tile issued in M passes by column range (merge_tile_engine::
-/// stream_vectors; M a power of two).  phase_ticks(TPB, IPT): the pass length the first part is chosen by, in ticks of the
-/// 100 MHz s_memrealtime clock -- measured on C2 (profiles/r04_phased_gather_experiments.txt): 512 x 8 tiles 3.1-4.4 us, best
-/// 3.75; 256 x 16 tiles 3.75-5, best 4.4; the optimum is flat (+- 25 % costs < 1 %).
+/// stream_vectors; M a power of two).  The part a tile starts with is (clock / period) mod M; shift and period are run-time
+/// values (`phase_args`, chosen by the launcher from the matrix's column count: kernels::phased_config_for).
 constexpr int phased_flag = 0x20000;
 constexpr int phased(int m) { return phased_flag | m; }
 constexpr int phases(int p) { return (p & phased_flag) != 0 ? (p & 0xff) : 0; }
-constexpr unsigned long long phase_ticks(int tpb, int ipt) { return tpb * ipt >= 4096 && ipt >= 16 ? 437 : 375; }
 }  // namespace policy
+
+/// Run-time side of the phased gathers: part of a column = min(col >> shift, M - 1); the clock's current part =
+/// umulhi(low 32 bits of s_memrealtime, inv_ticks) mod M with inv_ticks = 2^32 / (period in 10 ns ticks).
+struct phase_args {
+  unsigned int shift = 0;
+  unsigned int inv_ticks = 0;
+};
 
 /// 4 consecutive elements at byte offset `byte_off` of buffer `r` with cache-policy bits AUX (see policy).
 template <typename T, int AUX>
@@ -329,7 +334,7 @@ struct merge_tile_engine {
                                                         const index_t* __restrict__ indices,
                                                         const type_t* __restrict__ values,
                                                         const type_t* __restrict__ x, mark_t& mark,
-                                                        const unsigned int phase_shift = 0) {
+                                                        const detail::phase_args phase = {}) {
     const int tid = threadIdx.x;
     index_t col[KV][4];
     type_t val[KV][4];
@@ -377,15 +382,15 @@ struct merge_tile_engine {
       } else {
         if constexpr (detail::policy::phases(NT) > 1) {
           // PHASED gathers (merge_path_spmv_fused_phased): the tile's gathers leave in M passes, pass p taking
-          // the items whose column lies in part p of x (M parts of 2^phase_shift columns), execution-masked, each pass
+          // the items whose column lies in part p of x (M parts of 2^shift columns), execution-masked, each pass
           // drained (vmcnt(0)) and closed by a workgroup barrier before the next one starts.  Which part comes first is read
-          // off a clock every wavefront of the chip shares (s_memrealtime, 100 MHz) and `ticks` ~ the time a pass takes, so the
+          // off a clock every wavefront of the chip shares (s_memrealtime, 100 MHz; the period ~ the time a pass takes), so the
           // workgroups of an XCD gather from the SAME part of x at the same time: the working set of the XCD's L2 is
           // |x| / M + the streams instead of |x| + the streams.  Results are unchanged (the same loads, another order).
           constexpr unsigned int M = detail::policy::phases(NT);
           static_assert((M & (M - 1)) == 0, "phased gathers: a power-of-two number of parts");
-          constexpr unsigned long long ticks = detail::policy::phase_ticks(TPB, IPT);
-          const unsigned int first = static_cast<unsigned int>((__builtin_amdgcn_s_memrealtime() / ticks) & (M - 1));
+          const unsigned int now = static_cast<unsigned int>(__builtin_amdgcn_s_memrealtime());
+          const unsigned int first = __umulhi(now, phase.inv_ticks) & (M - 1);
 #pragma unroll
           for (int k = 0; k < KV; ++k)
 #pragma unroll
@@ -398,7 +403,7 @@ struct merge_tile_engine {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const unsigned int c = gather_index(col[k][j]);
-                unsigned int part = c >> phase_shift;
+                unsigned int part = c >> phase.shift;
                 part = part < M - 1 ? part : M - 1;
                 if (part == p) xv[k][j] = x[c];
               }
@@ -491,7 +496,7 @@ struct merge_tile_engine {
                                                   const index_t* __restrict__ indices,
                                                   const type_t* __restrict__ values, const type_t* __restrict__ x,
                                                   const store_t out, const type_t carry_in,
-                                                  mark_t mark = mark_t{}, const unsigned int phase_shift = 0) {
+                                                  mark_t mark = mark_t{}, const detail::phase_args phase = {}) {
     const int tid = threadIdx.x;
     const int nz1 = nz0 + natoms;
     // ---- 1. STREAM ------------------------------------------------------------------------
@@ -499,7 +504,7 @@ struct merge_tile_engine {
     const int shift = nz0 - abase;             // 0..3 leading elements owned by the previous tile
     if constexpr (VEC) {
       // every vector load of the tile in-bounds?  (uniform; false only for the last tile(s) of the matrix)
-      if (abase + KV * 4 * TPB <= nnz) stream_vectors<true>(s, abase, nz1, nnz, indices, values, x, mark, phase_shift);
+      if (abase + KV * 4 * TPB <= nnz) stream_vectors<true>(s, abase, nz1, nnz, indices, values, x, mark, phase);
       else stream_vectors<false>(s, abase, nz1, nnz, indices, values, x, mark);
     } else {
       // Unaligned arrays: coalesced 4-byte loads, one element per lane per round.
@@ -667,7 +672,7 @@ merge_path_spmv_tile_to(const coord_t* __restrict__ coords, const int rows, cons
                         const row_end_t row_end, const index_t* __restrict__ indices,
                         const type_t* __restrict__ values, const type_t* __restrict__ x, const store_t out,
                         int* __restrict__ carry_row, type_t* __restrict__ carry_val,
-                        const int* __restrict__ head_start = nullptr, const unsigned int phase_shift = 0) {
+                        const int* __restrict__ head_start = nullptr, const detail::phase_args phase = {}) {
   using offset_t = int;
   // SELF (self-completing plans, merge_path_head_check): the tile is EXTENDED backwards to the start of the row
   // it begins in -- at most TPB extra nonzeros -- so that row is summed completely here and nothing has to be
@@ -714,7 +719,7 @@ merge_path_spmv_tile_to(const coord_t* __restrict__ coords, const int rows, cons
       for (int i = tid; i < nrows; i += TPB)
         engine_t::mark_row_end(s_engine, i, static_cast<int>(row_end(row0 + i)), nz0);
     }
-  }, phase_shift);
+  }, phase);
   if constexpr (!SELF) {
     if (tid == 0) {
       carry_row[b] = row0 + nrows;  // == c1.x: the row still open when the tile ends
@@ -813,7 +818,7 @@ merge_path_spmv_fused_planned(const coord_t* __restrict__ coords, const int rows
 }
 
 /// merge_path_flat with PHASED x gathers (round 4): the same tile kernel, but a tile's gathers leave in PHASES passes by
-/// column range -- part = min(col >> phase_shift, PHASES - 1) -- and the pass a workgroup starts with is read off the
+/// column range -- part = min(col >> phase.shift, PHASES - 1) -- and the pass a workgroup starts with is read off the
 /// chip-wide clock, so the workgroups of an XCD work on the same part of x at the same time (merge_tile_engine::
 /// stream_vectors).  For matrices whose columns are scattered over an x of about the size of one XCD's L2 (C2: 4 MB = the L2):
 /// the matrix stream evicts a fifth of x there, and every evicted line costs an Infinity-Cache round trip; with 8 parts the
@@ -825,10 +830,10 @@ __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_phased(const coord_t* __restrict__ coords, const int rows, const int nnz,
                              const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                              const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
-                             int* __restrict__ carry_row, type_t* __restrict__ carry_val, const unsigned int phase_shift) {
+                             int* __restrict__ carry_row, type_t* __restrict__ carry_val, const detail::phase_args phase) {
   merge_path_spmv_tile_to<TPB, IPT, true, detail::policy::phased(PHASES), VEC, false, true>(
       coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x, plain_store<type_t>{y}, carry_row, carry_val, nullptr,
-      phase_shift);
+      phase);
 }
 
 /// (the same under the symbol of SpMV-plan handles: profile attribution only, as merge_path_spmv_fused_planned)
@@ -837,10 +842,10 @@ __global__ void __launch_bounds__(TPB)
 merge_path_spmv_fused_phased_planned(const coord_t* __restrict__ coords, const int rows, const int nnz,
                                      const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                                      const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
-                                     int* __restrict__ carry_row, type_t* __restrict__ carry_val, const unsigned int phase_shift) {
+                                     int* __restrict__ carry_row, type_t* __restrict__ carry_val, const detail::phase_args phase) {
   merge_path_spmv_tile_to<TPB, IPT, true, detail::policy::phased(PHASES), VEC, false, true>(
       coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x, plain_store<type_t>{y}, carry_row, carry_val, nullptr,
-      phase_shift);
+      phase);
 }
 
 /**

@@ -116,10 +116,11 @@ int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* off
  * tuning aids with the per-thread halving search instead: 4 (otherwise as 0), 1 = non-temporal streaming
  * loads, 2 = unpadded LDS product array, 3 = both.
  * LOOPS_VARIANT_PHASED = the default kernel with PHASED x gathers (plans of shape LOOPS_TILE_512x8 / LOOPS_TILE_256x16,
- * LOOPS_E_CONFIG otherwise): a tile's gathers leave in 8 passes by column range and the pass a workgroup starts with is read
- * off a chip-wide clock, so that the workgroups sharing an L2 gather from the same eighth of x at the same time.  Same bits as
- * variant 0; faster where the columns are scattered over an x of about one XCD's L2 (C2: 94.9 -> 84 us), slower by 2-10 %
- * where the gathers hit anyway -- pick it by measurement (loops_autotune_merge_path_variants_f32, LOOPS_PLAN_MEASURE).
+ * LOOPS_E_CONFIG otherwise): a tile's gathers leave in passes by column range and the pass a workgroup starts with is read
+ * off a chip-wide clock, so that the workgroups sharing an L2 gather from the same eighth of x at the same time (8 parts up
+ * to an x of 6 MB, 16 up to 24 MB, 32 beyond).  Same bits as variant 0; faster where the columns are scattered over an x of one
+ * XCD's L2 or more (C2, 4 MB: 94.8 -> 82.9 us; 8 / 16 / 32 / 64 MB: 1.65 / 1.9 / 1.45 / 1.3 x), slower by 2-10 % where the
+ * gathers hit anyway -- pick it by measurement (loops_autotune_merge_path_variants_f32, LOOPS_PLAN_MEASURE).
  * No reference counterpart (merge_path_flat.cuh:66-82 leaves the gather order to the hardware). */
 #define LOOPS_VARIANT_PHASED 8
 int loops_spmv_merge_path_f32(const loops_merge_plan_t* plan, int variant, int rows, int cols, int nnz,
@@ -364,8 +365,8 @@ int loops_spmv_plan_create_f64(int rows, int cols, int nnz, const int* offsets, 
 void loops_spmv_plan_destroy(loops_spmv_plan_t* plan);
 int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4);
 /* LOOPS_LAYOUT_CSR plans: the kernel variant the plan runs (0 or LOOPS_VARIANT_PHASED -- with LOOPS_PLAN_MEASURE the phased
- * twins of 512 x 8 and 256 x 16 are candidates when rows are long and x is 1-16 MB, adopted when > 2 % faster than the best
- * plain shape) and the best phased candidate's measured ms per product (-1 = not timed).  Either pointer may be NULL. */
+ * twins of 512 x 8 and 256 x 16 are candidates when rows are long and x is at least 1 MB, adopted when > 2 % faster than the
+ * best plain shape) and the best phased candidate's measured ms per product (-1 = not timed).  Either pointer may be NULL. */
 int loops_spmv_plan_variant(const loops_spmv_plan_t* plan, int* variant, float* ms_phased);
 int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream);
 int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream);

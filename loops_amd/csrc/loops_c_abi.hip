@@ -858,9 +858,9 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
   }
   p->merge = best;
   // The same CSR with PHASED x gathers (kernels::merge_path_spmv_fused_phased: no copy, same bits): a candidate where it can
-  // pay at all -- long rows (two-kernel plans) and an x between a quarter of and four times one XCD's L2 -- adopted when it is
-  // measurably (> 2 %) faster than the best plain shape.
-  if (!err && best && !best->self_complete && best->num_tiles > 1 && x_bytes >= (1ll << 20) && x_bytes <= (16ll << 20)) {
+  // pay at all -- long rows (two-kernel plans) and an x of at least a quarter of one XCD's L2 -- adopted when it is measurably
+  // (> 2 %) faster than the best plain shape (C2, x = 4 MB: 1.14 x; scattered columns over 8-64 MB: 1.3-1.9 x).
+  if (!err && best && !best->self_complete && best->num_tiles > 1 && x_bytes >= (1ll << 20)) {
     const int pshapes[2] = {LOOPS_TILE_512x8, LOOPS_TILE_256x16};
     for (int i = 0; !err && i < 2; ++i) {
       loops_merge_plan* m = nullptr;

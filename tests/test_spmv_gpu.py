@@ -744,7 +744,7 @@ def test_c4_full_size_bcsr_bit_exact():
 # Phased x gathers (LOOPS_VARIANT_PHASED, kernels::merge_path_spmv_fused_phased): the same loads in another order -- the result
 # must equal the default kernel's BIT FOR BIT on any input, not only on exactly summable ones.
 @pytest.mark.parametrize("tile", ["512x8", "256x16"])
-@pytest.mark.parametrize("cols", [1 << 13, 8191, 5000, 100003, 9, 1])
+@pytest.mark.parametrize("cols", [1 << 13, 8191, 5000, 100003, 9, 1, 1 << 21, (1 << 23) + 5])  # (x of 8 / 32 MB: 16 / 32 parts)
 def test_phased_gathers_equal_the_default_kernel_bit_for_bit(tile, cols):
     from loops_amd import spmv as S, generate as G, _lib
     from oracle import oracle as O
