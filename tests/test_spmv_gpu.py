@@ -699,26 +699,30 @@ def test_held_plans_are_hip_graph_capturable():
     cb = S.ColumnBlockedPlan(csr, 4)
     xs = [G.uniform_distribution_int(cols, seed=s) for s in (42, 7)]
     x = torch.from_numpy(xs[0]).cuda()
-    y1, y2 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    y1, y2, y3 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    from loops_amd import _lib
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):  # warm-up on the capture stream (lazy module loading must not happen inside a capture)
         S.merge_path_flat(csr, x, y1, plan=plan)
         cb.spmv(x, y2)
+        S.merge_path_flat(csr, x, y3, plan=plan, variant=_lib.VARIANT_PHASED)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         S.merge_path_flat(csr, x, y1, plan=plan)
         cb.spmv(x, y2)
+        S.merge_path_flat(csr, x, y3, plan=plan, variant=_lib.VARIANT_PHASED)  # (the phased-gather kernel reads a clock, nothing host-side)
     for xh in reversed(xs):   # replay on new data in the same buffers
         x.copy_(torch.from_numpy(xh))
         y1.fill_(-1.0)
         y2.fill_(-1.0)
+        y3.fill_(-1.0)
         graph.replay()
         torch.cuda.synchronize()
         ref = O.spmv_f32(off, idx, val, xh)
-        assert np.array_equal(y1.cpu().numpy(), ref) and np.array_equal(y2.cpu().numpy(), ref)
+        assert np.array_equal(y1.cpu().numpy(), ref) and np.array_equal(y2.cpu().numpy(), ref) and np.array_equal(y3.cpu().numpy(), ref)
 
 
 def test_c4_full_size_bcsr_bit_exact():
