@@ -282,13 +282,18 @@ def context_c3_standins(G, S, O, torch, iters=10):
         # merge_path_flat runs over a held 256 x 8 plan here: the headline's kernel symbol (merge_path_spmv_fused<512, 8>) must
         # stay exclusive to the C2 matrix in this process, so that rocprofv3's per-kernel average of this command is the headline's
         mplan = S.MergePathPlan(csr, "256x8")
+        # (and the phased-gather twin over 256 x 16 tiles -- 32 parts at this |x| -- a measured choice only: it gains where the
+        # columns are scattered and LOSES where they are local; another template instantiation than the headline's, 512 x 8 / 8 parts)
+        pplan = S.MergePathPlan(csr, "256x16")
         runs = {"group_mapped": lambda: S.spmv("group_mapped", csr, x, y), "work_oriented": lambda: S.spmv("work_oriented", csr, x, y),
-                "merge_path_flat": lambda: S.merge_path_flat(csr, x, y, plan=mplan)}
+                "merge_path_flat": lambda: S.merge_path_flat(csr, x, y, plan=mplan),
+                "merge_path_flat_phased_gathers": lambda: S.merge_path_flat(csr, x, y, plan=pplan, variant=VARIANT_PHASED)}
         for sched, fn in runs.items():
             ms = timed_ms(torch, fn, iters)
             res[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
                           "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
         mplan.close()
+        pplan.close()
         # what a caller gets by default from a held plan (loops_spmv_plan_*: tile shape + layout picked by measurement)
         sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
         ms = timed_ms(torch, lambda: sp.spmv(x, y), iters)

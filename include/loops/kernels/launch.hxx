@@ -134,8 +134,12 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
   static const int env_ticks = [] { const char* e = std::getenv("LOOPS_PHASED_TICKS"); return e ? std::atoi(e) : 0; }();
   const double x_mb = static_cast<double>(cols > 0 ? cols : 1) * elem_bytes / (1024.0 * 1024.0);
   int parts = x_mb <= 6.0 ? 8 : x_mb <= 24.0 ? 16 : 32;
-  if (env_parts == 8 || env_parts == 16 || env_parts == 32) parts = env_parts;
   double ticks = parts == 8 ? 375.0 : 187.0;             // 10 ns ticks per pass
+  if (elem_bytes == 8) {  // 8-byte values: 8 parts whatever |x| (16 / 32 passes of 8-byte masked loads cost more than they save:
+    parts = 8;            // |x| = 8 / 16 / 32 MB: 1.24 / 1.42 / 1.20 x with 8 parts, 0.75 / 0.9 / 0.6 x with 16 / 32)
+    ticks = x_mb > 24.0 ? 750.0 : 375.0;
+  }
+  if ((env_parts == 8 || env_parts == 16 || env_parts == 32) && elem_bytes != 8) parts = env_parts;
   if (env_ticks > 0) ticks = env_ticks;
   int bits = 0;
   while (bits < 31 && ((cols > 0 ? cols : 1) - 1) >> bits) ++bits;  // bits needed for cols - 1
@@ -171,12 +175,14 @@ int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& pl
         hipLaunchKernelGGL(plain, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
                            plan.carry_row, carry_val, cfg.args);
     };
-    if (cfg.parts == 8)
+    if (cfg.parts == 8 || sizeof(T) == 8) {  // (8-byte values: 8 parts only -- phased_config_for; the override cannot ask for more)
       go(merge_path_spmv_fused_phased<TPB, IPT, 8, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 8, true, index_t, offset_t, T>);
-    else if (cfg.parts == 16)
-      go(merge_path_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 16, true, index_t, offset_t, T>);
-    else
-      go(merge_path_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 32, true, index_t, offset_t, T>);
+    } else if constexpr (sizeof(T) != 8) {
+      if (cfg.parts == 16)
+        go(merge_path_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 16, true, index_t, offset_t, T>);
+      else
+        go(merge_path_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 32, true, index_t, offset_t, T>);
+    }
   }
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,

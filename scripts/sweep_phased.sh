@@ -9,6 +9,6 @@ for s in "${SIZES[@]}"; do
   timeout 300 python tests/perf/ab_phased.py 2>&1 | grep -v amdgpu.ids | sed "s/ eq=True//g"
   export PHASED_ONLY=1
   for p in $PARTS; do for t in $TICKS; do
-    LOOPS_PHASED_PARTS=$p LOOPS_PHASED_TICKS=$t timeout 300 python tests/perf/ab_phased.py 2>&1 | grep -v amdgpu.ids | sed "s/ eq=True//g; s/step *[0-9.]* *//g"
+    LOOPS_PHASED_PARTS=$p LOOPS_PHASED_TICKS=$t timeout 300 python tests/perf/ab_phased.py 2>&1 | grep -v amdgpu.ids | sed "s/ eq=True//g"
   done; done
 done

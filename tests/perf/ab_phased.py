@@ -17,18 +17,21 @@ def batch(fn, iters=100, warm=10):
 lr, ln = int(os.environ.get("LOG_ROWS", "20")), int(os.environ.get("LOG_NNZ", "24"))
 rows = 1 << lr
 cols = 1 << int(os.environ.get("LOG_COLS", str(lr)))
-deg = G.powerlaw_degrees(rows, 1 << ln)
+nnz_target = int(os.environ.get("NNZ", str(1 << ln)))
+deg = G.powerlaw_degrees(rows, nnz_target)
 off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, None)
-csr = S.CSR.from_numpy(rows, cols, off, idx, val)
-x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
-y = torch.empty(rows, device="cuda"); y0 = torch.empty(rows, device="cuda")
+f64 = os.environ.get("DTYPE", "f32") == "f64"
+dt = np.float64 if f64 else np.float32
+csr = S.CSR.from_numpy(rows, cols, off, idx, val.astype(dt))
+x = torch.from_numpy(G.uniform_distribution_int(cols).astype(dt)).cuda()
+y = torch.empty(rows, device="cuda", dtype=x.dtype); y0 = torch.empty(rows, device="cuda", dtype=x.dtype)
 out = []
 tiles = os.environ.get("TILES", "512x8,256x16").split(",")
 for tile in tiles:
     plan = S.MergePathPlan(csr, tile)
     S.merge_path_flat(csr, x, y0, plan=plan, variant=0)
     for v in ((_lib.VARIANT_PHASED,) if os.environ.get("PHASED_ONLY") else (0, _lib.VARIANT_PHASED)):
-        k = min(batch(lambda: S.merge_path_flat_stage(csr, x, y, plan, 0, v)) for _ in range(3))
+        k = min(batch(lambda: S.merge_path_flat_stage(csr, x, y, plan, 0, v)) for _ in range(3)) if not f64 else float('nan')  # (the stage entry is f32 only)
         s = min(batch(lambda: S.merge_path_flat(csr, x, y, plan=plan, variant=v)) for _ in range(3))
         out.append(f"{tile}{'+phased' if v else ''}: kernel {k:6.1f} step {s:6.1f} eq={bool(torch.equal(y, y0))}")
-print(f"2^{lr} rows x {cols} cols 2^{ln} nnz parts={os.environ.get('LOOPS_PHASED_PARTS', 'auto')} ticks={os.environ.get('LOOPS_PHASED_TICKS', 'auto')} | " + " | ".join(out), flush=True)
+print(("f64 " if f64 else "") + f"2^{lr} rows x {cols} cols {nnz_target} nnz ({(rows + nnz_target + 4095) // 4096} tiles of 4096) parts={os.environ.get('LOOPS_PHASED_PARTS', 'auto')} ticks={os.environ.get('LOOPS_PHASED_TICKS', 'auto')} | " + " | ".join(out), flush=True)
