@@ -294,7 +294,19 @@ static void misc() {
       for (std::size_t i = 0; i < g0.size(); ++i) same = same && std::fabs(g0[i] - g1[i]) <= 1e-9 + 1e-12 * std::fabs(g0[i]);
       CHECK(same);
     }
-  // phased x gathers (merge_path_flat_phased_async_with; spmv_plan_t's candidate for long rows over an x of 1-16 MB): the
+  // how the phased-gather kernels are configured (host logic, kernels::phased_config_for): parts by |x|, the shift that maps
+  // every column below `cols` to a part below `parts`, 8 parts for 8-byte values
+  for (long long cols : {1ll, 2ll, 9ll, 1000ll, 1ll << 20, (1ll << 20) + 1, 1ll << 21, 1ll << 23, (1ll << 24) - 3, (1ll << 31) - 1}) {
+    for (int bytes : {4, 8}) {
+      const kernels::phased_config c = kernels::phased_config_for(cols, bytes);
+      const double mb = static_cast<double>(cols) * bytes / (1024.0 * 1024.0);
+      CHECK(c.parts == (bytes == 8 ? 8 : mb <= 6.0 ? 8 : mb <= 24.0 ? 16 : 32));
+      CHECK(((cols - 1) >> c.args.shift) < c.parts);                          // the last column lands in an existing part
+      CHECK(c.args.shift == 0 || ((cols - 1) >> (c.args.shift - 1)) >= c.parts);  // ... and no smaller shift would do
+      CHECK(c.args.inv_ticks > 0);
+    }
+  }
+  // phased x gathers (merge_path_flat_phased_async_with; spmv_plan_t's candidate for long rows over an x of at least 1 MB): the
   // plain kernel's bits on real values, for a power-of-two and an odd column count, f32 and f64
   for (std::size_t cols : {std::size_t(1) << 19, std::size_t(300007)}) {
     const std::size_t rows = 1 << 12;

@@ -1,6 +1,6 @@
 """Soak: the tuned kernels launched back to back for a fixed wall time on C2 and on a self-completing band matrix; every
 result compared ON THE GPU with the first one (bit-equal) -- races / ordering bugs show up as a mismatch count > 0.
-usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3]     (r2 / r3 = only the kernels added in that round)"""
+usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3|r4]     (r2 / r3 / r4 = only the kernels added in that round)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -66,6 +66,47 @@ def round3():
         soak("bcsr", f"coalesced BCSR {R}x{R}, 2^16 block-rows x 16", lambda y, b=b, xb=xb: (S.bcsr_thread_mapped(b, xb, y, mfma="tuned"), None)[1], want, nbr * R)
 
 
+# ---- round 4: phased x gathers (clock-aligned passes with a workgroup barrier each: the product must equal the plain kernel's
+# bit for bit on every launch, exactly summable AND real values), 8 / 16 / 32 parts, both tile shapes, fp32 and fp64
+def round4():
+    from loops_amd import _lib
+    for lr, ln in ((20, 24), (21, 25), (23, 26)):
+        r = c = 1 << lr
+        deg = G.powerlaw_degrees(r, 1 << ln)
+        for exact in (True, False):
+            off, idx, val = G.csr_from_degrees(deg, c, 1, 0, exact)
+            xh = G.uniform_distribution_int(c) if exact else G.realistic_x(c)
+            for dt in (np.float32, np.float64):
+                if dt is np.float64 and lr != 20:
+                    continue
+                csr = S.CSR.from_numpy(r, c, off, idx, val.astype(dt))
+                x = torch.from_numpy(xh.astype(dt)).cuda()
+                for tile in ("512x8", "256x16"):
+                    plan = S.MergePathPlan(csr, tile)
+                    ref = S.merge_path_flat(csr, x, plan=plan, variant=0).clone()
+                    def run(y, csr=csr, x=x, plan=plan):
+                        S.merge_path_flat(csr, x, y, plan=plan, variant=_lib.VARIANT_PHASED)
+                    y_dtype = ref.dtype
+                    def soak_t(name, label, fn, ref, n_out):  # (soak() with the value type of this case)
+                        y = torch.empty(n_out, device="cuda", dtype=y_dtype)
+                        bad = torch.zeros((), dtype=torch.int64, device="cuda")
+                        rounds, t0 = 0, time.time()
+                        while time.time() - t0 < secs:
+                            for _ in range(100):
+                                y.fill_(float("nan"))
+                                fn(y)
+                                bad += (y != ref).any()
+                            rounds += 100
+                            torch.cuda.synchronize()
+                        print(f"{name:9s} {label:60s} rounds {rounds:7d} mismatching rounds {int(bad.item())}", flush=True)
+                    soak_t(f"2^{lr}", f"phased gathers {tile} {np.dtype(dt).name} {'exact' if exact else 'real'} values vs the plain kernel", run, ref, r)
+                    plan.close()
+                del csr
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "r4":
+    round4()
+    sys.exit(0)
 if only_r3:
     round3()
     sys.exit(0)
