@@ -44,9 +44,10 @@ int main(int argc, char** argv) {
   std::size_t errors = 0;
   for (std::size_t i = 0; i < a.size(); ++i) errors += std::fabs(a[i] - b[i]) > 1e-4f * (1.f + std::fabs(b[i]));
   const char* layouts[] = {"unmodified CSR", "column-blocked copy", "panel-binned copy"};
-  std::cout << "Layout:\t\t" << layouts[plan.layout] << (plan.layout == plan_t::csr_layout ? (plan.small ? ", 256 x 8 tiles" : ", 512 x 8 tiles") : "")
+  std::cout << "Layout:\t\t" << layouts[plan.layout] << (plan.layout == plan_t::csr_layout ? (plan.small ? ", 256 x 8 tiles" : plan.phased ? ", 512 x 8 tiles, phased x gathers" : ", 512 x 8 tiles") : "")
             << std::endl;
-  std::cout << "Measured (ms):\tcsr 256x8 " << plan.ms_small << ", csr 512x8 " << plan.ms_large << ", column-blocked " << plan.ms_blocked
+  std::cout << "Measured (ms):\tcsr 256x8 " << plan.ms_small << ", csr 512x8 " << plan.ms_large << ", csr 512x8 phased " << plan.ms_phased
+            << ", column-blocked " << plan.ms_blocked
             << ", panel-binned " << plan.ms_panel << "  (-1 = not a candidate)" << std::endl;
   std::cout << "Elapsed (ms):\t" << total_ms / static_cast<float>(iterations > 0 ? iterations : 1) << " per product, " << iterations
             << " products" << std::endl;
