@@ -96,11 +96,10 @@ struct spmv_plan_t {
     // (a shape must be measurably -- > 1 % -- faster to displace the structural choice)
     const bool keep_small = ms_small < 0.99f * ms_large || (short_rows && ms_small <= 1.01f * ms_large);
     float best = keep_small ? ms_small : ms_large;
-    // the same CSR with PHASED x gathers (no copy, same bits): a candidate where it can pay at all -- long rows (two-kernel
-    // plans) over an x of at least a quarter of one XCD's L2 -- adopted when > 2 % faster than the best plain shape (as
-    // loops_spmv_plan_create_*)
+    // the same CSR with PHASED x gathers (no copy, same bits): a candidate where it can pay at all -- an x of at least a quarter
+    // of one XCD's L2 -- adopted when > 2 % faster than the best plain shape (as loops_spmv_plan_create_*)
     if constexpr (large_block == 512 && large_items == 8) {
-      if (!large->self_complete() && large->merge_tiles() > 1 && x_bytes >= (std::size_t(1) << 20)) {
+      if (large->merge_tiles() > 1 && x_bytes >= (std::size_t(1) << 20)) {
         ms_phased = time_ms(repeats, stream, [&] { merge_path_flat_phased_async_with<512, 8>(*large, csr, x, y, stream, true); });
         if (ms_phased < 0.98f * best) {
           phased = true;

@@ -152,20 +152,34 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
   return c;
 }
 
-/// Fused merge-path SpMV with PHASED x gathers (merge_path_spmv_fused_phased; + fix-up).  Only the two-kernel form on
-/// 16-byte aligned arrays has a phased twin: a self-completing plan (no long rows), a single tile or unaligned arrays run the
-/// plain kernel -- same result either way.
+/// Fused merge-path SpMV with PHASED x gathers (merge_path_spmv_fused_phased + fix-up, or merge_path_spmv_fused_self_phased for
+/// self-completing plans).  A single tile or arrays that are not 16-byte aligned run the plain kernel -- same result either way.
 template <int TPB, int IPT, typename index_t, typename offset_t, typename T>
 int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& plan, int rows, int cols, int nnz,
                                    const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
                                    int stages = 3, bool planned = false) {
   const int m = plan.num_merge_tiles;
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-  if (m <= 1 || !aligned || (plan.self_complete && plan.head_start))
+  if (m <= 1 || !aligned)
     return launch_merge_path_fused<TPB, IPT, true, 0, index_t, offset_t, T, true>(stream, plan, rows, nnz, offsets, indices, values, x, y,
                                                                                  stages, false, planned);
   T* carry_val = static_cast<T*>(plan.carry_val);
   const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
+  if (plan.self_complete && plan.head_start) {  // one kernel, no carry-outs (the "fix-up" stage has nothing to do)
+    if (stages & 1) {
+      auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(m), dim3(TPB), 0, stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y,
+                           cfg.args);
+      };
+      if (cfg.parts == 8 || sizeof(T) == 8) {
+        go(merge_path_spmv_fused_self_phased<TPB, IPT, 8, true, index_t, offset_t, T>);
+      } else if constexpr (sizeof(T) != 8) {
+        if (cfg.parts == 16) go(merge_path_spmv_fused_self_phased<TPB, IPT, 16, true, index_t, offset_t, T>);
+        else go(merge_path_spmv_fused_self_phased<TPB, IPT, 32, true, index_t, offset_t, T>);
+      }
+    }
+    return launch_status();
+  }
   if (stages & 1) {
     auto go = [&](auto plain, auto from_plan) {
       if (planned)

@@ -836,6 +836,19 @@ merge_path_spmv_fused_phased(const coord_t* __restrict__ coords, const int rows,
       phase);
 }
 
+/// The SELF-COMPLETING form (plans over short rows: one kernel, no carry-outs, merge_path_spmv_fused_self) with phased gathers:
+/// short rows with scattered columns -- random graphs, "8 M rows x 2 nonzeros" -- gain as C2 does.
+template <int TPB, int IPT, int PHASES, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused_self_phased(const coord_t* __restrict__ coords, const int* __restrict__ head_start, const int rows,
+                                  const int nnz, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                                  const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                                  const detail::phase_args phase) {
+  merge_path_spmv_tile_to<TPB, IPT, true, detail::policy::phased(PHASES), VEC, true, true>(
+      coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x, plain_store<type_t>{y}, nullptr,
+      static_cast<type_t*>(nullptr), head_start, phase);
+}
+
 /// (the same under the symbol of SpMV-plan handles: profile attribution only, as merge_path_spmv_fused_planned)
 template <int TPB, int IPT, int PHASES, bool VEC, typename index_t, typename offset_t, typename type_t>
 __global__ void __launch_bounds__(TPB)

@@ -365,8 +365,7 @@ int loops_spmv_plan_create_f64(int rows, int cols, int nnz, const int* offsets, 
 void loops_spmv_plan_destroy(loops_spmv_plan_t* plan);
 int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4);
 /* LOOPS_LAYOUT_CSR plans: the kernel variant the plan runs (0 or LOOPS_VARIANT_PHASED -- with LOOPS_PLAN_MEASURE the phased
- * twins of 512 x 8 and 256 x 16 are candidates when rows are long and x is at least 1 MB, adopted when > 2 % faster than the
- * best plain shape) and the best phased candidate's measured ms per product (-1 = not timed).  Either pointer may be NULL. */
+ * twins of 512 x 8 and 256 x 16 are candidates when x is at least 1 MB, adopted when > 2 % faster than the best plain shape) and the best phased candidate's measured ms per product (-1 = not timed).  Either pointer may be NULL. */
 int loops_spmv_plan_variant(const loops_spmv_plan_t* plan, int* variant, float* ms_phased);
 int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream);
 int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream);
@@ -420,7 +419,7 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
                                   const float* values, const float* x, float* y, int repeats, void* stream,
                                   int* best_tile_config, float* ms_per_config);
 /* The same over tile shapes AND kernel variants: additionally times the phased-gather twin (LOOPS_VARIANT_PHASED) of the
- * shapes that have one, where the plan is not self-completing.  best_variant = 0 or LOOPS_VARIANT_PHASED, to be passed to
+ * shapes that have one (plans of more than one tile).  best_variant = 0 or LOOPS_VARIANT_PHASED, to be passed to
  * loops_spmv_merge_path_*; ms_per_config (optional, 12 entries): [cfg] = plain, [6 + cfg] = phased, -1 where not timed. */
 int loops_autotune_merge_path_variants_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
                                            const float* values, const float* x, float* y, int repeats, void* stream,

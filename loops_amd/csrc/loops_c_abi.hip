@@ -858,9 +858,9 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
   }
   p->merge = best;
   // The same CSR with PHASED x gathers (kernels::merge_path_spmv_fused_phased: no copy, same bits): a candidate where it can
-  // pay at all -- long rows (two-kernel plans) and an x of at least a quarter of one XCD's L2 -- adopted when it is measurably
+  // pay at all -- more than one tile and an x of at least a quarter of one XCD's L2 -- adopted when it is measurably
   // (> 2 %) faster than the best plain shape (C2, x = 4 MB: 1.14 x; scattered columns over 8-64 MB: 1.3-1.9 x).
-  if (!err && best && !best->self_complete && best->num_tiles > 1 && x_bytes >= (1ll << 20)) {
+  if (!err && best && best->num_tiles > 1 && x_bytes >= (1ll << 20)) {
     const int pshapes[2] = {LOOPS_TILE_512x8, LOOPS_TILE_256x16};
     for (int i = 0; !err && i < 2; ++i) {
       loops_merge_plan* m = nullptr;
@@ -868,7 +868,7 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
       if (!err) err = plan_compute(m, off, st);
       if (!err) err = plan_classify(m, off, st);
       float ms = 0.f;
-      if (!err && !m->self_complete)
+      if (!err)
         err = time_ms(st, repeats, &ms, [&]() { return spmv_merge_path<T>(m, LOOPS_VARIANT_PHASED, rows, nnz, off, idx, val, x, y, st, 3, true, cols); });
       if (err) { plan_release(m); break; }
       if (ms > 0.f && (p->ms_phased < 0.f || ms < p->ms_phased)) p->ms_phased = ms;
@@ -1386,7 +1386,7 @@ int autotune_merge_path(int rows, int cols, int nnz, const int* offsets, const i
     err = plan_alloc(rows, nnz, cfg, &p);
     if (!err) err = plan_compute(p, offsets, st);
     if (!err) err = plan_classify(p, offsets, st);  // time what a held plan of this shape would run
-    const bool twin = phased && !err && !p->self_complete && p->num_tiles > 1 && (cfg == LOOPS_TILE_512x8 || cfg == LOOPS_TILE_256x16);
+    const bool twin = phased && !err && p->num_tiles > 1 && (cfg == LOOPS_TILE_512x8 || cfg == LOOPS_TILE_256x16);
     for (int variant : {0, LOOPS_VARIANT_PHASED}) {
       if (err || (variant != 0 && !twin)) continue;
       for (int it = 0; !err && it < 2; ++it) err = spmv_merge_path<float>(p, variant, rows, nnz, offsets, indices, values, x, y, st, 3, false, cols);

@@ -72,6 +72,19 @@ for name, (deg, cols, window) in cases.items():
     tile, _ = S.autotune_merge_path(csr, x, 10)   # launch-box autotuner: the tile shape of the held plan
     row["tile"] = tile
     plan = S.MergePathPlan(csr, tile)
+    # round 4: the autotuner over shapes AND kernel variants (the phased-gather twins of 512x8 / 256x16, where the plan is not
+    # self-completing): what it picks on this structure and what the phased kernel costs / buys there
+    vtile, variant, table = S.autotune_merge_path_variants(csr, x, 10)
+    plain_best = min(v for k, v in table.items() if "+" not in k)
+    phased_best = min((v for k, v in table.items() if "+" in k), default=None)
+    row["variant_autotuner"] = {"pick": vtile + ("+phased" if variant else ""), "best_plain_us": round(plain_best * 1e3, 1),
+                                "best_phased_us": None if phased_best is None else round(phased_best * 1e3, 1),
+                                "phased_over_plain": None if phased_best is None else round(phased_best / plain_best, 3)}
+    vplan = S.MergePathPlan(csr, vtile)
+    ms = ev(lambda: S.merge_path_flat(csr, x, y, plan=vplan, variant=variant))
+    row["merge_path_flat_autotuned_variant"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6),
+                                                "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+    vplan.close()
     for label, fn in (("merge_path_flat", lambda: S.merge_path_flat(csr, x, y, plan=plan)),
                       ("work_oriented", lambda: S.spmv("work_oriented", csr, x, y)),
                       ("group_mapped", lambda: S.spmv("group_mapped", csr, x, y)),
@@ -95,6 +108,11 @@ for name, (deg, cols, window) in cases.items():
     row["held_spmv_plan"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "layout": sp.layout, "tile": sp.tile,
                              "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
     sp.close()
+    sp = S.SpmvPlan(csr, allow_copy=False, measure=True, repeats=10)  # the same WITHOUT a copy: tile shape + kernel variant only (round 4)
+    ms = ev(lambda: sp.spmv(x, y))
+    row["held_spmv_plan_no_copy"] = {"us": round(ms * 1e3, 1), "GBps": round(abytes / ms / 1e6), "tile": sp.info["tile"],
+                                     "bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+    sp.close()
     if R is not None:
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         for kind, label in ((2, "ref_hip_merge_path"), (1, "ref_hip_work_oriented"), (0, "ref_hip_thread_mapped")):
@@ -102,6 +120,7 @@ for name, (deg, cols, window) in cases.items():
             R.refgpu_spmv_f32(kind, C.c_long(rows), C.c_long(cols), C.c_long(nnz), p(off), p(idx), p(val), p(xh), p(yr), 3, C.byref(ms))
             row[label] = {"us": round(ms.value * 1e3, 1)}
     out[name] = row
-    print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} tile {tile} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict)), file=sys.stderr, flush=True)
+    print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} tile {tile} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict) and "us" in v)
+          + f" | variants: {row['variant_autotuner']}", file=sys.stderr, flush=True)
     del csr, x, y, plan
     print(json.dumps({name: row}), flush=True)   # one JSON object per case: a run cut short keeps what it measured

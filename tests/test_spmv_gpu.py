@@ -795,13 +795,18 @@ def test_phased_gathers_f64_self_completing_plans_and_unsupported_shapes():
     csr = _dev(off, idx, val, rows, cols)
     with pytest.raises(_lib.LoopsError):
         S.merge_path_flat(csr, torch.from_numpy(xi).cuda(), plan=S.MergePathPlan(csr, "256x8"), variant=_lib.VARIANT_PHASED)
-    # a self-completing plan (short rows only) has nothing to phase: the entry runs the one-kernel form
-    off, idx, val = G.csr_from_degrees(np.full(rows, 16, np.int64), cols, 1, 0, True, 64)
-    band = _dev(off, idx, val, rows, cols)
-    plan = S.MergePathPlan(band, "512x8")
-    assert plan.self_complete
-    y = S.merge_path_flat(band, torch.from_numpy(xi).cuda(), plan=plan, variant=_lib.VARIANT_PHASED)
-    assert np.array_equal(y.cpu().numpy(), O.spmv_f32(off, idx, val, xi))
+    # a self-completing plan (short rows only) runs the one-kernel form with phased gathers (merge_path_spmv_fused_self_phased):
+    # local and scattered columns, both shapes, fp32 and fp64
+    for window in (64, None):
+        off, idx, val = G.csr_from_degrees(np.full(rows, 16, np.int64), cols, 1, 0, True, window)
+        ref = O.spmv_f32(off, idx, val, xi)
+        for tile in ("512x8", "256x16"):
+            for dt in (np.float32, np.float64):
+                m = S.CSR.from_numpy(rows, cols, off, idx, val.astype(dt))
+                plan = S.MergePathPlan(m, tile)
+                assert plan.self_complete and plan.num_tiles > 1
+                y = S.merge_path_flat(m, torch.from_numpy(xi.astype(dt)).cuda(), plan=plan, variant=_lib.VARIANT_PHASED)
+                assert np.array_equal(y.cpu().numpy(), ref.astype(dt)), (window, tile, dt)
 
 
 def test_full_size_c2_phased_gathers_bit_exact_and_chosen_by_measurement():
