@@ -70,9 +70,14 @@ def round3():
 # bit for bit on every launch, exactly summable AND real values), 8 / 16 / 32 parts, both tile shapes, fp32 and fp64
 def round4():
     from loops_amd import _lib
-    for lr, ln in ((20, 24), (21, 25), (23, 26)):
+    only_self = len(sys.argv) > 3 and sys.argv[3] == "self"
+    for lr, ln in ((20, 24), (21, 25), (23, 26), (-20, 24), (-23, 25)):  # (negative: uniform degrees -> self-completing plans)
+        if only_self and lr > 0:
+            continue
+        uniform = lr < 0
+        lr = abs(lr)
         r = c = 1 << lr
-        deg = G.powerlaw_degrees(r, 1 << ln)
+        deg = np.full(r, (1 << ln) >> lr, np.int64) if uniform else G.powerlaw_degrees(r, 1 << ln)
         for exact in (True, False):
             off, idx, val = G.csr_from_degrees(deg, c, 1, 0, exact)
             xh = G.uniform_distribution_int(c) if exact else G.realistic_x(c)
@@ -99,7 +104,7 @@ def round4():
                             rounds += 100
                             torch.cuda.synchronize()
                         print(f"{name:9s} {label:60s} rounds {rounds:7d} mismatching rounds {int(bad.item())}", flush=True)
-                    soak_t(f"2^{lr}", f"phased gathers {tile} {np.dtype(dt).name} {'exact' if exact else 'real'} values vs the plain kernel", run, ref, r)
+                    soak_t(f"2^{lr}" + ("u" if uniform else ""), f"phased gathers {tile} {np.dtype(dt).name} {'exact' if exact else 'real'} values vs the plain kernel", run, ref, r)
                     plan.close()
                 del csr
 
