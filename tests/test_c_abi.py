@@ -36,6 +36,10 @@ def test_argument_errors_do_not_need_a_gpu():
     assert L.loops_merge_plan_num_tiles(None) == -1
     assert L.loops_spmv_merge_path_f32(None, 0, 1, 1, 1, None, None, None, None, None, None) == -1
     assert L.loops_spmv_bcsr_f32(4, 4, 0, 4, 1, 1, None, None, None, None, None, None) == -1
+    # round 4: the variant autotuner and the plan's variant accessor reject missing outputs / handles the same way
+    assert L.loops_autotune_merge_path_variants_f32(4, 4, 4, None, None, None, None, None, 1, None, None, None, None) == -1
+    assert L.loops_spmv_plan_variant(None, None, None) == -1
+    assert L.loops_spmv_merge_path_f32(None, _lib.VARIANT_PHASED, 1, 1, 1, None, None, None, None, None, None) == -1
 
 
 def test_product_never_imports_the_oracle():
