@@ -120,9 +120,9 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
 }
 
 /// How the phased-gather kernels are run on a matrix of `cols` columns of `elem_bytes`-byte values: the number of column
-/// parts M -- 8 up to |x| = 6 MB, 16 up to 24 MB, 32 beyond: parts of 0.5-2 MB -- the shift that maps a column to its part,
-/// min(col >> shift, M - 1), and the period the first part of a tile is chosen by: about the time a pass takes, 3.75 us with 8
-/// parts, 1.87 us with 16 or 32.  Measured optima over |x| = 4 ... 64 MB, flat within +- 25 %
+/// parts M -- 8 up to |x| = 6 MB, 16 up to 24 MB, 32 beyond: parts of 0.5-2 MB (8-byte values: 8 up to 12 MB, 16 beyond) -- the
+/// shift that maps a column to its part, min(col >> shift, M - 1), and the period the first part of a tile is chosen by: about
+/// the time a pass takes, 3.75 us with 8 parts, 1.87 us with 16 or 32.  Measured optima over |x| = 4 ... 64 MB, flat within +- 25 %
 /// (profiles/r04_phased_gather_experiments.txt, sections 2, 7 and 8).  LOOPS_PHASED_PARTS / LOOPS_PHASED_TICKS (environment, read
 /// once) override M and the period in 10 ns ticks: measurement aids (scripts/sweep_phased.sh).
 struct phased_config {
@@ -135,11 +135,11 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
   const double x_mb = static_cast<double>(cols > 0 ? cols : 1) * elem_bytes / (1024.0 * 1024.0);
   int parts = x_mb <= 6.0 ? 8 : x_mb <= 24.0 ? 16 : 32;
   double ticks = parts == 8 ? 375.0 : 187.0;             // 10 ns ticks per pass
-  if (elem_bytes == 8) {  // 8-byte values: 8 parts whatever |x| (16 / 32 passes of 8-byte masked loads cost more than they save:
-    parts = 8;            // |x| = 8 / 16 / 32 MB: 1.24 / 1.42 / 1.20 x with 8 parts, 0.75 / 0.9 / 0.6 x with 16 / 32)
-    ticks = x_mb > 24.0 ? 750.0 : 375.0;
+  if (elem_bytes == 8) {  // 8-byte values (the stream is twice as heavy per gather): 8 parts up to 12 MB, 16 beyond, never 32 --
+    parts = x_mb <= 12.0 ? 8 : 16;   // |x| = 8 / 16 / 32 MB: 1.54 / 1.43 / 1.30 x (experiments file, section 16)
+    ticks = x_mb <= 6.0 ? 375.0 : 187.0;
   }
-  if ((env_parts == 8 || env_parts == 16 || env_parts == 32) && elem_bytes != 8) parts = env_parts;
+  if (env_parts == 8 || env_parts == 16 || env_parts == 32) parts = env_parts;
   if (env_ticks > 0) ticks = env_ticks;
   int bits = 0;
   while (bits < 31 && ((cols > 0 ? cols : 1) - 1) >> bits) ++bits;  // bits needed for cols - 1
@@ -171,12 +171,9 @@ int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& pl
         hipLaunchKernelGGL(kernel, dim3(m), dim3(TPB), 0, stream, plan.coords, plan.head_start, rows, nnz, offsets, indices, values, x, y,
                            cfg.args);
       };
-      if (cfg.parts == 8 || sizeof(T) == 8) {
-        go(merge_path_spmv_fused_self_phased<TPB, IPT, 8, true, index_t, offset_t, T>);
-      } else if constexpr (sizeof(T) != 8) {
-        if (cfg.parts == 16) go(merge_path_spmv_fused_self_phased<TPB, IPT, 16, true, index_t, offset_t, T>);
-        else go(merge_path_spmv_fused_self_phased<TPB, IPT, 32, true, index_t, offset_t, T>);
-      }
+      if (cfg.parts == 8) go(merge_path_spmv_fused_self_phased<TPB, IPT, 8, true, index_t, offset_t, T>);
+      else if (cfg.parts == 16) go(merge_path_spmv_fused_self_phased<TPB, IPT, 16, true, index_t, offset_t, T>);
+      else go(merge_path_spmv_fused_self_phased<TPB, IPT, 32, true, index_t, offset_t, T>);
     }
     return launch_status();
   }
@@ -189,14 +186,12 @@ int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& pl
         hipLaunchKernelGGL(plain, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
                            plan.carry_row, carry_val, cfg.args);
     };
-    if (cfg.parts == 8 || sizeof(T) == 8) {  // (8-byte values: 8 parts only -- phased_config_for; the override cannot ask for more)
+    if (cfg.parts == 8)
       go(merge_path_spmv_fused_phased<TPB, IPT, 8, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 8, true, index_t, offset_t, T>);
-    } else if constexpr (sizeof(T) != 8) {
-      if (cfg.parts == 16)
-        go(merge_path_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 16, true, index_t, offset_t, T>);
-      else
-        go(merge_path_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 32, true, index_t, offset_t, T>);
-    }
+    else if (cfg.parts == 16)
+      go(merge_path_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 16, true, index_t, offset_t, T>);
+    else
+      go(merge_path_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>, merge_path_spmv_fused_phased_planned<TPB, IPT, 32, true, index_t, offset_t, T>);
   }
   if (stages & 2)
     hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row,

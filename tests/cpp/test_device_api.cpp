@@ -295,12 +295,12 @@ static void misc() {
       CHECK(same);
     }
   // how the phased-gather kernels are configured (host logic, kernels::phased_config_for): parts by |x|, the shift that maps
-  // every column below `cols` to a part below `parts`, 8 parts for 8-byte values
+  // every column below `cols` to a part below `parts`, at most 16 parts for 8-byte values
   for (long long cols : {1ll, 2ll, 9ll, 1000ll, 1ll << 20, (1ll << 20) + 1, 1ll << 21, 1ll << 23, (1ll << 24) - 3, (1ll << 31) - 1}) {
     for (int bytes : {4, 8}) {
       const kernels::phased_config c = kernels::phased_config_for(cols, bytes);
       const double mb = static_cast<double>(cols) * bytes / (1024.0 * 1024.0);
-      CHECK(c.parts == (bytes == 8 ? 8 : mb <= 6.0 ? 8 : mb <= 24.0 ? 16 : 32));
+      CHECK(c.parts == (bytes == 8 ? (mb <= 12.0 ? 8 : 16) : mb <= 6.0 ? 8 : mb <= 24.0 ? 16 : 32));
       CHECK(((cols - 1) >> c.args.shift) < c.parts);                          // the last column lands in an existing part
       CHECK(c.args.shift == 0 || ((cols - 1) >> (c.args.shift - 1)) >= c.parts);  // ... and no smaller shift would do
       CHECK(c.args.inv_ticks > 0);
