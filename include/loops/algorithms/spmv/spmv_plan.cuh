@@ -82,6 +82,26 @@ struct spmv_plan_t {
           large.reset();
         }
       }
+      // still on the CSR: columns that look scattered over an x of 3 MB or more get 512 x 8 tiles with phased x gathers (the
+      // structural guess of kernels::columns_look_scattered, as loops_spmv_plan_create_* without MEASURE)
+      if constexpr (large_block == 512 && large_items == 8) {
+        if (layout == csr_layout && work) {
+          vector_t<unsigned int> scratch(4);
+          if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
+                                              static_cast<int>(sizeof(type_t)), scratch.data().get())) {
+            if (!large) {
+              large = std::make_unique<large_t>(lay, stream, large_t::prepass_always);
+              large->classify(stream);
+            }
+            if (large->merge_tiles() > 1) {
+              small.reset();
+              phased = true;
+            } else if (small) {
+              large.reset();
+            }
+          }
+        }
+      }
       return;
     }
     vector_t<type_t> x(csr.cols), y(csr.rows);

@@ -152,6 +152,32 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
   return c;
 }
 
+/// A STRUCTURAL guess at whether the phased gathers pay on this matrix, for callers that cannot measure (the plan-less
+/// `algorithms::spmv::merge_path_flat(csr, x, y)`, whose set-up is untimed and synchronous anyway): true when x is at least 3 MB
+/// (6 MB for 8-byte values; below that it fits an L2 next to the stream), the matrix has at least 2^20 nonzeros, fewer than
+/// half of 65 536 sampled pairs of nonzeros ONE MERGE TILE APART share a part of x and fewer than a quarter of the sampled
+/// ADJACENT pairs share a 128-byte line of x (kernels::column_scatter_sample).  On the nine structures of
+/// tests/perf/sweep_structures.py and the three C3 stand-ins it agrees with the measured choice on all twelve.  One small kernel,
+/// one 16-byte copy, one stream synchronisation; `scratch` = 4 device words (16 bytes), zeroed here.  Measuring
+/// (loops_autotune_merge_path_variants_f32, LOOPS_PLAN_MEASURE) remains the reliable way.
+template <typename index_t>
+inline bool columns_look_scattered(hipStream_t stream, const index_t* indices, long long nnz, long long cols, int elem_bytes,
+                                   unsigned int* scratch) {
+  const double x_mb = static_cast<double>(cols) * elem_bytes / (1024.0 * 1024.0);
+  if (x_mb < (elem_bytes == 8 ? 6.0 : 3.0) || nnz < (1ll << 20) || !scratch) return false;  // (fp64 at 4 MB: nothing to gain)
+  const phased_config cfg = phased_config_for(cols, elem_bytes);
+  constexpr int samples = 65536;
+  constexpr long long far = 4096;  // nonzeros: about one 512 x 8 merge tile
+  const long long stride = nnz / samples > 1 ? nnz / samples : 1;
+  if (hipMemsetAsync(scratch, 0, 4 * sizeof(unsigned int), stream) != hipSuccess) return false;
+  hipLaunchKernelGGL(column_scatter_sample<index_t>, dim3(samples / 256), dim3(256), 0, stream, indices, nnz, stride, samples, far,
+                     cfg.args.shift, static_cast<unsigned int>(cfg.parts), elem_bytes == 8 ? 4u : 5u, scratch);
+  unsigned int host[4] = {0, 0, 0, 0};
+  if (hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
+  if (hipStreamSynchronize(stream) != hipSuccess) return false;
+  return host[1] >= 1024 && 2ull * host[0] < host[1] && 4ull * host[2] < host[3];
+}
+
 /// Fused merge-path SpMV with PHASED x gathers (merge_path_spmv_fused_phased + fix-up, or merge_path_spmv_fused_self_phased for
 /// self-completing plans).  A single tile or arrays that are not 16-byte aligned run the plain kernel -- same result either way.
 template <int TPB, int IPT, typename index_t, typename offset_t, typename T>

@@ -864,6 +864,51 @@ merge_path_spmv_fused_self_phased(const coord_t* __restrict__ coords, const int*
       static_cast<type_t*>(nullptr), head_start, phase);
 }
 
+/// Are the columns SCATTERED at the scale the phased gathers work on -- and not already cheap to gather?  `samples` positions
+/// i = k * stride of the nonzero stream are looked at twice:
+///   FAR   the pair (i, i + far + a per-sample offset below 4096), one to two merge tiles apart: do the two columns fall into the same part of x
+///         (min(col >> shift, parts - 1))?  Uniformly scattered columns: ~1 / parts of the pairs; bands, host blocks, dense hub
+///         rows: most of them (a tile's gathers then stay inside one or two parts whatever the order);
+///   NEAR  the pair (i, i + 1): do the two columns share a 128-byte line of x (col >> line_shift)?  Runs of consecutive
+///         columns do -- their gathers coalesce and hit L1, phasing them only adds passes.
+/// (Adjacent nonzeros say nothing about scatter: columns are sorted inside a row, so a row of 16 uniformly random columns
+/// has its neighbours half a part apart.)  out[0] += far pairs in one part, out[1] += far pairs seen, out[2] += near pairs in
+/// one line, out[3] += near pairs seen.
+template <typename index_t>
+__global__ void __launch_bounds__(256)
+column_scatter_sample(const index_t* __restrict__ indices, const long long nnz, const long long stride, const int samples,
+                      const long long far, const unsigned int shift, const unsigned int parts, const unsigned int line_shift,
+                      unsigned int* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  bool far_same = false, far_seen = false, near_same = false, near_seen = false;
+  if (k < samples) {
+    const long long i = static_cast<long long>(k) * stride;
+    if (i + 1 < nnz) {
+      const unsigned int c0 = static_cast<unsigned int>(indices[i]), c1 = static_cast<unsigned int>(indices[i + 1]);
+      near_seen = true;
+      near_same = (c0 >> line_shift) == (c1 >> line_shift);
+      // (the distance varies from sample to sample: with equal row lengths a fixed one would always meet the same rank inside
+      // the other row, and the k-th smallest of d random columns sits in much the same place in every row)
+      const long long j = i + far + static_cast<long long>((static_cast<unsigned int>(k) * 2654435761u) >> 20);
+      if (j < nnz) {
+        unsigned int a = c0 >> shift, b = static_cast<unsigned int>(indices[j]) >> shift;
+        a = a < parts - 1 ? a : parts - 1;
+        b = b < parts - 1 ? b : parts - 1;
+        far_seen = true;
+        far_same = a == b;
+      }
+    }
+  }
+  const unsigned long long m0 = __builtin_amdgcn_ballot_w64(far_same), m1 = __builtin_amdgcn_ballot_w64(far_seen),
+                           m2 = __builtin_amdgcn_ballot_w64(near_same), m3 = __builtin_amdgcn_ballot_w64(near_seen);
+  if (wave::lane() == 0) {
+    atomicAdd(out + 0, static_cast<unsigned int>(__builtin_popcountll(m0)));
+    atomicAdd(out + 1, static_cast<unsigned int>(__builtin_popcountll(m1)));
+    atomicAdd(out + 2, static_cast<unsigned int>(__builtin_popcountll(m2)));
+    atomicAdd(out + 3, static_cast<unsigned int>(__builtin_popcountll(m3)));
+  }
+}
+
 /// (the same under the symbol of SpMV-plan handles: profile attribution only, as merge_path_spmv_fused_planned)
 template <int TPB, int IPT, int PHASES, bool VEC, typename index_t, typename offset_t, typename type_t>
 __global__ void __launch_bounds__(TPB)

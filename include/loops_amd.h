@@ -345,6 +345,8 @@ int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x,
  *                                  a copy is taken when cols * sizeof(T) > 6 MB: the panel-binned one (4-byte values, or x >=
  *                                  32 MB), else the column-blocked one if the mean row holds >= 8 nonzeros.  (Structure does
  *                                  not show column locality -- a narrow band is faster from the CSR as given: MEASURE finds out.)
+ *                                  A plan that stays on the CSR takes 512 x 8 tiles with phased x gathers (LOOPS_VARIANT_PHASED) when
+ *                                  the columns LOOK scattered over an x of 3 MB or more (loops_columns_look_scattered).
  * Without ALLOW_COPY the product always runs on the caller's arrays.  Creation is synchronous.  One product in flight per plan.
  * loops_spmv_planned_*: y = A x; offsets / indices / values are the arrays the plan was created from (ignored -- may be NULL
  * -- when the plan holds the copy; after changing the VALUES of the matrix call loops_spmv_plan_refresh_values_* first).
@@ -421,6 +423,12 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
 /* The same over tile shapes AND kernel variants: additionally times the phased-gather twin (LOOPS_VARIANT_PHASED) of the
  * shapes that have one (plans of more than one tile).  best_variant = 0 or LOOPS_VARIANT_PHASED, to be passed to
  * loops_spmv_merge_path_*; ms_per_config (optional, 12 entries): [cfg] = plain, [6 + cfg] = phased, -1 where not timed. */
+/* A STRUCTURAL guess at the same question, for callers that cannot measure: *scattered = 1 when x (cols x value_bytes) is at
+ * least 3 MB (6 MB for 8-byte values), the matrix holds at least 2^20 nonzeros, fewer than half of 65 536 sampled pairs of
+ * nonzeros one merge tile apart share a part of x (uniformly random columns: ~1 in 8; bands, host blocks, dense hub rows: most)
+ * and fewer than a quarter of the adjacent pairs share a 128-byte line of x (runs of consecutive columns gather cheaply).  What the
+ * plan-less C++ wrapper algorithms::spmv::merge_path_flat(csr, x, y) consults in its untimed set-up.  Synchronous. */
+int loops_columns_look_scattered(int cols, int nnz, const int* indices, int value_bytes, void* stream, int* scattered);
 int loops_autotune_merge_path_variants_f32(int rows, int cols, int nnz, const int* offsets, const int* indices,
                                            const float* values, const float* x, float* y, int repeats, void* stream,
                                            int* best_tile_config, int* best_variant, float* ms_per_config);

@@ -53,7 +53,7 @@ SYMBOLS = [
     "loops_panel_plan_create_layout_f32", "loops_panel_plan_create_layout_f64", "loops_panel_plan_layout",
     "loops_row_ranges", "loops_comm_unique_id", "loops_comm_init", "loops_comm_destroy", "loops_comm_error_string",
     "loops_allgatherv_f32", "loops_allgatherv_f64",
-    "loops_autotune_merge_path_variants_f32", "loops_spmv_plan_variant",
+    "loops_autotune_merge_path_variants_f32", "loops_spmv_plan_variant", "loops_columns_look_scattered",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
 ]
 
@@ -233,6 +233,7 @@ def lib() -> C.CDLL:
         L.loops_autotune_merge_path_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), vp]
         L.loops_autotune_merge_path_variants_f32.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, C.POINTER(ci), C.POINTER(ci), vp]
         L.loops_spmv_plan_variant.argtypes = [vp, C.POINTER(ci), C.POINTER(C.c_float)]
+        L.loops_columns_look_scattered.argtypes = [ci, ci, vp, ci, vp, C.POINTER(ci)]
         _lib = L
     return _lib
 

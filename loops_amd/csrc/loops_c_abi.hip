@@ -829,6 +829,30 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
         err = 0;
       }
     }
+    // still on the CSR: columns that look scattered over an x of 3 MB or more (kernels::columns_look_scattered: 65 536 sampled
+    // pairs, one small kernel) get 512 x 8 tiles with phased x gathers -- the guess the plan-less C++ wrapper goes by
+    if (!err && p->layout == LOOPS_LAYOUT_CSR && rows > 0 && nnz > 0) {
+      unsigned int* scratch = nullptr;
+      if (hipMalloc(reinterpret_cast<void**>(&scratch), 4 * sizeof(unsigned int)) == hipSuccess) {
+        if (kernels::columns_look_scattered(st, idx, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)),
+                                            scratch)) {
+          loops_merge_plan* m = nullptr;
+          int perr = plan_alloc(rows, nnz, LOOPS_TILE_512x8, &m);
+          if (!perr) perr = plan_compute(m, off, st);
+          if (!perr) perr = plan_classify(m, off, st);
+          if (!perr && m->num_tiles > 1) {
+            plan_release(p->merge);
+            p->merge = m;
+            p->merge_variant = LOOPS_VARIANT_PHASED;
+          } else {
+            plan_release(m);
+          }
+        }
+        (void)hipFree(scratch);
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     if (err) { spmv_plan_free(p); return err; }
     *out = p;
     return 0;
@@ -1458,6 +1482,16 @@ int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_c
   if (num_blocks) *num_blocks = plan->blocked ? plan->blocked->K : plan->panel ? plan->panel->P : 0;
   if (ms4) for (int i = 0; i < 4; ++i) ms4[i] = plan->ms[i];
   return 0;
+}
+int loops_columns_look_scattered(int cols, int nnz, const int* indices, int value_bytes, void* stream, int* scattered) {
+  if (!scattered || cols < 0 || nnz < 0 || (nnz > 0 && !indices) || (value_bytes != 4 && value_bytes != 8)) return LOOPS_E_BADARG;
+  unsigned int* scratch = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), 4 * sizeof(unsigned int));
+  if (e != hipSuccess) return static_cast<int>(e);
+  *scattered = kernels::columns_look_scattered(as_stream(stream), indices, static_cast<long long>(nnz), static_cast<long long>(cols),
+                                               value_bytes, scratch) ? 1 : 0;
+  (void)hipFree(scratch);
+  return last_error();
 }
 int loops_spmv_plan_variant(const loops_spmv_plan_t* plan, int* variant, float* ms_phased) {
   if (!plan) return LOOPS_E_BADARG;

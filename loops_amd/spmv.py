@@ -627,6 +627,15 @@ def autotune_merge_path(csr: CSR, x, repeats: int = 5):
     return names[best.value], {names[i]: ms[i] for i in range(6) if ms[i] >= 0 and i in names}
 
 
+def columns_look_scattered(csr: CSR) -> bool:
+    """loops_columns_look_scattered: the structural guess at whether the phased-gather kernel pays on this matrix (what the
+    plan-less C++ wrapper consults); measuring -- autotune_merge_path_variants, SpmvPlan(measure=True) -- is the reliable way."""
+    out = C.c_int()
+    L.check(L.lib().loops_columns_look_scattered(csr.cols, csr.nnzs, _ptr(csr.indices), csr.values.element_size(), _stream(),
+                                                 C.byref(out)), "loops_columns_look_scattered")
+    return bool(out.value)
+
+
 def autotune_merge_path_variants(csr: CSR, x, repeats: int = 5):
     """The same over tile shapes AND kernel variants (loops_autotune_merge_path_variants_f32): the phased-gather twin of the
     shapes that have one is timed too.  Returns (best tile name, best variant, {name: ms}) with phased entries named

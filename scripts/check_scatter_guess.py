@@ -1,0 +1,21 @@
+import os, sys
+sys.path.insert(0, "/root/repo" if os.path.isdir("/root/repo/loops_amd") else os.getcwd())
+import numpy as np, torch
+sys.argv=[sys.argv[0]]
+from loops_amd import generate as G, spmv as S
+src=open("tests/perf/sweep_structures.py").read()
+# reuse the case definitions of the sweep (up to the loop over cases)
+pre=src[:src.index("so = os.path.join")]
+exec(pre)
+for name,(deg,cols,window) in cases.items():
+    off, idx, val = scale_free(deg, cols) if isinstance(window, str) else chunked(deg, cols, window)
+    csr = S.CSR.from_numpy(deg.size, cols, off, idx, val)
+    print(f"{name:50s} guess_scattered={S.columns_look_scattered(csr)}", flush=True)
+    del csr
+rows = cols = 7_414_866; nnz = 194_109_311
+deg = G.powerlaw_degrees(rows, nnz)
+for tag, window in (("uniform", None), ("band_65536", 65536), ("host_blocked", G.HOST_BLOCKED)):
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=G.host_blocks(cols) if window == G.HOST_BLOCKED else None)
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    print(f"C3 stand-in {tag:38s} guess_scattered={S.columns_look_scattered(csr)}", flush=True)
+    del csr

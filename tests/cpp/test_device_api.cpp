@@ -359,6 +359,60 @@ static void misc() {
     CHECK(plan_ok);
     CHECK(close);
   }
+  // the plan-less merge_path_flat(csr, x, y) guesses from the structure whether the phased gathers pay (kernels::
+  // columns_look_scattered): yes on uniformly scattered columns over an x of 4 MB, no on a band of the same size -- and gives the
+  // plain held plan's result either way, fp32 and fp64
+  for (int local = 0; local < 2; ++local) {
+    const std::size_t rows = 1 << 17, cols = 1 << 20, deg = 10;   // 1.3 M nonzeros, x = 4 MB (fp32) / 8 MB (fp64)
+    std::mt19937_64 rng(7 + local);
+    std::uniform_real_distribution<double> u(0.5, 1.5);
+    hcsr_t<float> hf(rows, cols, rows * deg);
+    hcsr_t<double> hd(rows, cols, rows * deg);
+    for (std::size_t r = 0; r <= rows; ++r) hf.offsets[r] = hd.offsets[r] = static_cast<int>(r * deg);
+    for (std::size_t r = 0; r < rows; ++r) {
+      const std::size_t step = local ? 8 : cols / deg;            // local: 10 columns inside a window of 80 at the diagonal
+      const std::size_t base = local ? (r * (cols / rows)) % (cols - deg * step) : 0;
+      for (std::size_t k = 0; k < deg; ++k) {
+        const int c = static_cast<int>(base + k * step + rng() % step);
+        const double v = u(rng);
+        hf.indices[r * deg + k] = hd.indices[r * deg + k] = c;
+        hf.values[r * deg + k] = static_cast<float>(v);
+        hd.values[r * deg + k] = v;
+      }
+    }
+    csr_t<int, int, float> a(hf);
+    csr_t<int, int, double> ad(hd);
+    vector_t<unsigned int> scratch(4);
+    const bool scattered = kernels::columns_look_scattered(0, a.indices.data().get(), static_cast<long long>(a.nnzs),
+                                                           static_cast<long long>(a.cols), 4, scratch.data().get());
+    CHECK(scattered == (local == 0));
+    vector_t<float, H> hx(cols);
+    vector_t<double, H> hxd(cols);
+    for (std::size_t c = 0; c < cols; ++c) { hxd[c] = u(rng); hx[c] = static_cast<float>(hxd[c]); }
+    vector_t<float> x(hx), y0(rows, -1.f), y1(rows, -2.f);
+    vector_t<double> xd(hxd), z0(rows, -1.0), z1(rows, -2.0);
+    using small_t = algorithms::spmv::merge_path_small_plan_t<int, int, float>;
+    const small_t::layout_t lay(a.offsets.data().get(), static_cast<int>(rows), static_cast<int>(rows * deg));
+    small_t plan(lay, 0, small_t::prepass_always);
+    plan.classify(0);
+    algorithms::spmv::merge_path_flat_async_with<algorithms::spmv::launch_t<float>::block_size, algorithms::spmv::launch_t<float>::items_per_thread>(plan, a, x, y0);
+    algorithms::spmv::merge_path_flat(a, x, y1);
+    using small_d = algorithms::spmv::merge_path_small_plan_t<int, int, double>;
+    small_d pland(small_d::layout_t(ad.offsets.data().get(), static_cast<int>(rows), static_cast<int>(rows * deg)), 0, small_d::prepass_always);
+    pland.classify(0);
+    algorithms::spmv::merge_path_flat_async_with<algorithms::spmv::launch_t<double>::block_size, algorithms::spmv::launch_t<double>::items_per_thread>(pland, ad, xd, z0);
+    algorithms::spmv::merge_path_flat(ad, xd, z1);
+    (void)xpu::stream_synchronize(0);
+    vector_t<float, H> h0(y0), h1(y1);
+    vector_t<double, H> g0(z0), g1(z1);
+    bool close = true, close_d = true;  // (another tile shape is another summation order: equal up to rounding, not bit for bit)
+    for (std::size_t i = 0; i < rows; ++i) {
+      close = close && std::fabs(h0[i] - h1[i]) <= 2e-6f * std::fabs(h0[i]);
+      close_d = close_d && std::fabs(g0[i] - g1[i]) <= 1e-14 * std::fabs(g0[i]);
+    }
+    CHECK(close);
+    CHECK(close_d);
+  }
   // the drop-in spmm::thread_mapped (merge-path SpMM since round 4) == the reference-shaped per-thread loop kept behind
   // thread_mapped_schedule_api == spmm::merge_path_flat (every battery matrix, several widths of B, f32 + f64)
   for (auto& dense : battery())

@@ -29,5 +29,5 @@ for tag, window in (("uniform", None), ("band_65536", 65536), ("host_blocked", G
             s = min(batch(lambda: S.merge_path_flat(csr, x, y, plan=plan, variant=v)) for _ in range(2))
             out.append(f"{tile}{'+phased' if v else ''} {s:7.1f} eq={bool(torch.equal(y, y0))}")
         plan.close()
-    print(f"C3 stand-in {tag}: " + " | ".join(out), flush=True)
+    print(f"C3 stand-in {tag}: guess_scattered={S.columns_look_scattered(csr)} | " + " | ".join(out), flush=True)
     del csr, off, idx, val

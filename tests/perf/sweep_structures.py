@@ -77,6 +77,7 @@ for name, (deg, cols, window) in cases.items():
     vtile, variant, table = S.autotune_merge_path_variants(csr, x, 10)
     plain_best = min(v for k, v in table.items() if "+" not in k)
     phased_best = min((v for k, v in table.items() if "+" in k), default=None)
+    row["structural_guess_scattered"] = S.columns_look_scattered(csr)   # what the plan-less C++ wrapper goes by
     row["variant_autotuner"] = {"pick": vtile + ("+phased" if variant else ""), "best_plain_us": round(plain_best * 1e3, 1),
                                 "best_phased_us": None if phased_best is None else round(phased_best * 1e3, 1),
                                 "phased_over_plain": None if phased_best is None else round(phased_best / plain_best, 3)}
@@ -121,6 +122,6 @@ for name, (deg, cols, window) in cases.items():
             row[label] = {"us": round(ms.value * 1e3, 1)}
     out[name] = row
     print(f"{name:46s} nnz {nnz:9d} maxdeg {int(deg.max()):7d} tile {tile} | " + " ".join(f"{k} {v['us']:8.1f}us" + ("" if v.get('bit_exact', True) else "(!)") for k, v in row.items() if isinstance(v, dict) and "us" in v)
-          + f" | variants: {row['variant_autotuner']}", file=sys.stderr, flush=True)
+          + f" | variants: {row['variant_autotuner']} guess_scattered={row['structural_guess_scattered']}", file=sys.stderr, flush=True)
     del csr, x, y, plan
     print(json.dumps({name: row}), flush=True)   # one JSON object per case: a run cut short keeps what it measured

@@ -39,6 +39,7 @@ def test_argument_errors_do_not_need_a_gpu():
     # round 4: the variant autotuner and the plan's variant accessor reject missing outputs / handles the same way
     assert L.loops_autotune_merge_path_variants_f32(4, 4, 4, None, None, None, None, None, 1, None, None, None, None) == -1
     assert L.loops_spmv_plan_variant(None, None, None) == -1
+    assert L.loops_columns_look_scattered(4, 4, None, 4, None, None) == -1
     assert L.loops_spmv_merge_path_f32(None, _lib.VARIANT_PHASED, 1, 1, 1, None, None, None, None, None, None) == -1
 
 

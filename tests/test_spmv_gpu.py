@@ -842,3 +842,29 @@ def test_full_size_c2_phased_gathers_bit_exact_and_chosen_by_measurement():
     xr = torch.from_numpy(G.realistic_x(cols)).cuda()
     plan = S.MergePathPlan(csr_r, "512x8")
     assert torch.equal(S.merge_path_flat(csr_r, xr, plan=plan, variant=0), S.merge_path_flat(csr_r, xr, plan=plan, variant=_lib.VARIANT_PHASED))
+
+
+def test_structural_scatter_guess_drives_the_unmeasured_plan():
+    """loops_columns_look_scattered (what callers that cannot measure go by: the plan-less C++ wrapper, SpMV plans without
+    LOOPS_PLAN_MEASURE): yes on scattered columns over an x of 4 MB, no on bands / runs / small x -- and an unmeasured plan
+    without a copy runs the phased-gather kernel exactly where the guess says so, with the oracle's bits."""
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    rows = cols = 1 << 20
+    deg = G.powerlaw_degrees(rows, 1 << 22)
+    xi = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xi).cuda()
+    for window, want in ((None, True), (8192, False), (-1, False)):
+        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
+        csr = _dev(off, idx, val, rows, cols)
+        assert S.columns_look_scattered(csr) is want, window
+        sp = S.SpmvPlan(csr, allow_copy=False, measure=False)
+        assert sp.layout == "csr" and (sp.variant == _lib.VARIANT_PHASED) is want, (window, sp.info)
+        assert np.array_equal(sp.spmv(x).cpu().numpy(), O.spmv_f32(off, idx, val, xi, omp=True)), window
+        sp.close()
+    # x below 3 MB, or a matrix too small to sample: never
+    small = 1 << 18
+    off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(small, 1 << 21), small, 1)
+    assert not S.columns_look_scattered(_dev(off, idx, val, small, small))
+    off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(1 << 12, 1 << 16, cap=1 << 11), cols, 1)
+    assert not S.columns_look_scattered(_dev(off, idx, val, 1 << 12, cols))
