@@ -117,7 +117,7 @@ util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<ty
   // Columns scattered over an x of 3 MB or more (a structural guess from 65 536 sampled pairs of nonzeros, part of
   // the untimed set-up: kernels::columns_look_scattered): 512 x 8 tiles with PHASED x gathers (C2 94.8 -> 82.9
   // us, same bits; fp64 188 -> 141) -- self-completing or not.
-  {
+  if (kernels::columns_worth_sampling(static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t)))) {
     vector_t<unsigned int> scratch(4);
     if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                         static_cast<int>(sizeof(type_t)), scratch.data().get())) {

@@ -85,7 +85,8 @@ struct spmv_plan_t {
       // still on the CSR: columns that look scattered over an x of 3 MB or more get 512 x 8 tiles with phased x gathers (the
       // structural guess of kernels::columns_look_scattered, as loops_spmv_plan_create_* without MEASURE)
       if constexpr (large_block == 512 && large_items == 8) {
-        if (layout == csr_layout && work) {
+        if (layout == csr_layout && work &&
+            kernels::columns_worth_sampling(static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t)))) {
           vector_t<unsigned int> scratch(4);
           if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                               static_cast<int>(sizeof(type_t)), scratch.data().get())) {

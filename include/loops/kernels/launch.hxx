@@ -160,11 +160,15 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
 /// tests/perf/sweep_structures.py and the three C3 stand-ins it agrees with the measured choice on all twelve.  One small kernel,
 /// one 16-byte copy, one stream synchronisation; `scratch` = 4 device words (16 bytes), zeroed here.  Measuring
 /// (loops_autotune_merge_path_variants_f32, LOOPS_PLAN_MEASURE) remains the reliable way.
+/// (the size test alone -- no device work: callers allocate the scratch words only when it passes)
+inline bool columns_worth_sampling(long long nnz, long long cols, int elem_bytes) {
+  const double x_mb = static_cast<double>(cols) * elem_bytes / (1024.0 * 1024.0);
+  return x_mb >= (elem_bytes == 8 ? 6.0 : 3.0) && nnz >= (1ll << 20);  // (fp64 at 4 MB: nothing to gain)
+}
 template <typename index_t>
 inline bool columns_look_scattered(hipStream_t stream, const index_t* indices, long long nnz, long long cols, int elem_bytes,
                                    unsigned int* scratch) {
-  const double x_mb = static_cast<double>(cols) * elem_bytes / (1024.0 * 1024.0);
-  if (x_mb < (elem_bytes == 8 ? 6.0 : 3.0) || nnz < (1ll << 20) || !scratch) return false;  // (fp64 at 4 MB: nothing to gain)
+  if (!columns_worth_sampling(nnz, cols, elem_bytes) || !scratch) return false;
   const phased_config cfg = phased_config_for(cols, elem_bytes);
   constexpr int samples = 65536;
   constexpr long long far = 4096;  // nonzeros: about one 512 x 8 merge tile

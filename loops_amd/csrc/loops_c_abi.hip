@@ -831,7 +831,8 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
     }
     // still on the CSR: columns that look scattered over an x of 3 MB or more (kernels::columns_look_scattered: 65 536 sampled
     // pairs, one small kernel) get 512 x 8 tiles with phased x gathers -- the guess the plan-less C++ wrapper goes by
-    if (!err && p->layout == LOOPS_LAYOUT_CSR && rows > 0 && nnz > 0) {
+    if (!err && p->layout == LOOPS_LAYOUT_CSR && rows > 0 && nnz > 0 &&
+        kernels::columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)))) {
       unsigned int* scratch = nullptr;
       if (hipMalloc(reinterpret_cast<void**>(&scratch), 4 * sizeof(unsigned int)) == hipSuccess) {
         if (kernels::columns_look_scattered(st, idx, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)),
@@ -1485,6 +1486,8 @@ int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_c
 }
 int loops_columns_look_scattered(int cols, int nnz, const int* indices, int value_bytes, void* stream, int* scattered) {
   if (!scattered || cols < 0 || nnz < 0 || (nnz > 0 && !indices) || (value_bytes != 4 && value_bytes != 8)) return LOOPS_E_BADARG;
+  *scattered = 0;
+  if (!kernels::columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), value_bytes)) return 0;
   unsigned int* scratch = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), 4 * sizeof(unsigned int));
   if (e != hipSuccess) return static_cast<int>(e);
