@@ -868,3 +868,33 @@ def test_structural_scatter_guess_drives_the_unmeasured_plan():
     assert not S.columns_look_scattered(_dev(off, idx, val, small, small))
     off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(1 << 12, 1 << 16, cap=1 << 11), cols, 1)
     assert not S.columns_look_scattered(_dev(off, idx, val, 1 << 12, cols))
+
+
+@pytest.mark.parametrize("tile", ["512x8", "256x16"])
+def test_phased_variant_on_the_reference_battery_and_degenerate_inputs(tile):
+    """The reference's own edge cases (identity, banded, block-diagonal, one heavy row, empty rows, all-empty: the battery of
+    unittests/test_spmv_battery.hxx, restated) through LOOPS_VARIANT_PHASED: single-tile plans run the plain kernel, the result
+    is the plain one's either way; plus 75 % empty rows over several tiles and a matrix without nonzeros."""
+    from loops_amd import spmv as S, generate as G, _lib
+    from oracle import oracle as O
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val, r, c)
+        x = torch.from_numpy(g[f"{name}.x_real"]).cuda()
+        plan = S.MergePathPlan(csr, tile)
+        y0 = S.merge_path_flat(csr, x, plan=plan, variant=0)
+        y8 = S.merge_path_flat(csr, x, plan=plan, variant=_lib.VARIANT_PHASED)
+        assert torch.equal(y0, y8), (name, tile)
+    rows, cols = 1 << 15, 1 << 21
+    deg = np.where(np.arange(rows) % 4 == 0, 24, 0).astype(np.int64)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1)
+    xi = G.uniform_distribution_int(cols)
+    csr = _dev(off, idx, val, rows, cols)
+    plan = S.MergePathPlan(csr, tile)
+    assert plan.num_tiles > 1
+    y = S.merge_path_flat(csr, torch.from_numpy(xi).cuda(), plan=plan, variant=_lib.VARIANT_PHASED)
+    assert np.array_equal(y.cpu().numpy(), O.spmv_f32(off, idx, val, xi))
+    empty = _dev(np.zeros(rows + 1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), rows, cols)
+    y = torch.full((rows,), -1.0, device="cuda")
+    S.merge_path_flat(empty, torch.from_numpy(xi).cuda(), y, plan=S.MergePathPlan(empty, tile), variant=_lib.VARIANT_PHASED)
+    assert float(y.abs().max()) == 0.0
