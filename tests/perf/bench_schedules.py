@@ -60,6 +60,18 @@ def rec(name, fn, check=True):
     res["rows"][name] = {"ms": round(ms, 4), "GFLOPs": round(2 * nnz / ms / 1e6, 1), "GBps": round(abytes / ms / 1e6, 1), "bit_exact": ok}
     print(f"{name:42s} {ms*1e3:9.1f} us {2*nnz/ms/1e6:8.1f} GFLOP/s {abytes/ms/1e6:8.1f} GB/s exact={ok}", file=sys.stderr, flush=True)
 rec("merge_path_flat (planned, fused+fixup)", lambda: S.merge_path_flat(csr, x, y, plan=plan))
+# round 4: tile shape AND kernel variant by measurement (the phased-gather twins), what the structural guess says, and the
+# held SpMV plans with / without a re-ordered copy
+vtile, variant, table = S.autotune_merge_path_variants(csr, x, 10)
+res["variant_autotuner"] = {"pick": vtile + ("+phased" if variant else ""), "ms": {k: round(v, 4) for k, v in table.items()},
+                            "structural_guess_scattered": S.columns_look_scattered(csr)}
+print(f"variant autotuner: {res['variant_autotuner']}", file=sys.stderr, flush=True)
+vplan = S.MergePathPlan(csr, vtile)
+rec(f"merge_path_flat (planned, {vtile}{'+phased' if variant else ''}: the autotuner's pick)", lambda: S.merge_path_flat(csr, x, y, plan=vplan, variant=variant))
+for allow in (False, True):
+    sp = S.SpmvPlan(csr, allow_copy=allow, measure=True, repeats=10)
+    rec(f"held SpMV plan, copy {'allowed' if allow else 'not allowed'}: {sp.info['layout']} {sp.info['tile']}", lambda: sp.spmv(x, y))
+    sp.close()
 for sched in ("merge_path_flat", "work_oriented", "group_mapped") + (() if args.tuned_only else ("thread_mapped", "original", "flat_partitioned")):
     rec(f"tuned {sched}", lambda: S.spmv(sched, csr, x, y))
 for sched in () if args.tuned_only else ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped", "flat_partitioned"):
