@@ -114,11 +114,11 @@ util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<ty
   // otherwise (rows longer than a tile) 512 x 8 tiles + the carry-out fix-up (C2: 94.4 against 95.9 us).
   const typename small_t::layout_t lay(csr.offsets.data().get(), static_cast<index_t>(csr.rows), static_cast<offset_t>(csr.nnzs));
   util::timer_t timer(stream);
-  // Columns scattered over an x of 3 MB or more (a structural guess from 65 536 sampled pairs of nonzeros, part of
+  // Columns scattered over an x of 3 MB or more (a structural guess from 16 384 sampled pairs of nonzeros, part of
   // the untimed set-up: kernels::columns_look_scattered): 512 x 8 tiles with PHASED x gathers (C2 94.8 -> 82.9
   // us, same bits; fp64 188 -> 141) -- self-completing or not.
   if (kernels::columns_worth_sampling(static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t)))) {
-    vector_t<unsigned int> scratch(4);
+    vector_t<unsigned int> scratch(kernels::scatter_scratch_words);
     if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                         static_cast<int>(sizeof(type_t)), scratch.data().get())) {
       using wide_t = merge_path_plan_of_t<512, 8, index_t, offset_t>;

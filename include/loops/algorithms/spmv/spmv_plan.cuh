@@ -87,7 +87,7 @@ struct spmv_plan_t {
       if constexpr (large_block == 512 && large_items == 8) {
         if (layout == csr_layout && work &&
             kernels::columns_worth_sampling(static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t)))) {
-          vector_t<unsigned int> scratch(4);
+          vector_t<unsigned int> scratch(kernels::scatter_scratch_words);
           if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                               static_cast<int>(sizeof(type_t)), scratch.data().get())) {
             if (!large) {

@@ -155,31 +155,72 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
 /// A STRUCTURAL guess at whether the phased gathers pay on this matrix, for callers that cannot measure (the plan-less
 /// `algorithms::spmv::merge_path_flat(csr, x, y)`, whose set-up is untimed and synchronous anyway): true when x is at least 3 MB
 /// (6 MB for 8-byte values; below that it fits an L2 next to the stream), the matrix has at least 2^20 nonzeros, fewer than
-/// half of 65 536 sampled pairs of nonzeros ONE MERGE TILE APART share a part of x and fewer than a quarter of the sampled
+/// half of 16 384 sampled pairs of nonzeros ONE TO TWO MERGE TILES APART share a part of x and fewer than a quarter of the sampled
 /// ADJACENT pairs share a 128-byte line of x (kernels::column_scatter_sample).  On the nine structures of
-/// tests/perf/sweep_structures.py and the three C3 stand-ins it agrees with the measured choice on all twelve.  One small kernel,
-/// one 16-byte copy, one stream synchronisation; `scratch` = 4 device words (16 bytes), zeroed here.  Measuring
+/// tests/perf/sweep_structures.py and the three C3 stand-ins it agrees with the measured choice on all twelve.  Two small kernels,
+/// one 16-byte copy, one stream synchronisation; `scratch` = kernels::scatter_scratch_words device words.  Measuring
 /// (loops_autotune_merge_path_variants_f32, LOOPS_PLAN_MEASURE) remains the reliable way.
 /// (the size test alone -- no device work: callers allocate the scratch words only when it passes)
-inline bool columns_worth_sampling(long long nnz, long long cols, int elem_bytes) {
+/// `timed_path`: the sample itself is paid by every call (the asynchronous plan-less C ABI entry: ~5 us for its two small
+/// kernels) -- ask only from 6 MB on, where scattered columns gain 1.5 x and more, not at 4 MB, where they gain 12 %.
+inline bool columns_worth_sampling(long long nnz, long long cols, int elem_bytes, bool timed_path = false) {
   const double x_mb = static_cast<double>(cols) * elem_bytes / (1024.0 * 1024.0);
-  return x_mb >= (elem_bytes == 8 ? 6.0 : 3.0) && nnz >= (1ll << 20);  // (fp64 at 4 MB: nothing to gain)
+  return x_mb >= (elem_bytes == 8 || timed_path ? 6.0 : 3.0) && nnz >= (1ll << 20);  // (fp64 at 4 MB: nothing to gain)
 }
 template <typename index_t>
 inline bool columns_look_scattered(hipStream_t stream, const index_t* indices, long long nnz, long long cols, int elem_bytes,
                                    unsigned int* scratch) {
   if (!columns_worth_sampling(nnz, cols, elem_bytes) || !scratch) return false;
   const phased_config cfg = phased_config_for(cols, elem_bytes);
-  constexpr int samples = 65536;
   constexpr long long far = 4096;  // nonzeros: about one 512 x 8 merge tile
-  const long long stride = nnz / samples > 1 ? nnz / samples : 1;
-  if (hipMemsetAsync(scratch, 0, 4 * sizeof(unsigned int), stream) != hipSuccess) return false;
-  hipLaunchKernelGGL(column_scatter_sample<index_t>, dim3(samples / 256), dim3(256), 0, stream, indices, nnz, stride, samples, far,
-                     cfg.args.shift, static_cast<unsigned int>(cfg.parts), elem_bytes == 8 ? 4u : 5u, scratch);
+  const long long stride = nnz / scatter_samples > 1 ? nnz / scatter_samples : 1;
+  hipLaunchKernelGGL(column_scatter_sample<index_t>, dim3(scatter_blocks), dim3(256), 0, stream, indices, nnz, stride, far, cfg.args.shift,
+                     static_cast<unsigned int>(cfg.parts), elem_bytes == 8 ? 4u : 5u, scratch + 4);
+  hipLaunchKernelGGL(column_scatter_decide, dim3(1), dim3(64), 0, stream, scratch + 4, scratch);
   unsigned int host[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
   if (hipStreamSynchronize(stream) != hipSuccess) return false;
   return host[1] >= 1024 && 2ull * host[0] < host[1] && 4ull * host[2] < host[3];
+}
+
+/// Launches the sample of columns_look_scattered WITHOUT reading it back: `stats` (scatter_scratch_words device words) then holds in [0..3] what
+/// merge_path_spmv_fused_auto decides by.  The caller has checked columns_worth_sampling.
+template <typename index_t>
+inline int launch_column_scatter_sample(hipStream_t stream, const index_t* indices, long long nnz, long long cols, int elem_bytes,
+                                        unsigned int* stats) {
+  const phased_config cfg = phased_config_for(cols, elem_bytes);
+  constexpr long long far = 4096;
+  const long long stride = nnz / scatter_samples > 1 ? nnz / scatter_samples : 1;
+  hipLaunchKernelGGL(column_scatter_sample<index_t>, dim3(scatter_blocks), dim3(256), 0, stream, indices, nnz, stride, far, cfg.args.shift,
+                     static_cast<unsigned int>(cfg.parts), elem_bytes == 8 ? 4u : 5u, stats + 4);
+  hipLaunchKernelGGL(column_scatter_decide, dim3(1), dim3(64), 0, stream, stats + 4, stats);
+  return launch_status();
+}
+
+/// The plan-less product on a matrix worth asking about: sample (async) -> merge_path_spmv_fused_auto (plain or phased gathers,
+/// decided on the device) -> fix-up.  Two-kernel form only (plan-less plans are never classified); unaligned arrays or a single
+/// tile run the plain kernel.
+template <int TPB, int IPT, typename index_t, typename offset_t, typename T>
+int launch_merge_path_fused_auto(hipStream_t stream, const merge_plan_view& plan, int rows, int cols, int nnz,
+                                 const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
+                                 unsigned int* stats) {
+  const int m = plan.num_merge_tiles;
+  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
+  if (m <= 1 || !aligned || !stats || !columns_worth_sampling(nnz, cols, static_cast<int>(sizeof(T)), true))
+    return launch_merge_path_fused<TPB, IPT, true, 0, index_t, offset_t, T, true>(stream, plan, rows, nnz, offsets, indices, values, x, y);
+  int err = launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), stats);
+  if (err) return err;
+  T* carry_val = static_cast<T*>(plan.carry_val);
+  const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
+  auto go = [&](auto kernel) {
+    hipLaunchKernelGGL(kernel, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y, plan.carry_row,
+                       carry_val, stats, cfg.args);
+  };
+  if (cfg.parts == 8) go(merge_path_spmv_fused_auto<TPB, IPT, 8, true, index_t, offset_t, T>);
+  else if (cfg.parts == 16) go(merge_path_spmv_fused_auto<TPB, IPT, 16, true, index_t, offset_t, T>);
+  else go(merge_path_spmv_fused_auto<TPB, IPT, 32, true, index_t, offset_t, T>);
+  hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(m, 256)), dim3(256), 0, stream, plan.carry_row, carry_val, m, rows, y);
+  return launch_status();
 }
 
 /// Fused merge-path SpMV with PHASED x gathers (merge_path_spmv_fused_phased + fix-up, or merge_path_spmv_fused_self_phased for

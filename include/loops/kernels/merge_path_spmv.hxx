@@ -82,6 +82,11 @@ constexpr unsigned int rsrc_flags = 0x00020000u;  // gfx9 raw buffer: DATA_FORMA
 constexpr int phased_flag = 0x20000;
 constexpr int phased(int m) { return phased_flag | m; }
 constexpr int phases(int p) { return (p & phased_flag) != 0 ? (p & 0xff) : 0; }
+/// policy::phased_auto(M): both forms in one kernel, chosen at RUN time by `phase_args::enabled` (workgroup-uniform): what the
+/// plan-less entry points launch behind column_scatter_sample -- the device decides, the host never waits for the answer.
+constexpr int phased_auto_flag = 0x40000;
+constexpr int phased_auto(int m) { return phased_flag | phased_auto_flag | m; }
+constexpr bool phased_is_auto(int p) { return (p & phased_auto_flag) != 0; }
 }  // namespace policy
 
 /// Run-time side of the phased gathers: part of a column = min(col >> shift, M - 1); the clock's current part =
@@ -89,6 +94,7 @@ constexpr int phases(int p) { return (p & phased_flag) != 0 ? (p & 0xff) : 0; }
 struct phase_args {
   unsigned int shift = 0;
   unsigned int inv_ticks = 0;
+  unsigned int enabled = 1;  ///< policy::phased_auto kernels only: 0 = gather as the plain kernel does
 };
 
 /// 4 consecutive elements at byte offset `byte_off` of buffer `r` with cache-policy bits AUX (see policy).
@@ -380,7 +386,10 @@ struct merge_tile_engine {
                 rx, gather_index(col[k][j]) * static_cast<unsigned int>(sizeof(type_t)));
         }
       } else {
+        bool phased_now = detail::policy::phases(NT) > 1;
+        if constexpr (detail::policy::phased_is_auto(NT)) phased_now = phase.enabled != 0;  // (workgroup-uniform)
         if constexpr (detail::policy::phases(NT) > 1) {
+         if (phased_now) {
           // PHASED gathers (merge_path_spmv_fused_phased): the tile's gathers leave in M passes, pass p taking
           // the items whose column lies in part p of x (M parts of 2^shift columns), execution-masked, each pass
           // drained (vmcnt(0)) and closed by a workgroup barrier before the next one starts.  Which part comes first is read
@@ -428,7 +437,9 @@ struct merge_tile_engine {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
           }
-        } else {
+         }
+        }
+        if (!phased_now) {
 #pragma unroll
           for (int k = 0; k < KV; ++k) {
 #pragma unroll
@@ -851,6 +862,24 @@ merge_path_spmv_fused_phased(const coord_t* __restrict__ coords, const int rows,
       phase);
 }
 
+/// The kernel of the PLAN-LESS entry points on matrices large enough to ask (kernels::columns_worth_sampling): plain or phased
+/// gathers by what column_scatter_sample -- launched in front of it on the same stream -- wrote to `stats` (the rule of
+/// columns_look_scattered, evaluated here by every workgroup: four scalar loads).  No host round trip: the call stays
+/// asynchronous.
+template <int TPB, int IPT, int PHASES, bool VEC, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+merge_path_spmv_fused_auto(const coord_t* __restrict__ coords, const int rows, const int nnz,
+                           const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                           const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
+                           int* __restrict__ carry_row, type_t* __restrict__ carry_val, const unsigned int* __restrict__ stats,
+                           detail::phase_args phase) {
+  const unsigned int far_same = stats[0], far_seen = stats[1], near_same = stats[2], near_seen = stats[3];
+  phase.enabled = (far_seen >= 1024u && 2u * far_same < far_seen && 4u * near_same < near_seen) ? 1u : 0u;
+  merge_path_spmv_tile_to<TPB, IPT, true, detail::policy::phased_auto(PHASES), VEC, false, true>(
+      coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x, plain_store<type_t>{y}, carry_row, carry_val, nullptr,
+      phase);
+}
+
 /// The SELF-COMPLETING form (plans over short rows: one kernel, no carry-outs, merge_path_spmv_fused_self) with phased gathers:
 /// short rows with scattered columns -- random graphs, "8 M rows x 2 nonzeros" -- gain as C2 does.
 template <int TPB, int IPT, int PHASES, bool VEC, typename index_t, typename offset_t, typename type_t>
@@ -872,40 +901,59 @@ merge_path_spmv_fused_self_phased(const coord_t* __restrict__ coords, const int*
 ///   NEAR  the pair (i, i + 1): do the two columns share a 128-byte line of x (col >> line_shift)?  Runs of consecutive
 ///         columns do -- their gathers coalesce and hit L1, phasing them only adds passes.
 /// (Adjacent nonzeros say nothing about scatter: columns are sorted inside a row, so a row of 16 uniformly random columns
-/// has its neighbours half a part apart.)  out[0] += far pairs in one part, out[1] += far pairs seen, out[2] += near pairs in
-/// one line, out[3] += near pairs seen.
+/// has its neighbours half a part apart.)  out[0] = far pairs in one part, out[1] = far pairs seen, out[2] = near pairs in one
+/// line, out[3] = near pairs seen.
+/// Launch geometry: scatter_blocks workgroups of 256 threads, one sample per thread (spread over the chip: one CU alone keeps
+/// ~94 reads in flight, and these are 49 152 scattered ones); a workgroup's counts are reduced in LDS and leave as four PLAIN
+/// stores into its own slot of `partials`, column_scatter_decide (one wavefront) adds the slots up into `out[0..3]`: no zero-fill
+/// in front, no global atomics.  (Tried first: an atomic per wavefront on four neighbouring words -- 4 096 atomics at ~88 per
+/// microsecond = a 46 us kernel; a memset + 64 atomics: 25 us per plan-less call; everything in one workgroup: 60 us.)
+constexpr int scatter_blocks = 64;
+constexpr int scatter_samples = scatter_blocks * 256;
+constexpr int scatter_scratch_words = 4 + 4 * scatter_blocks;  ///< out[4] followed by partials[scatter_blocks][4]
 template <typename index_t>
 __global__ void __launch_bounds__(256)
-column_scatter_sample(const index_t* __restrict__ indices, const long long nnz, const long long stride, const int samples,
-                      const long long far, const unsigned int shift, const unsigned int parts, const unsigned int line_shift,
-                      unsigned int* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  bool far_same = false, far_seen = false, near_same = false, near_seen = false;
-  if (k < samples) {
-    const long long i = static_cast<long long>(k) * stride;
-    if (i + 1 < nnz) {
-      const unsigned int c0 = static_cast<unsigned int>(indices[i]), c1 = static_cast<unsigned int>(indices[i + 1]);
-      near_seen = true;
-      near_same = (c0 >> line_shift) == (c1 >> line_shift);
-      // (the distance varies from sample to sample: with equal row lengths a fixed one would always meet the same rank inside
-      // the other row, and the k-th smallest of d random columns sits in much the same place in every row)
-      const long long j = i + far + static_cast<long long>((static_cast<unsigned int>(k) * 2654435761u) >> 20);
-      if (j < nnz) {
-        unsigned int a = c0 >> shift, b = static_cast<unsigned int>(indices[j]) >> shift;
-        a = a < parts - 1 ? a : parts - 1;
-        b = b < parts - 1 ? b : parts - 1;
-        far_seen = true;
-        far_same = a == b;
-      }
-    }
-  }
-  const unsigned long long m0 = __builtin_amdgcn_ballot_w64(far_same), m1 = __builtin_amdgcn_ballot_w64(far_seen),
-                           m2 = __builtin_amdgcn_ballot_w64(near_same), m3 = __builtin_amdgcn_ballot_w64(near_seen);
+column_scatter_sample(const index_t* __restrict__ indices, const long long nnz, const long long stride, const long long far,
+                      const unsigned int shift, const unsigned int parts, const unsigned int line_shift,
+                      unsigned int* __restrict__ partials) {
+  __shared__ unsigned int counts[4];
+  if (threadIdx.x < 4) counts[threadIdx.x] = 0u;
+  __syncthreads();
+  const int k = blockIdx.x * 256 + static_cast<int>(threadIdx.x);
+  const long long i = static_cast<long long>(k) * stride;
+  // (the distance varies from sample to sample: with equal row lengths a fixed one would always meet the same rank inside the
+  // other row, and the k-th smallest of d random columns sits in much the same place in every row)
+  const long long j = i + far + static_cast<long long>((static_cast<unsigned int>(k) * 2654435761u) >> 20);
+  const bool near_ok = i + 1 < nnz, far_ok = near_ok && j < nnz;
+  const unsigned int c0 = near_ok ? static_cast<unsigned int>(indices[i]) : 0u;
+  const unsigned int c1 = near_ok ? static_cast<unsigned int>(indices[i + 1]) : 0u;
+  const unsigned int c2 = far_ok ? static_cast<unsigned int>(indices[j]) : 0u;
+  unsigned int a = c0 >> shift, b2 = c2 >> shift;
+  a = a < parts - 1 ? a : parts - 1;
+  b2 = b2 < parts - 1 ? b2 : parts - 1;
+  const unsigned long long m0 = __builtin_amdgcn_ballot_w64(far_ok && a == b2), m1 = __builtin_amdgcn_ballot_w64(far_ok),
+                           m2 = __builtin_amdgcn_ballot_w64(near_ok && (c0 >> line_shift) == (c1 >> line_shift)),
+                           m3 = __builtin_amdgcn_ballot_w64(near_ok);
   if (wave::lane() == 0) {
-    atomicAdd(out + 0, static_cast<unsigned int>(__builtin_popcountll(m0)));
-    atomicAdd(out + 1, static_cast<unsigned int>(__builtin_popcountll(m1)));
-    atomicAdd(out + 2, static_cast<unsigned int>(__builtin_popcountll(m2)));
-    atomicAdd(out + 3, static_cast<unsigned int>(__builtin_popcountll(m3)));
+    atomicAdd(&counts[0], static_cast<unsigned int>(__builtin_popcountll(m0)));
+    atomicAdd(&counts[1], static_cast<unsigned int>(__builtin_popcountll(m1)));
+    atomicAdd(&counts[2], static_cast<unsigned int>(__builtin_popcountll(m2)));
+    atomicAdd(&counts[3], static_cast<unsigned int>(__builtin_popcountll(m3)));
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) partials[blockIdx.x * 4 + threadIdx.x] = counts[threadIdx.x];
+}
+
+/// out[c] = sum over the scatter_blocks slots of partials[slot][c] (one wavefront; scatter_blocks == 64 lanes).
+__global__ void __launch_bounds__(64) column_scatter_decide(const unsigned int* __restrict__ partials, unsigned int* __restrict__ out) {
+  static_assert(scatter_blocks == 64, "one lane per slot");
+  const int l = threadIdx.x;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    unsigned int v = partials[l * 4 + c];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (l == 0) out[c] = v;
   }
 }
 

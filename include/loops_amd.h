@@ -105,6 +105,9 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  * thread never do; entries of destroyed streams stay until evicted or loops_release_scratch() is called.)  A held plan (loops_merge_plan_t, loops_colblock_plan_t) owns ONE set of
  * scratch buffers and is passed as const only because its coordinates are read-only: it serves one product at a
  * time -- do not run the same plan on two streams or from two threads concurrently; create one plan per stream. */
+/* (LOOPS_MERGE_PATH_FLAT, round 4: from an x of 6 MB on and 2^20 nonzeros the call samples the columns on the device -- two small
+ * kernels, ~5 us -- and its tile kernel gathers in phases when they are scattered, loops_columns_look_scattered's rule evaluated on
+ * the device: the call stays asynchronous; |x| = 8 / 16 MB, scattered columns: 1.5 / 1.7 x.) */
 int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
                        const float* values, const float* x, float* y, void* stream);
 int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
@@ -424,7 +427,7 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
  * shapes that have one (plans of more than one tile).  best_variant = 0 or LOOPS_VARIANT_PHASED, to be passed to
  * loops_spmv_merge_path_*; ms_per_config (optional, 12 entries): [cfg] = plain, [6 + cfg] = phased, -1 where not timed. */
 /* A STRUCTURAL guess at the same question, for callers that cannot measure: *scattered = 1 when x (cols x value_bytes) is at
- * least 3 MB (6 MB for 8-byte values), the matrix holds at least 2^20 nonzeros, fewer than half of 65 536 sampled pairs of
+ * least 3 MB (6 MB for 8-byte values), the matrix holds at least 2^20 nonzeros, fewer than half of 16 384 sampled pairs of
  * nonzeros one merge tile apart share a part of x (uniformly random columns: ~1 in 8; bands, host blocks, dense hub rows: most)
  * and fewer than a quarter of the adjacent pairs share a 128-byte line of x (runs of consecutive columns gather cheaply).  What the
  * plan-less C++ wrapper algorithms::spmv::merge_path_flat(csr, x, y) consults in its untimed set-up.  Synchronous. */

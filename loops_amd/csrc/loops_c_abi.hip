@@ -86,6 +86,7 @@ struct loops_merge_plan {
   mutable size_t wide_carry_bytes;
   int* head_flag;      // device word written by merge_path_head_check
   int* head_start;     // M + 1: first nonzero of the row each tile starts in
+  unsigned int* scatter_stats;  // kernels::scatter_scratch_words words: what column_scatter_sample / _decide leave for the plan-less entry point
   int self_complete;   // 1: every tile head <= tpb -> one kernel, no carry-outs / fix-up (held plans only)
 };
 
@@ -122,7 +123,7 @@ int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
   p->num_tiles = static_cast<int>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(s.tpb) * s.ipt));
   p->capacity = p->num_tiles;
   const size_t m = static_cast<size_t>(p->num_tiles);
-  const size_t bytes = (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int)) + (m + 2) * sizeof(int);
+  const size_t bytes = (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int)) + (m + 2) * sizeof(int) + kernels::scatter_scratch_words * sizeof(unsigned int);
   hipError_t e = hipMalloc(&p->base, bytes);
   if (e != hipSuccess) { delete p; return static_cast<int>(e); }
   p->coords = static_cast<coord_t*>(p->base);
@@ -130,6 +131,7 @@ int plan_alloc(int rows, int nnz, int cfg, loops_merge_plan** out) {
   p->carry_row = reinterpret_cast<int*>(p->carry_val + (m + 2));
   p->head_flag = p->carry_row + (m + 2);
   p->head_start = p->head_flag + 1;
+  p->scatter_stats = reinterpret_cast<unsigned int*>(p->head_start + (m + 1));
   p->self_complete = 0;
   *out = p;
   return 0;
@@ -334,8 +336,14 @@ int spmv_tuned(int schedule, int rows, int cols, int nnz, const int* off, const 
       loops_merge_plan* p = scratch_plan(rows, nnz, LOOPS_TILE_512x8, stream, &err);
       if (!p) return err;
       if (p->num_tiles > 1) err = plan_compute(p, off, stream);  // a single-tile kernel derives its own coordinates
-      if (!err) err = spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
-      return err;
+      if (err) return err;
+      // large matrices over an x of 6 MB or more: a sample of the columns (two small kernels, ~5 us) decides ON THE DEVICE whether
+      // this product gathers in phases (kernels::merge_path_spmv_fused_auto) -- the call stays asynchronous
+      if (kernels::columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), /*timed_path=*/true)) {
+        kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, p->num_tiles};
+        return kernels::launch_merge_path_fused_auto<512, 8, int, int, T>(stream, view, rows, cols, nnz, off, idx, val, x, y, p->scatter_stats);
+      }
+      return spmv_merge_path<T>(p, 0, rows, nnz, off, idx, val, x, y, stream);
     }
     case LOOPS_THREAD_MAPPED:  // the schedule as given (a thread owns whole rows), the row's atoms 16 / 4 at a time
       return kernels::launch_thread_mapped(stream, std::size_t(rows), std::size_t(cols), std::size_t(nnz), off, idx, val, x, y);
@@ -834,7 +842,7 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
     if (!err && p->layout == LOOPS_LAYOUT_CSR && rows > 0 && nnz > 0 &&
         kernels::columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)))) {
       unsigned int* scratch = nullptr;
-      if (hipMalloc(reinterpret_cast<void**>(&scratch), 4 * sizeof(unsigned int)) == hipSuccess) {
+      if (hipMalloc(reinterpret_cast<void**>(&scratch), kernels::scatter_scratch_words * sizeof(unsigned int)) == hipSuccess) {
         if (kernels::columns_look_scattered(st, idx, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)),
                                             scratch)) {
           loops_merge_plan* m = nullptr;
@@ -1489,7 +1497,7 @@ int loops_columns_look_scattered(int cols, int nnz, const int* indices, int valu
   *scattered = 0;
   if (!kernels::columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), value_bytes)) return 0;
   unsigned int* scratch = nullptr;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), 4 * sizeof(unsigned int));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), kernels::scatter_scratch_words * sizeof(unsigned int));
   if (e != hipSuccess) return static_cast<int>(e);
   *scattered = kernels::columns_look_scattered(as_stream(stream), indices, static_cast<long long>(nnz), static_cast<long long>(cols),
                                                value_bytes, scratch) ? 1 : 0;

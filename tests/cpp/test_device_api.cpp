@@ -382,7 +382,7 @@ static void misc() {
     }
     csr_t<int, int, float> a(hf);
     csr_t<int, int, double> ad(hd);
-    vector_t<unsigned int> scratch(4);
+    vector_t<unsigned int> scratch(kernels::scatter_scratch_words);
     const bool scattered = kernels::columns_look_scattered(0, a.indices.data().get(), static_cast<long long>(a.nnzs),
                                                            static_cast<long long>(a.cols), 4, scratch.data().get());
     CHECK(scattered == (local == 0));
