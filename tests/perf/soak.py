@@ -109,7 +109,25 @@ def round4():
                 del csr
 
 
+def round4_planless():
+    """The asynchronous plan-less entry at |x| = 8 MB (the device samples the columns, merge_path_spmv_fused_auto takes the
+    plain or the phased path): every launch against the held plain plan's result, scattered and banded columns."""
+    r = c = 1 << 21
+    deg = G.powerlaw_degrees(r, 1 << 25)
+    for tag, window in (("scattered", None), ("band8192", 8192)):
+        off, idx, val = G.csr_from_degrees(deg, c, 1, 0, False, window)
+        csr = S.CSR.from_numpy(r, c, off, idx, val)
+        x = torch.from_numpy(G.realistic_x(c)).cuda()
+        plan = S.MergePathPlan(csr, "512x8")
+        ref = S.merge_path_flat(csr, x, plan=plan, variant=0).clone()
+        soak("2^21", f"plan-less merge_path_flat (device-decided), {tag}, real values", lambda y: (S.spmv("merge_path_flat", csr, x, y), None)[1], ref, r)
+        del csr, plan
+
+
 if len(sys.argv) > 2 and sys.argv[2] == "r4":
+    if len(sys.argv) > 3 and sys.argv[3] == "planless":
+        round4_planless()
+        sys.exit(0)
     round4()
     sys.exit(0)
 if only_r3:
