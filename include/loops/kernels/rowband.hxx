@@ -1,0 +1,706 @@
+/**
+ * @file rowband.hxx
+ * @brief Row-band layout: SpMV with the y accumulators of a band of rows in LDS and x read through sorted, coalescing
+ *        gathers -- the inverse of panel_binned.hxx (there: x in LDS, the products travel through memory).
+ *
+ * Why.  Every CSR kernel on this chip issues one L2 request per nonzero for its x gather, and the L2 serves ~266 G of them
+ * per second at best: 63 us on BASELINE C2 whatever the kernel does, 0.29 of the HBM roofline.  The
+ * panel-binned layout removes the gather but pays for it with 17 bytes of traffic per nonzero.  This layout keeps 8 bytes
+ * per nonzero AND removes most of the requests: inside a BAND of H consecutive rows the nonzeros are sorted by COLUMN, so the
+ * 64 gathers of one wavefront instruction fall on a handful of neighbouring 128-byte lines of x (the band of a C2-like
+ * matrix holds one nonzero per 4-8 columns) and the CU's L1 turns them into one L2 request per LINE.  What the sort destroys
+ * -- a row's nonzeros are no longer adjacent -- is repaired where it is cheap: the band's H sums live in LDS as fp64 words
+ * and every product is one `ds_add_f64` (3-8 lanes per clock and CU on gfx950, profiles/r03_lds_update_rates.txt).
+ *
+ * Layout (a re-ordered COPY of the matrix, built once on the device, O(nnz): one stable radix sort of (band, column) keys):
+ *   items sorted by (band b = row / H, column, CSR order), cut into SEGMENTS (b, column block cb = col >> 16) that are
+ *   padded to whole STEPS of 256 items (one wavefront load: 64 lanes x 4 items); per item the value and ONE packed word
+ *   `rc = (row - b H) << 16 | (col & 0xFFFF)`; per step `stepcol` = cb << 16.  Padding: value 0, row H (a dump accumulator),
+ *   column offset 0.  Inside a step the items are INTERLEAVED: sorted position q sits at lane (q % 64), element (q / 64) of
+ *   the lane's 16-byte vector, so the stream is read with 16-byte loads AND the 64 lanes of gather instruction e hold 64
+ *   CONSECUTIVE sorted items (neighbouring columns: few lines per instruction, quads of lanes share a line).
+ *   8 B per nonzero streamed, + 4 B per step.
+ *
+ * y = A x:
+ *   A  rowband_accumulate   one workgroup per CHUNK = a run of steps of ONE band: zero H fp64 words of LDS, stream the chunk,
+ *                           acc[row] += double(val * x[stepcol + off]), then store the H sums -- straight to y when the band is
+ *                           one chunk, else as an fp32 partial vector;
+ *   B  rowband_combine      bands cut into several chunks (few, long bands: the chunk is the unit of parallelism): y[r] = the
+ *                           partial vectors of r's band added in chunk order (fp64, rounded once).  8 H / chunk_items bytes
+ *                           per nonzero of extra traffic; not launched when every band is one chunk.
+ * y needs no zero-fill; no global atomics.  Products are fp32 (one rounding each, as in every other kernel here), all sums
+ * fp64: exactly summable inputs give the CSR kernels' bits; the LDS atomics of different wavefronts arrive in no fixed order,
+ * which cannot change an EXACT fp64 sum (fp32 products spanning < 53 - 24 - log2 n binary orders of magnitude per row).
+ *
+ * When it pays: nonzeros per band / columns spanned >= ~1/8, i.e. x of a few MB (C2) or column locality at band scale
+ * (web graphs in crawl order, FEM bands).  With scattered columns over an x of tens of MB every gather is its own line
+ * again (C5 shards, uniform C3 stand-in): panel-binned territory.  The SpMV plan adopts it by measurement only.
+ * No reference counterpart (the reference's merge_path_flat.cuh:71-82 pays one global atomic per nonzero).
+ */
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <queue>
+#include <utility>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/util/math.hxx>
+#include <loops/util/wave.hxx>
+
+namespace loops {
+namespace kernels {
+
+namespace rowband {
+constexpr int step_items = wave::size * 4;  ///< items of one step: one 16-byte load per lane
+constexpr int colblock_bits = 16;           ///< a step's columns lie in one block of 2^16: 16-bit column offsets
+constexpr int max_band_rows = 16384;        ///< (H + 1) fp64 accumulators in the 160 KB LDS of a CU
+constexpr int max_hubs = 32;                ///< rows per band that get replicated accumulators ("hubs")
+constexpr int hub_replicas = 16;            ///< accumulators per hub: the lanes of one instruction spread over them
+/// LDS words of a workgroup of kernel A: H accumulators, the dump word, the hubs' replicas.
+constexpr int lds_words(int H) { return H + 1 + max_hubs * hub_replicas; }
+}  // namespace rowband
+
+/// Device arrays of a row-band matrix (owned by rowband_storage).
+template <typename type_t>
+struct rowband_view {
+  int rows, cols, nnz;
+  int H, B;                    ///< rows per band (power of two), bands
+  int steps;                   ///< 256-item steps incl. padding
+  int num_chunks;              ///< workgroups of kernel A
+  int num_partials;            ///< partial vectors = chunks of bands that hold more than one
+  int num_multi;               ///< bands that hold more than one chunk
+  const type_t* val;           ///< [steps * 256] interleaved inside a step
+  const unsigned int* rc;      ///< [steps * 256] (row in band) << 16 | (column - stepcol); row H = padding
+  const int* stepcol;          ///< [steps] first column of the step's column block
+  const int* chunks;           ///< [4 * num_chunks] {band, first step, end step, partial slot or -1}
+  const int* multi;            ///< [3 * num_multi] {band, first partial slot, chunks}
+  const unsigned short* hubs;  ///< [B * (max_hubs + 1)] per band: the number of hubs, then their rows inside the band
+  type_t* partial;             ///< [num_partials * H]
+};
+
+namespace rowband {
+
+/// Kernel A.  WAVES wavefronts per workgroup, U steps per wavefront and batch (2 U 16-byte stream loads, then 4 U gathers).
+/// Software-pipelined: the stream loads of the NEXT batch are issued behind the gathers of the current one (the memory counter
+/// retires in order: waiting for the gathers then does not wait for the stream) and fly while the current batch is added up.
+/// Loads are branch-free (a step past the chunk's end re-reads the chunk's first step and adds into the dump word).
+/// Hub rows (rowband.hxx, file comment): row codes above H address one of hub_replicas accumulators per hub, folded into the
+/// hub's own word before the band's rows are stored.
+template <int WAVES, int U, bool NT, typename type_t, typename store_t, int DIAG = 0>
+__global__ void __launch_bounds__(WAVES * wave::size)
+rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ val, const unsigned int* __restrict__ rc,
+                   const int* __restrict__ stepcol, const unsigned short* __restrict__ hubs, const type_t* __restrict__ x, const int H,
+                   const int rows, type_t* __restrict__ partial, const store_t out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rowband_lds[];
+  double* acc = reinterpret_cast<double*>(rowband_lds);  // [lds_words(H)]: rows, the dump word H, the hubs' replicas
+  constexpr int TPB = WAVES * wave::size;
+  const int lane = wave::lane();
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / wave::size);
+  const int c = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int band = chunks[4 * c], sb = chunks[4 * c + 1], se = chunks[4 * c + 2], slot = chunks[4 * c + 3];
+  const int words = lds_words(H);
+  for (int j = threadIdx.x; j < words; j += TPB) acc[j] = 0.0;
+  __syncthreads();
+  [[maybe_unused]] double diag_sum = 0.0;
+  struct batch_t {
+    type_t v[U][4];
+    unsigned int r[U][4];
+    const type_t* xb[U];
+    bool live[U];
+  };
+  // stepcol of the batch AFTER the one being loaded is requested one batch ahead: a scalar load's wait (lgkmcnt(0)) also waits
+  // for every LDS atomic in flight, so it must find its data long there
+  int col_ahead[U];
+  auto prefetch_cols = [&](const int k) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int s = k + u * WAVES;
+      col_ahead[u] = stepcol[s < se ? s : sb];
+    }
+  };
+  auto load = [&](batch_t& t, const int k) {  // the U steps k, k + WAVES, ... of this wavefront (wave-uniform k)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int s = k + u * WAVES;
+      t.live[u] = s < se;
+      s = t.live[u] ? s : sb;
+      const long long at = static_cast<long long>(s) * step_items + lane * 4;
+      detail::load4<unsigned int, NT>(rc + at, t.r[u]);
+      detail::load4<type_t, NT>(val + at, t.v[u]);
+      t.xb[u] = x + col_ahead[u];
+    }
+    prefetch_cols(k + WAVES * U);
+  };
+  auto gather = [&](const batch_t& t, type_t (&xv)[U][4]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (DIAG & 2) xv[u][e] = type_t(t.r[u][e] & 0xFFFFu);  // DIAGNOSTIC: no gather
+        else xv[u][e] = t.xb[u][t.r[u][e] & 0xFFFFu];
+      }
+  };
+  auto update = [&](const batch_t& t, const type_t (&xv)[U][4]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned int row = t.live[u] ? t.r[u][e] >> 16 : static_cast<unsigned int>(H);
+        if constexpr (DIAG & 1) diag_sum += static_cast<double>(t.v[u][e] * xv[u][e]) + row;  // DIAGNOSTIC: no LDS update
+        else atomicAdd(&acc[row], static_cast<double>(t.v[u][e] * xv[u][e]));
+      }
+  };
+  constexpr int STRIDE = WAVES * U;
+  int k = sb + w;
+  if (k < se) {  // (wave-uniform)
+    batch_t a, b;
+    type_t xa[U][4], xb2[U][4];
+    prefetch_cols(k);
+    load(a, k);
+    gather(a, xa);
+    // (no exit between a batch's load and its gather: the compiler can neither sink the load past the update before it nor
+    //  lose count of the loads in flight at a wait)
+    for (;;) {
+      if (k + STRIDE >= se) { update(a, xa); break; }
+      load(b, k + STRIDE);
+      __builtin_amdgcn_sched_barrier(0);  // (keep every stream load of the batch ahead of the first wait for a gather)
+      update(a, xa);
+      gather(b, xb2);
+      k += STRIDE;
+      if (k + STRIDE >= se) { update(b, xb2); break; }
+      load(a, k + STRIDE);
+      __builtin_amdgcn_sched_barrier(0);
+      update(b, xb2);
+      gather(a, xa);
+      k += STRIDE;
+    }
+  }
+  if constexpr (DIAG & 1) acc[H] = diag_sum;
+  __syncthreads();
+  // hubs: replicas -> the row's own word (one thread per hub, fixed order)
+  const unsigned short* hb = hubs + static_cast<long long>(band) * (max_hubs + 1);
+  const int nh = hb[0];
+  if (static_cast<int>(threadIdx.x) < nh) {
+    const double* rep = acc + H + 1 + static_cast<int>(threadIdx.x) * hub_replicas;
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < hub_replicas; ++r) sum += rep[r];
+    acc[hb[1 + threadIdx.x]] += sum;
+  }
+  if (nh > 0) __syncthreads();  // (workgroup-uniform)
+  if (slot < 0) {
+    const long long row0 = static_cast<long long>(band) * H;
+    for (int j = threadIdx.x; j < H && row0 + j < rows; j += TPB) out(static_cast<int>(row0 + j), static_cast<type_t>(acc[j]));
+  } else {
+    type_t* to = partial + static_cast<long long>(slot) * H;
+    for (int j = threadIdx.x; j < H; j += TPB) to[j] = static_cast<type_t>(acc[j]);
+  }
+}
+
+/// Kernel B: rows of the bands that were cut into several chunks.  grid = (H / 1024, num_multi), 256 threads x 4 rows.
+template <typename type_t, typename store_t>
+__global__ void __launch_bounds__(256)
+rowband_combine(const int* __restrict__ multi, const type_t* __restrict__ partial, const int H, const int rows, const store_t out) {
+  const int m = blockIdx.y;
+  const int band = multi[3 * m], first = multi[3 * m + 1], count = multi[3 * m + 2];
+  const int j = (static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x)) * 4;
+  if (j >= H) return;
+  double sum[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < count; ++k) {
+    type_t p[4];
+    detail::load4<type_t, false>(partial + static_cast<long long>(first + k) * H + j, p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum[e] += static_cast<double>(p[e]);
+  }
+  const long long row0 = static_cast<long long>(band) * H + j;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (row0 + e < rows) out(static_cast<int>(row0 + e), static_cast<type_t>(sum[e]));
+}
+
+// ------------------------------------------------------------------------------------------------ plan-time kernels
+
+/// A row is a HUB of its band when it holds at least hub_threshold(items of the band) nonzeros: with a share p of the band's
+/// items, 64 p lanes of every update instruction meet in its accumulator and the LDS serialises them (C2: stream + updates
+/// 25-30 us with uniform row lengths, 37-40 us with its power-law rows).
+__host__ __device__ constexpr int hub_threshold(long long band_items) {
+  return band_items / 128 > 64 ? static_cast<int>(band_items / 128) : 64;
+}
+
+/// One workgroup per band: the first max_hubs rows (in row order) that reach the band's hub threshold.
+/// hubidx[row] = the row's hub number inside its band, or -1; hubs[b * (max_hubs + 1)] = count, then the rows inside the band.
+template <typename offset_t>
+__global__ void __launch_bounds__(256)
+find_hubs(const offset_t* __restrict__ offsets, const int rows, const int H, short* __restrict__ hubidx, unsigned short* __restrict__ hubs) {
+  using scan_t = hipcub::BlockScan<int, 256>;
+  __shared__ typename scan_t::TempStorage temp;
+  __shared__ int carry;
+  const int b = blockIdx.x;
+  const long long row0 = static_cast<long long>(b) * H;
+  const int n = rows - row0 < H ? static_cast<int>(rows - row0) : H;
+  const int threshold = hub_threshold(static_cast<long long>(offsets[row0 + n]) - static_cast<long long>(offsets[row0]));
+  unsigned short* hb = hubs + static_cast<long long>(b) * (max_hubs + 1);
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + static_cast<int>(threadIdx.x);
+    const bool hub = j < n && static_cast<int>(offsets[row0 + j + 1] - offsets[row0 + j]) >= threshold;
+    int pos = 0, total = 0;
+    scan_t(temp).ExclusiveSum(hub ? 1 : 0, pos, total);
+    const int base = carry;
+    if (j < n) {
+      const int h = base + pos;
+      const bool taken = hub && h < max_hubs;
+      hubidx[row0 + j] = taken ? static_cast<short>(h) : static_cast<short>(-1);
+      if (taken) hb[1 + h] = static_cast<unsigned short>(j);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry = base + total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) hb[0] = static_cast<unsigned short>(carry < max_hubs ? carry : max_hubs);
+}
+
+/// key[i] = band << cbits | column, item[i] = i, rin[i] = row inside the band, or 0x8000 | hub number for the rows of hubs.
+/// Lane per IPT consecutive nonzeros: one search for the row of the first, then a walk along the offsets (as panel::make_keys).
+template <int IPT, typename index_t, typename offset_t>
+__global__ void __launch_bounds__(256)
+make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indices, const short* __restrict__ hubidx, const int rows,
+          const int nnz, const int hshift, const int cbits, const int cols, unsigned long long* __restrict__ keys, int* __restrict__ item,
+          unsigned short* __restrict__ rin, int* __restrict__ bad) {
+  const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
+  if (base_ll >= nnz) return;
+  const int base = static_cast<int>(base_ll);
+  int row = 0, count = rows;
+  while (count > 0) {
+    const int half = count >> 1;
+    const int mid = row + half;
+    if (offsets[mid + 1] <= base) {
+      row = mid + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  offset_t row_end = offsets[row + 1];
+  int hub = hubidx[row];
+#pragma unroll
+  for (int j = 0; j < IPT; ++j) {
+    const int i = base + j;
+    if (i >= nnz) break;
+    if (i >= row_end) {
+      while (i >= row_end) row_end = offsets[++row + 1];  // skip empty rows
+      hub = hubidx[row];
+    }
+    unsigned int col = static_cast<unsigned int>(indices[i]);
+    if (col >= static_cast<unsigned int>(cols)) {  // (also a negative index) flagged, then clamped
+      *bad = 1;
+      col = 0;
+    }
+    const unsigned int b = static_cast<unsigned int>(row) >> hshift;
+    keys[i] = (static_cast<unsigned long long>(b) << cbits) | col;
+    item[i] = i;
+    rin[i] = hub >= 0 ? static_cast<unsigned short>(0x8000u | static_cast<unsigned int>(hub))
+                      : static_cast<unsigned short>(static_cast<unsigned int>(row) - (b << hshift));
+  }
+}
+
+/// seg_start[g] = the first sorted position whose (band, column block) is >= g = band * CB + cb (g <= n: seg_start[n] = nnz).
+__global__ void __launch_bounds__(256)
+segment_starts(const unsigned long long* __restrict__ sorted, const int nnz, const int n, const int CB, const int cbits,
+               int* __restrict__ seg_start) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g > n) return;
+  const unsigned long long b = static_cast<unsigned long long>(g / CB), cb = static_cast<unsigned long long>(g % CB);
+  const unsigned long long want = (b << cbits) | (cb << colblock_bits);
+  int lo = 0, count = nnz;
+  while (count > 0) {
+    const int half = count >> 1;
+    if (sorted[lo + half] < want) {
+      lo += half + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  seg_start[g] = lo;
+}
+
+/// seg_steps[g] = steps of segment g (g < n), 0 for g == n.
+__global__ void __launch_bounds__(256) segment_steps(const int* __restrict__ seg_start, const int n, int* __restrict__ seg_steps) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g <= n) seg_steps[g] = g < n ? (seg_start[g + 1] - seg_start[g] + step_items - 1) / step_items : 0;
+}
+
+/// band_step[b] = seg_step[b * CB] (b <= B).
+__global__ void __launch_bounds__(256)
+band_steps(const int* __restrict__ seg_step, const int B, const int CB, int* __restrict__ band_step) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= B) band_step[b] = seg_step[static_cast<long long>(b) * CB];
+}
+
+/// Every slot of the layout starts as padding: value 0, row H, column offset 0, no CSR position.
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+fill_padding(const long long n, const int H, type_t* __restrict__ val, unsigned int* __restrict__ rc, int* __restrict__ perm) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < n) {
+    val[j] = type_t(0);
+    rc[j] = static_cast<unsigned int>(H) << 16;
+    perm[j] = -1;
+  }
+}
+
+/// Sorted position j -> its slot: step = seg_step[g] + within / 256, inside the step lane (q % 64), element (q / 64).
+/// Row code: the row inside the band, or -- for a hub's item -- H + 1 + hub * hub_replicas + q % hub_replicas.
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+place(const unsigned long long* __restrict__ sorted, const int* __restrict__ item, const unsigned short* __restrict__ rin,
+      const int* __restrict__ seg_start, const int* __restrict__ seg_step, const type_t* __restrict__ values, const int nnz,
+      const int CB, const int cbits, const int H, type_t* __restrict__ val, unsigned int* __restrict__ rc, int* __restrict__ perm,
+      int* __restrict__ stepcol) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nnz) return;
+  const unsigned long long key = sorted[j];
+  const unsigned int col = static_cast<unsigned int>(key & ((1ull << cbits) - 1));
+  const int b = static_cast<int>(key >> cbits), cb = static_cast<int>(col >> colblock_bits);
+  const long long g = static_cast<long long>(b) * CB + cb;
+  const int within = j - seg_start[g];
+  const int step = seg_step[g] + within / step_items, q = within % step_items;
+  const long long at = static_cast<long long>(step) * step_items + (q % wave::size) * 4 + q / wave::size;
+  const int i = item[j];
+  const unsigned int code = rin[i];
+  const unsigned int row = (code & 0x8000u) ? static_cast<unsigned int>(H) + 1u + (code & 0x7FFFu) * hub_replicas + static_cast<unsigned int>(q % hub_replicas)
+                                            : code;
+  val[at] = values[i];
+  rc[at] = (row << 16) | (col & 0xFFFFu);
+  perm[at] = i;
+  if (q == 0) stepcol[step] = cb << colblock_bits;
+}
+
+template <typename type_t>
+__global__ void __launch_bounds__(256)
+refresh_values(const int* __restrict__ perm, const type_t* __restrict__ values, const long long n, type_t* __restrict__ val) {
+  const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j < n) {
+    const int i = perm[j];
+    val[j] = i >= 0 ? values[i] : type_t(0);
+  }
+}
+
+}  // namespace rowband
+
+constexpr int rowband_e_badarg = -1, rowband_e_range = -2;
+
+/// Tuning knobs read from the environment (experiments; 0 = the built-in choice).
+inline int rowband_env(const char* name) {
+  const char* e = std::getenv(name);
+  return e ? std::atoi(e) : 0;
+}
+
+/// Rows per band: 16384 (the tallest band the LDS holds: the taller the band, the denser its column-sorted nonzeros and the fewer
+/// lines a wavefront's 64 gathers touch), halved while the matrix would be left with fewer than 64 bands.
+inline int rowband_rows(int rows, int /*cols*/, int /*nnz*/) {
+  int h = rowband::max_band_rows;
+  while (h > 256 && rows / h < 64) h /= 2;
+  return h;
+}
+
+/// Workgroups of kernel A that are resident at once on `cus` compute units: one per CU above 64 KB of LDS, else two (1024 threads each).
+inline int rowband_resident_chunks(int H, int cus) {
+  const std::size_t lds = static_cast<std::size_t>(rowband::lds_words(H)) * sizeof(double);
+  return (cus > 0 ? cus : 256) * (2 * lds <= 160 * 1024 ? 2 : 1);
+}
+
+/// Kernel A's work list from the bands' step ranges (B + 1 entries).  The bands are cut into about `target_chunks` chunks in
+/// proportion to their steps (every band with nonzeros at least one; the next cut always goes to the band whose chunks are the
+/// longest), a band's chunks of equal size.  {band, first step, end step, partial slot or -1} per chunk, {band, first slot,
+/// chunks} per cut band.
+inline void rowband_chunk_list(const std::vector<int>& band_step, int B, int target_chunks, std::vector<int>& chunks, std::vector<int>& multi,
+                               int& num_partials) {
+  chunks.clear();
+  multi.clear();
+  num_partials = 0;
+  const long long total = B > 0 ? static_cast<long long>(band_step[B]) - band_step[0] : 0;
+  std::vector<int> pieces(static_cast<std::size_t>(B), 1);
+  long long sum = 0;
+  for (int b = 0; b < B; ++b) {
+    const long long n = band_step[b + 1] - band_step[b];
+    if (n > 0 && total > 0) {
+      long long p = n * target_chunks / total;
+      pieces[b] = static_cast<int>(p < 1 ? 1 : (p > n ? n : p));
+    }
+    sum += pieces[b];
+  }
+  if (sum < target_chunks) {  // hand the remaining cuts to the bands with the longest chunks
+    using entry = std::pair<double, int>;
+    std::priority_queue<entry> heap;
+    for (int b = 0; b < B; ++b) {
+      const int n = band_step[b + 1] - band_step[b];
+      if (n > pieces[b]) heap.push({static_cast<double>(n) / pieces[b], -b});
+    }
+    while (sum < target_chunks && !heap.empty()) {
+      const int b = -heap.top().second;
+      heap.pop();
+      const int n = band_step[b + 1] - band_step[b];
+      ++pieces[b];
+      ++sum;
+      if (n > pieces[b]) heap.push({static_cast<double>(n) / pieces[b], -b});
+    }
+  }
+  for (int b = 0; b < B; ++b) {
+    const int s0 = band_step[b], n = band_step[b + 1] - s0;
+    if (n <= 0) {  // a band without nonzeros still owns rows of y: an empty chunk stores its zeros
+      chunks.insert(chunks.end(), {b, s0, s0, -1});
+      continue;
+    }
+    const int size = (n + pieces[b] - 1) / pieces[b];
+    const int count = (n + size - 1) / size;
+    if (count > 1) multi.insert(multi.end(), {b, num_partials, count});
+    for (int k = 0; k < count; ++k) {
+      const int begin = s0 + k * size, end = begin + size < s0 + n ? begin + size : s0 + n;
+      chunks.insert(chunks.end(), {b, begin, end, count > 1 ? num_partials + k : -1});
+    }
+    if (count > 1) num_partials += count;
+  }
+}
+
+/// The device arrays of one row-band matrix, OWNED.  Type-erased over the value type (`vbytes`).
+struct rowband_storage {
+  int rows = 0, cols = 0, nnz = 0, vbytes = 0;
+  int H = 0, B = 0, CB = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0;
+  void *val = nullptr, *partial = nullptr;
+  unsigned int* rc = nullptr;
+  unsigned short* hubs = nullptr;
+  int *stepcol = nullptr, *perm = nullptr, *chunks = nullptr, *multi = nullptr, *band_step = nullptr;
+
+  rowband_storage() = default;
+  rowband_storage(const rowband_storage&) = delete;
+  rowband_storage& operator=(const rowband_storage&) = delete;
+  ~rowband_storage() { release(); }
+  void release() {
+    (void)hipFree(val); (void)hipFree(partial); (void)hipFree(rc); (void)hipFree(hubs); (void)hipFree(stepcol); (void)hipFree(perm);
+    (void)hipFree(chunks); (void)hipFree(multi); (void)hipFree(band_step);
+    val = partial = nullptr; rc = nullptr; hubs = nullptr; stepcol = perm = chunks = multi = band_step = nullptr;
+  }
+  template <typename type_t>
+  rowband_view<type_t> view() const {
+    return rowband_view<type_t>{rows, cols, nnz, H, B, steps, num_chunks, num_partials, num_multi, static_cast<const type_t*>(val), rc,
+                                stepcol, chunks, multi, hubs, static_cast<type_t*>(partial)};
+  }
+};
+
+/// Default number of chunks: the bands themselves when there are more of them than workgroups resident at once, rounded up to
+/// whole rounds of resident workgroups (the surplus cuts go to the heaviest bands) -- one round of equal chunks for C2-like
+/// inputs (64 bands of 16384 rows -> 256 chunks), no cuts but for outliers where bands are plenty.
+inline int rowband_target_chunks(int H, int B, int cus) {
+  const int resident = rowband_resident_chunks(H, cus);
+  const long long rounds = (static_cast<long long>(B > 0 ? B : 1) + resident - 1) / resident;
+  return static_cast<int>(rounds * resident);
+}
+
+/// (Re)builds the work lists of a built layout for about `target_chunks` chunks (0 = automatic); `band_step_host` = the B + 1 step
+/// starts.  Used by the builder and by tuning code that sweeps the cut without re-sorting.
+inline int rowband_set_chunks(rowband_storage& out, const std::vector<int>& band_step_host, int target_chunks) {
+  out.target_chunks = target_chunks > 0 ? target_chunks : rowband_target_chunks(out.H, out.B, out.cus);
+  std::vector<int> chunks, multi;
+  rowband_chunk_list(band_step_host, out.B, out.target_chunks, chunks, multi, out.num_partials);
+  out.num_chunks = static_cast<int>(chunks.size() / 4);
+  out.num_multi = static_cast<int>(multi.size() / 3);
+  (void)hipFree(out.chunks); (void)hipFree(out.multi); (void)hipFree(out.partial);
+  out.chunks = out.multi = nullptr;
+  out.partial = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&out.chunks), sizeof(int) * (chunks.empty() ? 4 : chunks.size()));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&out.multi), sizeof(int) * (multi.empty() ? 3 : multi.size()));
+  if (e == hipSuccess)
+    e = hipMalloc(&out.partial, static_cast<std::size_t>(out.vbytes) * (out.num_partials > 0 ? static_cast<std::size_t>(out.num_partials) * out.H : 4));
+  if (e == hipSuccess && !chunks.empty()) e = hipMemcpy(out.chunks, chunks.data(), sizeof(int) * chunks.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !multi.empty()) e = hipMemcpy(out.multi, multi.data(), sizeof(int) * multi.size(), hipMemcpyHostToDevice);
+  return static_cast<int>(e);
+}
+
+/// Builds the row-band copy of a CSR on the device.  band_rows: 0 = automatic, else a power of two in [64, 16384];
+/// target_chunks: 0 = automatic.  Returns 0, a hipError_t, rowband_e_badarg (also: a column index outside [0, cols)) or
+/// rowband_e_range (the padded layout may not fit 32-bit positions).
+template <typename index_t, typename offset_t, typename type_t>
+int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset_t* offsets, const index_t* indices, const type_t* values,
+                   int band_rows, int target_chunks, rowband_storage& out) {
+  static_assert(sizeof(index_t) == 4 && sizeof(offset_t) == 4, "rowband_create: 32-bit indices and offsets");
+  if (!offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values)) || target_chunks < 0) return rowband_e_badarg;
+  out.release();
+  out.rows = rows; out.cols = cols; out.nnz = nnz; out.vbytes = static_cast<int>(sizeof(type_t));
+  out.H = band_rows != 0 ? band_rows : rowband_rows(rows, cols, nnz);
+  if (out.H < 64 || out.H > rowband::max_band_rows || (out.H & (out.H - 1))) return rowband_e_badarg;
+  int hshift = 0;
+  while ((1 << hshift) < out.H) ++hshift;
+  out.B = rows > 0 ? static_cast<int>((static_cast<long long>(rows) + out.H - 1) / out.H) : 0;
+  out.CB = cols > 0 ? static_cast<int>((static_cast<long long>(cols) + (1 << rowband::colblock_bits) - 1) >> rowband::colblock_bits) : 1;
+  out.steps = out.num_chunks = out.num_partials = out.num_multi = 0;
+  if (rows == 0) return 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&out.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) out.cus = 256;
+  }
+  const int B = out.B, CB = out.CB;
+  const long long segments = static_cast<long long>(B) * CB;
+  // every segment may carry up to 255 padding items (an upper bound: the real padding is known only after the sort)
+  if (segments > (1ll << 26) || (static_cast<long long>(nnz) / rowband::step_items + segments + 1) * rowband::step_items >= (1ll << 31) - 4096)
+    return rowband_e_range;
+  const int nseg = static_cast<int>(segments);
+  int cbits = 1;
+  while (cbits < 31 && (static_cast<long long>(cols) >> cbits) != 0) ++cbits;
+  int bbits = 1;
+  while (bbits < 31 && (static_cast<long long>(B) >> bbits) != 0) ++bbits;
+
+  auto up = [](std::size_t v) { return (v + 255) & ~std::size_t(255); };
+  std::size_t sort_bytes = 0, scan_bytes = 0;
+  {
+    unsigned long long* k = nullptr;
+    int* ci = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k, k, ci, ci, nnz, 0, cbits + bbits);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, ci, ci, nseg + 1);
+  }
+  const std::size_t cub_bytes_total = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+  const std::size_t key_bytes = up((static_cast<std::size_t>(nnz) + 1) * 8), item_bytes = up((static_cast<std::size_t>(nnz) + 1) * 4);
+  const std::size_t rin_bytes = up((static_cast<std::size_t>(nnz) + 1) * 2), seg_bytes = up((static_cast<std::size_t>(nseg) + 1) * 4);
+  const std::size_t hub_bytes = up((static_cast<std::size_t>(rows) + 1) * 2);
+  const std::size_t temp_bytes = 2 * key_bytes + 2 * item_bytes + rin_bytes + hub_bytes + 3 * seg_bytes + 256 + cub_bytes_total;
+  char* base = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), temp_bytes);
+  struct guard_t {
+    char*& a;
+    ~guard_t() { (void)hipFree(a); }
+  } guard{base};
+  if (e != hipSuccess) return static_cast<int>(e);
+  char* at = base;
+  auto carve = [&](std::size_t bytes) { char* p = at; at += bytes; return p; };
+  auto* keys_in = reinterpret_cast<unsigned long long*>(carve(key_bytes));
+  auto* keys_out = reinterpret_cast<unsigned long long*>(carve(key_bytes));
+  int* item_in = reinterpret_cast<int*>(carve(item_bytes));
+  int* item_out = reinterpret_cast<int*>(carve(item_bytes));
+  auto* rin = reinterpret_cast<unsigned short*>(carve(rin_bytes));
+  auto* hubidx = reinterpret_cast<short*>(carve(hub_bytes));
+  int* seg_start = reinterpret_cast<int*>(carve(seg_bytes));
+  int* seg_steps = reinterpret_cast<int*>(carve(seg_bytes));
+  int* seg_step = reinterpret_cast<int*>(carve(seg_bytes));
+  int* bad = reinterpret_cast<int*>(carve(256));
+  void* cub_temp = carve(cub_bytes_total);
+  std::size_t cub_bytes = cub_bytes_total;
+
+  const std::size_t hubs_n = static_cast<std::size_t>(B) * (rowband::max_hubs + 1);
+  e = hipMalloc(reinterpret_cast<void**>(&out.hubs), sizeof(unsigned short) * hubs_n);
+  if (e == hipSuccess) e = hipMemsetAsync(out.hubs, 0, sizeof(unsigned short) * hubs_n, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  hipLaunchKernelGGL((rowband::find_hubs<offset_t>), dim3(B), dim3(256), 0, stream, offsets, rows, out.H, hubidx, out.hubs);
+  constexpr int KEYS_PER_LANE = 8;
+  if (nnz > 0) {
+    hipLaunchKernelGGL((rowband::make_keys<KEYS_PER_LANE, index_t, offset_t>), dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), dim3(256), 0,
+                       stream, offsets, indices, hubidx, rows, nnz, hshift, cbits, cols, keys_in, item_in, rin, bad);
+    e = hipcub::DeviceRadixSort::SortPairs(cub_temp, cub_bytes, keys_in, keys_out, item_in, item_out, nnz, 0, cbits + bbits, stream);
+    if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  }
+  const dim3 seg_grid(math::ceil_div(nseg + 1, 256));
+  hipLaunchKernelGGL(rowband::segment_starts, seg_grid, dim3(256), 0, stream, keys_out, nnz, nseg, CB, cbits, seg_start);
+  hipLaunchKernelGGL(rowband::segment_steps, seg_grid, dim3(256), 0, stream, seg_start, nseg, seg_steps);
+  cub_bytes = cub_bytes_total;
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, seg_steps, seg_step, nseg + 1, stream);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&out.band_step), sizeof(int) * (static_cast<std::size_t>(B) + 1));
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  hipLaunchKernelGGL(rowband::band_steps, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, seg_step, B, CB, out.band_step);
+  std::vector<int> bs(static_cast<std::size_t>(B) + 1, 0);
+  int h_bad = 0;
+  e = hipMemcpyAsync(bs.data(), out.band_step, sizeof(int) * bs.size(), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  if (h_bad != 0) { out.release(); return rowband_e_badarg; }
+  out.steps = bs[B];
+  const std::size_t n = static_cast<std::size_t>(out.steps > 0 ? out.steps : 1) * rowband::step_items;
+  auto alloc = [&](auto** ptr, std::size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes); };
+  alloc(&out.val, sizeof(type_t) * n);
+  alloc(&out.rc, sizeof(unsigned int) * n);
+  alloc(&out.perm, sizeof(int) * n);
+  alloc(&out.stepcol, sizeof(int) * (static_cast<std::size_t>(out.steps) + 1));
+  if (e == hipSuccess) e = hipMemsetAsync(out.stepcol, 0, sizeof(int) * (static_cast<std::size_t>(out.steps) + 1), stream);
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  hipLaunchKernelGGL((rowband::fill_padding<type_t>), dim3(static_cast<unsigned int>((n + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<long long>(n), out.H, static_cast<type_t*>(out.val), out.rc, out.perm);
+  if (nnz > 0)
+    hipLaunchKernelGGL((rowband::place<type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, item_out, rin, seg_start,
+                       seg_step, values, nnz, CB, cbits, out.H, static_cast<type_t*>(out.val), out.rc, out.perm, out.stepcol);
+  e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = static_cast<hipError_t>(rowband_set_chunks(out, bs, target_chunks));
+  if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  return 0;
+}
+
+/// Kernel-A shape: LOOPS_ROWBAND_CFG = WAVES * 10 + U (experiments), 0 = the built-in choice.
+inline int rowband_config() {
+  return rowband_env("LOOPS_ROWBAND_CFG");  // (read at every launch: a process can sweep it)
+}
+
+/// y = A x over a row-band matrix: kernel A, then kernel B if some band was cut.  stages: bit 0 = accumulate, bit 1 = combine.
+template <typename type_t, typename store_t>
+int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const type_t* x, const store_t out, int stages = 3) {
+  if (m.rows == 0) return 0;
+  // Non-temporal streams unless a product's working set (8 B per item with 4-byte values, x, y, partials) fits the Infinity Cache
+  const double items = static_cast<double>(m.steps) * rowband::step_items;
+  const bool nt = rowband_env("LOOPS_ROWBAND_NT") != 0 || items * (sizeof(type_t) + 4.0) + (static_cast<double>(m.rows) + m.cols + 2.0 * m.num_partials * m.H) * sizeof(type_t) > 240e6;
+  if ((stages & 1) && m.num_chunks > 0) {
+    const std::size_t lds = static_cast<std::size_t>(rowband::lds_words(m.H)) * sizeof(double);
+    auto go = [&](auto kernel, int waves) {
+      if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(waves * wave::size), lds, stream, m.chunks, m.val, m.rc, m.stepcol, m.hubs, x, m.H,
+                         m.rows, m.partial, out);
+    };
+    const int cfg = rowband_config();
+#define LOOPS_ROWBAND_GO(W, U)                                                         \
+  {                                                                                    \
+    const int diag = rowband_env("LOOPS_ROWBAND_DIAG");                                \
+    if (diag == 1) go(rowband::rowband_accumulate<W, U, false, type_t, store_t, 1>, W);      \
+    else if (diag == 2) go(rowband::rowband_accumulate<W, U, false, type_t, store_t, 2>, W); \
+    else if (diag == 3) go(rowband::rowband_accumulate<W, U, false, type_t, store_t, 3>, W); \
+    else if (nt) go(rowband::rowband_accumulate<W, U, true, type_t, store_t>, W);      \
+    else go(rowband::rowband_accumulate<W, U, false, type_t, store_t>, W);             \
+  }
+    switch (cfg) {
+      case 41: LOOPS_ROWBAND_GO(4, 1) break;
+      case 42: LOOPS_ROWBAND_GO(4, 2) break;
+      case 44: LOOPS_ROWBAND_GO(4, 4) break;
+      case 81: LOOPS_ROWBAND_GO(8, 1) break;
+      case 82: LOOPS_ROWBAND_GO(8, 2) break;
+      case 84: LOOPS_ROWBAND_GO(8, 4) break;
+      case 161: LOOPS_ROWBAND_GO(16, 1) break;
+      case 164: LOOPS_ROWBAND_GO(16, 4) break;
+      default: LOOPS_ROWBAND_GO(16, 2) break;
+    }
+#undef LOOPS_ROWBAND_GO
+  }
+  if ((stages & 2) && m.num_multi > 0) {
+    hipLaunchKernelGGL((rowband::rowband_combine<type_t, store_t>), dim3(math::ceil_div(m.H, 1024), m.num_multi), dim3(256), 0, stream,
+                       m.multi, m.partial, m.H, m.rows, out);
+  }
+  return static_cast<int>(hipGetLastError());
+}
+
+template <typename type_t>
+int launch_rowband(hipStream_t stream, const rowband_view<type_t>& m, const type_t* x, type_t* y, int stages = 3) {
+  return launch_rowband_to(stream, m, x, plain_store<type_t>{y}, stages);
+}
+
+template <typename type_t>
+int launch_rowband_fanout(hipStream_t stream, const rowband_view<type_t>& m, const type_t* x, type_t* y, const peer_fanout<type_t>& peers) {
+  if (peers.count < 0 || peers.count > max_peers) return static_cast<int>(hipErrorInvalidValue);
+  return launch_rowband_to(stream, m, x, fanout_store<type_t>{y, peers}, 3);
+}
+
+}  // namespace kernels
+}  // namespace loops

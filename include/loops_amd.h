@@ -337,6 +337,41 @@ int loops_spmv_panel_fanout_f32(const loops_panel_plan_t* plan, const float* x, 
 int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x, double* y, int num_peers, double* const* h_peer_y,
                                 void* stream);
 
+/* ---- row-band layout: y accumulators of a band of rows in LDS, x read through column-sorted (coalescing) gathers ----------
+ * No reference counterpart (the reference's merge_path_flat.cuh:71-82 issues one global atomic per nonzero; its CSR kernels one
+ * scattered x gather per nonzero).  The plan holds a re-ordered COPY of the matrix (include/loops/kernels/rowband.hxx): nonzeros
+ * sorted by (band of H consecutive rows, column, CSR order), cut at column blocks of 2^16 and padded to steps of 256 items; per
+ * item the value and one packed word (row code) << 16 | (column & 0xFFFF) -- 8 bytes per nonzero with 4-byte values.  Row code:
+ * the row inside the band; H = padding; above H: one of 16 replicated accumulators of a HUB row (a row holding >= 1/128 of its
+ * band's nonzeros, at most 32 per band), so that the lanes of one instruction do not meet in one LDS word.
+ * y = A x: one workgroup per chunk of a band adds its products into fp64 words of LDS (ds_add_f64) and stores the band's rows
+ * -- straight to y, or, where a band was cut into several chunks, as fp32 partial vectors that a second small kernel adds in
+ * chunk order.  Products are fp32 (one rounding each), all sums fp64, y is rounded once (twice where a band was cut): bit-equal to
+ * the CSR kernels on exactly summable inputs, within 1e-6 of the f64-accumulated product otherwise (util/reference.hxx:146-166);
+ * no global atomics; y needs no zero-fill.  4-byte values only.
+ * band_rows: 0 = automatic, else a power of two in [64, 16384]; target_chunks: 0 = automatic, else about how many workgroups
+ * the first kernel is cut into (LOOPS_E_BADARG otherwise).  LOOPS_E_RANGE when bands x column blocks exceed 2^26 or the padded
+ * layout may reach 2^31 items.  Creation is synchronous (device radix sort, O(nnz)).
+ * info8 = {H, bands, column blocks, steps of 256 items incl. padding, chunks, partial vectors, bands cut into several chunks,
+ * target chunks}.  loops_rowband_plan_arrays: HOST copies (any pointer may be NULL): values / rc / perm [steps * 256] (perm = CSR
+ * position of the item, -1 = padding), stepcol [steps], chunks [4 * chunks] = {band, first step, end step, partial slot or -1},
+ * multi [3 * cut bands] = {band, first partial slot, chunks}, hubs [bands * 33] = per band the number of hubs, then their rows
+ * inside the band.  loops_rowband_plan_set_chunks re-cuts the bands of a built plan (tuning; synchronous). */
+typedef struct loops_rowband_plan loops_rowband_plan_t;
+int loops_rowband_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
+                                  int band_rows, int target_chunks, void* stream, loops_rowband_plan_t** out);
+void loops_rowband_plan_destroy(loops_rowband_plan_t* plan);
+int loops_rowband_plan_info(const loops_rowband_plan_t* plan, int* info8);
+int loops_rowband_plan_arrays(const loops_rowband_plan_t* plan, void* values, unsigned int* rc, int* perm, int* stepcol, int* chunks,
+                              int* multi, unsigned short* hubs);
+int loops_rowband_plan_set_chunks(loops_rowband_plan_t* plan, int target_chunks);
+int loops_rowband_plan_refresh_values_f32(loops_rowband_plan_t* plan, const float* values, void* stream);
+int loops_spmv_rowband_f32(const loops_rowband_plan_t* plan, const float* x, float* y, void* stream);
+/* one kernel at a time for timing: stage 0 = accumulate, 1 = combine */
+int loops_spmv_rowband_stage_f32(const loops_rowband_plan_t* plan, int stage, const float* x, float* y, void* stream);
+int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float* x, float* y, int num_peers, float* const* h_peer_y,
+                                  void* stream);
+
 /* ---- SpMV plan: tile shape AND layout chosen at plan time ------------------------------------------------
  * What an iterative caller holds for one matrix.  The reference fixes both at compile time (launch_box.hxx:56-90) and always
  * runs the CSR as given; here the plan decides per matrix, once:

@@ -55,6 +55,9 @@ SYMBOLS = [
     "loops_allgatherv_f32", "loops_allgatherv_f64",
     "loops_autotune_merge_path_variants_f32", "loops_spmv_plan_variant", "loops_columns_look_scattered",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
+    "loops_rowband_plan_create_f32", "loops_rowband_plan_destroy", "loops_rowband_plan_info", "loops_rowband_plan_arrays",
+    "loops_rowband_plan_set_chunks", "loops_rowband_plan_refresh_values_f32", "loops_spmv_rowband_f32", "loops_spmv_rowband_stage_f32",
+    "loops_spmv_rowband_fanout_f32",
 ]
 
 
@@ -106,16 +109,22 @@ def _compile(src: str, out: str, extra_deps=(), force: bool = False, verbose: bo
 def built_from_current_sources(out: str = None, src: str = None, extra_deps=()) -> bool:
     """True when `out` (default: the product library) carries the digest of the sources as they are now."""
     out, src = out or LIB_PATH, src or SRC_PATH
-    deps = [src, *extra_deps]
+    deps = [src, *extra_deps, *(_abi_parts() if src == SRC_PATH else [])]
     for base, _, files in os.walk(INCLUDE_DIR):
         deps += [os.path.join(base, f) for f in files]
     stamp = out + ".srcdigest"
     return os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().split()[0] == source_digest(deps)
 
 
+def _abi_parts():
+    """The per-family parts of the C ABI that loops_c_abi.hip #includes (loops_amd/csrc/abi_*.inc)."""
+    csrc = os.path.dirname(SRC_PATH)
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.startswith("abi_") and f.endswith(".inc"))
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libloops_amd.so -- the product -- for gfx950 with hipcc (cross-compiles without a GPU)."""
-    return _compile(SRC_PATH, LIB_PATH, force=force, verbose=verbose)
+    return _compile(SRC_PATH, LIB_PATH, _abi_parts(), force=force, verbose=verbose)
 
 
 def build_probes(force: bool = False, verbose: bool = False) -> str:
@@ -212,6 +221,16 @@ def lib() -> C.CDLL:
         L.loops_panel_plan_destroy.restype = None
         L.loops_panel_plan_info.argtypes = [vp, vp]
         L.loops_panel_plan_layout.argtypes = [vp, vp]
+        L.loops_rowband_plan_create_f32.argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
+        L.loops_rowband_plan_destroy.argtypes = [vp]
+        L.loops_rowband_plan_destroy.restype = None
+        L.loops_rowband_plan_info.argtypes = [vp, vp]
+        L.loops_rowband_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.loops_rowband_plan_set_chunks.argtypes = [vp, ci]
+        L.loops_rowband_plan_refresh_values_f32.argtypes = [vp, vp, vp]
+        L.loops_spmv_rowband_f32.argtypes = [vp, vp, vp, vp]
+        L.loops_spmv_rowband_stage_f32.argtypes = [vp, ci, vp, vp, vp]
+        L.loops_spmv_rowband_fanout_f32.argtypes = [vp, vp, vp, ci, vp, vp]
         L.loops_row_ranges.argtypes = [ci, vp, ci, vp]
         L.loops_comm_unique_id.argtypes = [vp]
         L.loops_comm_init.argtypes = [ci, ci, vp, C.POINTER(vp)]

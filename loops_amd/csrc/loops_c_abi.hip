@@ -24,6 +24,7 @@
 #include <loops/kernels/launch.hxx>
 #include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/panel_binned.hxx>
+#include <loops/kernels/rowband.hxx>
 #include <loops/multi_gpu/partition.hxx>
 #include <loops/kernels/coo_spmv.hxx>
 #include <loops/kernels/ell_spmv.hxx>
@@ -752,6 +753,9 @@ int panel_refresh(loops_panel_plan* p, const T* values, hipStream_t st) {
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------ row-band layout
+#include "abi_rowband.inc"
 
 // ------------------------------------------------------------------ SpMV plan: tile shape AND layout chosen at plan time
 // What a caller that performs many products with one matrix should hold (loops_spmv_plan_*): the merge-path plan of the

@@ -397,6 +397,88 @@ class PanelBinnedPlan:
             pass
 
 
+class RowBandPlan:
+    """Row-band copy of a CSR (loops_rowband_plan_*; include/loops/kernels/rowband.hxx): the y accumulators of a band of H rows
+    live in LDS as fp64 words, the band's nonzeros are sorted by column so that a wavefront's 64 x gathers fall on a few
+    neighbouring lines; 8 bytes per nonzero streamed.  For x of a few MB, or column locality at band scale.  fp32 only."""
+
+    STEP = 256
+
+    def __init__(self, csr: CSR, band_rows: int = 0, target_chunks: int = 0):
+        assert csr.values.dtype == torch.float32
+        self.dtype = csr.values.dtype
+        self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
+        self._h = C.c_void_p()
+        L.check(L.lib().loops_rowband_plan_create_f32(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values),
+                                                      int(band_rows), int(target_chunks), _stream(), C.byref(self._h)),
+                "loops_rowband_plan_create_f32")
+        self._read_info()
+
+    def _read_info(self):
+        info = (C.c_int * 8)()
+        L.check(L.lib().loops_rowband_plan_info(self._h, info), "loops_rowband_plan_info")
+        (self.H, self.num_bands, self.num_colblocks, self.steps, self.num_chunks, self.num_partials, self.num_multi,
+         self.target_chunks) = list(info)
+        self.padded = self.steps * self.STEP
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_chunks(self, target_chunks: int = 0):
+        """Re-cut the bands into about ``target_chunks`` chunks (0 = automatic) without rebuilding the layout."""
+        L.check(L.lib().loops_rowband_plan_set_chunks(self._h, int(target_chunks)), "loops_rowband_plan_set_chunks")
+        self._read_info()
+
+    def arrays(self):
+        """(values, rc, perm, stepcol, chunks [n, 4], multi [m, 3], hubs [bands, 33]) copied to the host."""
+        val, rc = np.zeros(self.padded, np.float32), np.zeros(self.padded, np.uint32)
+        perm, stepcol = np.zeros(self.padded, np.int32), np.zeros(self.steps, np.int32)
+        chunks, multi = np.zeros((self.num_chunks, 4), np.int32), np.zeros((self.num_multi, 3), np.int32)
+        hubs = np.zeros((self.num_bands, 33), np.uint16)
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
+        L.check(L.lib().loops_rowband_plan_arrays(self._h, p(val), p(rc), p(perm), p(stepcol), p(chunks), p(multi), p(hubs)),
+                "loops_rowband_plan_arrays")
+        return val, rc, perm, stepcol, chunks, multi, hubs
+
+    def refresh_values(self, values: torch.Tensor):
+        assert values.dtype == self.dtype and values.numel() == self.nnz
+        L.check(L.lib().loops_rowband_plan_refresh_values_f32(self._h, _ptr(values), _stream()), "loops_rowband_plan_refresh_values_f32")
+
+    def _check(self, x, y):
+        assert x.dtype == self.dtype and y.dtype == self.dtype and x.numel() >= self.cols and y.numel() >= self.rows
+        assert x.is_contiguous() and y.is_contiguous()
+
+    def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+        if y is None:
+            y = torch.empty(self.rows, dtype=self.dtype, device=x.device)
+        self._check(x, y)
+        L.check(L.lib().loops_spmv_rowband_f32(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_rowband_f32")
+        return y
+
+    def spmv_stage(self, stage: int, x, y):
+        L.check(L.lib().loops_spmv_rowband_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_rowband_stage_f32")
+        return y
+
+    def spmv_fanout(self, x, y, peers):
+        """``spmv`` whose row stores also go to ``peers`` (loops_spmv_rowband_fanout_f32; see merge_path_flat_fanout)."""
+        self._check(x, y)
+        arr, n = _peer_array(peers)
+        L.check(L.lib().loops_spmv_rowband_fanout_f32(self._h, _ptr(x), _ptr(y), n, arr, _stream()), "loops_spmv_rowband_fanout_f32")
+        return y
+
+    def close(self):
+        if self._h:
+            L.lib().loops_rowband_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class SpmvPlan:
     """loops_spmv_plan_*: tile shape AND layout of one matrix chosen at plan time.  ``measure``: time the candidates on the
     device; ``allow_copy``: the plan may hold a column-blocked copy of the matrix when that is faster (x larger than the
