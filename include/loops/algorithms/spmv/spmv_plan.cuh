@@ -2,8 +2,8 @@
  * @file spmv_plan.cuh
  * @brief `algorithms::spmv::spmv_plan_t<index_t, offset_t, type_t>`: what an iterative caller holds for ONE matrix -- the
  * merge-path plan of the unmodified CSR in the tile shape that suits its structure, or, if the caller allows a copy and it
- * is measurably faster, a re-ordered copy of the matrix: column-blocked (column_blocked.cuh: x larger than the per-XCD L2, gathers
- * become L2 hits) or panel-binned (panel_binned.cuh: x panels in LDS, no memory gather at all).  The
+ * is measurably faster, a re-ordered copy of the matrix: row-band (rowband.cuh: y accumulators in LDS, column-sorted gathers that
+ * coalesce; 4-byte values) or panel-binned (panel_binned.cuh: x panels in LDS, no memory gather at all).  The
  * header-API twin of loops_spmv_plan_* (include/loops_amd.h).  The reference fixes the tile shape per architecture at
  * compile time (algorithms/spmv/launch_box.hxx:56-90) and always runs the CSR as given; no counterpart there.
  *
@@ -17,9 +17,9 @@
 #include <exception>
 #include <memory>
 
-#include <loops/algorithms/spmv/column_blocked.cuh>
 #include <loops/algorithms/spmv/merge_path_flat.cuh>
 #include <loops/algorithms/spmv/panel_binned.cuh>
+#include <loops/algorithms/spmv/rowband.cuh>
 
 namespace loops {
 namespace algorithms {
@@ -27,25 +27,25 @@ namespace spmv {
 
 template <typename index_t, typename offset_t, typename type_t>
 struct spmv_plan_t {
-  enum layout_kind { csr_layout = 0, column_blocked_layout = 1, panel_binned_layout = 2 };
+  enum layout_kind { csr_layout = 0, panel_binned_layout = 2, row_band_layout = 3 };  // (LOOPS_LAYOUT_* of include/loops_amd.h)
   using small_t = merge_path_small_plan_t<index_t, offset_t, type_t>;  // 256 x 8 (256 x 4 for 8-byte values)
   using large_t = merge_path_plan_t<index_t, offset_t, type_t>;        // 512 x 8 (512 x 4)
-  using blocked_t = column_blocked_t<index_t, offset_t, type_t>;
+  using band_t = rowband_t<index_t, offset_t, float>;  ///< (4-byte values only: never built for other value types)
   using panel_t = panel_binned_t<index_t, offset_t, type_t>;
   static constexpr std::size_t large_block = merge_path_launch_t<type_t>::block_size, large_items = merge_path_launch_t<type_t>::items_per_thread;
 
   layout_kind layout = csr_layout;
   bool phased = false;  ///< csr_layout over `large`: the product runs the phased-gather kernel (merge_path_flat_phased_async_with)
-  float ms_small = -1.f, ms_large = -1.f, ms_blocked = -1.f, ms_panel = -1.f;  ///< measured ms per product (-1: not timed)
+  float ms_small = -1.f, ms_large = -1.f, ms_band = -1.f, ms_panel = -1.f;  ///< measured ms per product (-1: not timed)
   float ms_phased = -1.f;
   std::unique_ptr<small_t> small;
   std::unique_ptr<large_t> large;
-  std::unique_ptr<blocked_t> blocked;
+  std::unique_ptr<band_t> band;
   std::unique_ptr<panel_t> panel;
 
   /// @param allow_copy the plan may keep a re-ordered copy of `csr` (adopted when >= 5 % faster than the best CSR shape;
-  ///        without `measure`: when cols * sizeof(type_t) > 6 MB -- panel-binned for 4-byte values or x >= 32 MB, else
-  ///        column-blocked if the mean row holds >= 8 nonzeros)
+  ///        without `measure`: panel-binned when cols * sizeof(type_t) > 6 MB, row-band from 2 MB for 4-byte values under a mean
+  ///        row of >= 8 nonzeros)
   /// @param measure time the candidates (`repeats` products each) instead of choosing by structure alone
   explicit spmv_plan_t(csr_t<index_t, offset_t, type_t>& csr, bool allow_copy = true, bool measure = true, int repeats = 10,
                        xpu::stream_t stream = 0) {
@@ -60,21 +60,24 @@ struct spmv_plan_t {
         large->classify(stream);
         small.reset();
       }
-      if (allow_copy && work && x_bytes > (std::size_t(6) << 20)) {   // (the rule of loops_spmv_plan_create_* without MEASURE)
-        const bool want_panel = sizeof(type_t) == 4 || x_bytes >= (std::size_t(32) << 20);
+      if (allow_copy && work && x_bytes >= (std::size_t(2) << 20)) {   // (the rule of loops_spmv_plan_create_* without MEASURE)
         // (the copy is OPTIONAL: a build that fails -- no memory for it -- leaves the plan on the CSR, as the measured path does)
         try {
-          if (want_panel && fits_panel(csr)) {
-            panel = std::make_unique<panel_t>(csr, 0, stream);
-            layout = panel_binned_layout;
-          } else if (!want_panel && csr.nnzs / csr.rows >= 8 && fits_blocked(csr)) {
-            blocked = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
-            layout = column_blocked_layout;
+          if (x_bytes > (std::size_t(6) << 20)) {
+            if (fits_panel(csr)) {
+              panel = std::make_unique<panel_t>(csr, 0, stream);
+              layout = panel_binned_layout;
+            }
+          } else if constexpr (sizeof(type_t) == 4) {
+            if (csr.nnzs / csr.rows >= 8 && band_t::fits(csr)) {
+              band = std::make_unique<band_t>(csr, 0, 0, stream);
+              layout = row_band_layout;
+            }
           }
         } catch (const std::exception&) {
           (void)hipGetLastError();  // clear the sticky error of the failed allocation
           panel.reset();
-          blocked.reset();
+          band.reset();
           layout = csr_layout;
         }
         if (layout != csr_layout) {
@@ -130,28 +133,31 @@ struct spmv_plan_t {
     }
     if (keep_small && !phased) large.reset();
     else small.reset();
-    if (allow_copy && x_bytes >= (std::size_t(2) << 20) && fits_blocked(csr)) {
-      auto cb = std::make_unique<blocked_t>(csr, 0, nullptr, stream);
-      ms_blocked = time_ms(repeats, stream, [&] { cb->spmv_async(x, y, stream); });
-      if (ms_blocked < 0.95f * best) {
-        blocked = std::move(cb);
-        layout = column_blocked_layout;
-        phased = false;
-        small.reset();
-        large.reset();
+    if constexpr (sizeof(type_t) == 4) {
+      if (allow_copy && x_bytes >= (std::size_t(1) << 20) && band_t::fits(csr)) {  // second candidate: the row-band copy, its shape tuned
+        auto rb = std::make_unique<band_t>(csr, 0, 0, stream);
+        rb->tune(repeats, stream);
+        ms_band = time_ms(repeats, stream, [&] { rb->spmv_async(x, y, stream); });
+        if (ms_band < 0.95f * best) {
+          band = std::move(rb);
+          layout = row_band_layout;
+          phased = false;
+          small.reset();
+          large.reset();
+        }
       }
     }
     if (allow_copy && x_bytes >= (std::size_t(2) << 20) && fits_panel(csr)) {  // third candidate: x panels in LDS, no gather
       auto pb = std::make_unique<panel_t>(csr, 0, stream);
       ms_panel = time_ms(repeats, stream, [&] { pb->spmv_async(x, y, stream); });
-      const float incumbent = blocked ? ms_blocked : best;
+      const float incumbent = band ? ms_band : best;
       if (ms_panel < 0.95f * incumbent && ms_panel < 0.95f * best) {
         panel = std::move(pb);
         layout = panel_binned_layout;
         phased = false;
         small.reset();
         large.reset();
-        blocked.reset();
+        band.reset();
       }
     }
   }
@@ -159,7 +165,9 @@ struct spmv_plan_t {
   /// y = csr * x on `stream` (asynchronous).  `csr` must be the matrix the plan was built from.
   void spmv_async(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
     if (panel) panel->spmv_async(x, y, stream);
-    else if (blocked) blocked->spmv_async(x, y, stream);
+    else if (band) {
+      if constexpr (sizeof(type_t) == 4) band->spmv_async(x, y, stream);
+    }
     else if (small)
       merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream, true);
     else if (phased) {
@@ -178,10 +186,6 @@ struct spmv_plan_t {
   }
 
  private:
-  static bool fits_blocked(const csr_t<index_t, offset_t, type_t>& csr) {
-    const int k = blocked_t::automatic_blocks(csr.cols, csr.rows, csr.nnzs);
-    return static_cast<unsigned long long>(k) * csr.rows + csr.nnzs < (1ull << 31) - 4096;
-  }
   static bool fits_panel(const csr_t<index_t, offset_t, type_t>& csr) {
     const int w = kernels::panel_columns<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.cols), static_cast<int>(csr.nnzs));
     const long long P = (static_cast<long long>(csr.cols) + w - 1) / w;

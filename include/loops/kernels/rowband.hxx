@@ -82,6 +82,7 @@ struct rowband_view {
   const int* multi;            ///< [3 * num_multi] {band, first partial slot, chunks}
   const unsigned short* hubs;  ///< [B * (max_hubs + 1)] per band: the number of hubs, then their rows inside the band
   type_t* partial;             ///< [num_partials * H]
+  int waves;                   ///< wavefronts per workgroup of kernel A: 8 or 16
 };
 
 namespace rowband {
@@ -92,7 +93,7 @@ namespace rowband {
 /// Loads are branch-free (a step past the chunk's end re-reads the chunk's first step and adds into the dump word).
 /// Hub rows (rowband.hxx, file comment): row codes above H address one of hub_replicas accumulators per hub, folded into the
 /// hub's own word before the band's rows are stored.
-template <int WAVES, int U, bool NT, typename type_t, typename store_t, int DIAG = 0>
+template <int WAVES, int U, bool NT, typename type_t, typename store_t>
 __global__ void __launch_bounds__(WAVES * wave::size)
 rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ val, const unsigned int* __restrict__ rc,
                    const int* __restrict__ stepcol, const unsigned short* __restrict__ hubs, const type_t* __restrict__ x, const int H,
@@ -107,7 +108,6 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
   const int words = lds_words(H);
   for (int j = threadIdx.x; j < words; j += TPB) acc[j] = 0.0;
   __syncthreads();
-  [[maybe_unused]] double diag_sum = 0.0;
   struct batch_t {
     type_t v[U][4];
     unsigned int r[U][4];
@@ -142,8 +142,7 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if constexpr (DIAG & 2) xv[u][e] = type_t(t.r[u][e] & 0xFFFFu);  // DIAGNOSTIC: no gather
-        else xv[u][e] = t.xb[u][t.r[u][e] & 0xFFFFu];
+        xv[u][e] = t.xb[u][t.r[u][e] & 0xFFFFu];
       }
   };
   auto update = [&](const batch_t& t, const type_t (&xv)[U][4]) {
@@ -152,8 +151,7 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned int row = t.live[u] ? t.r[u][e] >> 16 : static_cast<unsigned int>(H);
-        if constexpr (DIAG & 1) diag_sum += static_cast<double>(t.v[u][e] * xv[u][e]) + row;  // DIAGNOSTIC: no LDS update
-        else atomicAdd(&acc[row], static_cast<double>(t.v[u][e] * xv[u][e]));
+        atomicAdd(&acc[row], static_cast<double>(t.v[u][e] * xv[u][e]));
       }
   };
   constexpr int STRIDE = WAVES * U;
@@ -181,7 +179,6 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
       k += STRIDE;
     }
   }
-  if constexpr (DIAG & 1) acc[H] = diag_sum;
   __syncthreads();
   // hubs: replicas -> the row's own word (one thread per hub, fixed order)
   const unsigned short* hb = hubs + static_cast<long long>(band) * (max_hubs + 1);
@@ -197,7 +194,7 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
   if (slot < 0) {
     const long long row0 = static_cast<long long>(band) * H;
     for (int j = threadIdx.x; j < H && row0 + j < rows; j += TPB) out(static_cast<int>(row0 + j), static_cast<type_t>(acc[j]));
-  } else {
+  } else {  // the chunk's partial vector; rowband_combine adds the band's up
     type_t* to = partial + static_cast<long long>(slot) * H;
     for (int j = threadIdx.x; j < H; j += TPB) to[j] = static_cast<type_t>(acc[j]);
   }
@@ -398,24 +395,12 @@ refresh_values(const int* __restrict__ perm, const type_t* __restrict__ values, 
 
 constexpr int rowband_e_badarg = -1, rowband_e_range = -2;
 
-/// Tuning knobs read from the environment (experiments; 0 = the built-in choice).
-inline int rowband_env(const char* name) {
-  const char* e = std::getenv(name);
-  return e ? std::atoi(e) : 0;
-}
-
 /// Rows per band: 16384 (the tallest band the LDS holds: the taller the band, the denser its column-sorted nonzeros and the fewer
 /// lines a wavefront's 64 gathers touch), halved while the matrix would be left with fewer than 64 bands.
 inline int rowband_rows(int rows, int /*cols*/, int /*nnz*/) {
   int h = rowband::max_band_rows;
   while (h > 256 && rows / h < 64) h /= 2;
   return h;
-}
-
-/// Workgroups of kernel A that are resident at once on `cus` compute units: one per CU above 64 KB of LDS, else two (1024 threads each).
-inline int rowband_resident_chunks(int H, int cus) {
-  const std::size_t lds = static_cast<std::size_t>(rowband::lds_words(H)) * sizeof(double);
-  return (cus > 0 ? cus : 256) * (2 * lds <= 160 * 1024 ? 2 : 1);
 }
 
 /// Kernel A's work list from the bands' step ranges (B + 1 entries).  The bands are cut into about `target_chunks` chunks in
@@ -474,7 +459,7 @@ inline void rowband_chunk_list(const std::vector<int>& band_step, int B, int tar
 /// The device arrays of one row-band matrix, OWNED.  Type-erased over the value type (`vbytes`).
 struct rowband_storage {
   int rows = 0, cols = 0, nnz = 0, vbytes = 0;
-  int H = 0, B = 0, CB = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0;
+  int H = 0, B = 0, CB = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0, waves = 8;
   void *val = nullptr, *partial = nullptr;
   unsigned int* rc = nullptr;
   unsigned short* hubs = nullptr;
@@ -492,23 +477,23 @@ struct rowband_storage {
   template <typename type_t>
   rowband_view<type_t> view() const {
     return rowband_view<type_t>{rows, cols, nnz, H, B, steps, num_chunks, num_partials, num_multi, static_cast<const type_t*>(val), rc,
-                                stepcol, chunks, multi, hubs, static_cast<type_t*>(partial)};
+                                stepcol, chunks, multi, hubs, static_cast<type_t*>(partial), waves};
   }
 };
 
-/// Default number of chunks: the bands themselves when there are more of them than workgroups resident at once, rounded up to
-/// whole rounds of resident workgroups (the surplus cuts go to the heaviest bands) -- one round of equal chunks for C2-like
-/// inputs (64 bands of 16384 rows -> 256 chunks), no cuts but for outliers where bands are plenty.
-inline int rowband_target_chunks(int H, int B, int cus) {
-  const int resident = rowband_resident_chunks(H, cus);
-  const long long rounds = (static_cast<long long>(B > 0 ? B : 1) + resident - 1) / resident;
-  return static_cast<int>(rounds * resident);
+/// Default number of chunks: one per band where there are at least as many bands as compute units (the dispatcher balances
+/// them; only a band with twice the mean's items is cut), else one round of equal chunks (C2: 64 bands of 16384 rows -> 256
+/// chunks).  Measured (profiles/r05_rowband_sweep.txt): band C3 stand-in, 453 bands, uncut 268 us, 512 / 1024 chunks 275 / 305;
+/// C2 256 chunks 37 us, 512 chunks 44-54 (two workgroups per CU, twice the partial vectors).
+inline int rowband_target_chunks(int B, int cus) {
+  const int c = cus > 0 ? cus : 256;
+  return B >= c ? B : c;
 }
 
 /// (Re)builds the work lists of a built layout for about `target_chunks` chunks (0 = automatic); `band_step_host` = the B + 1 step
 /// starts.  Used by the builder and by tuning code that sweeps the cut without re-sorting.
 inline int rowband_set_chunks(rowband_storage& out, const std::vector<int>& band_step_host, int target_chunks) {
-  out.target_chunks = target_chunks > 0 ? target_chunks : rowband_target_chunks(out.H, out.B, out.cus);
+  out.target_chunks = target_chunks > 0 ? target_chunks : rowband_target_chunks(out.B, out.cus);
   std::vector<int> chunks, multi;
   rowband_chunk_list(band_step_host, out.B, out.target_chunks, chunks, multi, out.num_partials);
   out.num_chunks = static_cast<int>(chunks.size() / 4);
@@ -642,18 +627,18 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   return 0;
 }
 
-/// Kernel-A shape: LOOPS_ROWBAND_CFG = WAVES * 10 + U (experiments), 0 = the built-in choice.
-inline int rowband_config() {
-  return rowband_env("LOOPS_ROWBAND_CFG");  // (read at every launch: a process can sweep it)
-}
-
 /// y = A x over a row-band matrix: kernel A, then kernel B if some band was cut.  stages: bit 0 = accumulate, bit 1 = combine.
+/// Kernel A runs 8 or 16 wavefronts per workgroup (`m.waves`), one step per wavefront and batch.  Measured on MI355X
+/// (tests/perf/bench_rowband.py, profiles/r05_rowband_*): C2 36.9 / 40.1 us with 8 / 16 wavefronts (more wavefronts lengthen
+/// the queues of the CU's memory path without adding requests in flight: it sits at ~82 either way), U = 2 / 4 steps per batch
+/// 39.8 / 45.7; a matrix whose gathers hit the L1 (band C3 stand-in) 320 / 268 us.
 template <typename type_t, typename store_t>
 int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const type_t* x, const store_t out, int stages = 3) {
   if (m.rows == 0) return 0;
   // Non-temporal streams unless a product's working set (8 B per item with 4-byte values, x, y, partials) fits the Infinity Cache
+  // (C2, 150 MB: plain 35 us, non-temporal 49)
   const double items = static_cast<double>(m.steps) * rowband::step_items;
-  const bool nt = rowband_env("LOOPS_ROWBAND_NT") != 0 || items * (sizeof(type_t) + 4.0) + (static_cast<double>(m.rows) + m.cols + 2.0 * m.num_partials * m.H) * sizeof(type_t) > 240e6;
+  const bool nt = items * (sizeof(type_t) + 4.0) + (static_cast<double>(m.rows) + m.cols + 2.0 * m.num_partials * m.H) * sizeof(type_t) > 240e6;
   if ((stages & 1) && m.num_chunks > 0) {
     const std::size_t lds = static_cast<std::size_t>(rowband::lds_words(m.H)) * sizeof(double);
     auto go = [&](auto kernel, int waves) {
@@ -661,28 +646,13 @@ int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const t
       hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(waves * wave::size), lds, stream, m.chunks, m.val, m.rc, m.stepcol, m.hubs, x, m.H,
                          m.rows, m.partial, out);
     };
-    const int cfg = rowband_config();
-#define LOOPS_ROWBAND_GO(W, U)                                                         \
-  {                                                                                    \
-    const int diag = rowband_env("LOOPS_ROWBAND_DIAG");                                \
-    if (diag == 1) go(rowband::rowband_accumulate<W, U, false, type_t, store_t, 1>, W);      \
-    else if (diag == 2) go(rowband::rowband_accumulate<W, U, false, type_t, store_t, 2>, W); \
-    else if (diag == 3) go(rowband::rowband_accumulate<W, U, false, type_t, store_t, 3>, W); \
-    else if (nt) go(rowband::rowband_accumulate<W, U, true, type_t, store_t>, W);      \
-    else go(rowband::rowband_accumulate<W, U, false, type_t, store_t>, W);             \
-  }
-    switch (cfg) {
-      case 41: LOOPS_ROWBAND_GO(4, 1) break;
-      case 42: LOOPS_ROWBAND_GO(4, 2) break;
-      case 44: LOOPS_ROWBAND_GO(4, 4) break;
-      case 81: LOOPS_ROWBAND_GO(8, 1) break;
-      case 82: LOOPS_ROWBAND_GO(8, 2) break;
-      case 84: LOOPS_ROWBAND_GO(8, 4) break;
-      case 161: LOOPS_ROWBAND_GO(16, 1) break;
-      case 164: LOOPS_ROWBAND_GO(16, 4) break;
-      default: LOOPS_ROWBAND_GO(16, 2) break;
+    if (m.waves == 16) {
+      if (nt) go(rowband::rowband_accumulate<16, 1, true, type_t, store_t>, 16);
+      else go(rowband::rowband_accumulate<16, 1, false, type_t, store_t>, 16);
+    } else {
+      if (nt) go(rowband::rowband_accumulate<8, 1, true, type_t, store_t>, 8);
+      else go(rowband::rowband_accumulate<8, 1, false, type_t, store_t>, 8);
     }
-#undef LOOPS_ROWBAND_GO
   }
   if ((stages & 2) && m.num_multi > 0) {
     hipLaunchKernelGGL((rowband::rowband_combine<type_t, store_t>), dim3(math::ceil_div(m.H, 1024), m.num_multi), dim3(256), 0, stream,
@@ -694,6 +664,48 @@ int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const t
 template <typename type_t>
 int launch_rowband(hipStream_t stream, const rowband_view<type_t>& m, const type_t* x, type_t* y, int stages = 3) {
   return launch_rowband_to(stream, m, x, plain_store<type_t>{y}, stages);
+}
+
+/// Measures the product with 8 and with 16 wavefronts per workgroup of kernel A on this device (x = zeros: the time does not
+/// depend on the values) and keeps the faster shape in `m.waves`.  ms2 (may be null) receives the two times per product.
+/// Synchronous.
+template <typename type_t>
+int rowband_tune(hipStream_t stream, rowband_storage& m, int repeats, float* ms2) {
+  if (ms2) ms2[0] = ms2[1] = -1.f;
+  if (m.rows == 0 || m.steps == 0) return 0;
+  if (repeats < 1) repeats = 10;
+  type_t *x = nullptr, *y = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&x), sizeof(type_t) * static_cast<std::size_t>(m.cols > 0 ? m.cols : 1));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&y), sizeof(type_t) * static_cast<std::size_t>(m.rows));
+  if (e == hipSuccess) e = hipMemsetAsync(x, 0, sizeof(type_t) * static_cast<std::size_t>(m.cols > 0 ? m.cols : 1), stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  int err = static_cast<int>(e);
+  const int shapes[2] = {8, 16};
+  float best = 0.f;
+  int best_waves = m.waves;
+  for (int i = 0; !err && i < 2; ++i) {
+    m.waves = shapes[i];
+    const rowband_view<type_t> v = m.view<type_t>();
+    for (int it = 0; !err && it < 2; ++it) err = launch_rowband<type_t>(stream, v, x, y);
+    if (!err) err = static_cast<int>(hipEventRecord(e0, stream));
+    for (int it = 0; !err && it < repeats; ++it) err = launch_rowband<type_t>(stream, v, x, y);
+    if (!err) err = static_cast<int>(hipEventRecord(e1, stream));
+    if (!err) err = static_cast<int>(hipEventSynchronize(e1));
+    float ms = 0.f;
+    if (!err) err = static_cast<int>(hipEventElapsedTime(&ms, e0, e1));
+    if (err) break;
+    ms /= static_cast<float>(repeats);
+    if (ms2) ms2[i] = ms;
+    if (i == 0 || ms < 0.98f * best) { best = ms; best_waves = shapes[i]; }  // (16 wavefronts must be measurably faster)
+  }
+  m.waves = best_waves;
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(x);
+  (void)hipFree(y);
+  return err;
 }
 
 template <typename type_t>

@@ -353,10 +353,13 @@ int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x,
  * the first kernel is cut into (LOOPS_E_BADARG otherwise).  LOOPS_E_RANGE when bands x column blocks exceed 2^26 or the padded
  * layout may reach 2^31 items.  Creation is synchronous (device radix sort, O(nnz)).
  * info8 = {H, bands, column blocks, steps of 256 items incl. padding, chunks, partial vectors, bands cut into several chunks,
- * target chunks}.  loops_rowband_plan_arrays: HOST copies (any pointer may be NULL): values / rc / perm [steps * 256] (perm = CSR
+ * wavefronts per workgroup of the first kernel}.  loops_rowband_plan_arrays: HOST copies (any pointer may be NULL): values / rc / perm [steps * 256] (perm = CSR
  * position of the item, -1 = padding), stepcol [steps], chunks [4 * chunks] = {band, first step, end step, partial slot or -1},
  * multi [3 * cut bands] = {band, first partial slot, chunks}, hubs [bands * 33] = per band the number of hubs, then their rows
- * inside the band.  loops_rowband_plan_set_chunks re-cuts the bands of a built plan (tuning; synchronous). */
+ * inside the band.  loops_rowband_plan_set_chunks re-cuts the bands of a built plan (tuning; synchronous).
+ * loops_rowband_plan_tune times the product with 8 and 16 wavefronts per workgroup of the first kernel (`repeats` launches each,
+ * <= 0: 10; ms2, may be NULL: the two times in ms) and keeps the faster; loops_rowband_plan_set_waves sets it (8 or 16;
+ * a new plan runs 8). */
 typedef struct loops_rowband_plan loops_rowband_plan_t;
 int loops_rowband_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
                                   int band_rows, int target_chunks, void* stream, loops_rowband_plan_t** out);
@@ -365,6 +368,8 @@ int loops_rowband_plan_info(const loops_rowband_plan_t* plan, int* info8);
 int loops_rowband_plan_arrays(const loops_rowband_plan_t* plan, void* values, unsigned int* rc, int* perm, int* stepcol, int* chunks,
                               int* multi, unsigned short* hubs);
 int loops_rowband_plan_set_chunks(loops_rowband_plan_t* plan, int target_chunks);
+int loops_rowband_plan_tune(loops_rowband_plan_t* plan, int repeats, float* ms2, void* stream);
+int loops_rowband_plan_set_waves(loops_rowband_plan_t* plan, int waves);
 int loops_rowband_plan_refresh_values_f32(loops_rowband_plan_t* plan, const float* values, void* stream);
 int loops_spmv_rowband_f32(const loops_rowband_plan_t* plan, const float* x, float* y, void* stream);
 /* one kernel at a time for timing: stage 0 = accumulate, 1 = combine */
@@ -377,26 +382,27 @@ int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float*
  * runs the CSR as given; here the plan decides per matrix, once:
  *   flags & LOOPS_PLAN_MEASURE     time the candidates on the device at creation (256 x 8 and 512 x 8 merge tiles over the
  *                                  unmodified CSR; `repeats` launches each, <= 0: 10) instead of choosing by structure alone;
- *   flags & LOOPS_PLAN_ALLOW_COPY  the plan may keep a column-blocked COPY of the matrix (see "column-blocked CSR" above:
- *                                  + nnz * (8 + sizeof(T)) + K * rows * (4 + sizeof(T)) bytes) when x exceeds the per-XCD L2;
- *                                  with MEASURE it is adopted only if >= 5 % faster than the best CSR shape; without MEASURE
- *                                  a copy is taken when cols * sizeof(T) > 6 MB: the panel-binned one (4-byte values, or x >=
- *                                  32 MB), else the column-blocked one if the mean row holds >= 8 nonzeros.  (Structure does
- *                                  not show column locality -- a narrow band is faster from the CSR as given: MEASURE finds out.)
+ *   flags & LOOPS_PLAN_ALLOW_COPY  the plan may keep a re-ordered COPY of the matrix (about another nnz * (4 + sizeof(T)) bytes + tables):
+ *                                  the row-band copy (4-byte values; "row-band layout" above) or the panel-binned copy
+ *                                  ("panel-binned layout" above).  With MEASURE both are built and timed (x of at least 1 MB /
+ *                                  2 MB) and one is adopted only if >= 5 % faster than the best CSR shape (and than the other);
+ *                                  without MEASURE a copy is taken by size alone: panel-binned when cols * sizeof(T) > 6 MB,
+ *                                  row-band (4-byte values, mean row >= 8 nonzeros) from 2 MB.  (Structure does not show
+ *                                  column locality -- a narrow band is faster from the CSR as given, a wide one from the
+ *                                  row-band copy whatever the size of x: MEASURE finds out.)
  *                                  A plan that stays on the CSR takes 512 x 8 tiles with phased x gathers (LOOPS_VARIANT_PHASED) when
  *                                  the columns LOOK scattered over an x of 3 MB or more (loops_columns_look_scattered).
  * Without ALLOW_COPY the product always runs on the caller's arrays.  Creation is synchronous.  One product in flight per plan.
  * loops_spmv_planned_*: y = A x; offsets / indices / values are the arrays the plan was created from (ignored -- may be NULL
- * -- when the plan holds the copy; after changing the VALUES of the matrix call loops_spmv_plan_refresh_values_* first).
- * With ALLOW_COPY and MEASURE the panel-binned copy ("panel-binned layout" below) is the third candidate, adopted under the
- * same 5 % rule.
- * loops_spmv_plan_info: layout (LOOPS_LAYOUT_*), tile config, number of column blocks / panels (0 for CSR), and ms4[4] = measured
- * ms per product of {CSR 256 x 8, CSR 512 x 8, column-blocked, panel-binned}, -1 where not timed.  Any output pointer may be NULL. */
+ * -- when the plan holds a copy; after changing the VALUES of the matrix call loops_spmv_plan_refresh_values_* first).
+ * loops_spmv_plan_info: layout (LOOPS_LAYOUT_*), tile config, number of bands / panels (0 for CSR), and ms4[4] = measured
+ * ms per product of {CSR 256 x 8, CSR 512 x 8, row-band, panel-binned}, -1 where not timed.  Any output pointer may be NULL. */
 #define LOOPS_PLAN_MEASURE 1
 #define LOOPS_PLAN_ALLOW_COPY 2
 #define LOOPS_LAYOUT_CSR 0
-#define LOOPS_LAYOUT_COLUMN_BLOCKED 1
+#define LOOPS_LAYOUT_COLUMN_BLOCKED 1 /* retired with the column-blocked layout (round 5): never returned */
 #define LOOPS_LAYOUT_PANEL_BINNED 2
+#define LOOPS_LAYOUT_ROW_BAND 3
 typedef struct loops_spmv_plan loops_spmv_plan_t;
 int loops_spmv_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
                                int flags, int repeats, void* stream, loops_spmv_plan_t** out);

@@ -56,7 +56,7 @@ SYMBOLS = [
     "loops_autotune_merge_path_variants_f32", "loops_spmv_plan_variant", "loops_columns_look_scattered",
     "loops_spmv_panel_f32", "loops_spmv_panel_f64", "loops_spmv_panel_stage_f32", "loops_spmv_panel_stage_f64", "loops_spmv_panel_fanout_f32", "loops_spmv_panel_fanout_f64",
     "loops_rowband_plan_create_f32", "loops_rowband_plan_destroy", "loops_rowband_plan_info", "loops_rowband_plan_arrays",
-    "loops_rowband_plan_set_chunks", "loops_rowband_plan_refresh_values_f32", "loops_spmv_rowband_f32", "loops_spmv_rowband_stage_f32",
+    "loops_rowband_plan_set_chunks", "loops_rowband_plan_tune", "loops_rowband_plan_set_waves", "loops_rowband_plan_refresh_values_f32", "loops_spmv_rowband_f32", "loops_spmv_rowband_stage_f32",
     "loops_spmv_rowband_fanout_f32",
 ]
 
@@ -227,6 +227,8 @@ def lib() -> C.CDLL:
         L.loops_rowband_plan_info.argtypes = [vp, vp]
         L.loops_rowband_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.loops_rowband_plan_set_chunks.argtypes = [vp, ci]
+        L.loops_rowband_plan_tune.argtypes = [vp, ci, vp, vp]
+        L.loops_rowband_plan_set_waves.argtypes = [vp, ci]
         L.loops_rowband_plan_refresh_values_f32.argtypes = [vp, vp, vp]
         L.loops_spmv_rowband_f32.argtypes = [vp, vp, vp, vp]
         L.loops_spmv_rowband_stage_f32.argtypes = [vp, ci, vp, vp, vp]

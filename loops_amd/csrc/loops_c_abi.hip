@@ -759,17 +759,18 @@ int panel_refresh(loops_panel_plan* p, const T* values, hipStream_t st) {
 
 // ------------------------------------------------------------------ SpMV plan: tile shape AND layout chosen at plan time
 // What a caller that performs many products with one matrix should hold (loops_spmv_plan_*): the merge-path plan of the
-// unmodified CSR in the best tile shape, or -- if the caller allows a copy and it is measurably faster -- the column-blocked
-// copy of the matrix (x larger than an L2: C3-like and C5-like inputs run 2.1-2.4 x faster from it).
+// unmodified CSR in the best tile shape, or -- if the caller allows a copy and it is measurably faster -- a re-ordered copy of
+// the matrix: row-band (y accumulators in LDS, coalescing gathers: x of a few MB, column locality) or panel-binned (x panels
+// in LDS: x far beyond the L2).
 struct loops_spmv_plan {
   int rows, cols, nnz, vbytes, flags;
-  int layout;                   // LOOPS_LAYOUT_CSR / LOOPS_LAYOUT_COLUMN_BLOCKED
+  int layout;                   // LOOPS_LAYOUT_CSR / LOOPS_LAYOUT_ROW_BAND / LOOPS_LAYOUT_PANEL_BINNED
   loops_merge_plan* merge;      // held for LOOPS_LAYOUT_CSR
-  loops_colblock_plan* blocked; // held for LOOPS_LAYOUT_COLUMN_BLOCKED
+  loops_rowband_plan* band;     // held for LOOPS_LAYOUT_ROW_BAND
   loops_panel_plan* panel;      // held for LOOPS_LAYOUT_PANEL_BINNED
   int merge_variant;            // LOOPS_LAYOUT_CSR: 0 = the default kernel, LOOPS_VARIANT_PHASED = phased x gathers
   float ms_phased;              // measured ms per product of the best phased candidate; -1 = not timed
-  float ms[4];                  // measured ms per product: CSR 256 x 8, CSR 512 x 8, column-blocked, panel-binned; -1 = not timed
+  float ms[4];                  // measured ms per product: CSR 256 x 8, CSR 512 x 8, row-band, panel-binned; -1 = not timed
 };
 
 namespace {
@@ -777,7 +778,7 @@ namespace {
 void spmv_plan_free(loops_spmv_plan* p) {
   if (!p) return;
   plan_release(p->merge);
-  colblock_free(p->blocked);
+  rowband_free(p->band);
   panel_free(p->panel);
   delete p;
 }
@@ -820,19 +821,19 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
   const long long x_bytes = static_cast<long long>(cols) * static_cast<long long>(sizeof(T));
   int err = 0;
   if (!measure) {
-    // structural choice only: tile by the self-completing test; a copy when x exceeds 1.5 per-XCD L2s -- panel-binned (the
-    // fastest layout on every such input measured with 4-byte values, and with 8-byte values from x = 32 MB), else
-    // column-blocked if rows are long enough to be cut into blocks.  Structure cannot see column LOCALITY (a narrow band
-    // runs faster from the CSR as it is): callers who cannot rule it out should pass LOOPS_PLAN_MEASURE.
+    // structural choice only: tile by the self-completing test; a copy when the matrix is a candidate for one -- panel-binned
+    // when x exceeds 1.5 per-XCD L2s (the fastest layout on every such input with scattered columns), row-band (4-byte values)
+    // for an x between 2 and 6 MB under rows of >= 8 nonzeros (C2: 37 against 83 us).  Structure cannot see column LOCALITY
+    // (a narrow band runs faster from the CSR as it is, a wide one from the row-band copy whatever the size of x): callers who
+    // cannot rule it out should pass LOOPS_PLAN_MEASURE.
     err = plan_create_auto(rows, nnz, off, st, &p->merge);
-    if (!err && may_copy && x_bytes > (6ll << 20)) {
-      const bool panel = sizeof(T) == 4 || x_bytes >= (32ll << 20);
-      if (panel) {
+    if (!err && may_copy && x_bytes >= (2ll << 20)) {
+      if (x_bytes > (6ll << 20)) {
         err = panel_create<T>(rows, cols, nnz, off, idx, val, st, &p->panel);
         if (!err) p->layout = LOOPS_LAYOUT_PANEL_BINNED;
-      } else if (nnz / (rows > 0 ? rows : 1) >= 8) {
-        err = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &p->blocked);
-        if (!err) p->layout = LOOPS_LAYOUT_COLUMN_BLOCKED;
+      } else if (sizeof(T) == 4 && nnz / (rows > 0 ? rows : 1) >= 8) {
+        if constexpr (sizeof(T) == 4) err = rowband_create_plan<T>(rows, cols, nnz, off, idx, val, 0, 0, st, &p->band);
+        if (!err) p->layout = LOOPS_LAYOUT_ROW_BAND;
       }
       if (!err && p->layout != LOOPS_LAYOUT_CSR) { plan_release(p->merge); p->merge = nullptr; }
       else if (err == LOOPS_E_RANGE || err == LOOPS_E_CONFIG) err = 0;  // the copy does not fit 32-bit positions: stay on the CSR
@@ -919,41 +920,46 @@ int spmv_plan_create(int rows, int cols, int nnz, const int* off, const int* idx
       }
     }
   }
-  if (!err && may_copy && x_bytes >= (2ll << 20)) {
-    loops_colblock_plan* cb = nullptr;
-    int cerr = colblock_create<T>(rows, cols, nnz, off, idx, val, 0, nullptr, st, &cb);
-    if (!cerr) {
-      float ms = 0.f;
-      cerr = time_ms(st, repeats, &ms, [&]() { return colblock_spmv<T>(cb, 7, x, y, st); });
-      if (!cerr) p->ms[2] = ms;
-      if (!cerr && ms < 0.95f * best_ms) {  // the copy doubles the matrix's footprint: it has to pay for it
-        p->blocked = cb;
-        p->layout = LOOPS_LAYOUT_COLUMN_BLOCKED;
-        plan_release(p->merge);
-        p->merge = nullptr;
-        cb = nullptr;
+  if constexpr (sizeof(T) == 4) {
+    if (!err && may_copy && x_bytes >= (1ll << 20)) {
+      // second candidate: the row-band copy (4-byte values; y accumulators in LDS, column-sorted gathers), its kernel shape
+      // tuned by measurement too; adopted when >= 5 % faster than the best CSR shape (the copy doubles the matrix's footprint)
+      loops_rowband_plan* rb = nullptr;
+      int rerr = rowband_create_plan<T>(rows, cols, nnz, off, idx, val, 0, 0, st, &rb);
+      if (!rerr) {
+        float ms2[2] = {-1.f, -1.f};
+        rerr = kernels::rowband_tune<T>(st, *rb, repeats, ms2);
+        const float ms = rb->waves == 16 ? ms2[1] : ms2[0];
+        if (!rerr) p->ms[2] = ms;
+        if (!rerr && ms > 0.f && ms < 0.95f * best_ms) {
+          p->band = rb;
+          p->layout = LOOPS_LAYOUT_ROW_BAND;
+          plan_release(p->merge);
+          p->merge = nullptr;
+          rb = nullptr;
+        }
       }
+      rowband_free(rb);
+      if (rerr && rerr != LOOPS_E_RANGE && rerr != LOOPS_E_CONFIG && rerr != static_cast<int>(hipErrorOutOfMemory)) err = rerr;
+      if (rerr == static_cast<int>(hipErrorOutOfMemory)) (void)hipGetLastError();  // no room for the copy: stay on the CSR
     }
-    colblock_free(cb);
-    if (cerr && cerr != LOOPS_E_RANGE && cerr != LOOPS_E_CONFIG && cerr != static_cast<int>(hipErrorOutOfMemory)) err = cerr;
-    if (cerr == static_cast<int>(hipErrorOutOfMemory)) (void)hipGetLastError();  // no room for the copy: stay on the CSR
   }
   if (!err && may_copy && x_bytes >= (2ll << 20)) {
-    // third candidate: the panel-binned copy (x panels in LDS, no gather leaves the CU): adopted like the blocked copy
+    // third candidate: the panel-binned copy (x panels in LDS, no gather leaves the CU): adopted like the row-band copy
     loops_panel_plan* pp = nullptr;
     int perr = panel_create<T>(rows, cols, nnz, off, idx, val, st, &pp);
     if (!perr) {
       float ms = 0.f;
       perr = time_ms(st, repeats, &ms, [&]() { return panel_spmv<T>(pp, 3, x, y, st); });
       if (!perr) p->ms[3] = ms;
-      const float incumbent = p->blocked ? p->ms[2] : best_ms;
+      const float incumbent = p->band ? p->ms[2] : best_ms;
       if (!perr && ms < 0.95f * incumbent && ms < 0.95f * best_ms) {
         p->panel = pp;
         p->layout = LOOPS_LAYOUT_PANEL_BINNED;
         plan_release(p->merge);
         p->merge = nullptr;
-        colblock_free(p->blocked);
-        p->blocked = nullptr;
+        rowband_free(p->band);
+        p->band = nullptr;
         pp = nullptr;
       }
     }
@@ -974,7 +980,10 @@ int spmv_planned(const loops_spmv_plan* p, const int* off, const int* idx, const
   if (!p || p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
   if (p->rows == 0) return 0;
   if (!y || (p->nnz > 0 && !x)) return LOOPS_E_BADARG;
-  if (p->layout == LOOPS_LAYOUT_COLUMN_BLOCKED) return colblock_spmv<T>(p->blocked, 7, x, y, st);
+  if (p->layout == LOOPS_LAYOUT_ROW_BAND) {
+    if constexpr (sizeof(T) == 4) return rowband_spmv<T>(p->band, 3, x, y, st);
+    else return LOOPS_E_CONFIG;
+  }
   if (p->layout == LOOPS_LAYOUT_PANEL_BINNED) return panel_spmv<T>(p->panel, 3, x, y, st);
   int err = check_csr(p->rows, p->cols, p->nnz, off, idx, val, x, y);
   if (err) return err;
@@ -1069,7 +1078,9 @@ int csc_plan_refresh(loops_csc_plan* p, const T* values, hipStream_t st) {
   hipLaunchKernelGGL((kernels::gather_values<T>), dim3(math::ceil_div(p->nnz, 256)), dim3(256), 0, st, p->nnz, p->perm, values, static_cast<T*>(p->val));
   int err = static_cast<int>(hipGetLastError());
   if (!err && p->inner->panel) err = panel_refresh<T>(p->inner->panel, static_cast<const T*>(p->val), st);
-  else if (!err && p->inner->blocked) err = colblock_refresh<T>(p->inner->blocked, static_cast<const T*>(p->val), st);
+  else if (!err && p->inner->band) {
+    if constexpr (sizeof(T) == 4) err = rowband_refresh<T>(p->inner->band, static_cast<const T*>(p->val), st);
+  }
   return err;
 }
 
@@ -1492,7 +1503,7 @@ int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_c
   if (!plan) return LOOPS_E_BADARG;
   if (layout) *layout = plan->layout;
   if (tile_config) *tile_config = plan->merge ? plan->merge->cfg : COLBLOCK_TILE;
-  if (num_blocks) *num_blocks = plan->blocked ? plan->blocked->K : plan->panel ? plan->panel->P : 0;
+  if (num_blocks) *num_blocks = plan->band ? plan->band->B : plan->panel ? plan->panel->P : 0;
   if (ms4) for (int i = 0; i < 4; ++i) ms4[i] = plan->ms[i];
   return 0;
 }
@@ -1517,12 +1528,12 @@ int loops_spmv_plan_variant(const loops_spmv_plan_t* plan, int* variant, float* 
 int loops_spmv_plan_refresh_values_f32(loops_spmv_plan_t* plan, const float* values, void* stream) {
   if (!plan || plan->vbytes != 4) return LOOPS_E_BADARG;
   if (plan->panel) return panel_refresh<float>(plan->panel, values, as_stream(stream));
-  return plan->blocked ? colblock_refresh<float>(plan->blocked, values, as_stream(stream)) : 0;
+  return plan->band ? rowband_refresh<float>(plan->band, values, as_stream(stream)) : 0;
 }
 int loops_spmv_plan_refresh_values_f64(loops_spmv_plan_t* plan, const double* values, void* stream) {
   if (!plan || plan->vbytes != 8) return LOOPS_E_BADARG;
   if (plan->panel) return panel_refresh<double>(plan->panel, values, as_stream(stream));
-  return plan->blocked ? colblock_refresh<double>(plan->blocked, values, as_stream(stream)) : 0;
+  return 0;
 }
 int loops_spmv_planned_f32(const loops_spmv_plan_t* plan, const int* offsets, const int* indices, const float* values,
                            const float* x, float* y, void* stream) {

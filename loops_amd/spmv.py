@@ -418,7 +418,7 @@ class RowBandPlan:
         info = (C.c_int * 8)()
         L.check(L.lib().loops_rowband_plan_info(self._h, info), "loops_rowband_plan_info")
         (self.H, self.num_bands, self.num_colblocks, self.steps, self.num_chunks, self.num_partials, self.num_multi,
-         self.target_chunks) = list(info)
+         self.waves) = list(info)
         self.padded = self.steps * self.STEP
 
     @property
@@ -428,6 +428,17 @@ class RowBandPlan:
     def set_chunks(self, target_chunks: int = 0):
         """Re-cut the bands into about ``target_chunks`` chunks (0 = automatic) without rebuilding the layout."""
         L.check(L.lib().loops_rowband_plan_set_chunks(self._h, int(target_chunks)), "loops_rowband_plan_set_chunks")
+        self._read_info()
+
+    def tune(self, repeats: int = 10):
+        """Time the product with 8 and 16 wavefronts per workgroup and keep the faster (loops_rowband_plan_tune) -> (ms8, ms16)."""
+        ms = (C.c_float * 2)()
+        L.check(L.lib().loops_rowband_plan_tune(self._h, int(repeats), ms, _stream()), "loops_rowband_plan_tune")
+        self._read_info()
+        return float(ms[0]), float(ms[1])
+
+    def set_waves(self, waves: int):
+        L.check(L.lib().loops_rowband_plan_set_waves(self._h, int(waves)), "loops_rowband_plan_set_waves")
         self._read_info()
 
     def arrays(self):
@@ -484,7 +495,7 @@ class SpmvPlan:
     device; ``allow_copy``: the plan may hold a column-blocked copy of the matrix when that is faster (x larger than the
     per-XCD L2).  ``spmv(x, y)`` runs whatever was chosen; ``info`` says what that is."""
 
-    LAYOUTS = {0: "csr", 1: "column_blocked", 2: "panel_binned"}
+    LAYOUTS = {0: "csr", 2: "panel_binned", 3: "row_band"}
 
     def __init__(self, csr: CSR, allow_copy: bool = True, measure: bool = True, repeats: int = 10):
         self.csr = csr
@@ -499,7 +510,7 @@ class SpmvPlan:
         L.check(L.lib().loops_spmv_plan_info(self._h, C.byref(layout), C.byref(tile), C.byref(blocks), ms), "loops_spmv_plan_info")
         names = {cfg: name for name, (cfg, _, _) in L.TILES.items()}
         self.layout, self.tile, self.num_blocks = self.LAYOUTS[layout.value], names[tile.value], blocks.value
-        self.measured_ms = {k: (round(float(v), 5) if v >= 0 else None) for k, v in zip(("csr_256x8", "csr_512x8", "column_blocked", "panel_binned"), ms)}
+        self.measured_ms = {k: (round(float(v), 5) if v >= 0 else None) for k, v in zip(("csr_256x8", "csr_512x8", "row_band", "panel_binned"), ms)}
         variant, ms_phased = C.c_int(), C.c_float()
         L.check(L.lib().loops_spmv_plan_variant(self._h, C.byref(variant), C.byref(ms_phased)), "loops_spmv_plan_variant")
         self.variant = variant.value  # CSR layout: 0 or L.VARIANT_PHASED (phased x gathers)
