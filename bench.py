@@ -19,10 +19,11 @@ over RCCL every step; `value` = 2 * 2^29 flop / step time.  Rank 0 additionally 
 matrix on its one GPU outside the timed region (config.one_gpu_same_matrix), so the ">= 6x at 8 GPUs"
 target of BASELINE.md is a ratio inside one record (config.speedup_vs_one_gpu_same_matrix), and the
 gathered y is compared bit for bit with the one-GPU y.  --scaling weak keeps the round-1 mode
-(N x C2: N * 2^20 rows / N * 2^24 nnz) for context.  At N > 1 a rank holds its shard
-COLUMN-BLOCKED by owner (--layout, include/loops/kernels/column_blocked.hxx): x is larger than the
-4 MB per-XCD L2 there; the blocked layout keeps each XCD inside one x block (same fused kernel + a
-K-way row reduce).  The N = 1 headline runs on the unmodified CSR.
+(N x C2: N * 2^20 rows / N * 2^24 nnz) for context.  At N > 1 a rank holds its shard in a
+re-ordered copy (--layout): x is larger than the 4 MB per-XCD L2 there; panel-binned
+(include/loops/kernels/panel_binned.hxx: x panels in LDS) or row-band (include/loops/kernels/rowband.hxx:
+y accumulators in LDS, column-sorted gathers), whichever a start-up probe finds faster on the worst
+rank.  The N = 1 headline runs on the unmodified CSR.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline / cpu_baseline fields.
 """
@@ -75,7 +76,7 @@ def pmc_summary(args):
     at the kernel sources as they are now (`_kernel_sources_sha256`, written by scripts/pmc_summarize.py); otherwise
     (None, None, why)."""
     if args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 or args.variant not in (0, VARIANT_PHASED) \
-            or args.layout in ("blocked", "panel"):
+            or args.layout in ("rowband", "panel") or args.scaling == "strong":
         return None, None, "configuration differs from the profiled one (C2, N = 1, unmodified CSR)"
     import glob
     tag = args.tile + ("_phased" if args.variant == VARIANT_PHASED else "")
@@ -203,7 +204,7 @@ def timed_ms(torch, fn, iters, warm=3):
 
 def one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_gathered, iters=20):
     """BASELINE C5's denominator: the SAME matrix on ONE GPU (rank 0's, outside the timed region) -- the planned
-    merge_path_flat SpMV on the unmodified CSR and on the column-blocked layout the ranks use (automatic block count),
+    merge_path_flat SpMV on the unmodified CSR and the product of the held SpMV plan (layout by measurement),
     each y compared bit for bit with the vector the N ranks gathered (SURVEY 8e parity)."""
     t0 = time.time()
     csr = full_matrix_on_device(G, S, torch, degrees, cols)
@@ -215,14 +216,6 @@ def one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_gathered, iters=20):
     out = {"workload": f"{csr.rows} rows / {csr.nnzs} nnz on rank 0's GPU alone (x {cols * 4 >> 20} MB)",
            "csr_ms_per_spmv": round(ms_csr, 5), "csr_equals_gathered_y_bit_for_bit": eq_csr, "generate_upload_seconds": round(gen_s, 1)}
     plan.close()
-    try:
-        cb = S.ColumnBlockedPlan(csr)
-        ms_b = timed_ms(torch, lambda: cb.spmv(x, y), iters)
-        out.update({"blocked_ms_per_spmv": round(ms_b, 5), "blocked_blocks": cb.num_blocks,
-                    "blocked_equals_gathered_y_bit_for_bit": bool(torch.equal(y, y_gathered))})
-        cb.close()
-    except Exception as e:  # noqa: BLE001 -- the plain-CSR figure stands on its own
-        out["blocked_error"] = f"{type(e).__name__}: {e}"
     try:  # what a caller gets by default from a held plan: loops_spmv_plan_* picks tile shape and layout by measurement
         sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
         ms_p = timed_ms(torch, lambda: sp.spmv(x, y), iters)
@@ -301,15 +294,6 @@ def context_c3_standins(G, S, O, torch, iters=10):
                                  "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "choice": sp.info,
                                  "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
         sp.close()
-        if window is None:  # x (30 MB) is far larger than an L2: the same three schedules over the column-blocked copy
-            cb = S.ColumnBlockedPlan(csr)
-            blocked = {"blocks": cb.num_blocks, "note": "plan-time re-ordered copy (column_blocked.hxx); same fused kernels + K-way row reduce"}
-            for sched in ("group_mapped", "work_oriented"):  # (merge_path_flat over the stacked CSR shares its kernel symbol with the C2 context line)
-                ms = timed_ms(torch, lambda: cb.spmv_schedule(sched, x, y), iters)
-                blocked[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                                  "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
-            res["column_blocked"] = blocked
-            cb.close()
         out[tag] = res
         del csr, off, idx, val, y
     return out
@@ -356,8 +340,13 @@ def main():
     ap.add_argument("--log2-rows", type=int, default=20, help="N = 1 and --scaling weak: rows per GPU = 2^this (C2: 20)")
     ap.add_argument("--log2-nnz", type=int, default=24, help="N = 1 and --scaling weak: nnz per GPU = 2^this (C2: 24)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
-                    help="N > 1: strong = BASELINE C5, ONE matrix of 2^--c5-log2-rows rows / 2^--c5-log2-nnz nnz cut into N row "
-                         "ranges (default); weak = N x C2 (round-1 mode, context only)")
+                    help="strong = ONE matrix (--workload) cut into N row ranges -- the default at N > 1, and at N = 1 the like-for-like "
+                         "first point of the 1 -> 8 GPU curve (`--gpus 1 --scaling strong` runs C5 on one GPU with the timed step of "
+                         "N > 1 minus the exchange); weak = N x C2 (round-1 mode, context only); auto = C2 at N = 1, strong at N > 1")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c5"],
+                    help="the matrix of a strong-scaling run: c5 = 2^--c5-log2-rows rows / 2^--c5-log2-nnz nnz (BASELINE configs[4]; "
+                         "auto), c2 = 2^--log2-rows rows / 2^--log2-nnz nnz (BASELINE configs[1] 'reported at 1, 2, 4 and 8 GPUs': "
+                         "expect the exchange of y to bound it)")
     ap.add_argument("--c5-log2-rows", type=int, default=24, help="strong scaling: TOTAL rows = 2^this (C5: 24)")
     ap.add_argument("--c5-log2-nnz", type=int, default=29, help="strong scaling: TOTAL nnz = 2^this (C5: 29)")
     ap.add_argument("--no-one-gpu-reference", action="store_true",
@@ -390,11 +379,11 @@ def main():
                     help="N > 1: do not try the exchange fused into the SpMV epilogue (peer-mapped stores, SURVEY 8 f2)")
     ap.add_argument("--exchange", default="auto",
                     help="N > 1: allgatherv implementation; auto = the fastest of the start-up probe")
-    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "blocked", "panel"],
-                    help="how a rank holds its row-range shard: 'csr' as sliced; 'blocked' = column-blocked by owner "
-                         "(x of N x 4 MB does not fit the per-XCD L2: include/loops/kernels/column_blocked.hxx); 'panel' = "
+    ap.add_argument("--layout", default="auto", choices=["auto", "csr", "rowband", "panel"],
+                    help="how a rank holds its row-range shard: 'csr' as sliced; 'rowband' = row-band (y accumulators in LDS, "
+                         "column-sorted gathers: include/loops/kernels/rowband.hxx); 'panel' = "
                          "panel-binned (x panels in LDS, no gather: include/loops/kernels/panel_binned.hxx); "
-                         "auto = csr at N = 1 (the headline is the unmodified CSR), at N > 1 whichever of blocked / panel has the "
+                         "auto = csr at N = 1 (the headline is the unmodified CSR), at N > 1 whichever of rowband / panel has the "
                          "smaller worst-rank time in a probe before the timed region")
     args = ap.parse_args()
 
@@ -419,9 +408,12 @@ def main():
             dist.init_process_group("gloo")
 
     # ------------------------------------------------------------------ workload (synthetic)
-    strong = world > 1 and args.scaling in ("auto", "strong")
-    if strong:
+    strong = args.scaling == "strong" or (world > 1 and args.scaling == "auto")
+    workload = args.workload if args.workload != "auto" else ("c5" if strong else "c2")
+    if strong and workload == "c5":
         rows, nnz = 1 << args.c5_log2_rows, 1 << args.c5_log2_nnz
+    elif strong:
+        rows, nnz = 1 << args.log2_rows, 1 << args.log2_nnz
     else:
         rows, nnz = world << args.log2_rows, world << args.log2_nnz
     cols = rows
@@ -438,9 +430,11 @@ def main():
     y_loc = y_full[shard.row_begin:shard.row_end]
     gen_s = time.time() - t0
     tile_probe = None
-    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 else "auto")
+    # (the default N = 1 run is the headline: the unmodified CSR.  A strong-scaling run holds its shard -- at N = 1 the whole
+    # matrix -- as N > 1 does: in the re-ordered copy a start-up probe finds fastest)
+    layout = args.layout if args.layout != "auto" else ("csr" if world == 1 and not strong else "auto")
     if args.tile == "auto" and layout != "csr":
-        args.tile = "512x8"  # column-blocked plans are built for 512 x 8 tiles (COLBLOCK_TILE): nothing to tune on the CSR shard
+        args.tile = "512x8"  # the shard is held in a re-ordered copy: nothing to tune on the CSR shard
     if "+" in args.tile:  # "512x8+phased": the phased-gather twin of that shape
         args.tile, tag = args.tile.split("+", 1)
         assert tag == "phased", f"--tile {args.tile}+{tag}: unknown kernel variant"
@@ -468,26 +462,24 @@ def main():
             args.variant = VARIANT_PHASED
         tile_probe = {k: round(v, 5) for k, v in tile_probe.items()}
     plan = S.MergePathPlan(csr, args.tile)
-    blocked = None      # the shard's re-ordered copy, if any: a ColumnBlockedPlan or a PanelBinnedPlan
-    shard_kind = "csr"  # "csr" | "blocked" | "panel"
+    blocked = None      # the shard's re-ordered copy, if any: a RowBandPlan or a PanelBinnedPlan
+    shard_kind = "csr"  # "csr" | "rowband" | "panel"
     layout_probe = None
-    # column blocks: the owners' row ranges cut into ~2 MB pieces of x, at most half the mean row length of them
-    # (every block adds `rows` row-end items: C2-like shards, 16 nnz / row, are best at 8; C5 shards, 32 nnz / row, at 16)
-    max_blocks = 8
-    while max_blocks < 64 and max_blocks * 2 <= (nnz // rows) // 2:
-        max_blocks *= 2
-    col_bounds = P.column_block_bounds(bounds, max_blocks=max(max_blocks, world))
 
     def make_shard_plan(kind, sub=None):
         """The re-ordered copy of a CSR (this rank's shard, or a row chunk of it) in layout `kind`."""
         m = csr if sub is None else sub
-        return S.ColumnBlockedPlan(m, block_bounds=col_bounds) if kind == "blocked" else S.PanelBinnedPlan(m)
+        if kind == "rowband":
+            rb = S.RowBandPlan(m)
+            rb.tune(5)
+            return rb
+        return S.PanelBinnedPlan(m)
 
     if layout != "csr":
         # Which copy the shards are held in: both candidates are built and timed on every rank (10 products each, outside the
         # timed region) and the job adopts the one with the smaller WORST-rank time -- every rank the same layout.  A layout
         # that cannot be built on some rank (no memory for the copy, index range) is out for everybody.
-        cands = ["blocked", "panel"] if layout == "auto" else [layout]
+        cands = ["rowband", "panel"] if layout == "auto" else [layout]
         built, times = {}, {}
         for kind in cands:
             ok, ms = 1.0, float("inf")
@@ -692,11 +684,11 @@ def main():
             K_["main_avg"] = batch_event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
             K_["fix_avg"] = 0.0
             K_["reduce_avg"] = batch_event_time(lambda: blocked.spmv_stage(1, x, y_loc), iters)
-        elif blocked is not None:
+        elif blocked is not None:  # row-band: accumulate (band sums in LDS), then the combine of bands cut into chunks (if any)
             K_["main_single"], K_["main_med"] = event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
             K_["main_avg"] = batch_event_time(lambda: blocked.spmv_stage(0, x, y_loc), iters)
-            K_["fix_avg"], _ = event_time(lambda: blocked.spmv_stage(1, x, y_loc), iters)
-            K_["reduce_avg"], _ = event_time(lambda: blocked.spmv_stage(2, x, y_loc), iters)
+            K_["fix_avg"] = 0.0
+            K_["reduce_avg"] = batch_event_time(lambda: blocked.spmv_stage(1, x, y_loc), iters) if blocked.num_partials else 0.0
         else:
             K_["main_single"], K_["main_med"] = event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 0, args.variant), iters)
             K_["main_avg"] = batch_event_time(lambda: S.merge_path_flat_stage(csr, x, y_loc, plan, 0, args.variant), iters)
@@ -714,7 +706,7 @@ def main():
     exchange_probe = None
     exchange_dropped = {}
     safe = {"mode": None, "ms_per_step": None, "parity": None}
-    R_ = {"one_gpu": None, "ms_with_prepass": None, "blocked_info": None, "local_info": None, "schedules_info": None, "c4_info": None,
+    R_ = {"one_gpu": None, "ms_with_prepass": None, "rowband_info": None, "local_info": None, "schedules_info": None, "c4_info": None,
           "c3_info": None, "copy_gbps": None, "gather_gps": None, "ref_gpu": None, "cpu": None, "fused_note": None, "l2_gather_gps": None, "panel_info": None}
 
     def record(ms_per_step, parity, watchdog=None):
@@ -723,7 +715,7 @@ def main():
         loc_rows, loc_nnz = csr.rows, csr.nnzs
         abytes = algorithmic_bytes(loc_rows, cols, loc_nnz)
         k_main = K_["main_avg"]
-        if k_main and shard_kind == "panel":  # the product is two streaming kernels of similar weight: the roofline is quoted on their sum
+        if k_main and shard_kind in ("panel", "rowband"):  # the product is two kernels: the roofline is quoted on their sum
             k_main = K_["main_avg"] + K_["reduce_avg"]
         roofline = None
         if k_main:
@@ -731,7 +723,7 @@ def main():
             traffic, traffic_src, traffic_note = pmc_traffic(args)
             counters = pmc_bound(args)
             roofline = {"bound": "hbm", "kernel": {"csr": "loops::kernels::merge_path_spmv_fused" + ("_phased" if args.variant == VARIANT_PHASED else ""),
-                                                    "blocked": "loops::kernels::merge_path_spmv_fused_stacked",
+                                                    "rowband": "loops::kernels::rowband::rowband_accumulate + rowband_combine",
                                                     "panel": "loops::kernels::panel::panel_products + panel_reduce"}[shard_kind],
                         "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -758,11 +750,11 @@ def main():
                                  "request_rate_floor_frac": round(abytes / (loc_nnz / g2 / 1e6 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                  "kernel_over_request_rate_floor": round(k_main / (loc_nnz / g2 / 1e6), 3)})
             if K_["reduce_avg"] is not None:
-                roofline["panel_reduce_avg_launch_ms" if shard_kind == "panel" else "block_reduce_avg_launch_ms"] = round(K_["reduce_avg"], 5)
+                roofline["panel_reduce_avg_launch_ms" if shard_kind == "panel" else "rowband_combine_avg_launch_ms"] = round(K_["reduce_avg"], 5)
         mode = gather_mode["mode"] if watchdog is None else safe["mode"]
         one_gpu, spmv_only_ms = R_["one_gpu"], K_["spmv_only_ms"]
         step_includes = {"csr": "fused merge-tile kernel" + (" (phased x gathers: 8 passes by column range, clock-aligned across workgroups)"
-                                                            if args.variant == VARIANT_PHASED else "") + " + carry-out fix-up", "blocked": "fused merge-tile kernel + carry-out fix-up + block reduce",
+                                                            if args.variant == VARIANT_PHASED else "") + " + carry-out fix-up", "rowband": "row-band accumulate (band sums in LDS) + combine of the cut bands",
                          "panel": "panel products (x panels in LDS) + sub-band reduce"}[shard_kind]
         if world > 1:
             step_includes += f" + allgatherv(y) [{mode}"
@@ -774,19 +766,30 @@ def main():
         return {
             "metric": "CSR SpMV GFLOP/s, merge_path_flat", "value": round(gflops, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
-            "higher_is_better": True, "scaling": None if world == 1 else ("strong" if strong else "weak"), "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else (None if world == 1 else "weak"), "vs_baseline": None,
+            # the scaling curve's own figures at the top level: which matrix, what the step holds, the ratio to the SAME matrix on
+            # one GPU (N > 1: measured on rank 0 outside the timed region; N = 1 strong: this record is that denominator)
+            "scaling_detail": None if not strong else {
+                "workload": workload, "rows": rows, "nnz": nnz, "shard_layout": shard_kind,
+                "exchange": None if world == 1 else (gather_mode["mode"] if watchdog is None else safe["mode"]),
+                "spmv_only_ms_per_step": None if K_["spmv_only_ms"] is None else round(K_["spmv_only_ms"], 5),
+                "speedup_vs_one_gpu_same_matrix": None if not R_["one_gpu"] or world == 1 else
+                                                  round(R_["one_gpu"]["best_ms_per_spmv"] / ms_per_step, 3),
+                "like_for_like_first_point": "python bench.py --gpus 1 --scaling strong" + ("" if workload == "c5" else " --workload c2")},
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic power-law CSR, {rows} rows / {nnz} nnz total "
                                    + (f"(ONE matrix cut into {world} row ranges balanced by rows + nnz: {loc_nnz} nnz on rank 0)" if strong else
                                       f"({world} x 2^{args.log2_rows} rows / 2^{args.log2_nnz} nnz per GPU)") + ", max degree 2^14, "
                                    "fp32, merge_path_flat" + (f", columns banded (window {args.window})" if args.window else ", columns uniform")
                                    + (f", row-range sharded + allgatherv(y) over {'RCCL' if args.backend == 'nccl' else 'gloo (functional test)'}" if world > 1 else ""),
-                       "baseline_config": "BASELINE.json configs[1]" if world == 1 else
-                                          ("BASELINE.json configs[4] (C5), strong scaling" if strong else "configs[1] per GPU (weak scaling; context mode)"),
+                       "baseline_config": ("BASELINE.json configs[4] (C5), strong scaling" if workload == "c5" else
+                                           "BASELINE.json configs[1] (C2) as ONE matrix cut into N row ranges, strong scaling") if strong else
+                                          ("BASELINE.json configs[1]" if world == 1 else "configs[1] per GPU (weak scaling; context mode)"),
                        "tile": args.tile, "tile_autotune_ms": tile_probe, "variant": args.variant,
                        "merge_tiles_per_gpu": plan.num_tiles,
                        "shard_layout": "csr" if blocked is None else
-                                       (f"column-blocked by owner, {blocked.num_blocks} blocks (x per GPU {cols * 4 >> 20} MB)" if shard_kind == "blocked" else
+                                       (f"row-band, {blocked.num_bands} bands of {blocked.H} rows in {blocked.num_chunks} chunks, {blocked.waves} wavefronts "
+                                        f"(x per GPU {cols * 4 >> 20} MB)" if shard_kind == "rowband" else
                                         f"panel-binned{' (compact)' if blocked.compact else ''}, {blocked.num_panels} panels of {blocked.W} columns x "
                                         f"{blocked.num_subbands} sub-bands of {blocked.Hw} rows (x per GPU {cols * 4 >> 20} MB)"),
                        "shard_layout_probe_ms": layout_probe,
@@ -809,7 +812,7 @@ def main():
                        "fused_stores_note": R_["fused_note"],
                        "watchdog": watchdog,
                        "parity_vs_oracle_bit_exact": parity, "generate_seconds": round(gen_s, 1),
-                       "column_blocked_layout_same_matrix": R_["blocked_info"],
+                       "row_band_layout_same_matrix": R_["rowband_info"],
                        "panel_binned_layout_same_matrix": R_["panel_info"],
                        "same_kernel_local_columns": R_["local_info"],
                        "schedules_c2": R_["schedules_info"],
@@ -1013,7 +1016,7 @@ def main():
         wd.arm("one-GPU run of the same matrix", 1200)
 
     # BASELINE C5's denominator: the same matrix on one GPU (rank 0, outside the timed region; the others wait)
-    if strong and not args.no_one_gpu_reference:
+    if strong and world > 1 and not args.no_one_gpu_reference:
         step()  # (collective: every rank) y_full = the gathered vector the one-GPU result is compared with
         barrier()
         if rank == 0:
@@ -1039,45 +1042,46 @@ def main():
         torch.cuda.synchronize()
         R_["ms_with_prepass"] = (time.perf_counter() - t0) / iters * 1e3
 
-    # for context at N = 1: the same SpMV with the matrix held column-blocked (never `value`)
-    if world == 1 and blocked is None and rank == 0 and not args.no_context:
-        cb = S.ColumnBlockedPlan(csr, block_bounds=col_bounds)
-        yb = torch.empty_like(y_loc)
-        for _ in range(5):
-            cb.spmv(x, yb)
+    def build_price(make, layout_ms, csr_ms):
+        """(plan, wall ms of one creation incl. the device work, products after which the copy has paid for itself against the CSR)."""
+        make().close()  # (the first creation pays allocator warm-up)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(iters):
-            cb.spmv(x, yb)
+        plan_ = make()
         torch.cuda.synchronize()
-        ms_b = (time.perf_counter() - t0) / iters * 1e3
-        kb_avg, _ = event_time(lambda: cb.spmv_stage(0, x, yb), iters)
-        cb.spmv(x, yb)
+        b_ms = (time.perf_counter() - t0) * 1e3
+        return plan_, b_ms
+
+    def break_even(b_ms, layout_ms, csr_ms):
+        return round(b_ms / (csr_ms - layout_ms), 1) if layout_ms < csr_ms else None
+
+    # for context at N = 1: the same SpMV from the row-band copy (y accumulators in LDS, column-sorted gathers; never `value`)
+    if world == 1 and blocked is None and rank == 0 and not args.no_context:
+        rb, rb_build = build_price(lambda: S.RowBandPlan(csr), None, None)
+        tune8, tune16 = rb.tune(10)
+        yb = torch.empty_like(y_loc)
+        ms_b = batch_event_time(lambda: rb.spmv(x, yb), iters)
+        ms_ba = batch_event_time(lambda: rb.spmv_stage(0, x, yb), iters)
+        ms_bb = batch_event_time(lambda: rb.spmv_stage(1, x, yb), iters) if rb.num_partials else 0.0
+        rb.spmv(x, yb)
         torch.cuda.synchronize()
-        traffic_b = None
-        import glob
-        if pmc_summary(args)[0] is not None:  # the profiled configuration, counters collected at the current kernel sources
-            for pb in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c2_blocked_pmc_summary.json")), reverse=True):
-                db = json.load(open(pb))
-                if db.get("_kernel_sources_sha256") != kernel_sources_digest():
-                    continue
-                for k, v in db.items():
-                    if "merge_path_spmv_fused_stacked" in k and isinstance(v, dict) and "TCC_EA0_RDREQ_sum" in v and "WRITE_SIZE" in v:
-                        traffic_b = int(v["TCC_EA0_RDREQ_sum"]["mean"] * 128 + v["WRITE_SIZE"]["mean"] * 1024)
-                break
         ab = algorithmic_bytes(csr.rows, cols, csr.nnzs)
-        R_["blocked_info"] = {"blocks": cb.num_blocks, "ms_per_step": round(ms_b, 5),
-                              "roofline": {"kernel": "loops::kernels::merge_path_spmv_fused_stacked", "avg_launch_ms": round(kb_avg, 5),
-                                           "achieved": round(ab / (kb_avg * 1e-3) / 1e9, 1), "unit": "GB/s",
-                                           "frac": round(ab / (kb_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic_b},
-                              "GFLOPs": round(2.0 * nnz / (ms_b * 1e-3) / 1e9, 2), "equal_to_csr_result": bool(torch.equal(yb, y_loc)),
-                              "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/column_blocked.hxx); "
-                                      "same fused kernel + K-way row reduce; not the headline"}
-        cb.close()
+        csr_ms = K_["main_avg"] + (K_["fix_avg"] or 0.0) if K_["main_avg"] else None
+        R_["rowband_info"] = {"bands": rb.num_bands, "band_rows": rb.H, "chunks": rb.num_chunks, "partial_vectors": rb.num_partials,
+                              "wavefronts": rb.waves, "tune_ms": {"8": round(tune8, 5), "16": round(tune16, 5)},
+                              "padding_items_over_nnz": round((rb.padded - csr.nnzs) / max(csr.nnzs, 1), 4),
+                              "ms_per_step": round(ms_b, 5), "accumulate_ms": round(ms_ba, 5), "combine_ms": round(ms_bb, 5),
+                              "GFLOPs": round(2.0 * nnz / (ms_b * 1e-3) / 1e9, 2), "frac": round(ab / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "plan_build_ms": round(rb_build, 2),
+                              "break_even_products": None if csr_ms is None else break_even(rb_build, ms_b, csr_ms),
+                              "equal_to_csr_result": bool(torch.equal(yb, y_loc)),
+                              "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/rowband.hxx): 8 B per nonzero streamed, the "
+                                      "band's y sums in LDS (fp64), x gathered through column-sorted (coalescing) loads; not the headline"}
+        rb.close()
 
     # for context at N = 1: the same SpMV from the panel-binned copy (x panels in LDS, no memory gather; never `value`)
     if world == 1 and blocked is None and rank == 0 and not args.no_context:
-        pb = S.PanelBinnedPlan(csr)
+        pb, pb_build = build_price(lambda: S.PanelBinnedPlan(csr), None, None)
         yp = torch.empty_like(y_loc)
         ms_p = batch_event_time(lambda: pb.spmv(x, yp), iters)
         ms_pa = batch_event_time(lambda: pb.spmv_stage(0, x, yp), iters)
@@ -1089,6 +1093,8 @@ def main():
                             "compact": pb.compact, "runs_over_nnz": round(pb.runs / max(csr.nnzs, 1), 4),
                             "ms_per_step": round(ms_p, 5), "products_ms": round(ms_pa, 5), "reduce_ms": round(ms_pb, 5),
                             "GFLOPs": round(2.0 * nnz / (ms_p * 1e-3) / 1e9, 2), "frac": round(ab / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "plan_build_ms": round(pb_build, 2),
+                            "break_even_products": break_even(pb_build, ms_p, K_["main_avg"] + (K_["fix_avg"] or 0.0)) if K_["main_avg"] else None,
                             "equal_to_csr_result": bool(torch.equal(yp, y_loc)),
                             "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/panel_binned.hxx): 7 B read per nonzero + "
                                     "10 B per run of equal (row, panel) -- 17 B per nonzero when nothing is pre-summed -- instead of 8 B + a gather; "
@@ -1098,7 +1104,7 @@ def main():
     # for context at N = 1: the SAME kernel on a matrix of the same size whose columns are local (16 per row inside a
     # 64-column band): what the kernel does when the x gather is served by L1 -- its roofline fraction as a kernel,
     # next to the headline's, which is set by the random gather (never `value`)
-    if world == 1 and rank == 0 and not args.window and not args.no_local_context and not args.no_context:
+    if world == 1 and not strong and rank == 0 and not args.window and not args.no_local_context and not args.no_context:
         l_off, l_idx, l_val = G.csr_from_degrees(np.full(csr.rows, csr.nnzs // csr.rows, np.int64), cols, seed=1, window=64)
         l_csr = S.CSR.from_numpy(csr.rows, cols, l_off, l_idx, l_val)
         l_plan = S.MergePathPlan(l_csr, "256x8")
@@ -1119,7 +1125,7 @@ def main():
         del l_csr, l_plan, yl, y_tm
 
     # for context at N = 1: the other tuned schedules on the headline matrix, and BASELINE C4 (BCSR 4x4 + MFMA) at full size
-    if world == 1 and rank == 0 and not args.no_context and not args.window:
+    if world == 1 and not strong and rank == 0 and not args.no_context and not args.window:
         step()
         torch.cuda.synchronize()
         R_["schedules_info"] = context_schedules(S, torch, csr, x, y_loc.clone(), algorithmic_bytes(csr.rows, cols, csr.nnzs))
@@ -1180,7 +1186,7 @@ def main():
         R_["ref_gpu"] = ref_gpu
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not strong and not args.no_cpu_baseline:
         from oracle import oracle as O
         # bounded sample: ~10 s of single-core work (what --validate executes) + ~3 s of the OpenMP variant
         t0 = time.perf_counter()

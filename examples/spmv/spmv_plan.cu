@@ -1,7 +1,7 @@
 /**
  * @file spmv_plan.cu
  * @brief What an iterative caller does with this library: build ONE plan for the matrix (algorithms::spmv::spmv_plan_t picks
- * the merge-tile shape and, if a copy is allowed, the layout -- unmodified CSR, column-blocked or panel-binned -- by timing
+ * the merge-tile shape and, if a copy is allowed, the layout -- unmodified CSR, row-band or panel-binned -- by timing
  * the candidates on the device), then run many products through it.  Checked against merge_path_flat on the CSR.
  *
  *   loops.spmv.spmv_plan <matrix.mtx> [iterations = 20] [allow a re-ordered copy = 1] [measure = 1]
@@ -43,11 +43,11 @@ int main(int argc, char** argv) {
   vector_t<float, memory_space_t::host> a(y), b(y_ref);
   std::size_t errors = 0;
   for (std::size_t i = 0; i < a.size(); ++i) errors += std::fabs(a[i] - b[i]) > 1e-4f * (1.f + std::fabs(b[i]));
-  const char* layouts[] = {"unmodified CSR", "column-blocked copy", "panel-binned copy"};
+  const char* layouts[] = {"unmodified CSR", "-", "panel-binned copy", "row-band copy"};
   std::cout << "Layout:\t\t" << layouts[plan.layout] << (plan.layout == plan_t::csr_layout ? (plan.small ? ", 256 x 8 tiles" : plan.phased ? ", 512 x 8 tiles, phased x gathers" : ", 512 x 8 tiles") : "")
             << std::endl;
   std::cout << "Measured (ms):\tcsr 256x8 " << plan.ms_small << ", csr 512x8 " << plan.ms_large << ", csr 512x8 phased " << plan.ms_phased
-            << ", column-blocked " << plan.ms_blocked
+            << ", row-band " << plan.ms_band
             << ", panel-binned " << plan.ms_panel << "  (-1 = not a candidate)" << std::endl;
   std::cout << "Elapsed (ms):\t" << total_ms / static_cast<float>(iterations > 0 ? iterations : 1) << " per product, " << iterations
             << " products" << std::endl;

@@ -52,7 +52,7 @@ void merge_path_flat_async_with(const merge_path_plan_of_t<TPB, IPT, index_t, of
                                 static_cast<int>(plan.merge_tiles()), plan.self_complete(), plan.head_starts()};
   kernels::launch_merge_path_fused<static_cast<int>(TPB), static_cast<int>(IPT), (IPT % 2 == 0), false>(
       stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
-      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get(), 3, false, planned);
+      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get(), 3, planned);
 }
 
 /// The same product through the PHASED-gather kernel (kernels::merge_path_spmv_fused_phased: a tile's x gathers in 8 passes by

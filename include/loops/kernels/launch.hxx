@@ -71,20 +71,19 @@ inline int launch_merge_path_coordinates_ell(hipStream_t stream, int rows, int p
 }
 
 /// Fused merge-path SpMV (+ fix-up).  stages: bit 0 = tile kernel, bit 1 = fix-up.
-/// `stacked`: the matrix is a column-blocked CSR -- same code under its own kernel symbol; `planned`: the product comes from an
-/// SpMV plan handle -- again the same code under its own symbol.
+/// `planned`: the product comes from an SpMV plan handle -- the same code under its own kernel symbol (profile attribution).
 /// MASK (default): bit-mask split instead of the per-thread search (merge_tile_engine<..., MASK = true>):
 /// 1-2 % faster on every input measured (C2 103.3 -> 102.5 us, band-8192 50.4 -> 49.5, runs 43.7 -> 42.7).
 template <int TPB, int IPT, bool PAD, int NT, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
                             const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
-                            int stages = 3, bool stacked = false, bool planned = false) {
+                            int stages = 3, bool planned = false) {
   const int m = plan.num_merge_tiles;
   if (m == 0) return 0;
   if (m == 1) stages &= ~2;  // one tile holds every row completely: no carry-out to add (launch-bound sizes: 1 kernel)
   T* carry_val = static_cast<T*>(plan.carry_val);
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-  if (plan.self_complete && plan.head_start && m > 1) {  // (plain and column-blocked CSRs alike)
+  if (plan.self_complete && plan.head_start && m > 1) {
     // no row crosses more than one tile boundary with more than TPB nonzeros behind it: tiles complete their
     // rows themselves -- one kernel, no carry-outs (the "fix-up" stage has nothing to do)
     if (stages & 1) {
@@ -102,10 +101,7 @@ int launch_merge_path_fused(hipStream_t stream, const merge_plan_view& plan, int
       hipLaunchKernelGGL(kernel, dim3(m), dim3(TPB), 0, stream, plan.coords, rows, nnz, offsets, indices, values, x, y,
                          plan.carry_row, carry_val);
     };
-    if (stacked) {
-      if (aligned) go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
-      else go(merge_path_spmv_fused_stacked<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);
-    } else if (planned) {  // (same code under the symbol of SpMV-plan handles: profile attribution only)
+    if (planned) {  // (same code under the symbol of SpMV-plan handles: profile attribution only)
       if (aligned) go(merge_path_spmv_fused_planned<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>);
       else go(merge_path_spmv_fused_planned<TPB, IPT, PAD, NT, false, index_t, offset_t, T, MASK>);
     } else {
@@ -233,7 +229,7 @@ int launch_merge_path_fused_phased(hipStream_t stream, const merge_plan_view& pl
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
   if (m <= 1 || !aligned)
     return launch_merge_path_fused<TPB, IPT, true, 0, index_t, offset_t, T, true>(stream, plan, rows, nnz, offsets, indices, values, x, y,
-                                                                                 stages, false, planned);
+                                                                                 stages, planned);
   T* carry_val = static_cast<T*>(plan.carry_val);
   const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
   if (plan.self_complete && plan.head_start) {  // one kernel, no carry-outs (the "fix-up" stage has nothing to do)

@@ -816,20 +816,7 @@ merge_path_spmv_fused_self(const coord_t* __restrict__ coords, const int* __rest
                                                            nullptr, static_cast<type_t*>(nullptr), head_start);
 }
 
-/// The same kernel under its own symbol for column-blocked ("stacked") CSRs (column_blocked.hxx), so
-/// that profiles attribute those launches separately from the plain-CSR SpMV.
-template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,
-          bool MASK = false>
-__global__ void __launch_bounds__(TPB)
-merge_path_spmv_fused_stacked(const coord_t* __restrict__ coords, const int rows, const int nnz,
-                              const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
-                              const type_t* __restrict__ values, const type_t* __restrict__ x,
-                              type_t* __restrict__ y, int* __restrict__ carry_row, type_t* __restrict__ carry_val) {
-  merge_path_spmv_tile<TPB, IPT, PAD, NT, VEC, false, MASK>(coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values,
-                                                            x, y, carry_row, carry_val);
-}
-
-/// And under a third symbol for products issued through an SpMV plan handle (loops_spmv_plan_*, algorithms::spmv::spmv_plan_t:
+/// The same kernel under a second symbol for products issued through an SpMV plan handle (loops_spmv_plan_*, algorithms::spmv::spmv_plan_t:
 /// the candidates it times at creation and the products it runs afterwards), so that the plain symbol's per-kernel statistics
 /// in a profile are those of the direct entry points only (bench.py: the headline kernel on the headline matrix).
 template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t,

@@ -4,9 +4,8 @@
  *
  * Why.  CSR SpMV issues one scattered 4-byte gather of x per nonzero, and on MI355X that gather -- not HBM -- sets the
  * time: a CU keeps ~95 reads in flight, each gather holds a slot for its whole round trip (L2 hit ~220 clks, Infinity
- * Cache ~950), so the chip serves 265 G gathers/s at best from L2 and ~55 G/s beyond it.  The
- * column-blocked layout (column_blocked.hxx) turns Infinity-Cache gathers into L2 hits; this layout removes the gathers
- * from the memory system altogether: x is read in PANELS of W consecutive columns that fit the 160 KB LDS of a CU, and a
+ * Cache ~950), so the chip serves 265 G gathers/s at best from L2 and ~55 G/s beyond it.  This layout removes
+ * the gathers from the memory system altogether: x is read in PANELS of W consecutive columns that fit the 160 KB LDS of a CU, and a
  * nonzero's x value comes out of LDS (ds_read: ~9 random reads per clock and CU, twenty times the L2 path).
  *
  * Layout (a re-ordered COPY of the matrix, built once on the device, O(nnz)): nonzeros sorted by (panel p = col / W,
@@ -119,7 +118,7 @@ constexpr unsigned short pad_row = 0xFFFFu;
 
 /// key[i] = (segment of nonzero i) << 32 | i and rc[i] = (row inside the sub-band) << 16 | (column inside the panel): everything
 /// the later passes need of a nonzero besides its value, so that they gather ONE word per item.  Lane per IPT consecutive
-/// nonzeros: one search for the row of the first, then a walk along the offsets (as colblock::make_keys).  No counting here:
+/// nonzeros: one search for the row of the first, then a walk along the offsets .  No counting here:
 /// the per-segment counts come from the SORTED keys (segment_starts) -- one global atomic per item was 0.9 of this kernel's
 /// 0.92 ms on C2 (scattered atomics into L2 retire at ~18 G/s).
 template <int IPT, typename index_t, typename offset_t>

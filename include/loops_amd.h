@@ -70,7 +70,7 @@ int loops_release_scratch(void);
  * of SpMVs with the same offsets array.
  * ONE PRODUCT IN FLIGHT PER PLAN: a plan owns a single set of carry-out buffers that every product through it writes,
  * so two products that use the same plan must be ordered (same stream, or an event between them).  The same holds for
- * loops_colblock_plan_t (its partial-result vectors).  One plan per stream for concurrent products. */
+ * layout plans (loops_rowband_plan_t: partial vectors; loops_panel_plan_t: products scratch).  One plan per stream for concurrent products. */
 typedef struct loops_merge_plan loops_merge_plan_t;
 
 int loops_merge_plan_create(int rows, int nnz, const int* offsets, int tile_config, void* stream,
@@ -102,7 +102,7 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  * issued from one thread on several streams may overlap.  (At most 16 such buffers are cached per thread; the
  * least recently used is released first.  Growing or evicting a buffer calls hipFree, which waits for the DEVICE:
  * an otherwise asynchronous call then blocks once -- steady-state calls on up to 16 (stream, tile shape) pairs per
- * thread never do; entries of destroyed streams stay until evicted or loops_release_scratch() is called.)  A held plan (loops_merge_plan_t, loops_colblock_plan_t) owns ONE set of
+ * thread never do; entries of destroyed streams stay until evicted or loops_release_scratch() is called.)  A held plan (loops_merge_plan_t, loops_rowband_plan_t, loops_panel_plan_t) owns ONE set of
  * scratch buffers and is passed as const only because its coordinates are read-only: it serves one product at a
  * time -- do not run the same plan on two streams or from two threads concurrently; create one plan per stream. */
 /* (LOOPS_MERGE_PATH_FLAT, round 4: from an x of 6 MB on and 2^20 nonzeros the call samples the columns on the device -- two small
@@ -144,7 +144,7 @@ int loops_spmv_work_oriented_f64(const loops_merge_plan_t* plan, int rows, int c
 /* ---- multi-GPU: allgatherv(y) fused into the SpMV epilogue ----------------------------------------------
  * No reference counterpart (the reference is single-GPU).  A rank of a row-range sharded SpMV owns rows
  * [row_begin, row_end) of y; instead of exchanging its slice afterwards, the kernels that FINISH rows of y (the fused
- * merge-tile kernel and its fix-up; for column-blocked shards the K-way block reduce) also store every finished value to
+ * merge-tile kernel and its fix-up; for row-band and panel-binned shards the kernels that store rows of y) also store every finished value to
  * the same element of up to 7 peer vectors over xGMI.  h_peer_y: HOST array of num_peers device-accessible pointers,
  * h_peer_y[p] = where THIS shard's y[0] lives in peer p's full-length vector (a hipIpcOpenMemHandle / peer-access
  * mapping; loops_enable_peer_access(peer device) first).  The peers' copies are complete when the launches have
@@ -231,52 +231,6 @@ int loops_spmm_merge_path_f32(const loops_merge_plan_t* plan, int rows, int cols
 int loops_spmm_merge_path_f64(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
                               const int* indices, const double* values, const double* B, int n, double* C,
                               void* stream);
-
-/* ---- column-blocked CSR: SpMV for matrices / shards whose x does not fit the per-XCD L2 ---------
- * No reference counterpart (the reference is single-GPU and leaves the x gather to the cache).
- * The plan holds a re-ordered COPY of the matrix: the columns are cut into K blocks and stacked row
- * (k * rows + r) holds the part of row r inside block k -- an ordinary CSR of K * rows rows that the
- * fused merge_path_flat kernel runs unchanged, each XCD staying inside (about) one column block so its
- * L2 holds cols * 4 / K bytes of x; a K-way row reduce finishes y (include/loops/kernels/column_blocked.hxx).
- * num_blocks <= 0: automatic (x[block] ~ 2 MB, at most half the mean row length and at most 64 blocks).  block_bounds: NULL for equal blocks, or
- * num_blocks + 1 ascending HOST ints with [0] = 0 and [num_blocks] = cols (multi-GPU: the owners' row
- * ranges).  Creation is synchronous on `stream` (device radix sort + scan, O(nnz)).
- * y = A x is deterministic; it sums each row block by block, so it is bit-identical to the plain
- * kernels for exactly-summable inputs and within the usual fp32 reordering bound otherwise. */
-typedef struct loops_colblock_plan loops_colblock_plan_t;
-int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
-                               const float* values, int num_blocks, const int* block_bounds, void* stream,
-                               loops_colblock_plan_t** out);
-int loops_colblock_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices,
-                                   const double* values, int num_blocks, const int* block_bounds, void* stream,
-                                   loops_colblock_plan_t** out);
-void loops_colblock_plan_destroy(loops_colblock_plan_t* plan);
-/* num_blocks and (if non-NULL) the num_blocks + 1 HOST column boundaries */
-int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks, int* block_bounds);
-/* copies of the stacked CSR (K * rows + 1 offsets, nnz indices / values) and of the permutation
- * (stacked position -> original position) into HOST buffers (any may be NULL); synchronous; for
- * inspection and tests */
-int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_offsets, int* stacked_indices,
-                               void* stacked_values /* float or double, as created */, int* perm);
-/* new numerical values, same structure */
-int loops_colblock_plan_refresh_values(loops_colblock_plan_t* plan, const float* values, void* stream);
-int loops_colblock_plan_refresh_values_f64(loops_colblock_plan_t* plan, const double* values, void* stream);
-/* the value type must match the plan's (LOOPS_E_BADARG otherwise) */
-int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream);
-int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, double* y, void* stream);
-/* the same product with the tuned kernel of another schedule over the stacked CSR: LOOPS_MERGE_PATH_FLAT
- * (= loops_spmv_colblock_f32), LOOPS_WORK_ORIENTED or LOOPS_GROUP_MAPPED; LOOPS_E_CONFIG otherwise */
-int loops_spmv_colblock_schedule_f32(const loops_colblock_plan_t* plan, int schedule, const float* x, float* y,
-                                     void* stream);
-/* loops_spmv_colblock_f32 with the peer fan-out of the finished y (see loops_spmv_merge_path_fanout_f32): the block
- * reduce writes y and, with 16-byte non-temporal stores, the num_peers peer copies. */
-int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const float* x, float* y, int num_peers,
-                                   float* const* h_peer_y, void* stream);
-int loops_spmv_colblock_fanout_f64(const loops_colblock_plan_t* plan, const double* x, double* y, int num_peers,
-                                   double* const* h_peer_y, void* stream);
-/* one kernel at a time for timing: stage 0 = fused tile kernel, 1 = carry fix-up, 2 = block reduce */
-int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
-                                  void* stream);
 
 /* ---- panel-binned layout: SpMV without a gather, for x far larger than the per-XCD L2 ------------------------------
  * No reference counterpart.  The plan holds a re-ordered COPY of the matrix (include/loops/kernels/panel_binned.hxx): nonzeros
@@ -400,7 +354,7 @@ int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float*
 #define LOOPS_PLAN_MEASURE 1
 #define LOOPS_PLAN_ALLOW_COPY 2
 #define LOOPS_LAYOUT_CSR 0
-#define LOOPS_LAYOUT_COLUMN_BLOCKED 1 /* retired with the column-blocked layout (round 5): never returned */
+/* (1 was the column-blocked layout, retired in round 5: never returned) */
 #define LOOPS_LAYOUT_PANEL_BINNED 2
 #define LOOPS_LAYOUT_ROW_BAND 3
 typedef struct loops_spmv_plan loops_spmv_plan_t;

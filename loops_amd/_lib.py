@@ -38,12 +38,9 @@ SYMBOLS = [
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
     "loops_work_oriented_grid", "loops_spmv_bcsr_f32",
     "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_spmv_csc_f32", "loops_autotune_merge_path_f32",
-    "loops_colblock_plan_create", "loops_colblock_plan_destroy", "loops_colblock_plan_info", "loops_colblock_plan_arrays",
-    "loops_colblock_plan_refresh_values", "loops_spmv_colblock_f32", "loops_spmv_colblock_stage_f32",
-    "loops_spmv_bcsr_f64", "loops_spmm_merge_path_f64", "loops_spmv_coo_f64", "loops_spmv_ell_f64", "loops_spmv_csc_f64",
+        "loops_spmv_bcsr_f64", "loops_spmm_merge_path_f64", "loops_spmv_coo_f64", "loops_spmv_ell_f64", "loops_spmv_csc_f64",
     "loops_spmv_dia_f32", "loops_spmv_dia_f64",
-    "loops_spmv_work_oriented_f32", "loops_spmv_work_oriented_f64", "loops_enable_peer_access", "loops_spmv_merge_path_fanout_f32", "loops_spmv_colblock_fanout_f32", "loops_spmv_colblock_fanout_f64",
-    "loops_colblock_plan_create_f64", "loops_spmv_colblock_schedule_f32", "loops_colblock_plan_refresh_values_f64", "loops_spmv_colblock_f64",
+    "loops_spmv_work_oriented_f32", "loops_spmv_work_oriented_f64", "loops_enable_peer_access", "loops_spmv_merge_path_fanout_f32",
     "loops_spmv_plan_create_f32", "loops_spmv_plan_create_f64", "loops_spmv_plan_destroy", "loops_spmv_plan_info",
     "loops_spmv_plan_refresh_values_f32", "loops_spmv_plan_refresh_values_f64", "loops_spmv_planned_f32", "loops_spmv_planned_f64",
     "loops_panel_plan_create_f32", "loops_panel_plan_create_f64", "loops_panel_plan_destroy", "loops_panel_plan_info",
@@ -175,8 +172,6 @@ def lib() -> C.CDLL:
             getattr(L, name).argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_enable_peer_access.argtypes = [ci]
         L.loops_spmv_merge_path_fanout_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp]
-        L.loops_spmv_colblock_fanout_f32.argtypes = [vp, vp, vp, ci, vp, vp]
-        L.loops_spmv_colblock_fanout_f64.argtypes = [vp, vp, vp, ci, vp, vp]
         L.loops_spmv_merge_path_stage_f32.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_spmv_csr_schedule_api_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
         L.loops_schedule_dump_merge_path.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
@@ -190,18 +185,6 @@ def lib() -> C.CDLL:
         L.loops_spmm_csr_f64.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmm_merge_path_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmm_merge_path_f64.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
-        L.loops_colblock_plan_create.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
-        L.loops_colblock_plan_create_f64.argtypes = [ci, ci, ci, vp, vp, vp, ci, vp, vp, C.POINTER(vp)]
-        L.loops_colblock_plan_refresh_values_f64.argtypes = [vp, vp, vp]
-        L.loops_spmv_colblock_f64.argtypes = [vp, vp, vp, vp]
-        L.loops_spmv_colblock_schedule_f32.argtypes = [vp, ci, vp, vp, vp]
-        L.loops_colblock_plan_destroy.argtypes = [vp]
-        L.loops_colblock_plan_destroy.restype = None
-        L.loops_colblock_plan_info.argtypes = [vp, C.POINTER(ci), vp]
-        L.loops_colblock_plan_arrays.argtypes = [vp, vp, vp, vp, vp]
-        L.loops_colblock_plan_refresh_values.argtypes = [vp, vp, vp]
-        L.loops_spmv_colblock_f32.argtypes = [vp, vp, vp, vp]
-        L.loops_spmv_colblock_stage_f32.argtypes = [vp, ci, vp, vp, vp]
         for sfx in ("f32", "f64"):
             getattr(L, "loops_spmv_coo_" + sfx).argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
             getattr(L, "loops_spmv_ell_" + sfx).argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp]

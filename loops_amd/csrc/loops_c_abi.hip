@@ -22,7 +22,6 @@
 #include <loops/util/launch_box.hxx>
 #include <loops/util/math.hxx>
 #include <loops/kernels/launch.hxx>
-#include <loops/kernels/column_blocked.hxx>
 #include <loops/kernels/panel_binned.hxx>
 #include <loops/kernels/rowband.hxx>
 #include <loops/multi_gpu/partition.hxx>
@@ -68,14 +67,6 @@ inline int check_csr(int rows, int cols, int nnz, const void* off, const void* i
 }  // namespace
 
 // ------------------------------------------------------------------------------------ plan
-// merge-tile shape of column-blocked plans (both schedules): 512 x 8 measured best on shards whose x exceeds an L2
-#ifndef LOOPS_COLBLOCK_TPB
-#define LOOPS_COLBLOCK_TPB 512
-#endif
-constexpr int COLBLOCK_TPB = LOOPS_COLBLOCK_TPB;
-constexpr int COLBLOCK_TILE = COLBLOCK_TPB == 512 ? LOOPS_TILE_512x8 : LOOPS_TILE_256x8;
-static_assert(COLBLOCK_TPB == 512 || COLBLOCK_TPB == 256, "column-blocked plans: 512 x 8 or 256 x 8 tiles");
-
 struct loops_merge_plan {
   int rows, nnz, cfg, tpb, ipt, num_tiles;
   int capacity;        // merge tiles the allocation can hold (>= num_tiles)
@@ -237,7 +228,7 @@ int launch_fused(const loops_merge_plan* p, int num_tiles, int rows, int nnz, co
                  const T* val, const T* x, T* y, hipStream_t stream, int stages, bool planned = false) {
   kernels::merge_plan_view view{p->coords, p->carry_row, p->carry_val, num_tiles, p->self_complete != 0, p->head_start};
   return kernels::launch_merge_path_fused<TPB, IPT, PAD, NT, int, int, T, MASK>(stream, view, rows, nnz, off, idx, val, x, y,
-                                                                                  stages, false, planned);
+                                                                                  stages, planned);
 }
 
 template <typename T>
@@ -546,128 +537,6 @@ int spmv_dia(int mode, int rows, int cols, int num_diagonals, size_t stride, con
 
 }  // namespace
 
-// --------------------------------------------------------------------- column-blocked CSR
-struct loops_colblock_plan {
-  int rows, cols, nnz, K;
-  int* bounds_dev;            // K + 1
-  int bounds_host[65];
-  int *soff, *sidx, *perm;    // stacked CSR structure + permutation
-  int vbytes;                 // 4 (float) or 8 (double) values
-  void* sval;                 // nnz stacked values
-  void* ys;                   // K * rows partial results
-  loops_merge_plan* merge;    // merge-path plan of the stacked CSR
-};
-
-namespace {
-
-void colblock_free(loops_colblock_plan* p) {
-  if (!p) return;
-  (void)hipFree(p->bounds_dev); (void)hipFree(p->soff); (void)hipFree(p->sidx); (void)hipFree(p->perm);
-  (void)hipFree(p->sval); (void)hipFree(p->ys);
-  if (p->merge) { (void)hipFree(p->merge->wide_carry); (void)hipFree(p->merge->base); delete p->merge; }
-  delete p;
-}
-
-// Automatic block count: x[block] of about 2 MB (half a per-XCD L2), but never more blocks than half the
-// mean row length -- every block adds `rows` row-end items to the merge path (measured: N=8 shard of C2,
-// 16 nnz/row: K = 8 beats 16; C5 shard, 32 nnz/row, x = 64 MB: K = 16 beats 8 and 32) -- and at most 64.
-int colblock_auto(int cols, int vbytes, int rows, int nnz) {
-  const long long bytes = static_cast<long long>(cols) * vbytes;
-  int k = 1;
-  while (k < 64 && bytes / k > (2ll << 20)) k *= 2;
-  const long long mean = rows > 0 ? nnz / rows : 0;
-  int cap = 2;
-  while (cap < 64 && cap * 2 <= mean / 2) cap *= 2;
-  return k < cap ? k : cap;
-}
-
-template <typename T>
-int colblock_spmv(const loops_colblock_plan* p, int stages, const T* x, T* y, hipStream_t stream,
-                  int schedule = LOOPS_MERGE_PATH_FLAT) {
-  if (p->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
-  if (p->rows == 0) return 0;
-  int err = 0;
-  T* ys = static_cast<T*>(p->ys);
-  if (schedule != LOOPS_MERGE_PATH_FLAT) {  // the other two fused CSR kernels over the same stacked CSR
-    kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles};
-    const T* sval = static_cast<const T*>(p->sval);
-    if (schedule == LOOPS_WORK_ORIENTED)
-      err = kernels::launch_work_oriented_fused<COLBLOCK_TPB, 8, true>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);  // the plan's tile shape
-    else if (schedule == LOOPS_GROUP_MAPPED)
-      err = kernels::launch_group_mapped_fused<256, 8, true>(stream, p->K * p->rows, p->nnz, p->soff, p->sidx, sval, x, ys);
-    else
-      return LOOPS_E_CONFIG;
-    if (!err) err = kernels::launch_reduce_blocks<T>(stream, ys, p->rows, p->K, y);
-    return err;
-  }
-  if (stages & 3) {
-    kernels::merge_plan_view view{p->merge->coords, p->merge->carry_row, p->merge->carry_val, p->merge->num_tiles,
-                                  p->merge->self_complete != 0, p->merge->head_start};
-    err = kernels::launch_merge_path_fused<COLBLOCK_TPB, 8, true, false>(stream, view, p->K * p->rows, p->nnz, p->soff, p->sidx,
-                                                                static_cast<const T*>(p->sval), x, ys, stages & 3,
-                                                                /*stacked=*/true);
-  }
-  if (!err && (stages & 4)) err = kernels::launch_reduce_blocks<T>(stream, ys, p->rows, p->K, y);
-  return err;
-}
-
-template <typename T>
-int colblock_create(int rows, int cols, int nnz, const int* offsets, const int* indices, const T* values,
-                    int num_blocks, const int* block_bounds, hipStream_t st, loops_colblock_plan** out) {
-  if (!out || !offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values))) return LOOPS_E_BADARG;
-  int K = num_blocks > 0 ? num_blocks : colblock_auto(cols, static_cast<int>(sizeof(T)), rows, nnz);
-  if (K > 64) return LOOPS_E_CONFIG;
-  if (K > cols && cols > 0) K = cols;
-  if (K < 1) K = 1;
-  if (static_cast<long long>(K) * rows + nnz >= (1ll << 31) - 4096) return LOOPS_E_RANGE;
-  auto* p = new (std::nothrow) loops_colblock_plan();
-  if (!p) return static_cast<int>(hipErrorOutOfMemory);
-  p->rows = rows; p->cols = cols; p->nnz = nnz; p->K = K; p->vbytes = static_cast<int>(sizeof(T));
-  for (int k = 0; k <= K; ++k) {
-    p->bounds_host[k] = block_bounds ? block_bounds[k]
-                                     : static_cast<int>(static_cast<long long>(cols) * k / K);
-    if (k > 0 && p->bounds_host[k] < p->bounds_host[k - 1]) { delete p; return LOOPS_E_BADARG; }
-  }
-  if (p->bounds_host[0] != 0 || p->bounds_host[K] != cols) { delete p; return LOOPS_E_BADARG; }
-  const size_t srows = static_cast<size_t>(K) * rows, n = static_cast<size_t>(nnz);
-  void* temp = nullptr;
-  const size_t temp_bytes = kernels::column_blocked_temp_bytes(nnz, static_cast<int>(srows));
-  hipError_t e = hipSuccess;
-  auto alloc = [&](auto** ptr, size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes ? bytes : 4); };
-  alloc(&p->bounds_dev, sizeof(int) * (K + 1));
-  alloc(&p->soff, sizeof(int) * (srows + 1));
-  alloc(&p->sidx, sizeof(int) * n);
-  alloc(&p->perm, sizeof(int) * n);
-  alloc(&p->sval, sizeof(T) * n);
-  alloc(&p->ys, sizeof(T) * srows);
-  alloc(&temp, temp_bytes);
-  int err = static_cast<int>(e);
-  if (!err) err = static_cast<int>(hipMemcpyAsync(p->bounds_dev, p->bounds_host, sizeof(int) * (K + 1), hipMemcpyHostToDevice, st));
-  if (!err) {
-    kernels::column_blocked_view<int, int, T> view{rows, cols, nnz, K, p->soff, p->sidx, static_cast<T*>(p->sval), p->perm};
-    err = kernels::build_column_blocked(st, offsets, indices, values, p->bounds_dev, view, temp, temp_bytes);
-  }
-  if (!err) err = plan_alloc(static_cast<int>(srows), nnz, COLBLOCK_TILE, &p->merge);
-  if (!err) err = plan_compute(p->merge, p->soff, st);
-  if (!err) err = plan_classify(p->merge, p->soff, st);  // short stacked rows only: no carry-outs, no fix-up launch
-  if (!err) err = static_cast<int>(hipStreamSynchronize(st));  // the temporaries go away below
-  (void)hipFree(temp);
-  if (err) { colblock_free(p); return err; }
-  *out = p;
-  return 0;
-}
-
-template <typename T>
-int colblock_refresh(loops_colblock_plan* plan, const T* values, hipStream_t stream) {
-  if (!plan || (plan->nnz > 0 && !values) || plan->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
-  if (plan->nnz == 0) return 0;
-  hipLaunchKernelGGL((kernels::colblock::gather_values<T>), dim3(math::ceil_div(plan->nnz, 256)), dim3(256), 0, stream,
-                     plan->perm, values, plan->nnz, static_cast<T*>(plan->sval));
-  return static_cast<int>(hipGetLastError());
-}
-
-}  // namespace
-
 namespace {
 template <typename T>
 int fanout_peers(int num_peers, T* const* h_peer_y, kernels::peer_fanout<T>* peers) {
@@ -698,18 +567,6 @@ int merge_path_fanout(const loops_merge_plan* plan, int rows, int cols, int nnz,
   else return kernels::launch_merge_path_fused_fanout<512, IPT>(stream, view, rows, nnz, offsets, indices, values, x, y, peers);
 }
 
-template <typename T>
-int colblock_fanout(const loops_colblock_plan* plan, const T* x, T* y, int num_peers, T* const* h_peer_y, hipStream_t stream) {
-  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
-  kernels::peer_fanout<T> peers;
-  int err = fanout_peers<T>(num_peers, h_peer_y, &peers);
-  if (err) return err;
-  if (plan->vbytes != static_cast<int>(sizeof(T))) return LOOPS_E_BADARG;
-  if (plan->rows == 0) return 0;
-  err = colblock_spmv<T>(plan, 3, x, y, stream);  // tile kernel (+ fix-up) into the K partial vectors
-  if (!err) err = kernels::launch_reduce_blocks_fanout<T>(stream, static_cast<const T*>(plan->ys), plan->rows, plan->K, y, peers);
-  return err;
-}
 }  // namespace
 
 // ------------------------------------------------------------------------------------ panel-binned layout
@@ -1192,15 +1049,6 @@ int loops_spmv_merge_path_fanout_f32(const loops_merge_plan_t* plan, int rows, i
   return merge_path_fanout<float>(plan, rows, cols, nnz, offsets, indices, values, x, y, num_peers, h_peer_y, as_stream(stream));
 }
 
-int loops_spmv_colblock_fanout_f32(const loops_colblock_plan_t* plan, const float* x, float* y, int num_peers,
-                                   float* const* h_peer_y, void* stream) {
-  return colblock_fanout<float>(plan, x, y, num_peers, h_peer_y, as_stream(stream));
-}
-int loops_spmv_colblock_fanout_f64(const loops_colblock_plan_t* plan, const double* x, double* y, int num_peers,
-                                   double* const* h_peer_y, void* stream) {
-  return colblock_fanout<double>(plan, x, y, num_peers, h_peer_y, as_stream(stream));
-}
-
 int loops_spmv_work_oriented_f32(const loops_merge_plan_t* plan, int rows, int cols, int nnz, const int* offsets,
                                  const int* indices, const float* values, const float* x, float* y, void* stream) {
   return spmv_work_oriented_planned<float>(plan, rows, cols, nnz, offsets, indices, values, x, y, as_stream(stream));
@@ -1323,68 +1171,6 @@ int loops_spmm_merge_path_f64(const loops_merge_plan_t* plan, int rows, int cols
   return spmm_merge_path<double>(plan, rows, cols, nnz, offsets, indices, values, B, n, C, as_stream(stream));
 }
 
-int loops_colblock_plan_create(int rows, int cols, int nnz, const int* offsets, const int* indices,
-                               const float* values, int num_blocks, const int* block_bounds, void* stream,
-                               loops_colblock_plan_t** out) {
-  return colblock_create<float>(rows, cols, nnz, offsets, indices, values, num_blocks, block_bounds, as_stream(stream), out);
-}
-int loops_colblock_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices,
-                                   const double* values, int num_blocks, const int* block_bounds, void* stream,
-                                   loops_colblock_plan_t** out) {
-  return colblock_create<double>(rows, cols, nnz, offsets, indices, values, num_blocks, block_bounds, as_stream(stream), out);
-}
-
-void loops_colblock_plan_destroy(loops_colblock_plan_t* plan) { colblock_free(plan); }
-
-int loops_colblock_plan_info(const loops_colblock_plan_t* plan, int* num_blocks, int* block_bounds) {
-  if (!plan) return LOOPS_E_BADARG;
-  if (num_blocks) *num_blocks = plan->K;
-  if (block_bounds) for (int k = 0; k <= plan->K; ++k) block_bounds[k] = plan->bounds_host[k];
-  return 0;
-}
-
-int loops_colblock_plan_arrays(const loops_colblock_plan_t* plan, int* stacked_offsets, int* stacked_indices,
-                               void* stacked_values, int* perm) {
-  if (!plan) return LOOPS_E_BADARG;
-  const size_t srows = static_cast<size_t>(plan->K) * plan->rows, n = static_cast<size_t>(plan->nnz);
-  hipError_t e = hipDeviceSynchronize();
-  auto copy = [&](void* dst, const void* src, size_t bytes) {
-    if (e == hipSuccess && dst && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
-  };
-  copy(stacked_offsets, plan->soff, sizeof(int) * (srows + 1));
-  copy(stacked_indices, plan->sidx, sizeof(int) * n);
-  copy(stacked_values, plan->sval, static_cast<size_t>(plan->vbytes) * n);
-  copy(perm, plan->perm, sizeof(int) * n);
-  return static_cast<int>(e);
-}
-
-int loops_colblock_plan_refresh_values(loops_colblock_plan_t* plan, const float* values, void* stream) {
-  return colblock_refresh<float>(plan, values, as_stream(stream));
-}
-int loops_colblock_plan_refresh_values_f64(loops_colblock_plan_t* plan, const double* values, void* stream) {
-  return colblock_refresh<double>(plan, values, as_stream(stream));
-}
-
-int loops_spmv_colblock_f32(const loops_colblock_plan_t* plan, const float* x, float* y, void* stream) {
-  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
-  return colblock_spmv<float>(plan, 7, x, y, as_stream(stream));
-}
-int loops_spmv_colblock_schedule_f32(const loops_colblock_plan_t* plan, int schedule, const float* x, float* y,
-                                     void* stream) {
-  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
-  return colblock_spmv<float>(plan, 7, x, y, as_stream(stream), schedule);
-}
-int loops_spmv_colblock_f64(const loops_colblock_plan_t* plan, const double* x, double* y, void* stream) {
-  if (!plan || !y || (plan->nnz > 0 && !x)) return LOOPS_E_BADARG;
-  return colblock_spmv<double>(plan, 7, x, y, as_stream(stream));
-}
-
-int loops_spmv_colblock_stage_f32(const loops_colblock_plan_t* plan, int stage, const float* x, float* y,
-                                  void* stream) {
-  if (!plan || !y || stage < 0 || stage > 2) return LOOPS_E_BADARG;
-  return colblock_spmv<float>(plan, 1 << stage, x, y, as_stream(stream));
-}
-
 int loops_spmv_coo_f32(int mode, int rows, int cols, int nnz, const int* row_indices, const int* col_indices,
                        const float* values, const float* x, float* y, void* stream) {
   return spmv_coo<float>(mode, rows, cols, nnz, row_indices, col_indices, values, x, y, as_stream(stream));
@@ -1502,7 +1288,7 @@ void loops_spmv_plan_destroy(loops_spmv_plan_t* plan) { spmv_plan_free(plan); }
 int loops_spmv_plan_info(const loops_spmv_plan_t* plan, int* layout, int* tile_config, int* num_blocks, float* ms4) {
   if (!plan) return LOOPS_E_BADARG;
   if (layout) *layout = plan->layout;
-  if (tile_config) *tile_config = plan->merge ? plan->merge->cfg : COLBLOCK_TILE;
+  if (tile_config) *tile_config = plan->merge ? plan->merge->cfg : LOOPS_TILE_512x8;  // (copies: no merge tiles; a valid id)
   if (num_blocks) *num_blocks = plan->band ? plan->band->B : plan->panel ? plan->panel->P : 0;
   if (ms4) for (int i = 0; i < 4; ++i) ms4[i] = plan->ms[i];
   return 0;

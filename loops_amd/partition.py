@@ -249,27 +249,10 @@ def chunk_bounds_from_degrees(degrees: np.ndarray, bounds: np.ndarray, chunks: i
     return out
 
 
-def column_block_bounds(owner_bounds, max_blocks: int = 8, target_bytes: int = 2 << 20, elem_bytes: int = 4):
-    """Column boundaries for the column-blocked layout of a shard (spmv.ColumnBlockedPlan): the owners'
-    row ranges (x[block k] = the y slice rank k produces), each cut into s equal pieces so that a block
-    of x is about ``target_bytes`` (half a per-XCD L2) without exceeding ``max_blocks`` (one per XCD)."""
-    owner_bounds = np.asarray(owner_bounds, np.int64)
-    world = owner_bounds.size - 1
-    widest = int(np.diff(owner_bounds).max()) if world else 0
-    s = 1
-    while world * s * 2 <= max_blocks and widest * elem_bytes // s > target_bytes:
-        s *= 2
-    out = [0]
-    for a, b in zip(owner_bounds[:-1], owner_bounds[1:]):
-        for j in range(1, s + 1):
-            out.append(int(a + (b - a) * j // s))
-    return np.asarray(out, np.int32)
-
-
 class FusedFanout:
     """allgatherv(y) fused into the SpMV epilogue: instead of exchanging its slice after the kernels, a
     rank's SpMV stores every finished row of y to the same element of every peer's full-length vector through
-    peer-mapped memory over xGMI (loops_spmv_merge_path_fanout_f32 / loops_spmv_colblock_fanout_f32).
+    peer-mapped memory over xGMI (loops_spmv_merge_path_fanout_f32 / loops_spmv_rowband_fanout_f32 / loops_spmv_panel_fanout_*).
 
     ``peer_views``: for every OTHER rank a tensor aliasing that rank's y_full (same length as the local one).  Real
     multi-GPU runs get them from :meth:`map_peers` (CUDA IPC handles exchanged over the process group); the single-GPU
@@ -280,7 +263,7 @@ class FusedFanout:
     reading: alternate between two y_full buffers, or put a barrier in front of the next ``run``."""
 
     def __init__(self, y_full: torch.Tensor, shard: Shard, peer_views, group=None):
-        assert y_full.dtype in (torch.float32, torch.float64)  # (fp64: column-blocked shards only)
+        assert y_full.dtype in (torch.float32, torch.float64)  # (fp64: panel-binned shards only)
         self.y_full, self.shard, self.group = y_full, shard, group
         self.peer_views = list(peer_views)  # keep the mappings alive
         a, b = int(shard.bounds[shard.rank]), int(shard.bounds[shard.rank + 1])

@@ -214,98 +214,6 @@ def spmv_schedule_api(schedule: str, csr: CSR, x, y=None, tile: str = "256x8"):
     return y
 
 
-# ------------------------------------------------------------------------- column-blocked CSR
-class ColumnBlockedPlan:
-    """Column-blocked ("stacked") copy of a CSR for matrices / shards whose x does not fit the per-XCD
-    L2 (loops_colblock_plan_*; include/loops/kernels/column_blocked.hxx).  ``num_blocks`` 0 = automatic;
-    ``block_bounds`` = num_blocks + 1 ascending column boundaries (multi-GPU: the owners' row ranges)."""
-
-    def __init__(self, csr: CSR, num_blocks: int = 0, block_bounds=None):
-        assert csr.values.dtype in (torch.float32, torch.float64)
-        self.dtype = csr.values.dtype
-        self._sfx = "" if self.dtype == torch.float32 else "_f64"
-        self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
-        self._h = C.c_void_p()
-        bounds = None
-        if block_bounds is not None:
-            bounds = np.ascontiguousarray(block_bounds, np.int32)
-            num_blocks = bounds.size - 1
-        create = getattr(L.lib(), "loops_colblock_plan_create" + self._sfx)
-        L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
-                                                   _ptr(csr.values), int(num_blocks),
-                                                   None if bounds is None else bounds.ctypes.data_as(C.c_void_p),
-                                                   _stream(), C.byref(self._h)), "loops_colblock_plan_create")
-        k = C.c_int()
-        L.check(L.lib().loops_colblock_plan_info(self._h, C.byref(k), None), "loops_colblock_plan_info")
-        self.num_blocks = k.value
-        b = np.zeros(self.num_blocks + 1, np.int32)
-        L.check(L.lib().loops_colblock_plan_info(self._h, None, b.ctypes.data_as(C.c_void_p)), "loops_colblock_plan_info")
-        self.block_bounds = b
-
-    @property
-    def handle(self):
-        return self._h
-
-    def arrays(self):
-        """(stacked offsets, stacked indices, stacked values, perm) copied to the host."""
-        srows = self.num_blocks * self.rows
-        off, idx = np.zeros(srows + 1, np.int32), np.zeros(self.nnz, np.int32)
-        val = np.zeros(self.nnz, np.float32 if self.dtype == torch.float32 else np.float64)
-        perm = np.zeros(self.nnz, np.int32)
-        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
-        L.check(L.lib().loops_colblock_plan_arrays(self._h, p(off), p(idx), p(val), p(perm)), "loops_colblock_plan_arrays")
-        return off, idx, val, perm
-
-    def refresh_values(self, values: torch.Tensor):
-        assert values.dtype == self.dtype and values.numel() == self.nnz
-        fn = getattr(L.lib(), "loops_colblock_plan_refresh_values" + self._sfx)
-        L.check(fn(self._h, _ptr(values), _stream()), "loops_colblock_plan_refresh_values")
-
-    def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
-        if y is None:
-            y = torch.empty(self.rows, dtype=self.dtype, device=x.device)
-        assert x.dtype == self.dtype and y.dtype == self.dtype and x.numel() == self.cols and y.numel() == self.rows
-        assert x.is_contiguous() and y.is_contiguous()
-        fn = L.lib().loops_spmv_colblock_f32 if self.dtype == torch.float32 else L.lib().loops_spmv_colblock_f64
-        L.check(fn(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock")
-        return y
-
-    def spmv_fanout(self, x, y, peers):
-        """``spmv`` whose block reduce also stores the finished y to ``peers`` (loops_spmv_colblock_fanout_f32; see
-        merge_path_flat_fanout)."""
-        assert x.dtype == self.dtype and y.dtype == self.dtype
-        assert x.numel() == self.cols and y.numel() == self.rows and x.is_contiguous() and y.is_contiguous()
-        arr, n = _peer_array(peers)
-        fn = L.lib().loops_spmv_colblock_fanout_f32 if self.dtype == torch.float32 else L.lib().loops_spmv_colblock_fanout_f64
-        L.check(fn(self._h, _ptr(x), _ptr(y), n, arr, _stream()), "loops_spmv_colblock_fanout")
-        return y
-
-    def spmv_schedule(self, schedule: str, x, y=None):
-        """y = A x with the tuned kernel of ``schedule`` (merge_path_flat / work_oriented / group_mapped) over
-        the stacked CSR (f32 plans)."""
-        assert self.dtype == torch.float32 and x.dtype == torch.float32 and x.numel() == self.cols
-        if y is None:
-            y = torch.empty(self.rows, dtype=torch.float32, device=x.device)
-        L.check(L.lib().loops_spmv_colblock_schedule_f32(self._h, L.SCHEDULES[schedule], _ptr(x), _ptr(y), _stream()),
-                "loops_spmv_colblock_schedule_f32(" + schedule + ")")
-        return y
-
-    def spmv_stage(self, stage: int, x, y):
-        L.check(L.lib().loops_spmv_colblock_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_colblock_stage_f32")
-        return y
-
-    def close(self):
-        if self._h:
-            L.lib().loops_colblock_plan_destroy(self._h)
-            self._h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
 class PanelBinnedPlan:
     """Panel-binned copy of a CSR (loops_panel_plan_*; include/loops/kernels/panel_binned.hxx): SpMV without a memory gather
     -- x panels in LDS, products streamed, one wavefront per sub-band of rows adds them up in LDS.  For x far larger than
@@ -519,7 +427,7 @@ class SpmvPlan:
     @property
     def info(self):
         return {"layout": self.layout, "tile": self.tile + ("+phased" if self.variant == L.VARIANT_PHASED else ""),
-                "column_blocks": self.num_blocks, "measured_ms": self.measured_ms}
+                "bands_or_panels": self.num_blocks, "measured_ms": self.measured_ms}
 
     def spmv(self, x: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
         c = self.csr

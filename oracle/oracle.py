@@ -284,38 +284,6 @@ def spmm(offsets, indices, values, B):
     return out
 
 
-def column_blocked(offsets, indices, values, bounds):
-    """Specification of the column-blocked ("stacked") CSR of include/loops/kernels/column_blocked.hxx
-    (our own layout -- the reference has no counterpart): stacked row k * rows + r holds the nonzeros
-    of row r with bounds[k] <= col < bounds[k + 1], in their original order.  Returns
-    (stacked offsets, stacked indices, stacked values, perm)."""
-    offsets, indices = np.asarray(offsets, np.int64), np.asarray(indices, np.int64)
-    bounds = np.asarray(bounds, np.int64)
-    rows, K = offsets.size - 1, bounds.size - 1
-    rowid = np.repeat(np.arange(rows, dtype=np.int64), np.diff(offsets))
-    blk = np.searchsorted(bounds[1:], indices, side="right")          # last k with bounds[k] <= col
-    blk = np.minimum(blk, K - 1)
-    key = blk * rows + rowid
-    perm = np.argsort(key, kind="stable")
-    soff = np.zeros(K * rows + 1, np.int64)
-    np.add.at(soff, key + 1, 1)
-    return (np.cumsum(soff).astype(np.int32), indices[perm].astype(np.int32), np.asarray(values)[perm],
-            perm.astype(np.int32))
-
-
-def auto_blocks(cols, rows, nnz, vbytes=4):
-    """K the library picks when asked for num_blocks = 0: x[block] about 2 MB, at most half the mean row
-    length (power of two, at least 2) and at most 64."""
-    k = 1
-    while k < 64 and cols * vbytes // k > (2 << 20):
-        k *= 2
-    mean = nnz // rows if rows else 0
-    cap = 2
-    while cap < 64 and cap * 2 <= mean // 2:
-        cap *= 2
-    return min(k, cap)
-
-
 # --------------------------------------------------------------------------- reference (real)
 def ref_load_mtx(path):
     r = ref()

@@ -28,7 +28,7 @@ build "$REF/examples/saxpy/saxpy.cu" "$OUT/loops.saxpy" "" &
 build "$REF/examples/range/range.cu" "$OUT/loops.range" "" &
 # this repository's own example drivers for the paths the reference does not have
 build "$ROOT/examples/spmm/merge_path_flat.cu" "$OUT/loops.spmm.merge_path_flat" "" &
-build "$ROOT/examples/spmv/column_blocked.cu" "$OUT/loops.spmv.column_blocked" "" &
+build "$ROOT/examples/spmv/rowband.cu" "$OUT/loops.spmv.rowband" "" &
 build "$ROOT/examples/spmv/spmv_plan.cu" "$OUT/loops.spmv.spmv_plan" "" &
 wait
 # which headers these binaries were built from: tests/test_examples_gpu.py refuses stale binaries

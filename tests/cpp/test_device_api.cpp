@@ -28,7 +28,7 @@
 #include <loops/algorithms/spmv/ell_merge_path.cuh>
 #include <loops/algorithms/spmm/thread_mapped.cuh>
 #include <loops/algorithms/spmm/merge_path_flat.cuh>
-#include <loops/algorithms/spmv/column_blocked.cuh>
+#include <loops/algorithms/spmv/rowband.cuh>
 #include <loops/algorithms/spmv/spmv_plan.cuh>
 
 using namespace loops;
@@ -213,27 +213,27 @@ static void misc() {
       ok = ok && std::fabs(sum - Ch[r * 10 + j]) <= 1e-3f + 1e-4f * std::fabs(sum);
     }
   CHECK(ok);
-  // column-blocked layout: same y as the plain merge_path_flat, automatic and explicit block counts
+  // row-band layout: same y as the plain merge_path_flat, automatic and smallest bands, bands cut into chunks, 8 and 16 wavefronts
   for (auto& dense : battery())
-    for (int blocks : {0, 1, 3}) {
+    for (int cfg : {0, 1, 2}) {
       hcsr_t<float> hf = from_dense<float>(dense);
       csr_t<int, int, float> a(hf);
-      if (blocks > int(hf.cols)) continue;
       vector_t<float> xb(hf.cols), y0(hf.rows), y1(hf.rows, -1.f);
       generate::random::uniform_distribution(xb.begin(), xb.end(), 1, 10, 9u);
       algorithms::spmv::merge_path_flat(a, xb, y0);
-      algorithms::spmv::column_blocked_t<int, int, float> blocked(a, blocks);
-      blocked.spmv(xb, y1);
+      algorithms::spmv::rowband_t<int, int, float> banded(a, cfg == 0 ? 0 : 64, cfg == 2 ? 5 : 0);
+      if (cfg == 2) banded.arrays.waves = 16;
+      banded.spmv(xb, y1);
       vector_t<float, H> h0(y0), h1(y1);
       bool same = true;
       for (std::size_t i = 0; i < h0.size(); ++i) same = same && std::fabs(h0[i] - h1[i]) <= 1e-3f + 1e-5f * std::fabs(h0[i]);
       CHECK(same);
-      // block reduce with the peer fan-out: y and the stand-in peer equal the blocked result bit for bit
+      // the peer fan-out: y and the stand-in peer equal the plain result bit for bit
       vector_t<float> y2(hf.rows, -1.f), peer(hf.rows, -2.f);
       kernels::peer_fanout<float> peers{};
       peers.count = 1;
       peers.base[0] = peer.data().get();
-      blocked.spmv_fanout_async(xb, y2, peers);
+      banded.spmv_fanout_async(xb, y2, peers);
       (void)xpu::stream_synchronize(0);
       vector_t<float, H> h2(y2), hp(peer);
       bool equal = true;

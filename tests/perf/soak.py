@@ -162,7 +162,7 @@ off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
 ref = torch.from_numpy(O.spmv_f32(off, idx, val, xh, omp=True)).cuda()
 csr = S.CSR.from_numpy(rows, cols, off, idx, val)
 plan = S.MergePathPlan(csr, "512x8")
-cb = S.ColumnBlockedPlan(csr)
+cb = S.RowBandPlan(csr)
 peers = [torch.empty(rows, device="cuda") for _ in range(2)]
 def fan_csr(y):
     for p in peers: p.fill_(float("nan"))
@@ -173,7 +173,7 @@ def fan_blocked(y):
     cb.spmv_fanout(x, y, peers)
     return peers
 soak("c2", "merge_path_flat + epilogue fan-out (2 peers)", fan_csr, ref, rows)
-soak("c2", "column-blocked + reduce fan-out (2 peers)", fan_blocked, ref, rows)
+soak("c2", "row-band + fan-out (2 peers)", fan_blocked, ref, rows)
 del csr, plan, cb, peers
 if only_r2:
     sys.exit(0)
@@ -187,11 +187,14 @@ for name, (deg, window) in cases.items():
     csr = S.CSR.from_numpy(rows, cols, off, idx, val)
     x = torch.from_numpy(xh).cuda()
     plans = {t: S.MergePathPlan(csr, t) for t in ("256x8", "512x8")}
-    cb = S.ColumnBlockedPlan(csr)
+    cb = S.RowBandPlan(csr)
+    cb16 = S.RowBandPlan(csr, 0, 700)
+    cb16.set_waves(16)
     kernels = {f"merge_path_flat {t} (self={int(p.self_complete)})": (lambda y, p=p: S.merge_path_flat(csr, x, y, plan=p)) for t, p in plans.items()}
     kernels["work_oriented"] = lambda y: S.spmv("work_oriented", csr, x, y)
     kernels["group_mapped"] = lambda y: S.spmv("group_mapped", csr, x, y)
-    kernels["column_blocked"] = lambda y: cb.spmv(x, y)
+    kernels["row_band"] = lambda y: cb.spmv(x, y)
+    kernels["row_band, cut bands, 16 wavefronts"] = lambda y: cb16.spmv(x, y)
     for label, fn in kernels.items():
         y = torch.empty(rows, device="cuda")
         bad = torch.zeros((), dtype=torch.int64, device="cuda")

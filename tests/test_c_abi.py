@@ -86,9 +86,9 @@ def test_argument_errors_of_the_newer_entry_points():
     assert L.loops_spmm_csr_f32(0, 4, 4, 4, None, None, None, None, 8, None, None) == -1
     assert L.loops_spmm_csr_f32(0, 4, 4, 4, None, None, None, None, -1, None, None) == -1
     assert L.loops_spmm_merge_path_f32(None, 4, 4, 4, None, None, None, None, 8, None, None) == -1
-    assert L.loops_colblock_plan_create(4, 4, 4, None, None, None, 2, None, None, None) == -1
-    assert L.loops_colblock_plan_info(None, None, None) == -1
-    assert L.loops_spmv_colblock_f32(None, None, None, None) == -1
+    assert L.loops_rowband_plan_create_f32(4, 4, 4, None, None, None, 0, 0, None, None) == -1
+    assert L.loops_rowband_plan_info(None, None) == -1
+    assert L.loops_spmv_rowband_f32(None, None, None, None) == -1
     assert L.loops_spmv_coo_f32(1, 4, 4, 4, None, None, None, None, None, None) == -1
     assert L.loops_spmv_coo_f32(7, 4, 4, 0, None, None, None, None, 1, None) == -1       # unknown mode
     assert L.loops_spmv_ell_f32(1, 4, 4, 2, None, None, None, None, None) == -1
@@ -128,4 +128,4 @@ def test_argument_errors_of_the_round_2_entry_points():
     assert L.loops_spmm_merge_path_f64(None, 4, 4, 4, None, None, None, None, 8, None, None) == -1
     # fused allgatherv: a plan is required, at most 7 peers, peer pointers must be given
     assert L.loops_spmv_merge_path_fanout_f32(None, 4, 4, 4, None, None, None, None, None, 0, None, None) == -1
-    assert L.loops_spmv_colblock_fanout_f32(None, None, None, 0, None, None) == -1
+    assert L.loops_spmv_rowband_fanout_f32(None, None, None, 0, None, None) == -1

@@ -70,10 +70,10 @@ def test_reference_spmm_saxpy_range_examples_run():
 
 
 @pytest.mark.parametrize("exe,arg", [("loops.spmm.merge_path_flat", "10"), ("loops.spmm.merge_path_flat", "64"),
-                                     ("loops.spmv.column_blocked", "0"), ("loops.spmv.column_blocked", "4"),
+                                     ("loops.spmv.rowband", "0"), ("loops.spmv.rowband", "64"),
                                      ("loops.spmv.spmv_plan", "5")])
 def test_own_examples_for_the_new_paths(exe, arg):
-    """This repository's drivers for the paths the reference does not have (tuned SpMM, column-blocked
+    """This repository's drivers for the paths the reference does not have (tuned SpMM, row-band
     SpMV, the SpMV plan): each checks itself against the reference-shaped / plain-CSR kernel and prints Errors: 0."""
     r = _run(exe, MTX, arg)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]

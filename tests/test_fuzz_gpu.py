@@ -55,14 +55,13 @@ def test_every_tuned_path_matches_the_oracle(seed, kind):
             y = torch.full((rows,), 5.0, device="cuda")
             S.merge_path_flat(csr, x, y, plan=S.MergePathPlan(csr, tile), variant=variant)
             assert np.array_equal(y.cpu().numpy(), want), ("planned", tile, variant) + tag
-    # column-blocked plans
-    for K in (0, 1, 3, 8):
-        if K > cols:
-            continue
-        cb = S.ColumnBlockedPlan(csr, K)
-        assert np.array_equal(cb.spmv(x).cpu().numpy(), want), ("blocked", K) + tag
-        for sch in ("work_oriented", "group_mapped"):
-            assert np.array_equal(cb.spmv_schedule(sch, x).cpu().numpy(), want), ("blocked", K, sch) + tag
+    # row-band copy: automatic and smallest bands, uncut and cut into chunks, both kernel shapes
+    for hb, target, waves in ((0, 0, 8), (64, 0, 16), (64, 9, 8)):
+        rb = S.RowBandPlan(csr, hb, target)
+        rb.set_waves(waves)
+        y = torch.full((rows,), 5.0, device="cuda")
+        assert np.array_equal(rb.spmv(x, y).cpu().numpy(), want), ("row_band", hb, target, waves) + tag
+        rb.close()
     # panel-binned copy (automatic and smallest sub-bands) and the measured SpMV plan that may pick it
     # (both forms of the B order: one slot per nonzero, and -- compact -- one per run of equal (row, panel) pre-summed by kernel A;
     # with <= 9000 columns everything is one panel, so a row is one run cut only at kernel A's 256-item windows)

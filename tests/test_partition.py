@@ -97,49 +97,6 @@ def test_allgatherv_gloo(world):
     assert all(ok for _, ok in res) and len(res) == world
 
 
-def test_column_block_bounds_follow_owner_ranges():
-    """Blocks never straddle an owner's range; each owner's range is cut into equal pieces until a block
-    of x is <= 2 MB or 8 blocks are reached."""
-    from loops_amd import partition as P
-    owners = np.array([0, 1_000_000, 2_100_000, 3_000_000, 4_194_304], np.int64)   # 4 ranks, x = 16 MB
-    b = P.column_block_bounds(owners)
-    assert b[0] == 0 and b[-1] == owners[-1] and np.all(np.diff(b) >= 0) and b.size - 1 == 8
-    assert set(owners.tolist()) <= set(b.tolist())
-    assert P.column_block_bounds(np.array([0, 1 << 20])).size - 1 == 2            # N = 1: 4 MB -> 2 blocks
-    assert P.column_block_bounds(np.arange(9) << 20).size - 1 == 8                # N = 8: one block per owner
-    assert P.column_block_bounds(np.array([0, 1000, 2000])).tolist() == [0, 1000, 2000]   # small x: owners only
-
-
-def test_chunk_bounds_from_degrees_cover_each_slice():
-    from loops_amd import generate as G, partition as P
-    deg = G.powerlaw_degrees(1 << 13, 1 << 17, cap=1 << 11)
-    bounds = P.row_ranges_from_degrees(deg, 4)
-    cb = P.chunk_bounds_from_degrees(deg, bounds, 3)
-    assert len(cb) == 4
-    for r in range(4):
-        assert cb[r][0] == bounds[r] and cb[r][-1] == bounds[r + 1] and cb[r].size == 4 and (np.diff(cb[r]) >= 0).all()
-
-
-def test_column_block_bounds_respect_owners_and_budget():
-    """Column blocks of a shard's blocked layout: the owners' row ranges are always block boundaries (block k of x is the
-    slice some rank sends), the pieces are cut towards ~2 MB of x without exceeding the block budget, and the bounds are a
-    valid partition of the columns -- for the world sizes and budgets bench.py uses (C2-like: 8, C5: 16)."""
-    from loops_amd import partition as P
-    for world in (1, 2, 3, 4, 8):
-        for cols, max_blocks in ((1 << 20, 8), (1 << 24, 16), (999_983, 8), (1 << 24, 64)):
-            rng = np.random.default_rng(world + max_blocks)
-            cuts = np.sort(rng.choice(np.arange(1, cols), size=world - 1, replace=False)) if world > 1 else np.zeros(0, np.int64)
-            owners = np.concatenate([[0], cuts, [cols]]).astype(np.int64)
-            b = P.column_block_bounds(owners, max_blocks=max(max_blocks, world))
-            assert b[0] == 0 and b[-1] == cols and np.all(np.diff(b) >= 0)
-            assert set(owners.tolist()) <= set(b.tolist())                       # owners' boundaries are kept
-            k = b.size - 1
-            assert k % world == 0 and k <= max(max_blocks, world)                # s pieces per owner, within the budget
-            s = k // world
-            if world * s * 2 <= max(max_blocks, world):                          # stopped early only because pieces are small enough
-                assert int(np.diff(owners).max()) * 4 // s <= (2 << 20)
-
-
 def test_native_row_ranges_match_the_numpy_specification():
     """loops_row_ranges (include/loops/multi_gpu/partition.hxx through the C ABI: the kernels' own search on N - 1 diagonals,
     a host function -- no GPU needed) against the numpy / Python-integer specification: battery matrices, power-law degrees,

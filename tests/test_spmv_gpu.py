@@ -376,14 +376,14 @@ def test_bench_two_ranks_functional():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parity_vs_oracle_bit_exact"] is True
     assert "configs[4]" in d["config"]["baseline_config"] and f"{1 << 17} rows / {1 << 21} nnz" in d["config"]["workload"]
     one = d["config"]["one_gpu_same_matrix"]
-    assert one["csr_equals_gathered_y_bit_for_bit"] is True and one["blocked_equals_gathered_y_bit_for_bit"] is True
+    assert one["csr_equals_gathered_y_bit_for_bit"] is True and one["planned_equals_gathered_y_bit_for_bit"] is True
     assert one["best_ms_per_spmv"] > 0 and d["config"]["speedup_vs_one_gpu_same_matrix"]["spmv_plus_allgatherv"] > 0
     assert d["config"]["spmv_only_ms_per_step"] > 0 and d["config"]["spmv_plus_allgatherv_ms_per_step"] == d["ms_per_step"]
     assert d["value"] > 0 and d["cpu_baseline"] is None
     # the N > 1 default: whichever re-ordered copy probes faster on the worst rank, the same on every rank
-    assert d["config"]["shard_layout"].startswith(("column-blocked by owner", "panel-binned"))
-    assert set(d["config"]["shard_layout_probe_ms"]) == {"blocked", "panel"}
-    for forced, prefix in (("blocked", "column-blocked by owner"), ("panel", "panel-binned")):
+    assert d["config"]["shard_layout"].startswith(("row-band", "panel-binned"))
+    assert set(d["config"]["shard_layout_probe_ms"]) == {"rowband", "panel"}
+    for forced, prefix in (("rowband", "row-band"), ("panel", "panel-binned")):
         r = subprocess.run(cmd + ["--layout", forced, "--no-one-gpu-reference"], capture_output=True, text=True, timeout=300, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-3000:]
         dl = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -431,6 +431,27 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["config"]["parity_vs_oracle_bit_exact"] is True
     regions = d["config"]["timed_regions_ms_per_step"]
     assert len(regions) >= 5 and abs(d["ms_per_step"] - float(np.median(regions))) < 1e-4
+    # the scaling curve's figures at the top level, and its like-for-like first point: the SAME matrix through `--gpus 1 --scaling
+    # strong` (the timed step of N > 1 minus the exchange, the shard -- here the whole matrix -- in the probed re-ordered copy)
+    sd = d["scaling_detail"]
+    assert d["scaling"] == "strong" and sd["workload"] == "c5" and sd["rows"] == 1 << 17 and sd["nnz"] == 1 << 21
+    assert sd["exchange"] in d["config"]["allgatherv_probe_ms_per_step"] and sd["shard_layout"] in ("rowband", "panel")
+    assert sd["spmv_only_ms_per_step"] > 0 and sd["like_for_like_first_point"] == "python bench.py --gpus 1 --scaling strong"
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong", "--steps", "5", "--warmup", "2",
+                          "--c5-log2-rows", "17", "--c5-log2-nnz", "21"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["parity_vs_oracle_bit_exact"] is True
+    assert d1["scaling_detail"]["rows"] == sd["rows"] and d1["scaling_detail"]["nnz"] == sd["nnz"] and d1["scaling_detail"]["exchange"] is None
+    assert d1["scaling_detail"]["shard_layout"] in ("rowband", "panel") and f"{1 << 17} rows / {1 << 21} nnz" in d1["config"]["workload"]
+    # BASELINE C2 "reported at 1, 2, 4 and 8 GPUs": the C2 matrix as ONE matrix cut into N row ranges
+    c2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--steps", "5", "--warmup", "2",
+                         "--backend", "gloo", "--single-device", "--log2-rows", "16", "--log2-nnz", "20", "--no-one-gpu-reference"],
+                        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert c2.returncode == 0, c2.stderr[-3000:]
+    dc = json.loads([ln for ln in c2.stdout.splitlines() if ln.startswith("{")][0])
+    assert dc["scaling"] == "strong" and dc["scaling_detail"]["workload"] == "c2" and dc["scaling_detail"]["rows"] == 1 << 16
+    assert "configs[1] (C2)" in dc["config"]["baseline_config"] and dc["config"]["parity_vs_oracle_bit_exact"] is True
     # a rank that dies takes the job down with a non-zero status (an unknown exchange name fails on every rank)
     r = subprocess.run(cmd + ["--exchange", "no-such-exchange"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -514,7 +535,7 @@ def test_planless_calls_on_two_streams_do_not_share_scratch():
             assert np.array_equal(y.cpu().numpy(), ref), sched
 
 
-@pytest.mark.parametrize("layout", ["csr", "blocked"])
+@pytest.mark.parametrize("layout", ["csr", "row_band", "panel"])
 def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
     """SURVEY 8 f2 as far as one GPU allows: the SpMV of every simulated rank also stores its finished rows to the
     "peers" -- here distinct full-length buffers on the same device standing in for peer-mapped memory.  After all
@@ -539,12 +560,12 @@ def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
                 plan = S.MergePathPlan(csr, "512x8")
                 fan.run(lambda y, peers: S.merge_path_flat_fanout(csr, x, y, plan, peers))
             else:
-                cb = S.ColumnBlockedPlan(csr, block_bounds=P.column_block_bounds(bounds, max_blocks=max(8, world)))
+                cb = S.RowBandPlan(csr, 0, 40) if layout == "row_band" else S.PanelBinnedPlan(csr)   # (cut bands: the combine kernel fans out)
                 fan.run(lambda y, peers: cb.spmv_fanout(x, y, peers))
             torch.cuda.synchronize()
         for rank in range(world):
             assert np.array_equal(fulls[rank].cpu().numpy(), ref), (layout, world, rank)
-    if layout == "blocked":  # the fp64 twin of the block-reduce fan-out
+    if layout == "panel":  # the fp64 twin of the panel-binned fan-out
         world = 3
         ref64 = O.spmv_f64(off, idx, val.astype(np.float64), xh.astype(np.float64))
         bounds = P.row_ranges(off.astype(np.int64), world)
@@ -552,17 +573,17 @@ def test_fused_allgatherv_epilogue_stores_on_one_gpu(layout):
         for rank in range(world):
             shard = P.Shard(rank, world, int(bounds[rank]), int(bounds[rank + 1]), bounds)
             so, si, sv = P.slice_csr(off, idx, val, shard.row_begin, shard.row_end)
-            cb = S.ColumnBlockedPlan(_dev(so, si, sv.astype(np.float64), shard.row_end - shard.row_begin, cols), 4)
+            cb = S.PanelBinnedPlan(_dev(so, si, sv.astype(np.float64), shard.row_end - shard.row_begin, cols))
             fan = P.FusedFanout(fulls[rank], shard, [fulls[p] for p in range(world) if p != rank])
             fan.run(lambda y, peers: cb.spmv_fanout(x.double(), y, peers))
             torch.cuda.synchronize()
         for rank in range(world):
-            assert np.array_equal(fulls[rank].cpu().numpy(), ref64), ("blocked f64", rank)
+            assert np.array_equal(fulls[rank].cpu().numpy(), ref64), ("panel f64", rank)
 
 
 def test_c5_full_size_all_eight_shards_with_fanout():
     """BASELINE config C5 at FULL size on one GPU: the 2^24-row / 2^29-nnz matrix cut into the 8 owner row ranges
-    bench.py --gpus 8 uses; every shard is run in the N > 1 default layout (column-blocked by owner, 16 blocks) through
+    bench.py --gpus 8 uses; every shard is run panel-binned (the N > 1 default layout on this input) through
     the fan-out entry with the other seven y_full buffers as its peers -- the full-size twin of
     test_fused_allgatherv_epilogue_stores_on_one_gpu.  Each of the eight vectors must equal the oracle's y AND the y of
     the whole matrix as ONE unmodified CSR on this GPU, bit for bit.  The chunked-overlap candidate's kernels (each
@@ -575,8 +596,6 @@ def test_c5_full_size_all_eight_shards_with_fanout():
     degrees = G.powerlaw_degrees(rows, nnz)
     assert int(degrees.sum()) == nnz
     bounds = P.row_ranges_from_degrees(degrees, world)
-    col_bounds = P.column_block_bounds(bounds, max_blocks=16)   # bench.py's choice at 32 nnz / row
-    assert col_bounds.size - 1 == 16
     xh = G.uniform_distribution_int(cols)
     x = torch.from_numpy(xh).cuda()
     fulls = [torch.full((rows,), float("nan"), device="cuda") for _ in range(world)]
@@ -589,27 +608,27 @@ def test_c5_full_size_all_eight_shards_with_fanout():
         assert abs(idx.size - nnz // world) < nnz // world // 50     # balanced by rows + nnz: within 2 % of 2^26
         ref[a:b] = O.spmv_f32(off, idx, val, xh, omp=True)
         csr = S.CSR.from_numpy(b - a, cols, off, idx, val)
-        cb = S.ColumnBlockedPlan(csr, block_bounds=col_bounds)
+        cb = S.PanelBinnedPlan(csr)
         fan = P.FusedFanout(fulls[rank], shard, [fulls[p] for p in range(world) if p != rank])
         fan.run(lambda y, peers: cb.spmv_fanout(x, y, peers))
         torch.cuda.synchronize()
         cb.close()
-        # the other shard layout of bench.py --gpus N: panel-binned, same fan-out contract (into rank (r + 1) % 8's buffer only:
+        # the other shard layout of bench.py --gpus N: row-band, same fan-out contract (into rank (r + 1) % 8's buffer only:
         # every buffer already holds this slice, so a wrong store would show)
-        pb = S.PanelBinnedPlan(csr)
-        y_pb = torch.full((b - a,), float("nan"), device="cuda")
-        pb.spmv_fanout(x, y_pb, [fulls[(rank + 1) % world][a:b]])
+        rb = S.RowBandPlan(csr)
+        y_rb = torch.full((b - a,), float("nan"), device="cuda")
+        rb.spmv_fanout(x, y_rb, [fulls[(rank + 1) % world][a:b]])
         torch.cuda.synchronize()
-        assert np.array_equal(y_pb.cpu().numpy(), ref[a:b]), ("panel-binned", rank)
-        pb.close()
-        # the chunked candidate: two row chunks with their own column-blocked plans
+        assert np.array_equal(y_rb.cpu().numpy(), ref[a:b]), ("row-band", rank)
+        rb.close()
+        # the chunked candidate: two row chunks with their own panel-binned plans
         y_chunks = torch.full((b - a,), float("nan"), device="cuda")
         mine = chunk_bounds[rank] - a
         for c in range(2):
             ca, cz = int(mine[c]), int(mine[c + 1])
             so, si, sv = P.slice_csr(off, idx, val, ca, cz)
             sub = S.CSR.from_numpy(cz - ca, cols, so, si, sv)
-            pl = S.ColumnBlockedPlan(sub, block_bounds=col_bounds)
+            pl = S.PanelBinnedPlan(sub)
             pl.spmv(x, y_chunks[ca:cz])
             torch.cuda.synchronize()
             pl.close()
@@ -671,7 +690,8 @@ def test_non_finite_x_stays_in_its_rows():
     runs = {sch: S.spmv(sch, csr, x) for sch in ("merge_path_flat", "work_oriented", "group_mapped", "thread_mapped")}
     for tile in ("256x8", "512x8", "128x7"):
         runs["planned " + tile] = S.merge_path_flat(csr, x, plan=S.MergePathPlan(csr, tile))
-    runs["column-blocked"] = S.ColumnBlockedPlan(csr, 4).spmv(x)
+    runs["row-band"] = S.RowBandPlan(csr).spmv(x)
+    runs["row-band, cut bands"] = S.RowBandPlan(csr, 4096, 37).spmv(x)
     for name, y in runs.items():
         y = y.cpu().numpy()
         assert np.array_equal(np.isnan(y), np.isnan(ref)), name             # NaN rows: the same set
@@ -686,7 +706,7 @@ def test_non_finite_x_stays_in_its_rows():
 
 
 def test_held_plans_are_hip_graph_capturable():
-    """A step built from held plans (merge-path plan, column-blocked plan, BCSR) makes no allocation and no
+    """A step built from held plans (merge-path plan, row-band plan, BCSR) makes no allocation and no
     synchronisation: it can be captured into a HIP graph on the caller's stream and replayed -- the launch-bound end of
     the path (small matrices, many right-hand sides in a solver loop) without per-launch host work."""
     from loops_amd import spmv as S, generate as G
@@ -696,7 +716,7 @@ def test_held_plans_are_hip_graph_capturable():
     off, idx, val = G.csr_from_degrees(deg, cols, 1)
     csr = _dev(off, idx, val, rows, cols)
     plan = S.MergePathPlan(csr, "512x8")
-    cb = S.ColumnBlockedPlan(csr, 4)
+    cb = S.RowBandPlan(csr, 1024, 40)
     xs = [G.uniform_distribution_int(cols, seed=s) for s in (42, 7)]
     x = torch.from_numpy(xs[0]).cuda()
     y1, y2, y3 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
