@@ -17,8 +17,6 @@
 #pragma once
 
 #include <cstddef>
-#include <cstdio>
-#include <cstdlib>
 #include <type_traits>
 
 #include <hip/hip_runtime.h>
@@ -201,89 +199,6 @@ bcsr4x4_mfma_spmv(const int rows, const int num_block_rows, const int* __restric
   }
 }
 
-/// EXPERIMENT (round 5, LOOPS_BCSR_PHASED): the C2 mechanism -- phased x gathers -- in the 4 x 4 MFMA kernel.  A wavefront owns one
-/// group of 4 block-rows (H = 4) and takes 16 blocks of each per batch: the batch's block rows and columns are streamed first,
-/// then the 16-byte x gathers leave in M passes by block-column range (execution-masked, each pass drained), the pass a
-/// wavefront starts with read off the shared clock, then the MFMAs run in the blocks' order (same products, same order, same
-/// bits as bcsr4x4_mfma_spmv<.., 4>).
-template <int TPB, int M>
-__global__ void __launch_bounds__(TPB)
-bcsr4x4_mfma_spmv_phased(const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
-                         const int* __restrict__ block_cols, const float* __restrict__ values, const float* __restrict__ x,
-                         float* __restrict__ y, const unsigned int shift, const unsigned int inv_ticks) {
-  constexpr int H = 4, SLOTS = 4, U = 4;
-  const int lane = wave::lane();
-  const int q = lane >> 2, slot = q / H, h = q % H, i = lane & 3;
-  const long long g = (static_cast<long long>(blockIdx.x) * TPB + threadIdx.x) / wave::size;
-  const long long total_groups = (static_cast<long long>(num_block_rows) + SLOTS - 1) / SLOTS;
-  if (g >= total_groups) return;  // (wave-uniform)
-  const long long br = g * SLOTS + slot;
-  int beg = 0, len = 0;
-  if (br < num_block_rows) {
-    beg = block_offsets[br];
-    len = block_offsets[br + 1] - beg;
-  }
-  int steps = (len + H - 1) / H;
-#pragma unroll
-  for (int d = 32; d >= 4; d >>= 1) {
-    const int o = __shfl_xor(steps, d);
-    steps = o > steps ? o : steps;
-  }
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < steps; k0 += U) {
-    f32x4 a[U], xv[U];
-    int bc[U];
-    bool live[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = (k0 + u) * H + h;
-      live[u] = k < len;
-      const int b = live[u] ? beg + k : 0;
-      a[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(values + static_cast<size_t>(b) * 16 + i * 4));
-      bc[u] = __builtin_nontemporal_load(block_cols + b);
-      if (!live[u]) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      xv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const unsigned int now = static_cast<unsigned int>(__builtin_amdgcn_s_memrealtime());
-    const unsigned int first = __umulhi(now, inv_ticks) & (M - 1);
-#pragma unroll
-    for (unsigned int pp = 0; pp < M; ++pp) {
-      const unsigned int p = (pp + first) & (M - 1);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        unsigned int part = static_cast<unsigned int>(bc[u]) >> shift;
-        part = part < M - 1 ? part : M - 1;
-        if (part == p && live[u]) xv[u] = *reinterpret_cast<const f32x4*>(x + static_cast<size_t>(bc[u]) * 4);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].x, xv[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].y, xv[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].z, xv[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[u].w, xv[u].w, acc, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int d = 4; d < 4 * H; d <<= 1) {
-    acc.x += __shfl_xor(acc.x, d);
-    acc.y += __shfl_xor(acc.y, d);
-    acc.z += __shfl_xor(acc.z, d);
-    acc.w += __shfl_xor(acc.w, d);
-  }
-  if (i == 0 && h == 0 && br < num_block_rows) {
-    const long long r0 = br * 4;
-    if (r0 + 3 < rows) {
-      *reinterpret_cast<f32x4*>(y + r0) = acc;
-    } else {
-      if (r0 + 0 < rows) y[r0 + 0] = acc.x;
-      if (r0 + 1 < rows) y[r0 + 1] = acc.y;
-      if (r0 + 2 < rows) y[r0 + 2] = acc.z;
-    }
-  }
-}
-
 /// `unroll`: steps in flight (1, 2, 4, 8); `h`: blocks of one block-row per step.  0 = automatic from the
 /// mean blocks per block-row m: h = 1 (m < 1.5), 2 (m < 3), else 4; unroll = the power of two covering
 /// m / (2 h), at most 8 (C4, m = 16: h = 4, unroll = 2 -- 69.0 us against 72.1 us for unroll = 4 by rocprofv3's kernel
@@ -298,22 +213,6 @@ inline int launch_bcsr4x4_mfma(hipStream_t stream, int rows, int num_block_rows,
     // no block at all: y = 0.  The kernel's masked-off steps read block 0 ("an in-bounds index whenever a block
     // exists"), and the caller may pass null block_cols / values / x for an empty matrix.
     return rows > 0 ? static_cast<int>(hipMemsetAsync(y, 0, sizeof(float) * static_cast<size_t>(rows), stream)) : 0;
-  }
-  if (const char* e = std::getenv("LOOPS_BCSR_PHASED")) {  // EXPERIMENT: "parts,shift,ticks" (parts in {2, 4, 8}; ticks of 10 ns per pass)
-    int parts = 0, shift = 0, ticks = 0;
-    if (std::sscanf(e, "%d,%d,%d", &parts, &shift, &ticks) == 3 && ticks > 1) {
-      const long long groups4 = math::ceil_div(static_cast<long long>(num_block_rows), 4ll);
-      const dim3 grid(static_cast<unsigned>(math::ceil_div(groups4, static_cast<long long>(TPB / 64))));
-      const unsigned int inv = static_cast<unsigned int>(4294967296.0 / ticks);
-      auto run = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, dim3(TPB), 0, stream, rows, num_block_rows, block_offsets, block_cols, values, x, y,
-                           static_cast<unsigned int>(shift), inv);
-      };
-      if (parts == 2) run(bcsr4x4_mfma_spmv_phased<TPB, 2>);
-      else if (parts == 4) run(bcsr4x4_mfma_spmv_phased<TPB, 4>);
-      else run(bcsr4x4_mfma_spmv_phased<TPB, 8>);
-      return static_cast<int>(hipGetLastError());
-    }
   }
   const double mean = static_cast<double>(num_blocks) / num_block_rows;
   if (h == 0) h = mean < 1.5 ? 1 : mean < 3 ? 2 : 4;
