@@ -180,6 +180,29 @@ void loops_gen_x_int(long long start, long long n, int lo, int hi, unsigned seed
   }
 }
 
+
+// R-MAT / Kronecker edges (generate.py::rmat_edges is the specification): edge e draws one hashed u per level,
+// u = (splitmix64(splitmix64(seed) + e * 64 + level) >> 11) * 2^-53, and descends into quadrant (0,0) | (0,1) | (1,0) | (1,1)
+// for u < a | < a + b | < a + b + c | else (Graph500: a, b, c = 0.57, 0.19, 0.19); level 0 sets the most significant bit.
+void loops_gen_rmat_edges(int scale, long long nedges, double a, double b, double c, unsigned long long seed, int* row, int* col) {
+  const std::uint64_t base = splitmix64(seed);
+  const double ab = a + b, abc = a + b + c;
+#pragma omp parallel for schedule(static)
+  for (long long e = 0; e < nedges; ++e) {
+    std::uint32_t r = 0, cc = 0;
+    for (int level = 0; level < scale; ++level) {
+      const std::uint64_t h = splitmix64(base + static_cast<std::uint64_t>(e) * 64ull + static_cast<std::uint64_t>(level));
+      const double u = static_cast<double>(h >> 11) * (1.0 / 9007199254740992.0);
+      const std::uint32_t rb = u >= ab ? 1u : 0u;
+      const std::uint32_t cb = (u >= a && u < ab) || u >= abc ? 1u : 0u;
+      r = (r << 1) | rb;
+      cc = (cc << 1) | cb;
+    }
+    row[e] = static_cast<int>(r);
+    col[e] = static_cast<int>(cc);
+  }
+}
+
 }  // extern "C"
 
 #include <omp.h>

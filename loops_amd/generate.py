@@ -76,6 +76,8 @@ def native(required: bool = False):
         L.loops_gen_csr_rows_hosts.argtypes = [vp, vp, ll, ll, C.c_ulonglong, ll, C.c_int, vp, ll, vp, vp]
         L.loops_gen_x_int.argtypes = [ll, ll, C.c_int, C.c_int, C.c_uint, vp]
         L.loops_gen_x_int.restype = None
+        L.loops_gen_rmat_edges.argtypes = [C.c_int, ll, C.c_double, C.c_double, C.c_double, C.c_ulonglong, vp, vp]
+        L.loops_gen_rmat_edges.restype = None
         L.loops_gen_set_threads.argtypes = [C.c_int]
         L.loops_gen_set_threads.restype = None
         L.loops_gen_set_threads(usable_cpus())
@@ -305,6 +307,61 @@ def powerlaw_csr(rows, cols, nnz, alpha=0.8, cap=1 << 14, seed=1, row_begin=0, r
 def realistic_x(n, seed=7, start=0):
     h = splitmix64(np.arange(start, start + n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B9))
     return (0.5 + (h >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------ R-MAT (Graph500-like graphs)
+def rmat_edges(scale, nedges, a=0.57, b=0.19, c=0.19, seed=1, native=None):
+    """Directed R-MAT / Kronecker edges over 2^scale vertices (Graph500: a, b, c = 0.57, 0.19, 0.19, d = 1 - a - b - c): edge e
+    draws one hashed u per level -- u = (splitmix64(splitmix64(seed) + 64 e + level) >> 11) 2^-53 -- and descends into quadrant
+    (row bit, column bit) = (0, 0) | (0, 1) | (1, 0) | (1, 1) for u < a | < a + b | < a + b + c | else; level 0 sets the most
+    significant bit.  Counter-based (any range of edges independently); low vertex ids are the hubs.  -> (row, col) int32."""
+    lib = _use_native(native)
+    if lib is not None:
+        row, col = np.empty(nedges, np.int32), np.empty(nedges, np.int32)
+        lib.loops_gen_rmat_edges(int(scale), int(nedges), float(a), float(b), float(c), int(seed), row.ctypes.data, col.ctypes.data)
+        return row, col
+    base = splitmix64(np.array([seed], np.uint64))[0]
+    e = np.arange(nedges, dtype=np.uint64) * np.uint64(64)
+    row, col = np.zeros(nedges, np.int64), np.zeros(nedges, np.int64)
+    for level in range(scale):
+        u = (splitmix64(base + e + np.uint64(level)) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        rb = (u >= a + b).astype(np.int64)
+        cb = (((u >= a) & (u < a + b)) | (u >= a + b + c)).astype(np.int64)
+        row, col = (row << 1) | rb, (col << 1) | cb
+    return row.astype(np.int32), col.astype(np.int32)
+
+
+def rmat_csr(scale, edge_factor=16, a=0.57, b=0.19, c=0.19, seed=1, relabel="random", native=None):
+    """The adjacency matrix of an R-MAT graph as a CSR (2^scale rows and columns, edge_factor * 2^scale nonzeros, multi-edges kept
+    as separate nonzeros, columns sorted inside a row, values k/8: exactly summable with integer x).  ``relabel``:
+    "none"    the generator's own ids: hubs at the low ids, the recursive quadrant structure shows as locality;
+    "random"  a hashed permutation of the ids (what Graph500 prescribes: no locality left);
+    "degree"  ids by descending out-degree (a locality-restoring order: hub rows first, hub columns adjacent).
+    -> (offsets int32, indices int32, values float32)"""
+    n, nedges = 1 << scale, edge_factor << scale
+    row, col = rmat_edges(scale, nedges, a, b, c, seed, native)
+    row, col = row.astype(np.int64), col.astype(np.int64)
+    if relabel == "random":
+        perm = np.argsort(splitmix64(np.arange(n, dtype=np.uint64) ^ np.uint64(seed * 0x9E3779B97F4A7C15 & 0xFFFFFFFFFFFFFFFF)), kind="stable")
+        new_id = np.empty(n, np.int64)
+        new_id[perm] = np.arange(n)
+        row, col = new_id[row], new_id[col]
+    elif relabel == "degree":
+        deg = np.bincount(row, minlength=n) + np.bincount(col, minlength=n)
+        order = np.argsort(-deg, kind="stable")
+        new_id = np.empty(n, np.int64)
+        new_id[order] = np.arange(n)
+        row, col = new_id[row], new_id[col]
+    elif relabel != "none":
+        raise ValueError("relabel: none | random | degree")
+    key = (row << 32) | col
+    key.sort()
+    row, col = key >> 32, key & 0xFFFFFFFF
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum(np.bincount(row, minlength=n), out=offsets[1:])
+    vh = splitmix64(np.arange(nedges, dtype=np.uint64) + np.uint64(seed) * np.uint64(7919))
+    values = (((vh >> np.uint64(33)) % np.uint64(8)) + np.uint64(1)).astype(np.float32) / np.float32(8)
+    return offsets.astype(np.int32), col.astype(np.int32), values
 
 
 # ------------------------------------------------------------------------------ BCSR

@@ -8,7 +8,11 @@ src=open("tests/perf/sweep_structures.py").read()
 pre=src[:src.index("so = os.path.join")]
 exec(pre)
 for name,(deg,cols,window) in cases.items():
-    off, idx, val = scale_free(deg, cols) if isinstance(window, str) else chunked(deg, cols, window)
+    if isinstance(window, str) and window.startswith("rmat:"):
+        off, idx, val = G.rmat_csr(20, 16, relabel=window[5:])
+        deg = np.diff(off.astype(np.int64))
+    else:
+        off, idx, val = scale_free(deg, cols) if isinstance(window, str) else chunked(deg, cols, window)
     csr = S.CSR.from_numpy(deg.size, cols, off, idx, val)
     print(f"{name:50s} guess_scattered={S.columns_look_scattered(csr)}", flush=True)
     del csr

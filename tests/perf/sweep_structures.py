@@ -54,6 +54,11 @@ cases["extreme skew: 64 rows hold ~all nnz"] = (d, 1 << 18, None)
 d = np.where(np.arange(1 << 21) % 4 == 0, 32, 0).astype(np.int64)
 cases["75 % empty rows, degree 32 otherwise"] = (d, 1 << 21, None)
 
+# round 5: closer proxies of real graphs -- R-MAT / Kronecker (Graph500 a, b, c = 0.57, 0.19, 0.19), 2^20 vertices, 16 edges per
+# vertex: labels scattered (what Graph500 prescribes), the generator's own order, and relabelled by degree (locality restored)
+for relabel in ("random", "none", "degree"):
+    cases[f"R-MAT scale 20 x 16, labels: {relabel}"] = (None, 1 << 20, "rmat:" + relabel)
+
 so = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "oracle", "_ref", "libloops_ref_gpu.so")
 R = _lib.load_shared(so) if os.path.exists(so) else None
 only = [a for a in sys.argv[1:] if not a.startswith("-")]   # optional: substrings of the case names to run
@@ -61,7 +66,11 @@ out = {}
 for name, (deg, cols, window) in cases.items():
     if only and not any(o in name for o in only):
         continue
-    off, idx, val = scale_free(deg, cols) if isinstance(window, str) else chunked(deg, cols, window)
+    if isinstance(window, str) and window.startswith("rmat:"):
+        off, idx, val = G.rmat_csr(20, 16, relabel=window[5:])
+        deg = np.diff(off.astype(np.int64))
+    else:
+        off, idx, val = scale_free(deg, cols) if isinstance(window, str) else chunked(deg, cols, window)
     rows, nnz = deg.size, int(off[-1])
     xh = G.uniform_distribution_int(cols)
     ref = O.spmv_f32(off, idx, val, xh, omp=True)

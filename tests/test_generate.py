@@ -77,3 +77,27 @@ def test_native_builder_equals_the_numpy_specification():
     a = G.csr_from_degrees(deg, 64, 5, 0, True, None, native=False)
     b = G.csr_from_degrees(deg, 64, 5, 0, True, None, native=True)
     assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+def test_rmat_generator_native_equals_specification_and_is_scale_free():
+    """R-MAT / Kronecker graphs (Graph500 a, b, c = 0.57, 0.19, 0.19; round 5: closer proxies of real graphs than hashed columns):
+    the native edge generator equals the numpy specification bit for bit; the CSR keeps every edge, columns sorted inside a row;
+    relabelling permutes ids without changing the degree multiset; the degree distribution is heavy-tailed."""
+    from loops_amd import generate as G
+    r0, c0 = G.rmat_edges(12, 1 << 16, native=False)
+    if G.native() is not None:
+        r1, c1 = G.rmat_edges(12, 1 << 16, native=True)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
+    assert r0.min() >= 0 and r0.max() < 1 << 12 and c0.min() >= 0 and c0.max() < 1 << 12
+    degs = {}
+    for relabel in ("none", "random", "degree"):
+        off, idx, val = G.rmat_csr(12, 16, relabel=relabel, native=False)
+        assert off[0] == 0 and off[-1] == 16 << 12 and idx.size == 16 << 12 and val.min() > 0
+        rows = np.repeat(np.arange(1 << 12), np.diff(off))
+        assert np.all(np.diff((rows.astype(np.int64) << 32) | idx) >= 0)       # sorted by (row, column), multi-edges kept
+        degs[relabel] = np.sort(np.diff(off))
+    assert np.array_equal(degs["none"], degs["random"]) and np.array_equal(degs["none"], degs["degree"])
+    assert degs["none"][-1] > 50 * 16 and (degs["none"] == 0).mean() > 0.2      # hubs and many isolated vertices
+    off, _, _ = G.rmat_csr(12, 16, relabel="degree", native=False)
+    d = np.diff(off)
+    assert d[:64].sum() > d[-2048:].sum()                                        # hub rows come first after the relabel
