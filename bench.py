@@ -753,7 +753,7 @@ def main():
                 roofline["panel_reduce_avg_launch_ms" if shard_kind == "panel" else "rowband_combine_avg_launch_ms"] = round(K_["reduce_avg"], 5)
         mode = gather_mode["mode"] if watchdog is None else safe["mode"]
         one_gpu, spmv_only_ms = R_["one_gpu"], K_["spmv_only_ms"]
-        step_includes = {"csr": "fused merge-tile kernel" + (" (phased x gathers: 8 passes by column range, clock-aligned across workgroups)"
+        step_includes = {"csr": "fused merge-tile kernel" + (f" (phased x gathers: {8 if cols * 4 <= (6 << 20) else 16 if cols * 4 <= (24 << 20) else 32} passes by column range, clock-aligned across workgroups)"
                                                             if args.variant == VARIANT_PHASED else "") + " + carry-out fix-up", "rowband": "row-band accumulate (band sums in LDS) + combine of the cut bands",
                          "panel": "panel products (x panels in LDS) + sub-band reduce"}[shard_kind]
         if world > 1:
@@ -797,6 +797,8 @@ def main():
                        "ms_per_step_with_prepass": None if R_["ms_with_prepass"] is None else round(R_["ms_with_prepass"], 5),
                        "timed_regions_ms_per_step": regions["ms_per_step"],
                        "timed_region_statistic": "median of the K-step regions listed in timed_regions_ms_per_step",
+                       # the single contract-bracketed region (W warm-up steps, then exactly K steps between barrier + synchronize):
+                       "first_region_ms_per_step": regions["ms_per_step"][0] if regions["ms_per_step"] else None,
                        "achieved_GBps_whole_step": round(algorithmic_bytes(rows, cols, nnz) / world / (ms_per_step * 1e-3) / 1e9, 1),
                        "spmv_only_ms_per_step": None if spmv_only_ms is None else round(spmv_only_ms, 5),
                        "spmv_only_GFLOPs": None if spmv_only_ms is None else round(2.0 * nnz / (spmv_only_ms * 1e-3) / 1e9, 2),

@@ -348,15 +348,20 @@ __device__ __forceinline__ void load_x_panel(type_t* __restrict__ xs, const type
 }
 
 /// 16 bytes of a group's products to `to`.
+/// (`to` is aligned to the element only -- the compact B order starts a group's slots wherever its runs begin -- so the vector
+/// types are declared element-aligned: one global_store_dwordx4 either way, without the undefined behaviour of a misaligned
+/// naturally-aligned vector store.)
 template <typename type_t>
 __device__ __forceinline__ void store4(type_t* __restrict__ to, const type_t a, const type_t b, const type_t c, const type_t d) {
   if constexpr (sizeof(type_t) == 4) {
     using o4 = type_t __attribute__((ext_vector_type(4)));
-    *reinterpret_cast<o4*>(to) = o4{a, b, c, d};
+    using o4_st = type_t __attribute__((ext_vector_type(4), aligned(sizeof(type_t))));
+    *reinterpret_cast<o4_st*>(to) = o4{a, b, c, d};
   } else {
     using o2 = type_t __attribute__((ext_vector_type(2)));
-    *reinterpret_cast<o2*>(to) = o2{a, b};
-    *reinterpret_cast<o2*>(to + 2) = o2{c, d};
+    using o2_st = type_t __attribute__((ext_vector_type(2), aligned(sizeof(type_t))));
+    *reinterpret_cast<o2_st*>(to) = o2{a, b};
+    *reinterpret_cast<o2_st*>(to + 2) = o2{c, d};
   }
 }
 

@@ -77,21 +77,30 @@ __global__ void __launch_bounds__(256) rebase_offsets(const offset_t* __restrict
 }  // namespace detail
 
 /// Rows [row_begin, row_end) of `csr` as a standalone device CSR (offsets rebased to 0, global column ids): one rank's shard.
+/// Work is issued on `stream` (the copies are ordered behind it); returns after the shard is complete.  Throws on any failed copy.
 template <typename index_t, typename offset_t, typename type_t>
-inline csr_t<index_t, offset_t, type_t> slice_rows(const csr_t<index_t, offset_t, type_t>& csr, std::size_t row_begin, std::size_t row_end) {
+inline csr_t<index_t, offset_t, type_t> slice_rows(const csr_t<index_t, offset_t, type_t>& csr, std::size_t row_begin, std::size_t row_end,
+                                                    hipStream_t stream = 0) {
   error::throw_if_exception(row_begin > row_end || row_end > csr.rows, "multi_gpu::slice_rows: bad row range");
   offset_t ends[2] = {0, 0};
-  (void)hipMemcpy(&ends[0], csr.offsets.data().get() + row_begin, sizeof(offset_t), hipMemcpyDeviceToHost);
-  (void)hipMemcpy(&ends[1], csr.offsets.data().get() + row_end, sizeof(offset_t), hipMemcpyDeviceToHost);
+  hipError_t e = hipMemcpyAsync(&ends[0], csr.offsets.data().get() + row_begin, sizeof(offset_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&ends[1], csr.offsets.data().get() + row_end, sizeof(offset_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  error::throw_if_exception(e != hipSuccess, "multi_gpu::slice_rows: cannot read the row range's offsets");
+  error::throw_if_exception(ends[1] < ends[0], "multi_gpu::slice_rows: offsets are not ascending");
   const std::size_t rows = row_end - row_begin, nnz = static_cast<std::size_t>(ends[1] - ends[0]);
   csr_t<index_t, offset_t, type_t> out(rows, csr.cols, nnz);
-  hipLaunchKernelGGL(detail::rebase_offsets<offset_t>, dim3(static_cast<unsigned>((rows + 256) / 256)), dim3(256), 0, 0,
+  hipLaunchKernelGGL(detail::rebase_offsets<offset_t>, dim3(static_cast<unsigned>((rows + 256) / 256)), dim3(256), 0, stream,
                      csr.offsets.data().get() + row_begin, rows + 1, out.offsets.data().get());
+  e = hipGetLastError();
   if (nnz) {
-    (void)hipMemcpy(out.indices.data().get(), csr.indices.data().get() + ends[0], sizeof(index_t) * nnz, hipMemcpyDeviceToDevice);
-    (void)hipMemcpy(out.values.data().get(), csr.values.data().get() + ends[0], sizeof(type_t) * nnz, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(out.indices.data().get(), csr.indices.data().get() + ends[0], sizeof(index_t) * nnz, hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(out.values.data().get(), csr.values.data().get() + ends[0], sizeof(type_t) * nnz, hipMemcpyDeviceToDevice, stream);
   }
-  error::throw_if_exception(hipDeviceSynchronize() != hipSuccess, "multi_gpu::slice_rows: copy failed");
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  error::throw_if_exception(e != hipSuccess, "multi_gpu::slice_rows: copy failed");
   return out;
 }
 

@@ -102,7 +102,8 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  * issued from one thread on several streams may overlap.  (At most 16 such buffers are cached per thread; the
  * least recently used is released first.  Growing or evicting a buffer calls hipFree, which waits for the DEVICE:
  * an otherwise asynchronous call then blocks once -- steady-state calls on up to 16 (stream, tile shape) pairs per
- * thread never do; entries of destroyed streams stay until evicted or loops_release_scratch() is called.)  A held plan (loops_merge_plan_t, loops_rowband_plan_t, loops_panel_plan_t) owns ONE set of
+ * thread never do; entries of destroyed streams stay until evicted or loops_release_scratch() is called.  HIP-graph capture of a
+ * plan-less call works on a stream the same call has run on before -- the scratch exists then; the first call on a stream allocates.)  A held plan (loops_merge_plan_t, loops_rowband_plan_t, loops_panel_plan_t) owns ONE set of
  * scratch buffers and is passed as const only because its coordinates are read-only: it serves one product at a
  * time -- do not run the same plan on two streams or from two threads concurrently; create one plan per stream. */
 /* (LOOPS_MERGE_PATH_FLAT, round 4: from an x of 6 MB on and 2^20 nonzeros the call samples the columns on the device -- two small

@@ -918,3 +918,55 @@ def test_phased_variant_on_the_reference_battery_and_degenerate_inputs(tile):
     y = torch.full((rows,), -1.0, device="cuda")
     S.merge_path_flat(empty, torch.from_numpy(xi).cuda(), y, plan=S.MergePathPlan(empty, tile), variant=_lib.VARIANT_PHASED)
     assert float(y.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("window", [None, 4096], ids=["scattered", "banded"])
+def test_planless_device_decided_kernel(window, dtype):
+    """The asynchronous plan-less entry `loops_spmv_csr_*(MERGE_PATH_FLAT)` above its thresholds (x >= 6 MB, nnz >= 2^20): a sample
+    of the columns decides ON THE DEVICE whether the product gathers in phases (kernels::merge_path_spmv_fused_auto).  Both
+    outcomes -- scattered columns (phased) and a 4096-wide band (plain) -- must give the bits of the held 512x8 plan, also from
+    two streams at once and from a captured HIP graph (the decision is device-side: nothing host-side may depend on it)."""
+    from loops_amd import spmv as S, generate as G
+    rows, cols = 1 << 18, 1 << 21                                   # x = 8 MB (f32) / 16 MB (f64)
+    deg = G.powerlaw_degrees(rows, 1 << 21, cap=1 << 12)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
+    assert idx.size >= 1 << 20
+    csr = _dev(off, idx, val.astype(dtype), rows, cols)
+    xs = [torch.from_numpy(G.uniform_distribution_int(cols, seed=s).astype(dtype)).cuda() for s in (42, 7)]
+    plan = S.MergePathPlan(csr, "512x8")
+    want = [S.merge_path_flat(csr, x, plan=plan).clone() for x in xs]
+    if dtype == np.float32:   # the structural guess the device-side decision restates
+        assert S.columns_look_scattered(csr) == (window is None)
+    for x, w in zip(xs, want):
+        y = torch.full((rows,), 5.0, dtype=x.dtype, device="cuda")
+        assert torch.equal(S.spmv("merge_path_flat", csr, x, y), w)
+    # two streams at once: each stream owns its scratch (coordinates, carry-outs, sample statistics)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ys = [torch.full((rows,), -1.0, dtype=xs[0].dtype, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for st, x, y in zip(streams, xs, ys):
+            with torch.cuda.stream(st):
+                S.spmv("merge_path_flat", csr, x, y)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], want[0]) and torch.equal(ys[1], want[1])
+    # graph capture of the plan-less call ON THE STREAM IT WAS WARMED UP ON: the entry keeps its scratch (coordinates, carry-outs,
+    # sample statistics) per (thread, device, stream, tile shape), and growing it -- a hipMalloc -- must not happen inside a capture
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    x, yg = xs[0].clone(), torch.empty(rows, dtype=xs[0].dtype, device="cuda")
+    with torch.cuda.stream(side):
+        S.spmv("merge_path_flat", csr, x, yg)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        S.spmv("merge_path_flat", csr, x, yg)
+    for xn, w in zip(reversed(xs), reversed(want)):
+        x.copy_(xn)
+        yg.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, w)
+    plan.close()
