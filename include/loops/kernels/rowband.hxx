@@ -39,6 +39,7 @@
  */
 #pragma once
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
@@ -454,6 +455,20 @@ inline void rowband_chunk_list(const std::vector<int>& band_step, int B, int tar
     }
     if (count > 1) num_partials += count;
   }
+  // Order of the work list: by piece number first, bands ascending inside -- the workgroups an XCD runs together (it walks one
+  // contiguous run of the list, xcd_contiguous) then sweep the SAME share of the columns of neighbouring bands, so the XCD's
+  // L2 has to hold that share of x only (C2, 4 pieces per band: 1 MB instead of the 4 MB that fill it).  Uncut bands are piece 0.
+  const std::size_t n_chunks = chunks.size() / 4;
+  std::vector<int> piece(n_chunks, 0), order(n_chunks);
+  for (std::size_t c = 0; c < n_chunks; ++c) {
+    order[c] = static_cast<int>(c);
+    if (c > 0 && chunks[4 * c] == chunks[4 * (c - 1)]) piece[c] = piece[c - 1] + 1;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return piece[a] < piece[b]; });
+  std::vector<int> sorted(chunks.size());
+  for (std::size_t c = 0; c < n_chunks; ++c)
+    for (int f = 0; f < 4; ++f) sorted[4 * c + f] = chunks[4 * static_cast<std::size_t>(order[c]) + f];
+  chunks.swap(sorted);
 }
 
 /// The device arrays of one row-band matrix, OWNED.  Type-erased over the value type (`vbytes`).

@@ -39,27 +39,23 @@ for H in ints("RB_H", "8192"):
         assert plan.steps == stepcol.size, (plan.steps, stepcol.size)
         assert np.array_equal(dhubs, hubs), (dhubs[:2], hubs[:2])
         assert np.array_equal(dv, v) and np.array_equal(drc, rc) and np.array_equal(dperm, perm) and np.array_equal(dstepcol, stepcol)
-        ch, mu = spec.chunk_list(bs, plan.target_chunks)
+        ch, mu = spec.chunk_list(bs, plan.num_bands if plan.num_bands >= 256 else 256)
         assert np.array_equal(dchunks[:, :4], ch) and np.array_equal(dmulti, mu), (dchunks[:4], ch[:4])
         checked = True
         print("layout == specification (H %d, steps %d, padding %.2f %%)" % (H, plan.steps, 100.0 * (plan.padded - nnz) / max(nnz, 1)), file=sys.stderr, flush=True)
     for CHK in ints("RB_G", "0"):
+        if checked is True and CHK:
+            pass
         plan.set_chunks(CHK)
         for cfg in ints("RB_CFG", "162"):
-            os.environ["LOOPS_ROWBAND_CFG"] = str(cfg)
+            plan.set_waves(16 if cfg // 10 == 16 else 8)
             plan.spmv(x, y1)
             eq = bool(torch.equal(y0, y1))
             diag = {}
-            os.environ["LOOPS_ROWBAND_FUSED"] = "0"
-            plan.spmv(x, y1)
-            diag["unfused_equal"] = bool(torch.equal(y0, y1))
-            diag["unfused_us"] = round(batch_ms(lambda: plan.spmv(x, y1)) * 1e3, 2)
-            os.environ["LOOPS_ROWBAND_FUSED"] = "1"
-            y1.fill_(-7.0)
             t = batch_ms(lambda: plan.spmv(x, y1))
             ta = batch_ms(lambda: plan.spmv_stage(0, x, y1))
             tb = batch_ms(lambda: plan.spmv_stage(1, x, y1)) if plan.num_multi else 0.0
-            row = {"H": H, "target_chunks": plan.target_chunks, "cfg": cfg, "chunks": plan.num_chunks, "partials": plan.num_partials,
+            row = {"H": H, "target_chunks": CHK, "cfg": cfg, "chunks": plan.num_chunks, "partials": plan.num_partials,
                    "us": round(t * 1e3, 2), "accumulate_us": round(ta * 1e3, 2), "combine_us": round(tb * 1e3, 2),
                    "frac": round(abytes / t / 1e6 / 8000, 4), "equal": eq, "build_ms": round(b_ms, 2),
                    "padding_pct": round(100.0 * (plan.padded - nnz) / max(nnz, 1), 2), **diag}

@@ -99,6 +99,13 @@ def chunk_list(band_step, target_chunks):
             chunks.append((b, begin, min(begin + size, s0 + nb), partials + k if count > 1 else -1))
         if count > 1:
             partials += count
+    # the work list's order: by piece number first (uncut bands are piece 0), bands ascending inside
+    piece, last = [], None
+    for c in chunks:
+        piece.append(piece[-1] + 1 if c[0] == last else 0)
+        last = c[0]
+    order = np.argsort(np.asarray(piece, np.int64), kind="stable") if chunks else []
+    chunks = [chunks[i] for i in order]
     return np.array(chunks, np.int32).reshape(-1, 4), np.array(multi, np.int32).reshape(-1, 3)
 
 

@@ -49,7 +49,7 @@ def _check_layout(plan, off, idx, val, target_chunks=0):
     assert plan.num_partials == (int(mu[:, 2].sum()) if mu.size else 0)
     # the chunks of a band tile its steps exactly
     for b in range(B):
-        mine = ch[ch[:, 0] == b]
+        mine = ch[ch[:, 0] == b]                        # (list order: by piece number, so a band's chunks appear in piece order)
         assert mine[0, 1] == bs[b] and mine[-1, 2] == bs[b + 1] and np.array_equal(mine[1:, 1], mine[:-1, 2])
 
 
