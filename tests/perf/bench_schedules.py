@@ -42,7 +42,8 @@ else:
     rows = cols = args.rows or (1 << args.log2_rows)
     nnz = args.nnz or (1 << args.log2_nnz)
     deg = G.powerlaw_degrees(rows, nnz, cap=args.cap)
-    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, args.window or None)
+    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, args.window or None,
+                                       hosts=G.host_blocks(cols) if args.window == G.HOST_BLOCKED else None)
 xh = G.uniform_distribution_int(cols)
 csr = S.CSR.from_numpy(rows, cols, off, idx, val)
 x = torch.from_numpy(xh).cuda()
