@@ -2,7 +2,7 @@
  * @file rowband.cuh
  * @brief `algorithms::spmv::rowband_t<index_t, offset_t, float>`: a CSR held in the row-band layout (loops/kernels/rowband.hxx)
  * -- the y accumulators of a band of rows live in LDS, the band's nonzeros are sorted by column so that a wavefront's x gathers
- * fall on a few neighbouring lines; 8 bytes per nonzero streamed.  For an x of a few MB or column locality at band scale.  The
+ * fall on a few neighbouring lines; 7 bytes per nonzero streamed (columns as one-byte deltas).  For an x of a few MB or column locality at band scale.  The
  * header-API twin of loops_rowband_plan_* (include/loops_amd.h).  No reference counterpart (its merge_path_flat.cuh:71-82 pays
  * one global atomic per nonzero, its CSR kernels one scattered gather).
  *
@@ -39,16 +39,16 @@ struct rowband_t {
         csr.values.data().get(), band_rows, target_chunks, arrays);
     error::throw_if_exception(err == kernels::rowband_e_badarg,
                               "rowband_t: band_rows must be a power of two in [64, 16384] and every column index inside [0, cols)");
-    error::throw_if_exception(err == kernels::rowband_e_range, "rowband_t: bands x column blocks must stay below 2^26 and nnz + padding below 2^31");
+    error::throw_if_exception(err == kernels::rowband_e_range, "rowband_t: nnz + padding (bands x (cols / 255 + 256)) must stay below 2^31");
     error::throw_if_exception(err != 0, "rowband_t: build failed");
   }
 
   /// Whether rowband_create can take the matrix at all (the bounds it checks before it sorts).
   static bool fits(const csr_t<index_t, offset_t, type_t>& csr) {
     const int h = kernels::rowband_rows(static_cast<int>(csr.rows), static_cast<int>(csr.cols), static_cast<int>(csr.nnzs));
-    const long long bands = (static_cast<long long>(csr.rows) + h - 1) / h, blocks = ((static_cast<long long>(csr.cols) + 65535) >> 16);
-    const long long segments = bands * (blocks > 0 ? blocks : 1);
-    return segments <= (1ll << 26) && (static_cast<long long>(csr.nnzs) / 256 + segments + 1) * 256 < (1ll << 31) - 4096;
+    const long long bands = (static_cast<long long>(csr.rows) + h - 1) / h;
+    return bands <= (1ll << 26) &&
+           static_cast<long long>(csr.nnzs) + bands * (static_cast<long long>(csr.cols) / kernels::rowband::max_delta + kernels::rowband::step_items) < (1ll << 31) - 4096;
   }
 
   kernels::rowband_view<type_t> view() const { return arrays.template view<type_t>(); }

@@ -6,24 +6,25 @@
  * Why.  Every CSR kernel on this chip issues one L2 request per nonzero for its x gather, and the L2 serves ~266 G of them
  * per second at best: 63 us on BASELINE C2 whatever the kernel does, 0.29 of the HBM roofline.  The
  * panel-binned layout removes the gather but pays for it with 17 bytes of traffic per nonzero.  This layout keeps 8 bytes
- * per nonzero AND removes most of the requests: inside a BAND of H consecutive rows the nonzeros are sorted by COLUMN, so the
+ * per nonzero (7 since the columns are stored as deltas) AND removes most of the requests: inside a BAND of H consecutive rows the nonzeros are sorted by COLUMN, so the
  * 64 gathers of one wavefront instruction fall on a handful of neighbouring 128-byte lines of x (the band of a C2-like
  * matrix holds one nonzero per 4-8 columns) and the CU's L1 turns them into one L2 request per LINE.  What the sort destroys
  * -- a row's nonzeros are no longer adjacent -- is repaired where it is cheap: the band's H sums live in LDS as fp64 words
  * and every product is one `ds_add_f64` (3-8 lanes per clock and CU on gfx950, profiles/r03_lds_update_rates.txt).
  *
  * Layout (a re-ordered COPY of the matrix, built once on the device, O(nnz): one stable radix sort of (band, column) keys):
- *   items sorted by (band b = row / H, column, CSR order), cut into SEGMENTS (b, column block cb = col >> 16) that are
- *   padded to whole STEPS of 256 items (one wavefront load: 64 lanes x 4 items); per item the value and ONE packed word
- *   `rc = (row - b H) << 16 | (col & 0xFFFF)`; per step `stepcol` = cb << 16.  Padding: value 0, row H (a dump accumulator),
- *   column offset 0.  Inside a step the items are INTERLEAVED: sorted position q sits at lane (q % 64), element (q / 64) of
- *   the lane's 16-byte vector, so the stream is read with 16-byte loads AND the 64 lanes of gather instruction e hold 64
- *   CONSECUTIVE sorted items (neighbouring columns: few lines per instruction, quads of lanes share a line).
- *   8 B per nonzero streamed, + 4 B per step.
+ *   items sorted by (band b = row / H, column, CSR order); every band padded to whole STEPS of 256 slots (one wavefront load: 64
+ *   lanes x 4 slots).  Per slot 7 BYTES: the value (4), a row code (2: the row inside the band; H = padding, a dump accumulator)
+ *   and the column DELTA to the previous slot (1: the columns of a band ascend, C2's by 4 on average); a gap of more than 255
+ *   columns is bridged by padding slots of delta 255; per step and group of 64 slots the absolute column of the group's first
+ *   slot (`stepbase`, 16 B per step; that slot's own delta is stored as 0), so a lane's column is the group's base + the 64-lane prefix sum of the deltas (DPP).
+ *   Inside a step the slots are INTERLEAVED: sorted position q sits at lane (q % 64), element (q / 64) of the lane's vectors, so
+ *   the streams are read with 16- / 8- / 4-byte loads AND the 64 lanes of gather instruction e hold 64 CONSECUTIVE sorted slots
+ *   (neighbouring columns: few lines per instruction, quads of lanes share a line).
  *
  * y = A x:
  *   A  rowband_accumulate   one workgroup per CHUNK = a run of steps of ONE band: zero H fp64 words of LDS, stream the chunk,
- *                           acc[row] += double(val * x[stepcol + off]), then store the H sums -- straight to y when the band is
+ *                           acc[row] += double(val * x[column]), then store the H sums -- straight to y when the band is
  *                           one chunk, else as an fp32 partial vector;
  *   B  rowband_combine      bands cut into several chunks (few, long bands: the chunk is the unit of parallelism): y[r] = the
  *                           partial vectors of r's band added in chunk order (fp64, rounded once).  8 H / chunk_items bytes
@@ -59,7 +60,7 @@ namespace kernels {
 
 namespace rowband {
 constexpr int step_items = wave::size * 4;  ///< items of one step: one 16-byte load per lane
-constexpr int colblock_bits = 16;           ///< a step's columns lie in one block of 2^16: 16-bit column offsets
+constexpr int max_delta = 255;              ///< column deltas are one byte: longer gaps are bridged by padding slots
 constexpr int max_band_rows = 16384;        ///< (H + 1) fp64 accumulators in the 160 KB LDS of a CU
 constexpr int max_hubs = 32;                ///< rows per band that get replicated accumulators ("hubs")
 constexpr int hub_replicas = 16;            ///< accumulators per hub: the lanes of one instruction spread over them
@@ -77,8 +78,9 @@ struct rowband_view {
   int num_partials;            ///< partial vectors = chunks of bands that hold more than one
   int num_multi;               ///< bands that hold more than one chunk
   const type_t* val;           ///< [steps * 256] interleaved inside a step
-  const unsigned int* rc;      ///< [steps * 256] (row in band) << 16 | (column - stepcol); row H = padding
-  const int* stepcol;          ///< [steps] first column of the step's column block
+  const unsigned int* meta;    ///< [steps * 192] per lane of a step 3 words: its 4 row codes (16 bits each: the row inside the band; H =
+                               ///< padding; above H: a hub's replica), then its 4 column deltas (8 bits each, to the previous sorted slot)
+  const int* stepbase;         ///< [steps * 4] absolute column of the first slot of each group of 64 sorted slots
   const int* chunks;           ///< [4 * num_chunks] {band, first step, end step, partial slot or -1}
   const int* multi;            ///< [3 * num_multi] {band, first partial slot, chunks}
   const unsigned short* hubs;  ///< [B * (max_hubs + 1)] per band: the number of hubs, then their rows inside the band
@@ -96,8 +98,8 @@ namespace rowband {
 /// hub's own word before the band's rows are stored.
 template <int WAVES, int U, bool NT, typename type_t, typename store_t>
 __global__ void __launch_bounds__(WAVES * wave::size)
-rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ val, const unsigned int* __restrict__ rc,
-                   const int* __restrict__ stepcol, const unsigned short* __restrict__ hubs, const type_t* __restrict__ x, const int H,
+rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ val, const unsigned int* __restrict__ meta,
+                   const int* __restrict__ stepbase, const unsigned short* __restrict__ hubs, const type_t* __restrict__ x, const int H,
                    const int rows, type_t* __restrict__ partial, const store_t out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rowband_lds[];
   double* acc = reinterpret_cast<double*>(rowband_lds);  // [lds_words(H)]: rows, the dump word H, the hubs' replicas
@@ -109,20 +111,23 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
   const int words = lds_words(H);
   for (int j = threadIdx.x; j < words; j += TPB) acc[j] = 0.0;
   __syncthreads();
+  using u32x3 = unsigned int __attribute__((ext_vector_type(3)));
+  using u32x3_ld = unsigned int __attribute__((ext_vector_type(3), aligned(4)));
+  using i32x4 = int __attribute__((ext_vector_type(4)));
   struct batch_t {
     type_t v[U][4];
-    unsigned int r[U][4];
-    const type_t* xb[U];
+    u32x3 m[U];  // row codes 0 | 1, row codes 2 | 3, four one-byte deltas
+    i32x4 base[U];
     bool live[U];
   };
-  // stepcol of the batch AFTER the one being loaded is requested one batch ahead: a scalar load's wait (lgkmcnt(0)) also waits
-  // for every LDS atomic in flight, so it must find its data long there
-  int col_ahead[U];
-  auto prefetch_cols = [&](const int k) {
+  // the group bases of the batch AFTER the one being loaded are requested one batch ahead: a scalar load's wait (lgkmcnt(0)) also
+  // waits for every LDS atomic in flight, so it must find its data long there
+  i32x4 base_ahead[U];
+  auto prefetch_bases = [&](const int k) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int s = k + u * WAVES;
-      col_ahead[u] = stepcol[s < se ? s : sb];
+      base_ahead[u] = *reinterpret_cast<const i32x4*>(stepbase + 4 * static_cast<long long>(s < se ? s : sb));
     }
   };
   auto load = [&](batch_t& t, const int k) {  // the U steps k, k + WAVES, ... of this wavefront (wave-uniform k)
@@ -132,26 +137,35 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
       t.live[u] = s < se;
       s = t.live[u] ? s : sb;
       const long long at = static_cast<long long>(s) * step_items + lane * 4;
-      detail::load4<unsigned int, NT>(rc + at, t.r[u]);
+      const unsigned int* mp = meta + static_cast<long long>(s) * (3 * wave::size) + lane * 3;  // one 12-byte load per lane
+      if constexpr (NT) t.m[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_ld*>(mp));
+      else t.m[u] = *reinterpret_cast<const u32x3_ld*>(mp);
       detail::load4<type_t, NT>(val + at, t.v[u]);
-      t.xb[u] = x + col_ahead[u];
+      t.base[u] = base_ahead[u];
     }
-    prefetch_cols(k + WAVES * U);
+    prefetch_bases(k + WAVES * U);
   };
   auto gather = [&](const batch_t& t, type_t (&xv)[U][4]) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xv[u][e] = t.xb[u][t.r[u][e] & 0xFFFFu];
-      }
+    for (int u = 0; u < U; ++u) {
+      // column of sorted slot 64 e + lane = the group's base + the deltas of lanes 1 .. lane (the first slot of a group carries
+      // delta 0: the base IS its column).  Two groups per prefix sum: their running sums stay below 64 * 255 < 2^16.
+      const unsigned int d = t.m[u].z;
+      const unsigned int s01 = wave::inclusive_sum((d & 0xFFu) | ((d & 0xFF00u) << 8));
+      const unsigned int s23 = wave::inclusive_sum(((d >> 16) & 0xFFu) | ((d >> 24) << 16));
+      xv[u][0] = x[static_cast<unsigned int>(t.base[u][0]) + (s01 & 0xFFFFu)];
+      xv[u][1] = x[static_cast<unsigned int>(t.base[u][1]) + (s01 >> 16)];
+      xv[u][2] = x[static_cast<unsigned int>(t.base[u][2]) + (s23 & 0xFFFFu)];
+      xv[u][3] = x[static_cast<unsigned int>(t.base[u][3]) + (s23 >> 16)];
+    }
   };
   auto update = [&](const batch_t& t, const type_t (&xv)[U][4]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const unsigned int row = t.live[u] ? t.r[u][e] >> 16 : static_cast<unsigned int>(H);
+        const unsigned int code = ((e < 2 ? t.m[u].x : t.m[u].y) >> (16 * (e & 1))) & 0xFFFFu;
+        const unsigned int row = t.live[u] ? code : static_cast<unsigned int>(H);
         atomicAdd(&acc[row], static_cast<double>(t.v[u][e] * xv[u][e]));
       }
   };
@@ -160,7 +174,7 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
   if (k < se) {  // (wave-uniform)
     batch_t a, b;
     type_t xa[U][4], xb2[U][4];
-    prefetch_cols(k);
+    prefetch_bases(k);
     load(a, k);
     gather(a, xa);
     // (no exit between a batch's load and its gather: the compiler can neither sink the load past the update before it nor
@@ -309,14 +323,12 @@ make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indi
   }
 }
 
-/// seg_start[g] = the first sorted position whose (band, column block) is >= g = band * CB + cb (g <= n: seg_start[n] = nnz).
+/// band_start[b] = the first sorted position whose band is >= b (b <= B: band_start[B] = nnz).
 __global__ void __launch_bounds__(256)
-segment_starts(const unsigned long long* __restrict__ sorted, const int nnz, const int n, const int CB, const int cbits,
-               int* __restrict__ seg_start) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g > n) return;
-  const unsigned long long b = static_cast<unsigned long long>(g / CB), cb = static_cast<unsigned long long>(g % CB);
-  const unsigned long long want = (b << cbits) | (cb << colblock_bits);
+band_starts(const unsigned long long* __restrict__ sorted, const int nnz, const int B, const int cbits, int* __restrict__ band_start) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > B) return;
+  const unsigned long long want = static_cast<unsigned long long>(b) << cbits;
   int lo = 0, count = nnz;
   while (count > 0) {
     const int half = count >> 1;
@@ -327,59 +339,105 @@ segment_starts(const unsigned long long* __restrict__ sorted, const int nnz, con
       count = half;
     }
   }
-  seg_start[g] = lo;
+  band_start[b] = lo;
 }
 
-/// seg_steps[g] = steps of segment g (g < n), 0 for g == n.
-__global__ void __launch_bounds__(256) segment_steps(const int* __restrict__ seg_start, const int n, int* __restrict__ seg_steps) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g <= n) seg_steps[g] = g < n ? (seg_start[g + 1] - seg_start[g] + step_items - 1) / step_items : 0;
+/// Column gap of sorted item j to its predecessor in the band (0 for a band's first item) and the padding slots that bridge it.
+__device__ __forceinline__ void gap_of(const unsigned long long* __restrict__ sorted, const int j, const int cbits, unsigned int& gap,
+                                       unsigned int& pads) {
+  gap = 0;
+  if (j > 0) {
+    const unsigned long long key = sorted[j], prev = sorted[j - 1];
+    if ((key >> cbits) == (prev >> cbits)) gap = static_cast<unsigned int>(key - prev);  // same band: the keys differ in the column only
+  }
+  pads = gap > static_cast<unsigned int>(max_delta) ? (gap - 1u) / static_cast<unsigned int>(max_delta) : 0u;
 }
 
-/// band_step[b] = seg_step[b * CB] (b <= B).
+/// slots[j] = 1 + the padding slots in front of sorted item j (j < nnz), slots[nnz] = 0: the exclusive scan numbers the slots.
 __global__ void __launch_bounds__(256)
-band_steps(const int* __restrict__ seg_step, const int B, const int CB, int* __restrict__ band_step) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b <= B) band_step[b] = seg_step[static_cast<long long>(b) * CB];
+count_slots(const unsigned long long* __restrict__ sorted, const int nnz, const int cbits, int* __restrict__ slots) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > nnz) return;
+  unsigned int gap = 0, pads = 0;
+  if (j < nnz) gap_of(sorted, j, cbits, gap, pads);
+  slots[j] = j < nnz ? static_cast<int>(1u + pads) : 0;
 }
 
-/// Every slot of the layout starts as padding: value 0, row H, column offset 0, no CSR position.
+/// steps[b] = whole steps of band b (its slots rounded up to 256), steps[B] = 0.
+__global__ void __launch_bounds__(256)
+band_step_counts(const int* __restrict__ band_start, const int* __restrict__ slot_pos, const int B, int* __restrict__ steps) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= B) steps[b] = b < B ? (slot_pos[band_start[b + 1]] - slot_pos[band_start[b]] + step_items - 1) / step_items : 0;
+}
+
+/// Every slot of the layout starts as padding: value 0, row code H, delta 0, no CSR position; every group base 0.
 template <typename type_t>
 __global__ void __launch_bounds__(256)
-fill_padding(const long long n, const int H, type_t* __restrict__ val, unsigned int* __restrict__ rc, int* __restrict__ perm) {
+fill_padding(const long long n, const int H, type_t* __restrict__ val, unsigned int* __restrict__ meta, int* __restrict__ perm,
+             int* __restrict__ stepbase) {
   const long long j = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (j < n) {
     val[j] = type_t(0);
-    rc[j] = static_cast<unsigned int>(H) << 16;
     perm[j] = -1;
+    if ((j & 63) == 0) stepbase[j >> 6] = 0;
+    if ((j & 3) == 0) {  // the 3 meta words of the lane that owns slots j .. j + 3
+      unsigned int* m = meta + (j >> 2) * 3;
+      m[0] = m[1] = static_cast<unsigned int>(H) | (static_cast<unsigned int>(H) << 16);
+      m[2] = 0u;
+    }
   }
 }
 
-/// Sorted position j -> its slot: step = seg_step[g] + within / 256, inside the step lane (q % 64), element (q / 64).
-/// Row code: the row inside the band, or -- for a hub's item -- H + 1 + hub * hub_replicas + q % hub_replicas.
+/// Row code / column delta of the slot at memory position `at` (= 4 * (lane of its step, counted over all steps) + element): the
+/// lane's words hold 16-bit codes and 8-bit deltas; slots of one lane are written by different threads, hence the atomics.
+__device__ __forceinline__ void set_meta(unsigned int* __restrict__ meta, const long long at, const unsigned int code, const unsigned int delta,
+                                         const bool with_code, const unsigned int H) {
+  unsigned int* m = meta + (at >> 2) * 3;
+  const int e = static_cast<int>(at & 3);
+  if (with_code) {  // (the word was filled with the padding code H in both halves: replace this half)
+    const unsigned int shift = 16u * (e & 1);
+    atomicXor(m + (e >> 1), ((code ^ H) & 0xFFFFu) << shift);
+  }
+  if (delta) atomicOr(m + 2, (delta & 0xFFu) << (8 * e));
+}
+
+/// Memory position of sorted slot s (counted from the start of the arrays): inside its step lane (q % 64), element (q / 64).
+__device__ __forceinline__ long long slot_at(const long long s) {
+  const long long q = s % step_items;
+  return (s / step_items) * step_items + (q % wave::size) * 4 + q / wave::size;
+}
+
+/// Sorted item j -> its slot (and the padding slots in front of it that bridge a long column gap).
+/// Row code: the row inside the band, or -- for a hub's item -- H + 1 + hub * hub_replicas + q % hub_replicas (q = slot in the step).
 template <typename type_t>
 __global__ void __launch_bounds__(256)
 place(const unsigned long long* __restrict__ sorted, const int* __restrict__ item, const unsigned short* __restrict__ rin,
-      const int* __restrict__ seg_start, const int* __restrict__ seg_step, const type_t* __restrict__ values, const int nnz,
-      const int CB, const int cbits, const int H, type_t* __restrict__ val, unsigned int* __restrict__ rc, int* __restrict__ perm,
-      int* __restrict__ stepcol) {
+      const int* __restrict__ band_start, const int* __restrict__ slot_pos, const int* __restrict__ band_step,
+      const type_t* __restrict__ values, const int nnz, const int cbits, const int H, type_t* __restrict__ val,
+      unsigned int* __restrict__ meta, int* __restrict__ perm, int* __restrict__ stepbase) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nnz) return;
   const unsigned long long key = sorted[j];
   const unsigned int col = static_cast<unsigned int>(key & ((1ull << cbits) - 1));
-  const int b = static_cast<int>(key >> cbits), cb = static_cast<int>(col >> colblock_bits);
-  const long long g = static_cast<long long>(b) * CB + cb;
-  const int within = j - seg_start[g];
-  const int step = seg_step[g] + within / step_items, q = within % step_items;
-  const long long at = static_cast<long long>(step) * step_items + (q % wave::size) * 4 + q / wave::size;
+  const int b = static_cast<int>(key >> cbits);
+  unsigned int gap, pads;
+  gap_of(sorted, j, cbits, gap, pads);
+  const long long s = static_cast<long long>(band_step[b]) * step_items + (slot_pos[j] - slot_pos[band_start[b]]) + pads;
+  for (unsigned int t = 0; t < pads; ++t) {  // (rare: a gap of more than 255 columns)
+    const long long ps = s - pads + t;
+    set_meta(meta, slot_at(ps), 0u, (ps & 63) == 0 ? 0u : static_cast<unsigned int>(max_delta), false, static_cast<unsigned int>(H));
+    if ((ps & 63) == 0) stepbase[ps >> 6] = static_cast<int>(col - gap + static_cast<unsigned int>(max_delta) * (t + 1u));
+  }
+  const long long at = slot_at(s);
+  const int q = static_cast<int>(s % step_items);
   const int i = item[j];
   const unsigned int code = rin[i];
   const unsigned int row = (code & 0x8000u) ? static_cast<unsigned int>(H) + 1u + (code & 0x7FFFu) * hub_replicas + static_cast<unsigned int>(q % hub_replicas)
                                             : code;
   val[at] = values[i];
-  rc[at] = (row << 16) | (col & 0xFFFFu);
+  set_meta(meta, at, row, (s & 63) == 0 ? 0u : gap - static_cast<unsigned int>(max_delta) * pads, true, static_cast<unsigned int>(H));
   perm[at] = i;
-  if (q == 0) stepcol[step] = cb << colblock_bits;
+  if ((s & 63) == 0) stepbase[s >> 6] = static_cast<int>(col);
 }
 
 template <typename type_t>
@@ -474,32 +532,33 @@ inline void rowband_chunk_list(const std::vector<int>& band_step, int B, int tar
 /// The device arrays of one row-band matrix, OWNED.  Type-erased over the value type (`vbytes`).
 struct rowband_storage {
   int rows = 0, cols = 0, nnz = 0, vbytes = 0;
-  int H = 0, B = 0, CB = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0, waves = 8;
+  int H = 0, B = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0, waves = 8;
+  long long gap_pads = 0;      ///< padding slots that bridge column gaps of more than 255
   void *val = nullptr, *partial = nullptr;
-  unsigned int* rc = nullptr;
   unsigned short* hubs = nullptr;
-  int *stepcol = nullptr, *perm = nullptr, *chunks = nullptr, *multi = nullptr, *band_step = nullptr;
+  unsigned int* meta = nullptr;
+  int *stepbase = nullptr, *perm = nullptr, *chunks = nullptr, *multi = nullptr, *band_step = nullptr;
 
   rowband_storage() = default;
   rowband_storage(const rowband_storage&) = delete;
   rowband_storage& operator=(const rowband_storage&) = delete;
   ~rowband_storage() { release(); }
   void release() {
-    (void)hipFree(val); (void)hipFree(partial); (void)hipFree(rc); (void)hipFree(hubs); (void)hipFree(stepcol); (void)hipFree(perm);
-    (void)hipFree(chunks); (void)hipFree(multi); (void)hipFree(band_step);
-    val = partial = nullptr; rc = nullptr; hubs = nullptr; stepcol = perm = chunks = multi = band_step = nullptr;
+    (void)hipFree(val); (void)hipFree(partial); (void)hipFree(meta); (void)hipFree(hubs); (void)hipFree(stepbase);
+    (void)hipFree(perm); (void)hipFree(chunks); (void)hipFree(multi); (void)hipFree(band_step);
+    val = partial = nullptr; hubs = nullptr; meta = nullptr; stepbase = perm = chunks = multi = band_step = nullptr;
   }
   template <typename type_t>
   rowband_view<type_t> view() const {
-    return rowband_view<type_t>{rows, cols, nnz, H, B, steps, num_chunks, num_partials, num_multi, static_cast<const type_t*>(val), rc,
-                                stepcol, chunks, multi, hubs, static_cast<type_t*>(partial), waves};
+    return rowband_view<type_t>{rows, cols, nnz, H, B, steps, num_chunks, num_partials, num_multi, static_cast<const type_t*>(val), meta,
+                                stepbase, chunks, multi, hubs, static_cast<type_t*>(partial), waves};
   }
 };
 
 /// Default number of chunks: one per band where there are at least as many bands as compute units (the dispatcher balances
 /// them; only a band with twice the mean's items is cut), else one round of equal chunks (C2: 64 bands of 16384 rows -> 256
-/// chunks).  Measured (profiles/r05_rowband_sweep.txt): band C3 stand-in, 453 bands, uncut 268 us, 512 / 1024 chunks 275 / 305;
-/// C2 256 chunks 37 us, 512 chunks 44-54 (two workgroups per CU, twice the partial vectors).
+/// chunks).  Measured (profiles/r05_rowband_experiments.txt, the 8-byte layout): band C3 stand-in, 453 bands, uncut 268 us, 512 /
+/// 1024 chunks 275 / 305; C2 256 chunks 37 us, 512 chunks 44-54 (two workgroups per CU, twice the partial vectors).
 inline int rowband_target_chunks(int B, int cus) {
   const int c = cus > 0 ? cus : 256;
   return B >= c ? B : c;
@@ -540,19 +599,19 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   int hshift = 0;
   while ((1 << hshift) < out.H) ++hshift;
   out.B = rows > 0 ? static_cast<int>((static_cast<long long>(rows) + out.H - 1) / out.H) : 0;
-  out.CB = cols > 0 ? static_cast<int>((static_cast<long long>(cols) + (1 << rowband::colblock_bits) - 1) >> rowband::colblock_bits) : 1;
   out.steps = out.num_chunks = out.num_partials = out.num_multi = 0;
+  out.gap_pads = 0;
   if (rows == 0) return 0;
   {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&out.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) out.cus = 256;
   }
-  const int B = out.B, CB = out.CB;
-  const long long segments = static_cast<long long>(B) * CB;
-  // every segment may carry up to 255 padding items (an upper bound: the real padding is known only after the sort)
-  if (segments > (1ll << 26) || (static_cast<long long>(nnz) / rowband::step_items + segments + 1) * rowband::step_items >= (1ll << 31) - 4096)
+  const int B = out.B;
+  // upper bound of the slots: the nonzeros, the padding slots that bridge column gaps (a band's gaps sum to less than `cols`),
+  // the padding of every band to whole steps
+  if (B > (1 << 26) ||
+      static_cast<long long>(nnz) + static_cast<long long>(B) * (static_cast<long long>(cols) / rowband::max_delta + rowband::step_items) >= (1ll << 31) - 4096)
     return rowband_e_range;
-  const int nseg = static_cast<int>(segments);
   int cbits = 1;
   while (cbits < 31 && (static_cast<long long>(cols) >> cbits) != 0) ++cbits;
   int bbits = 1;
@@ -564,13 +623,13 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
     unsigned long long* k = nullptr;
     int* ci = nullptr;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k, k, ci, ci, nnz, 0, cbits + bbits);
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, ci, ci, nseg + 1);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, ci, ci, (nnz > B ? nnz : B) + 1);
   }
   const std::size_t cub_bytes_total = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
   const std::size_t key_bytes = up((static_cast<std::size_t>(nnz) + 1) * 8), item_bytes = up((static_cast<std::size_t>(nnz) + 1) * 4);
-  const std::size_t rin_bytes = up((static_cast<std::size_t>(nnz) + 1) * 2), seg_bytes = up((static_cast<std::size_t>(nseg) + 1) * 4);
+  const std::size_t rin_bytes = up((static_cast<std::size_t>(nnz) + 1) * 2), band_bytes = up((static_cast<std::size_t>(B) + 1) * 4);
   const std::size_t hub_bytes = up((static_cast<std::size_t>(rows) + 1) * 2);
-  const std::size_t temp_bytes = 2 * key_bytes + 2 * item_bytes + rin_bytes + hub_bytes + 3 * seg_bytes + 256 + cub_bytes_total;
+  const std::size_t temp_bytes = 2 * key_bytes + 2 * item_bytes + rin_bytes + hub_bytes + 2 * band_bytes + 256 + cub_bytes_total;
   char* base = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), temp_bytes);
   struct guard_t {
@@ -586,11 +645,12 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   int* item_out = reinterpret_cast<int*>(carve(item_bytes));
   auto* rin = reinterpret_cast<unsigned short*>(carve(rin_bytes));
   auto* hubidx = reinterpret_cast<short*>(carve(hub_bytes));
-  int* seg_start = reinterpret_cast<int*>(carve(seg_bytes));
-  int* seg_steps = reinterpret_cast<int*>(carve(seg_bytes));
-  int* seg_step = reinterpret_cast<int*>(carve(seg_bytes));
+  int* band_start = reinterpret_cast<int*>(carve(band_bytes));
+  int* steps_of = reinterpret_cast<int*>(carve(band_bytes));
   int* bad = reinterpret_cast<int*>(carve(256));
   void* cub_temp = carve(cub_bytes_total);
+  int* slots = reinterpret_cast<int*>(keys_in);    // (over keys_in once the sort is done) [nnz + 1]: slots of item j incl. its gap pads
+  int* slot_pos = item_in;                         // (over item_in once the sort is done) [nnz + 1]: their exclusive scan
   std::size_t cub_bytes = cub_bytes_total;
 
   const std::size_t hubs_n = static_cast<std::size_t>(B) * (rowband::max_hubs + 1);
@@ -606,35 +666,38 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
     e = hipcub::DeviceRadixSort::SortPairs(cub_temp, cub_bytes, keys_in, keys_out, item_in, item_out, nnz, 0, cbits + bbits, stream);
     if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   }
-  const dim3 seg_grid(math::ceil_div(nseg + 1, 256));
-  hipLaunchKernelGGL(rowband::segment_starts, seg_grid, dim3(256), 0, stream, keys_out, nnz, nseg, CB, cbits, seg_start);
-  hipLaunchKernelGGL(rowband::segment_steps, seg_grid, dim3(256), 0, stream, seg_start, nseg, seg_steps);
+  hipLaunchKernelGGL(rowband::band_starts, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, keys_out, nnz, B, cbits, band_start);
+  hipLaunchKernelGGL(rowband::count_slots, dim3(math::ceil_div(nnz + 1, 256)), dim3(256), 0, stream, keys_out, nnz, cbits, slots);
   cub_bytes = cub_bytes_total;
-  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, seg_steps, seg_step, nseg + 1, stream);
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, slots, slot_pos, nnz + 1, stream);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&out.band_step), sizeof(int) * (static_cast<std::size_t>(B) + 1));
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
-  hipLaunchKernelGGL(rowband::band_steps, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, seg_step, B, CB, out.band_step);
+  hipLaunchKernelGGL(rowband::band_step_counts, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, band_start, slot_pos, B, steps_of);
+  cub_bytes = cub_bytes_total;
+  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, steps_of, out.band_step, B + 1, stream);
   std::vector<int> bs(static_cast<std::size_t>(B) + 1, 0);
-  int h_bad = 0;
-  e = hipMemcpyAsync(bs.data(), out.band_step, sizeof(int) * bs.size(), hipMemcpyDeviceToHost, stream);
+  int h_bad = 0, h_slots = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(bs.data(), out.band_step, sizeof(int) * bs.size(), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_slots, slot_pos + nnz, sizeof(int), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   if (h_bad != 0) { out.release(); return rowband_e_badarg; }
   out.steps = bs[B];
+  out.gap_pads = static_cast<long long>(h_slots) - nnz;
   const std::size_t n = static_cast<std::size_t>(out.steps > 0 ? out.steps : 1) * rowband::step_items;
   auto alloc = [&](auto** ptr, std::size_t bytes) { if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(ptr), bytes); };
   alloc(&out.val, sizeof(type_t) * n);
-  alloc(&out.rc, sizeof(unsigned int) * n);
+  alloc(&out.meta, sizeof(unsigned int) * (n / 4) * 3);
   alloc(&out.perm, sizeof(int) * n);
-  alloc(&out.stepcol, sizeof(int) * (static_cast<std::size_t>(out.steps) + 1));
-  if (e == hipSuccess) e = hipMemsetAsync(out.stepcol, 0, sizeof(int) * (static_cast<std::size_t>(out.steps) + 1), stream);
+  alloc(&out.stepbase, sizeof(int) * (n / 64));
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   hipLaunchKernelGGL((rowband::fill_padding<type_t>), dim3(static_cast<unsigned int>((n + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<long long>(n), out.H, static_cast<type_t*>(out.val), out.rc, out.perm);
+                     static_cast<long long>(n), out.H, static_cast<type_t*>(out.val), out.meta, out.perm, out.stepbase);
   if (nnz > 0)
-    hipLaunchKernelGGL((rowband::place<type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, item_out, rin, seg_start,
-                       seg_step, values, nnz, CB, cbits, out.H, static_cast<type_t*>(out.val), out.rc, out.perm, out.stepcol);
+    hipLaunchKernelGGL((rowband::place<type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, item_out, rin, band_start,
+                       slot_pos, out.band_step, values, nnz, cbits, out.H, static_cast<type_t*>(out.val), out.meta, out.perm,
+                       out.stepbase);
   e = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = static_cast<hipError_t>(rowband_set_chunks(out, bs, target_chunks));
@@ -644,21 +707,21 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
 
 /// y = A x over a row-band matrix: kernel A, then kernel B if some band was cut.  stages: bit 0 = accumulate, bit 1 = combine.
 /// Kernel A runs 8 or 16 wavefronts per workgroup (`m.waves`), one step per wavefront and batch.  Measured on MI355X
-/// (tests/perf/bench_rowband.py, profiles/r05_rowband_*): C2 36.9 / 40.1 us with 8 / 16 wavefronts (more wavefronts lengthen
-/// the queues of the CU's memory path without adding requests in flight: it sits at ~82 either way), U = 2 / 4 steps per batch
-/// 39.8 / 45.7; a matrix whose gathers hit the L1 (band C3 stand-in) 320 / 268 us.
+/// (tests/perf/bench_rowband.py, profiles/r05_rowband_experiments.txt): C2 32.6 / 35.7 us with 8 / 16 wavefronts (more wavefronts
+/// lengthen the queues of the CU's memory path without adding requests in flight), 2 / 4 steps per batch +3 / +9 us; a matrix
+/// whose gathers hit the L1 (band C3 stand-in) 372 / 291 us.
 template <typename type_t, typename store_t>
 int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const type_t* x, const store_t out, int stages = 3) {
   if (m.rows == 0) return 0;
-  // Non-temporal streams unless a product's working set (8 B per item with 4-byte values, x, y, partials) fits the Infinity Cache
-  // (C2, 150 MB: plain 35 us, non-temporal 49)
+  // Non-temporal streams unless a product's working set (7 B per slot with 4-byte values, x, y, partials) fits the Infinity Cache
+  // (C2, 135 MB: plain 33 us, non-temporal 49 with the 8-byte layout)
   const double items = static_cast<double>(m.steps) * rowband::step_items;
-  const bool nt = items * (sizeof(type_t) + 4.0) + (static_cast<double>(m.rows) + m.cols + 2.0 * m.num_partials * m.H) * sizeof(type_t) > 240e6;
+  const bool nt = items * (sizeof(type_t) + 3.0) + (static_cast<double>(m.rows) + m.cols + 2.0 * m.num_partials * m.H) * sizeof(type_t) > 240e6;
   if ((stages & 1) && m.num_chunks > 0) {
     const std::size_t lds = static_cast<std::size_t>(rowband::lds_words(m.H)) * sizeof(double);
     auto go = [&](auto kernel, int waves) {
       if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(waves * wave::size), lds, stream, m.chunks, m.val, m.rc, m.stepcol, m.hubs, x, m.H,
+      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(waves * wave::size), lds, stream, m.chunks, m.val, m.meta, m.stepbase, m.hubs, x, m.H,
                          m.rows, m.partial, out);
     };
     if (m.waves == 16) {

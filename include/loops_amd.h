@@ -295,21 +295,22 @@ int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x,
 /* ---- row-band layout: y accumulators of a band of rows in LDS, x read through column-sorted (coalescing) gathers ----------
  * No reference counterpart (the reference's merge_path_flat.cuh:71-82 issues one global atomic per nonzero; its CSR kernels one
  * scattered x gather per nonzero).  The plan holds a re-ordered COPY of the matrix (include/loops/kernels/rowband.hxx): nonzeros
- * sorted by (band of H consecutive rows, column, CSR order), cut at column blocks of 2^16 and padded to steps of 256 items; per
- * item the value and one packed word (row code) << 16 | (column & 0xFFFF) -- 8 bytes per nonzero with 4-byte values.  Row code:
- * the row inside the band; H = padding; above H: one of 16 replicated accumulators of a HUB row (a row holding >= 1/128 of its
- * band's nonzeros, at most 32 per band), so that the lanes of one instruction do not meet in one LDS word.
+ * sorted by (band of H consecutive rows, column, CSR order), every band padded to steps of 256 slots; per slot the value, a 16-bit
+ * row code and the one-byte column DELTA to the previous slot -- 7 bytes per nonzero with 4-byte values -- plus, per group of 64
+ * slots, the absolute column of its first slot; gaps of more than 255 columns are bridged by padding slots.  Row code: the row
+ * inside the band; H = padding; above H: one of 16 replicated accumulators of a HUB row (a row holding >= 1/128 of its band's
+ * nonzeros, at most 32 per band), so that the lanes of one instruction do not meet in one LDS word.
  * y = A x: one workgroup per chunk of a band adds its products into fp64 words of LDS (ds_add_f64) and stores the band's rows
  * -- straight to y, or, where a band was cut into several chunks, as fp32 partial vectors that a second small kernel adds in
  * chunk order.  Products are fp32 (one rounding each), all sums fp64, y is rounded once (twice where a band was cut): bit-equal to
  * the CSR kernels on exactly summable inputs, within 1e-6 of the f64-accumulated product otherwise (util/reference.hxx:146-166);
  * no global atomics; y needs no zero-fill.  4-byte values only.
  * band_rows: 0 = automatic, else a power of two in [64, 16384]; target_chunks: 0 = automatic, else about how many workgroups
- * the first kernel is cut into (LOOPS_E_BADARG otherwise).  LOOPS_E_RANGE when bands x column blocks exceed 2^26 or the padded
- * layout may reach 2^31 items.  Creation is synchronous (device radix sort, O(nnz)).
- * info8 = {H, bands, column blocks, steps of 256 items incl. padding, chunks, partial vectors, bands cut into several chunks,
- * wavefronts per workgroup of the first kernel}.  loops_rowband_plan_arrays: HOST copies (any pointer may be NULL): values / rc / perm [steps * 256] (perm = CSR
- * position of the item, -1 = padding), stepcol [steps], chunks [4 * chunks] = {band, first step, end step, partial slot or -1},
+ * the first kernel is cut into (LOOPS_E_BADARG otherwise).  LOOPS_E_RANGE when the padded layout may reach 2^31 slots (nnz +
+ * bands x (cols / 255 + 256)).  Creation is synchronous (device radix sort, O(nnz)).
+ * info8 = {H, bands, padding slots that bridge column gaps, steps of 256 slots incl. padding, chunks, partial vectors, bands cut into several chunks,
+ * wavefronts per workgroup of the first kernel}.  loops_rowband_plan_arrays: HOST copies (any pointer may be NULL): values / row16 / delta8 / perm [steps * 256]
+ * (perm = CSR position of the slot, -1 = padding), stepbase [4 * steps], chunks [4 * chunks] = {band, first step, end step, partial slot or -1},
  * multi [3 * cut bands] = {band, first partial slot, chunks}, hubs [bands * 33] = per band the number of hubs, then their rows
  * inside the band.  loops_rowband_plan_set_chunks re-cuts the bands of a built plan (tuning; synchronous).
  * loops_rowband_plan_tune times the product with 8 and 16 wavefronts per workgroup of the first kernel (`repeats` launches each,
@@ -320,8 +321,8 @@ int loops_rowband_plan_create_f32(int rows, int cols, int nnz, const int* offset
                                   int band_rows, int target_chunks, void* stream, loops_rowband_plan_t** out);
 void loops_rowband_plan_destroy(loops_rowband_plan_t* plan);
 int loops_rowband_plan_info(const loops_rowband_plan_t* plan, int* info8);
-int loops_rowband_plan_arrays(const loops_rowband_plan_t* plan, void* values, unsigned int* rc, int* perm, int* stepcol, int* chunks,
-                              int* multi, unsigned short* hubs);
+int loops_rowband_plan_arrays(const loops_rowband_plan_t* plan, void* values, unsigned short* row16, unsigned char* delta8, int* perm,
+                              int* stepbase, int* chunks, int* multi, unsigned short* hubs);
 int loops_rowband_plan_set_chunks(loops_rowband_plan_t* plan, int target_chunks);
 int loops_rowband_plan_tune(loops_rowband_plan_t* plan, int repeats, float* ms2, void* stream);
 int loops_rowband_plan_set_waves(loops_rowband_plan_t* plan, int waves);

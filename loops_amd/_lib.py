@@ -208,7 +208,7 @@ def lib() -> C.CDLL:
         L.loops_rowband_plan_destroy.argtypes = [vp]
         L.loops_rowband_plan_destroy.restype = None
         L.loops_rowband_plan_info.argtypes = [vp, vp]
-        L.loops_rowband_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        L.loops_rowband_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.loops_rowband_plan_set_chunks.argtypes = [vp, ci]
         L.loops_rowband_plan_tune.argtypes = [vp, ci, vp, vp]
         L.loops_rowband_plan_set_waves.argtypes = [vp, ci]

@@ -308,7 +308,7 @@ class PanelBinnedPlan:
 class RowBandPlan:
     """Row-band copy of a CSR (loops_rowband_plan_*; include/loops/kernels/rowband.hxx): the y accumulators of a band of H rows
     live in LDS as fp64 words, the band's nonzeros are sorted by column so that a wavefront's 64 x gathers fall on a few
-    neighbouring lines; 8 bytes per nonzero streamed.  For x of a few MB, or column locality at band scale.  fp32 only."""
+    neighbouring lines; 7 bytes per nonzero streamed (columns as one-byte deltas).  For x of a few MB, or column locality at band scale.  fp32 only."""
 
     STEP = 256
 
@@ -325,7 +325,7 @@ class RowBandPlan:
     def _read_info(self):
         info = (C.c_int * 8)()
         L.check(L.lib().loops_rowband_plan_info(self._h, info), "loops_rowband_plan_info")
-        (self.H, self.num_bands, self.num_colblocks, self.steps, self.num_chunks, self.num_partials, self.num_multi,
+        (self.H, self.num_bands, self.gap_pads, self.steps, self.num_chunks, self.num_partials, self.num_multi,
          self.waves) = list(info)
         self.padded = self.steps * self.STEP
 
@@ -350,15 +350,15 @@ class RowBandPlan:
         self._read_info()
 
     def arrays(self):
-        """(values, rc, perm, stepcol, chunks [n, 4], multi [m, 3], hubs [bands, 33]) copied to the host."""
-        val, rc = np.zeros(self.padded, np.float32), np.zeros(self.padded, np.uint32)
-        perm, stepcol = np.zeros(self.padded, np.int32), np.zeros(self.steps, np.int32)
+        """(values, row16, delta8, perm, stepbase [steps, 4], chunks [n, 4], multi [m, 3], hubs [bands, 33]) copied to the host."""
+        val, row16, delta8 = np.zeros(self.padded, np.float32), np.zeros(self.padded, np.uint16), np.zeros(self.padded, np.uint8)
+        perm, stepbase = np.zeros(self.padded, np.int32), np.zeros((self.steps, 4), np.int32)
         chunks, multi = np.zeros((self.num_chunks, 4), np.int32), np.zeros((self.num_multi, 3), np.int32)
         hubs = np.zeros((self.num_bands, 33), np.uint16)
         p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
-        L.check(L.lib().loops_rowband_plan_arrays(self._h, p(val), p(rc), p(perm), p(stepcol), p(chunks), p(multi), p(hubs)),
+        L.check(L.lib().loops_rowband_plan_arrays(self._h, p(val), p(row16), p(delta8), p(perm), p(stepbase), p(chunks), p(multi), p(hubs)),
                 "loops_rowband_plan_arrays")
-        return val, rc, perm, stepcol, chunks, multi, hubs
+        return val, row16, delta8, perm, stepbase, chunks, multi, hubs
 
     def refresh_values(self, values: torch.Tensor):
         assert values.dtype == self.dtype and values.numel() == self.nnz

@@ -34,11 +34,11 @@ checked = False
 for H in ints("RB_H", "8192"):
     plan, b_ms = build_ms(lambda: S.RowBandPlan(csr, H, 0))
     if not checked and "--nocheck" not in sys.argv:   # the device-built layout against the specification (once)
-        v, rc, perm, stepcol, bs, hubs = spec.layout(off, idx, val, rows, cols, H)
-        dv, drc, dperm, dstepcol, dchunks, dmulti, dhubs = plan.arrays()
-        assert plan.steps == stepcol.size, (plan.steps, stepcol.size)
+        v, r16, d8, perm, base, bs, hubs = spec.layout(off, idx, val, rows, cols, H)
+        dv, dr16, dd8, dperm, dbase, dchunks, dmulti, dhubs = plan.arrays()
+        assert plan.steps == base.shape[0], (plan.steps, base.shape)
         assert np.array_equal(dhubs, hubs), (dhubs[:2], hubs[:2])
-        assert np.array_equal(dv, v) and np.array_equal(drc, rc) and np.array_equal(dperm, perm) and np.array_equal(dstepcol, stepcol)
+        assert np.array_equal(dv, v) and np.array_equal(dr16, r16) and np.array_equal(dd8, d8) and np.array_equal(dperm, perm) and np.array_equal(dbase, base)
         ch, mu = spec.chunk_list(bs, plan.num_bands if plan.num_bands >= 256 else 256)
         assert np.array_equal(dchunks[:, :4], ch) and np.array_equal(dmulti, mu), (dchunks[:4], ch[:4])
         checked = True

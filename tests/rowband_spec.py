@@ -5,7 +5,6 @@ import heapq
 import numpy as np
 
 STEP = 256
-COLBLOCK_BITS = 16
 MAX_HUBS = 32
 HUB_REPLICAS = 16
 
@@ -29,40 +28,68 @@ def hub_table(off, rows, H):
 
 
 def layout(off, idx, val, rows, cols, H):
-    """-> (val [steps * 256], rc, perm, stepcol [steps], band_step [bands + 1], hubs [bands, 33]).
-    Items sorted by (band = row // H, column, CSR position); segments (band, column >> 16) padded to whole steps of 256; inside a
-    step sorted position q sits at lane q % 64, element q // 64; rc = (row code) << 16 | (column & 0xFFFF), row code = row - band * H,
-    or H + 1 + hub * 16 + q % 16 for the items of a hub row; padding: value 0, row code H, offset 0, perm -1."""
+    """-> (val [steps * 256], row16, delta8, perm, stepbase [steps, 4], band_step [bands + 1], hubs [bands, 33]).
+    Items sorted by (band = row // H, column, CSR position).  Inside a band a gap of more than 255 columns between neighbours is
+    bridged by (gap - 1) // 255 padding slots of delta 255 in front of the item; every band is padded to whole steps of 256 slots.
+    Inside a step slot q sits at lane q % 64, element q // 64.  Per slot: the value, the row code (row - band * H, or
+    H + 1 + hub * 16 + q % 16 for the items of a hub row; H = padding), the column delta to the previous slot (0 .. 255; 0 for trailing
+    padding and for the first slot of every group of 64) and perm (CSR position, -1 = padding); per step and group of 64 slots the absolute column of the group's first slot."""
     nnz = idx.size
     B = -(-rows // H) if rows else 0
-    CB = max(1, -(-cols // (1 << COLBLOCK_BITS)))
     hubidx, hubs = hub_table(off, rows, H)
     row_of = np.repeat(np.arange(rows, dtype=np.int64), np.diff(off.astype(np.int64)))
     band = row_of // H
     col = idx.astype(np.int64)
     order = np.lexsort((np.arange(nnz), col, band))
-    g = band[order] * CB + (col[order] >> COLBLOCK_BITS)
-    counts = np.bincount(g, minlength=B * CB).astype(np.int64)
-    seg_steps = -(-counts // STEP)
-    seg_step = np.r_[0, np.cumsum(seg_steps)]
-    seg_start = np.r_[0, np.cumsum(counts)]
-    steps = int(seg_step[-1])
-    within = np.arange(nnz, dtype=np.int64) - seg_start[g]
-    step = seg_step[g] + within // STEP
-    q = within % STEP
-    at = step * STEP + (q % 64) * 4 + q // 64
-    v = np.zeros(steps * STEP, val.dtype)
-    rc = np.full(steps * STEP, H << 16, np.uint32)
-    perm = np.full(steps * STEP, -1, np.int32)
-    stepcol = np.zeros(steps, np.int32)
+    sb, sc, sr = band[order], col[order], row_of[order]
+    first = np.r_[True, sb[1:] != sb[:-1]] if nnz else np.zeros(0, bool)
+    gap = np.where(first, 0, sc - np.r_[0, sc[:-1]])
+    pads = np.where(gap > 255, (gap - 1) // 255, 0)
+    cnt = 1 + pads
+    pos = np.r_[0, np.cumsum(cnt)]                                    # running slot count, band after band (not yet step-aligned)
+    band_start = np.searchsorted(sb, np.arange(B + 1), side="left")
+    tot = pos[band_start[1:]] - pos[band_start[:-1]]
+    band_step = np.r_[0, np.cumsum(-(-tot // STEP))].astype(np.int64)
+    steps = int(band_step[-1])
+    n = steps * STEP
+    v = np.zeros(n, val.dtype)
+    row16 = np.full(n, H, np.uint16)
+    delta8 = np.zeros(n, np.uint8)
+    perm = np.full(n, -1, np.int32)
+    colabs = np.zeros(n, np.int64)                                    # absolute column of every slot (for the step bases)
+    slot_in_band = pos[:-1] - pos[band_start[sb]] + pads              # of the item itself; its pads sit right in front
+    s_abs = band_step[sb] * STEP + slot_in_band                       # slot number counted in sorted order
+    def mem(s):                                                       # sorted slot number -> position in the arrays
+        q = s % STEP
+        return (s // STEP) * STEP + (q % 64) * 4 + q // 64
+    at = mem(s_abs)
     v[at] = val[order]
-    h = hubidx[row_of[order]].astype(np.int64)
-    code = np.where(h >= 0, H + 1 + h * HUB_REPLICAS + q % HUB_REPLICAS, row_of[order] - band[order] * H)
-    rc[at] = ((code << 16) | (col[order] & 0xFFFF)).astype(np.uint32)
+    h = hubidx[sr].astype(np.int64)
+    q = s_abs % STEP
+    code = np.where(h >= 0, H + 1 + h * HUB_REPLICAS + q % HUB_REPLICAS, sr - sb * H)
+    row16[at] = code.astype(np.uint16)
+    delta8[at] = (gap - 255 * pads).astype(np.uint8)
     perm[at] = order.astype(np.int32)
-    stepcol[step] = ((col[order] >> COLBLOCK_BITS) << COLBLOCK_BITS).astype(np.int32)
-    band_step = seg_step[np.arange(B + 1) * CB].astype(np.int32)
-    return v, rc, perm, stepcol, band_step, hubs
+    colabs[at] = sc
+    # the padding slots that bridge gaps: pad t (0-based) of item j sits pads_j - t slots in front of it, at column prev + 255 (t + 1)
+    jj = np.flatnonzero(pads > 0)
+    if jj.size:
+        rep = np.repeat(jj, pads[jj])
+        t = np.arange(rep.size) - np.repeat(np.cumsum(pads[jj]) - pads[jj], pads[jj])
+        ps = s_abs[rep] - pads[rep] + t
+        pat = mem(ps)
+        delta8[pat] = 255
+        colabs[pat] = (sc[rep] - gap[rep]) + 255 * (t + 1)
+    # step bases: the absolute column of the first slot of every group of 64 sorted slots (an item's own column, a bridging
+    # pad's column); 0 for groups that are trailing padding altogether (their deltas are 0: they gather x[0] into the dump word)
+    used = np.zeros(n, bool)
+    used[at] = True
+    if jj.size:
+        used[pat] = True
+    first_of_group = mem(np.arange(0, n, 64, dtype=np.int64))
+    delta8[first_of_group] = 0                                        # (the group's base IS the column of its first slot)
+    stepbase = np.where(used[first_of_group], colabs[first_of_group], 0).reshape(steps, 4).astype(np.int32) if steps else np.zeros((0, 4), np.int32)
+    return v, row16, delta8, perm, stepbase, band_step.astype(np.int32), hubs
 
 
 def chunk_list(band_step, target_chunks):
@@ -109,15 +136,18 @@ def chunk_list(band_step, target_chunks):
     return np.array(chunks, np.int32).reshape(-1, 4), np.array(multi, np.int32).reshape(-1, 3)
 
 
-def product(v, rc, stepcol, band_step, hubs, H, rows, x):
+def product(v, row16, delta8, stepbase, band_step, hubs, H, rows, x):
     """What the kernels compute, in numpy (fp32 products, fp64 sums): the specification of y for a layout."""
     y = np.zeros(rows)
     if v.size == 0:
         return y
+    steps = v.size // STEP
+    # memory position (step, lane, e) holds sorted slot 64 e + lane: columns = base of the group + running sum of the deltas
+    d = delta8.reshape(steps, 64, 4).transpose(0, 2, 1).astype(np.int64)          # [step, e, lane]
+    c = (stepbase.astype(np.int64)[:, :, None] + np.cumsum(d, axis=2)).transpose(0, 2, 1).reshape(-1)   # back to memory order
     step = np.arange(v.size) // STEP
     band = np.searchsorted(band_step, step, side="right") - 1
-    code = (rc >> 16).astype(np.int64)
-    c = stepcol[step].astype(np.int64) + (rc & 0xFFFF)
+    code = row16.astype(np.int64)
     prod = (v * x[c]).astype(np.float64)
     plain = code < H
     np.add.at(y, (band * H + code)[plain], prod[plain])

@@ -1,6 +1,7 @@
 """Row-band layout (loops_rowband_plan_*, include/loops/kernels/rowband.hxx): the device-built layout against its numpy
-specification (tests/rowband_spec.py: array for array -- items by (band, column, CSR order), segments padded to steps of 256,
-the interleave inside a step, hub rows with replicated accumulators, the chunk list), and the SpMV over it against the oracle
+specification (tests/rowband_spec.py: array for array -- items by (band, column, CSR order), one-byte column deltas with padding
+slots bridging long gaps, bands padded to steps of 256, the interleave inside a step, hub rows with replicated accumulators,
+the chunk list), and the SpMV over it against the oracle
 -- bit for bit on exactly summable inputs, within 1e-6 of the f64-accumulated product otherwise, identical bits from run to
 run, with the peer fan-out, bands cut into several chunks (second kernel) and uncut, 8 and 16 wavefronts, from the battery up
 to BASELINE C2 / C3-band / C5-shard sizes; and the SpMV plan adopting it where it wins."""
@@ -34,14 +35,16 @@ def _check_layout(plan, off, idx, val, target_chunks=0):
     if rows == 0:
         assert plan.steps == 0 and plan.num_chunks == 0
         return
-    v, rc, perm, stepcol, bs, hubs = spec.layout(off, idx, val, rows, cols, plan.H)
-    dv, drc, dperm, dstepcol, dchunks, dmulti, dhubs = plan.arrays()
-    assert plan.num_bands == -(-rows // plan.H) and plan.steps == stepcol.size
+    v, r16, d8, perm, base, bs, hubs = spec.layout(off, idx, val, rows, cols, plan.H)
+    dv, dr16, dd8, dperm, dbase, dchunks, dmulti, dhubs = plan.arrays()
+    assert plan.num_bands == -(-rows // plan.H) and plan.steps == base.shape[0]
     assert np.array_equal(dhubs, hubs)
-    assert np.array_equal(dperm, perm) and np.array_equal(drc, rc) and np.array_equal(dv, v) and np.array_equal(dstepcol, stepcol)
+    assert np.array_equal(dperm, perm) and np.array_equal(dr16, r16) and np.array_equal(dd8, d8) and np.array_equal(dv, v)
+    assert np.array_equal(dbase, base)
     real = perm >= 0
     assert real.sum() == idx.size and np.array_equal(np.sort(perm[real]), np.arange(idx.size))   # every nonzero exactly once
-    assert np.all(v[~real] == 0) and np.all((rc[~real] >> 16) == plan.H) and np.all((rc[~real] & 0xFFFF) == 0)  # inert padding
+    assert np.all(v[~real] == 0) and np.all(r16[~real] == plan.H)                                 # inert padding
+    assert plan.gap_pads >= int((d8[~real] == 255).sum())                                         # the slots that bridge column gaps (a group's first slot stores delta 0)
     B = plan.num_bands
     target = target_chunks or (B if B >= _cus() else _cus())
     ch, mu = spec.chunk_list(bs, target)
@@ -73,8 +76,8 @@ def test_battery_layout_and_product():
 
 
 @pytest.mark.parametrize("band_rows,target", [(0, 0), (16384, 0), (8192, 700), (2048, 0), (256, 1000)])
-def test_many_bands_and_column_blocks_bit_exact(band_rows, target):
-    """More rows than one band, more columns than one 2^16 block, power-law rows with hubs (replicated accumulators), empty
+def test_many_bands_bit_exact(band_rows, target):
+    """More rows than one band, columns beyond 2^16, power-law rows with hubs (replicated accumulators), empty
     rows, a ragged tail; bands uncut and cut into several chunks (partial vectors + the second kernel): bit-exact vs the oracle,
     the numpy specification of the product, the fan-out twin, a value refresh, and two runs give identical bits."""
     from loops_amd import spmv as S, generate as G
@@ -88,11 +91,11 @@ def test_many_bands_and_column_blocks_bit_exact(band_rows, target):
     csr = _dev(off, idx, val, rows, cols)
     x = torch.from_numpy(xh).cuda()
     plan = S.RowBandPlan(csr, band_rows, target)
-    assert plan.num_colblocks == 3 and plan.num_bands == -(-rows // plan.H)
+    assert plan.num_bands == -(-rows // plan.H)
     _check_layout(plan, off, idx, val, target)
-    v, rc, perm, stepcol, bs, hubs = spec.layout(off, idx, val, rows, cols, plan.H)
+    v, r16, d8, perm, base, bs, hubs = spec.layout(off, idx, val, rows, cols, plan.H)
     assert hubs[:, 0].max() > 0                                          # some band has hub rows
-    assert np.array_equal(spec.product(v, rc, stepcol, bs, hubs, plan.H, rows, xh).astype(np.float32), ref)
+    assert np.array_equal(spec.product(v, r16, d8, base, bs, hubs, plan.H, rows, xh).astype(np.float32), ref)
     if target:
         assert plan.num_partials > 0
     for waves in (8, 16):
@@ -113,9 +116,9 @@ def test_many_bands_and_column_blocks_bit_exact(band_rows, target):
     plan.close()
 
 
-def test_short_rows_over_many_column_blocks():
-    """Very short rows over 16 column blocks: segments (band, column block) of a few dozen items, so most steps are mostly
-    padding (dump-word adds), hub rows among the short ones.  Bit-exact on exactly summable inputs; identical bits from run to
+def test_short_rows_with_long_column_gaps():
+    """Very short rows over a million columns: the mean column gap inside a band is far beyond 255, so padding slots that bridge
+    the gaps outnumber the nonzeros (dump-word adds of x values that are read but never used), hub rows among the short ones.  Bit-exact on exactly summable inputs; identical bits from run to
     run and 1e-6 with real values."""
     from loops_amd import spmv as S, generate as G
     from oracle import oracle as O
@@ -129,7 +132,7 @@ def test_short_rows_over_many_column_blocks():
     ref = O.spmv_f32(off, idx, val, xh, omp=True)
     csr = _dev(off, idx, val, rows, cols)
     plan = S.RowBandPlan(csr)
-    assert plan.num_colblocks == 16 and plan.padded > 1.2 * nnz
+    assert plan.gap_pads > 0.05 * nnz and plan.padded >= nnz + plan.gap_pads        # (mean column gap of a band ~ 90: one in ten beyond 255)
     _check_layout(plan, off, idx, val)
     x = torch.from_numpy(xh).cuda()
     assert np.array_equal(plan.spmv(x).cpu().numpy(), ref)
@@ -212,7 +215,7 @@ def test_full_size_configurations_bit_exact(case):
     mp = S.MergePathPlan(csr, "512x8")
     want = S.merge_path_flat(csr, x, plan=mp)
     plan = S.RowBandPlan(csr)
-    assert plan.H == 16384 and plan.padded - nnz <= 255 * plan.num_bands * plan.num_colblocks
+    assert plan.H == 16384 and plan.padded - nnz - plan.gap_pads <= 255 * plan.num_bands
     for waves in (8, 16):
         plan.set_waves(waves)
         got = plan.spmv(x)

@@ -21,30 +21,35 @@ def test_layout_holds_every_nonzero_once_and_reproduces_the_product_on_the_batte
         if r == 0:
             continue
         for H in (64, 256):
-            v, rc, perm, stepcol, bs, hubs = spec.layout(off, idx, val, r, c, H)
+            v, r16, d8, perm, base, bs, hubs = spec.layout(off, idx, val, r, c, H)
             real = perm >= 0
             assert real.sum() == idx.size and np.array_equal(np.sort(perm[real]), np.arange(idx.size)), name
-            assert v.size % spec.STEP == 0 and bs[0] == 0 and bs[-1] * spec.STEP == v.size
-            assert np.all(v[~real] == 0) and np.all((rc[~real] >> 16) == H)
+            assert v.size % spec.STEP == 0 and bs[0] == 0 and bs[-1] * spec.STEP == v.size and base.shape == (v.size // spec.STEP, 4)
+            assert np.all(v[~real] == 0) and np.all(r16[~real] == H)
             x = g[f"{name}.x_int"].astype(np.float32)
-            assert np.array_equal(spec.product(v, rc, stepcol, bs, hubs, H, r, x), _csr_product(off, idx, val, x)), (name, H)
+            assert np.array_equal(spec.product(v, r16, d8, base, bs, hubs, H, r, x), _csr_product(off, idx, val, x)), (name, H)
 
 
-def test_hubs_column_blocks_and_chunk_lists():
+def test_hubs_gap_pads_and_chunk_lists():
     from loops_amd import generate as G
     rows, cols = 9_001, 150_001
     deg = G.powerlaw_degrees(rows, 1 << 18, cap=1 << 12)
     deg[::7] = 0
     off, idx, val = G.csr_from_degrees(deg, cols, 1)
     H = 2048
-    v, rc, perm, stepcol, bs, hubs = spec.layout(off, idx, val, rows, cols, H)
+    v, r16, d8, perm, base, bs, hubs = spec.layout(off, idx, val, rows, cols, H)
     hubidx, table = spec.hub_table(off, rows, H)
     assert np.array_equal(table, hubs) and hubs[:, 0].max() > 0 and hubs[:, 0].max() <= spec.MAX_HUBS
-    code = (rc >> 16).astype(np.int64)
-    assert code.max() <= H + spec.MAX_HUBS * spec.HUB_REPLICAS                  # row codes fit the LDS words of a workgroup
-    assert np.all(stepcol % (1 << spec.COLBLOCK_BITS) == 0) and set(np.unique(stepcol >> spec.COLBLOCK_BITS)) <= {0, 1, 2}
+    assert int(r16.max()) <= H + spec.MAX_HUBS * spec.HUB_REPLICAS              # row codes fit the LDS words of a workgroup
+    assert base.min() >= 0 and base.max() < cols
     x = G.uniform_distribution_int(cols)
-    assert np.array_equal(spec.product(v, rc, stepcol, bs, hubs, H, rows, x), _csr_product(off, idx, val, x))
+    assert np.array_equal(spec.product(v, r16, d8, base, bs, hubs, H, rows, x), _csr_product(off, idx, val, x))
+    # a sparse band: column gaps far beyond 255 are bridged by padding slots of delta 255 that contribute nothing
+    o2, i2, v2 = G.csr_from_degrees(np.full(300, 3, np.int64), 3_000_000, 1)
+    a = spec.layout(o2, i2, v2, 300, 3_000_000, 256)
+    assert (a[3] < 0).sum() > 5 * i2.size and (a[2][a[3] < 0] == 255).sum() > i2.size
+    x2 = G.uniform_distribution_int(3_000_000)
+    assert np.array_equal(spec.product(a[0], a[1], a[2], a[4], a[5], a[6], 256, 300, x2), _csr_product(o2, i2, v2, x2))
     B = bs.size - 1
     for target in (1, B, 7, 64, 1000, 10 ** 6):
         ch, mu = spec.chunk_list(bs, target)
