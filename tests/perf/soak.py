@@ -1,6 +1,6 @@
 """Soak: the tuned kernels launched back to back for a fixed wall time on C2 and on a self-completing band matrix; every
 result compared ON THE GPU with the first one (bit-equal) -- races / ordering bugs show up as a mismatch count > 0.
-usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3|r4]     (r2 / r3 / r4 = only the kernels added in that round)"""
+usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3|r4|r5]     (rN = only the kernels added in that round)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -123,6 +123,52 @@ def round4_planless():
         soak("2^21", f"plan-less merge_path_flat (device-decided), {tag}, real values", lambda y: (S.spmv("merge_path_flat", csr, x, y), None)[1], ref, r)
         del csr, plan
 
+
+# ---- round 5: the row-band layout -- LDS fp64 atomics from 8 / 16 wavefronts, hub replicas, partial vectors + combine, DPP prefix
+# sums of the column deltas; exactly summable inputs (any order gives the same bits) and real values (run-to-run identity)
+def round5():
+    off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    ref = torch.from_numpy(O.spmv_f32(off, idx, val, xh, omp=True)).cuda()
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    peers = [torch.empty(rows, device="cuda") for _ in range(2)]
+    for label, band_rows, target, waves in (("automatic (H 16384, 256 chunks)", 0, 0, 8), ("H 8192, 256 chunks, 16 wavefronts", 8192, 256, 16),
+                                            ("H 4096, uncut", 4096, 256, 8), ("H 16384, 1000 chunks", 16384, 1000, 8)):
+        rb = S.RowBandPlan(csr, band_rows, target)
+        rb.set_waves(waves)
+        soak("c2", "row_band " + label, lambda y: (rb.spmv(x, y), None)[1], ref, rows)
+        rb.close()
+    rb = S.RowBandPlan(csr)
+    def fan(y):
+        for p in peers: p.fill_(float("nan"))
+        rb.spmv_fanout(x, y, peers)
+        return peers
+    soak("c2", "row_band + fan-out (2 peers)", fan, ref, rows)
+    sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
+    soak("c2", f"held SpMV plan ({sp.layout})", lambda y: (sp.spmv(x, y), None)[1], ref, rows)
+    rb.close(); sp.close()
+    off2, idx2, val2 = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1, 0, False)
+    csr2 = S.CSR.from_numpy(rows, cols, off2, idx2, val2)
+    xr = torch.from_numpy(G.realistic_x(cols)).cuda()
+    for target in (0, 1000):
+        rb2 = S.RowBandPlan(csr2, 0, target)
+        first = rb2.spmv(xr).clone()
+        soak("c2real", f"row_band, real values, {rb2.num_chunks} chunks: run-to-run bit identity", lambda y: (rb2.spmv(xr, y), None)[1], first, rows)
+        rb2.close()
+    del csr, csr2
+    off3, idx3, val3 = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1, 0, True, 8192)
+    ref3 = torch.from_numpy(O.spmv_f32(off3, idx3, val3, xh, omp=True)).cuda()
+    csr3 = S.CSR.from_numpy(rows, cols, off3, idx3, val3)
+    rb3 = S.RowBandPlan(csr3)
+    rb3.set_waves(16)
+    soak("band", "row_band, columns in an 8192-wide band, 16 wavefronts", lambda y: (rb3.spmv(x, y), None)[1], ref3, rows)
+    rb3.close()
+
+
+if len(sys.argv) > 2 and sys.argv[2] == "r5":
+    round5()
+    sys.exit(0)
 
 if len(sys.argv) > 2 and sys.argv[2] == "r4":
     if len(sys.argv) > 3 and sys.argv[3] == "planless":
