@@ -87,6 +87,13 @@ constexpr int phases(int p) { return (p & phased_flag) != 0 ? (p & 0xff) : 0; }
 constexpr int phased_auto_flag = 0x40000;
 constexpr int phased_auto(int m) { return phased_flag | phased_auto_flag | m; }
 constexpr bool phased_is_auto(int p) { return (p & phased_auto_flag) != 0; }
+/// policy::windowed(L) -- MEASUREMENT ONLY (libloops_probes.so; profiles/r05_c3_lds_window_experiment.txt): every interior tile
+/// copies 2^L consecutive elements of x, centred on the column of the tile's middle row (`phase_args::window_cols` = the column
+/// count), into LDS with coalesced 16-byte loads; gathers whose column falls inside are served from LDS, the others from
+/// memory.  For matrices whose nonzeros sit near the diagonal at the scale of a tile's rows.  Same products, same bits.
+constexpr int windowed_flag = 0x80000;
+constexpr int windowed(int log2_w) { return windowed_flag | log2_w; }
+constexpr int window(int p) { return (p & windowed_flag) != 0 ? 1 << (p & 0xff) : 0; }
 }  // namespace policy
 
 /// Run-time side of the phased gathers: part of a column = min(col >> shift, M - 1); the clock's current part =
@@ -95,7 +102,17 @@ struct phase_args {
   unsigned int shift = 0;
   unsigned int inv_ticks = 0;
   unsigned int enabled = 1;  ///< policy::phased_auto kernels only: 0 = gather as the plain kernel does
+  unsigned int window_cols = 0;  ///< policy::windowed kernels only: columns of the matrix (>= the window)
+  unsigned int window_lo = 0;    ///< (set per tile by the engine: first column of the tile's window)
 };
+
+/// LDS window of x of a policy::windowed engine (nothing otherwise: empty base, the storage keeps its size).
+template <typename T, int W>
+struct window_store {
+  alignas(16) T xwin[W];
+};
+template <typename T>
+struct window_store<T, 0> {};
 
 /// 4 consecutive elements at byte offset `byte_off` of buffer `r` with cache-policy bits AUX (see policy).
 template <typename T, int AUX>
@@ -307,7 +324,10 @@ struct merge_tile_engine {
   static constexpr int NPROD = TILE + 4;                            // + alignment slack
   static constexpr int KV = (NPROD + 4 * TPB - 1) / (4 * TPB);      // vector-load rounds per thread
 
-  struct storage_t {
+  static constexpr int WINDOW = detail::policy::window(NT);
+  static_assert(WINDOW % (4 * TPB) == 0, "x window: whole 16-byte vectors per thread");
+
+  struct storage_t : detail::window_store<type_t, WINDOW> {
     // + a 4-slot dump group for the surplus lanes of the last STREAM round; 16-byte aligned so that unpadded engines
     // store a lane's four products with one ds_write_b128 (4 x ds_write_b32 at a 16-byte lane stride conflict 4 ways)
     alignas(16) type_t prod[PAD ? (NPROD + 4) + ((NPROD + 4) >> 5) + 1 : NPROD + 4];
@@ -346,6 +366,13 @@ struct merge_tile_engine {
     type_t val[KV][4];
     type_t xv[KV][4];
     if constexpr (INTERIOR) {
+      // (windowed engines: the window's loads leave first -- their address needs nothing but the tile's coordinates)
+      constexpr int WV = WINDOW > 0 ? WINDOW / (4 * TPB) : 1;
+      type_t win[WV][4];
+      if constexpr (WINDOW > 0) {
+#pragma unroll
+        for (int v = 0; v < WV; ++v) detail::load4<type_t, false>(x + phase.window_lo + (v * TPB + tid) * 4, win[v]);
+      }
       // Branch-free: a lane whose vector lies behind the tile's last nonzero loads the tile's LAST vector instead
       // (same line for all of them) and its products land in slots the walk never reads.
       int emax = (nz1 - 1) & ~3;
@@ -384,6 +411,42 @@ struct merge_tile_engine {
           for (int j = 0; j < 4; ++j)
             xv[k][j] = detail::buffer_load1<type_t, detail::policy::x_aux(NT)>(
                 rx, gather_index(col[k][j]) * static_cast<unsigned int>(sizeof(type_t)));
+        }
+      } else if constexpr (WINDOW > 0) {
+        // window -> LDS; gathers outside it leave first (execution-masked), then every lane reads LDS (index clamped:
+        // no branch), then the select
+#pragma unroll
+        for (int v = 0; v < WV; ++v) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s.xwin[(v * TPB + tid) * 4 + j] = win[v][j];
+        }
+        __syncthreads();
+        type_t xl[KV][4];
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned int c = gather_index(col[k][j]);
+            xv[k][j] = type_t(0);
+            if (c - phase.window_lo >= static_cast<unsigned int>(WINDOW)) xv[k][j] = x[c];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            unsigned int d = gather_index(col[k][j]) - phase.window_lo;
+            d = d < static_cast<unsigned int>(WINDOW) ? d : static_cast<unsigned int>(WINDOW - 1);
+            xl[k][j] = s.xwin[d];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < KV; ++k) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned int d = gather_index(col[k][j]) - phase.window_lo;
+            xv[k][j] = d < static_cast<unsigned int>(WINDOW) ? xl[k][j] : xv[k][j];
+          }
         }
       } else {
         bool phased_now = detail::policy::phases(NT) > 1;
@@ -530,7 +593,19 @@ struct merge_tile_engine {
     const int shift = nz0 - abase;             // 0..3 leading elements owned by the previous tile
     if constexpr (VEC) {
       // every vector load of the tile in-bounds?  (uniform; false only for the last tile(s) of the matrix)
-      if (abase + KV * 4 * TPB <= nnz) stream_vectors<true>(s, abase, nz1, nnz, indices, values, x, mark, phase);
+      if (abase + KV * 4 * TPB <= nnz) {
+        if constexpr (WINDOW > 0) {
+          // the window: WINDOW columns around the column of the tile's middle row, 16-byte aligned, inside [0, cols)
+          detail::phase_args ph = phase;
+          int lo = (row0 + (nrows >> 1) - WINDOW / 2) & ~3;
+          const int hi = (static_cast<int>(phase.window_cols) - WINDOW) & ~3;
+          lo = lo < hi ? lo : hi;
+          ph.window_lo = static_cast<unsigned int>(lo > 0 ? lo : 0);
+          stream_vectors<true>(s, abase, nz1, nnz, indices, values, x, mark, ph);
+        } else {
+          stream_vectors<true>(s, abase, nz1, nnz, indices, values, x, mark, phase);
+        }
+      }
       else stream_vectors<false>(s, abase, nz1, nnz, indices, values, x, mark);
     } else {
       // Unaligned arrays: coalesced 4-byte loads, one element per lane per round.

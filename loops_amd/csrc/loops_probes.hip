@@ -47,11 +47,15 @@ constexpr int kPolicies[] = {
     pol::make(0, 0, pol::sc0 | pol::sc1),            // 15
     pol::make(pol::nt, pol::nt, pol::sc1),           // 16
     pol::make(pol::nt | pol::sc1, pol::nt | pol::sc1, pol::sc1),  // 17
+    pol::windowed(11),                               // 18 LDS window of x: 2048 columns around the tile's middle row
+    pol::windowed(12),                               // 19 4096 columns (16 KB: still 4 workgroups per CU)
+    pol::windowed(13),                               // 20 8192 columns (32 KB: 3 workgroups per CU)
 };
 const char* const kPolicyNames[] = {
     "global plain", "global nontemporal", "buffer plain", "stream sc0", "stream nt", "stream sc1", "stream sc0+sc1",
     "stream nt+sc1", "stream nt+sc0", "stream sc0+sc1+nt", "idx nt / val plain", "idx plain / val nt", "gather sc0",
     "gather sc1", "gather nt", "gather sc0+sc1", "stream nt, gather sc1", "stream nt+sc1, gather sc1",
+    "x window 2048 in LDS", "x window 4096 in LDS", "x window 8192 in LDS",
 };
 constexpr int kNumPolicies = sizeof(kPolicies) / sizeof(kPolicies[0]);
 static_assert(kNumPolicies == sizeof(kPolicyNames) / sizeof(kPolicyNames[0]), "policy tables out of step");
@@ -71,17 +75,35 @@ scratch_view carve(void* scratch, int rows, int nnz) {
   return {coords, reinterpret_cast<float*>(carry_val), carry_row, m};
 }
 
+// policy::windowed engines: the fused tile kernel with the column count handed to the engine
+template <int NTP>
+__global__ void __launch_bounds__(TPB)
+windowed_tile_kernel(const coord_t* __restrict__ coords, const int rows, const int cols, const int nnz, const int* __restrict__ offsets,
+                     const int* __restrict__ indices, const float* __restrict__ values, const float* __restrict__ x,
+                     float* __restrict__ y, int* __restrict__ carry_row, float* __restrict__ carry_val) {
+  kernels::detail::phase_args phase;
+  phase.window_cols = static_cast<unsigned int>(cols);
+  kernels::merge_path_spmv_tile_to<TPB, IPT, true, NTP, true, false, true>(
+      coords, rows, nnz, kernels::csr_row_end<int>{offsets}, indices, values, x, kernels::plain_store<float>{y}, carry_row,
+      carry_val, nullptr, phase);
+}
+
 template <int P>
-void launch_policy(const scratch_view& v, int rows, int nnz, const int* off, const int* idx, const float* val,
+void launch_policy(const scratch_view& v, int rows, int cols, int nnz, const int* off, const int* idx, const float* val,
                    const float* x, float* y, hipStream_t stream) {
+  if constexpr (pol::window(kPolicies[P]) > 0) {
+    hipLaunchKernelGGL((windowed_tile_kernel<kPolicies[P]>), dim3(v.m), dim3(TPB), 0, stream, v.coords, rows, cols, nnz, off, idx,
+                       val, x, y, v.carry_row, v.carry_val);
+    return;
+  }
   hipLaunchKernelGGL((kernels::merge_path_spmv_fused<TPB, IPT, true, kPolicies[P], true, int, int, float, true>), dim3(v.m),
                      dim3(TPB), 0, stream, v.coords, rows, nnz, off, idx, val, x, y, v.carry_row, v.carry_val);
 }
 
 template <int... Ps>
-bool dispatch(int policy, std::integer_sequence<int, Ps...>, const scratch_view& v, int rows, int nnz, const int* off,
+bool dispatch(int policy, std::integer_sequence<int, Ps...>, const scratch_view& v, int rows, int cols, int nnz, const int* off,
               const int* idx, const float* val, const float* x, float* y, hipStream_t stream) {
-  return ((policy == Ps ? (launch_policy<Ps>(v, rows, nnz, off, idx, val, x, y, stream), true) : false) || ...);
+  return ((policy == Ps ? (launch_policy<Ps>(v, rows, cols, nnz, off, idx, val, x, y, stream), true) : false) || ...);
 }
 
 // Tile-shape experiment: shapes the product does not ship (a 512 x 16 tile halves the number of resident workgroups and
@@ -191,9 +213,9 @@ const char* loops_probe_policy_name(int policy) {
 int loops_probe_merge_path_f32(int policy, int stages, int rows, int cols, int nnz, const int* offsets,
                                const int* indices, const float* values, const float* x, float* y, void* scratch,
                                void* stream) {
-  (void)cols;
   if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz <= 0) return E_BADARG;
   if (policy < 0 || policy >= kNumPolicies) return E_CONFIG;
+  if (pol::window(kPolicies[policy]) > cols) return E_CONFIG;
   if ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) return E_BADARG;
   hipStream_t st = as_stream(stream);
   const scratch_view v = carve(scratch, rows, nnz);
@@ -203,7 +225,7 @@ int loops_probe_merge_path_f32(int policy, int stages, int rows, int cols, int n
     if (err) return err;
   }
   if (stages & 1) {
-    if (!dispatch(policy, std::make_integer_sequence<int, kNumPolicies>{}, v, rows, nnz, offsets, indices, values, x, y, st))
+    if (!dispatch(policy, std::make_integer_sequence<int, kNumPolicies>{}, v, rows, cols, nnz, offsets, indices, values, x, y, st))
       return E_CONFIG;
   }
   if (stages & 2)

@@ -4,6 +4,7 @@ stream and the x gather), tile kernel only, back-to-back launches between one pa
 kernel + fix-up against policy 0.
 
     python tests/perf/ab_policy.py [--iters 50] [--window W] [--only 0,4,13] [--json out.json]
+    python tests/perf/ab_policy.py --rows 7414866 --nnz 194109311 --window -4 --only 0,18,19,20 --no-shapes   (LDS window of x)
 
 Run it under `rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum ... --kernel-trace` to get the L2 hit rate per policy: the
 kernels differ in one template argument (the engine's NT parameter), printed here as `nt_param`."""
@@ -19,11 +20,17 @@ ap.add_argument("--only", default="")
 ap.add_argument("--json", default="")
 ap.add_argument("--log2-rows", type=int, default=20)
 ap.add_argument("--log2-nnz", type=int, default=24)
+ap.add_argument("--rows", type=int, default=0, help="exact row count (C3 stand-ins: 7414866)")
+ap.add_argument("--nnz", type=int, default=0, help="exact nonzero count (C3 stand-ins: 194109311)")
+ap.add_argument("--cap", type=int, default=1 << 14)
+ap.add_argument("--no-shapes", action="store_true", help="skip the tile-shape instantiations")
 args = ap.parse_args()
 
-rows = cols = 1 << args.log2_rows
-deg = G.powerlaw_degrees(rows, 1 << args.log2_nnz)
-off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, args.window or None)
+# --window: 0 = uniform columns, W > 0 = a band of W columns, -4 (generate.HOST_BLOCKED) = the host-blocked stand-in
+rows = cols = args.rows or (1 << args.log2_rows)
+deg = G.powerlaw_degrees(rows, args.nnz or (1 << args.log2_nnz), cap=args.cap)
+off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, args.window or None,
+                                   hosts=G.host_blocks(cols) if args.window == G.HOST_BLOCKED else None)
 csr = S.CSR.from_numpy(rows, cols, off, idx, val)
 x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
 y = torch.empty(rows, device="cuda")
@@ -50,8 +57,8 @@ for p in only:
     out[p] = {"name": names[p], "us": round(us, 2), "exact": ok}
     print(f"policy {p:2d} {names[p]:28s} {us:8.2f} us  exact={ok}", flush=True)
 # tile shapes the product does not ship (same kernel, plain loads)
-shapes = PR.ShapeRunner(csr)
-for i, name in enumerate(PR.SHAPES):
+shapes = None if args.no_shapes else PR.ShapeRunner(csr)
+for i, name in enumerate([] if args.no_shapes else PR.SHAPES):
     y.zero_()
     shapes.run(i, x, y)
     ok = bool(torch.equal(y, ref))
