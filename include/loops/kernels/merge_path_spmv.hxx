@@ -564,6 +564,71 @@ struct merge_tile_engine {
     __device__ __forceinline__ void operator()() const {}
   };
 
+  // ---- MEASUREMENT ONLY (libloops_probes.so, profiles/r05_c2_persistent_ordering_experiment.txt): a persistent workgroup that
+  // issues a tile's x gathers BEFORE the stream loads of its next tile.  The col_idx / values vectors of a tile live in a
+  // `tile_regs` the caller owns; `tile_pipe` hands the engine the loaded set of this tile and the set to fill for the next one.
+  struct tile_regs {
+    index_t col[KV][4];
+    type_t val[KV][4];
+  };
+  struct no_pipe {
+    static constexpr bool active = false;
+  };
+  /// LATE = false: the next tile's streams leave right behind this tile's gathers; true: once the gathers have RETURNED and
+  /// the products are in LDS (they are in flight during the walk either way).
+  template <bool LATE>
+  struct tile_pipe {
+    static constexpr bool active = true;
+    static constexpr bool late = LATE;
+    tile_regs& cur;    ///< this tile's vectors, issued by the previous tile (or the prologue) with issue_streams(abase)
+    tile_regs& next;   ///< filled here, behind this tile's gathers
+    int next_abase;    ///< 16-byte aligned element base of the next tile (this tile's again when there is none)
+    int next_nz1;      ///< end of the next tile on the nonzero axis
+  };
+  /// Branch-free stream loads of the tile [abase, nz1) (abase a multiple of 4, nnz % 4 == 0): as in stream_vectors, a lane whose
+  /// vector lies behind the tile's last nonzero loads the tile's LAST vector -- its products land in slots the walk never reads.
+  static __device__ __forceinline__ void issue_streams(tile_regs& r, const int abase, const int nz1,
+                                                       const index_t* __restrict__ indices, const type_t* __restrict__ values) {
+    const int tid = threadIdx.x;
+    int last = (nz1 - 1) & ~3;
+    last = last > abase ? last : abase;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      int e = abase + (k * TPB + tid) * 4;
+      e = e < last ? e : last;
+      detail::load4<index_t, false>(indices + static_cast<unsigned int>(e), r.col[k]);
+      detail::load4<type_t, false>(values + static_cast<unsigned int>(e), r.val[k]);
+    }
+  }
+  template <typename mark_t, typename pipe_t>
+  static __device__ __forceinline__ void stream_vectors_pipelined(storage_t& s, const int nnz, const index_t* __restrict__ indices,
+                                                                  const type_t* __restrict__ values, const type_t* __restrict__ x,
+                                                                  mark_t& mark, const pipe_t& pipe) {
+    const int tid = threadIdx.x;
+    type_t xv[KV][4];
+    mark();
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[k][j] = x[gather_index(pipe.cur.col[k][j])];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the gathers leave before the next tile's streams
+    if constexpr (!pipe_t::late) issue_streams(pipe.next, pipe.next_abase, pipe.next_nz1, indices, values);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      int i = (k * TPB + tid) * 4;
+      if ((k + 1) * TPB * 4 > NPROD) i = i < NPROD ? i : NPROD;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s.prod[detail::slot<PAD>(i + j)] = product(pipe.cur.col[k][j], pipe.cur.val[k][j], xv[k][j]);
+    }
+    if constexpr (pipe_t::late) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_streams(pipe.next, pipe.next_abase, pipe.next_nz1, indices, values);
+    }
+  }
+
   /// `mark` (MASK engines): called once, after the tile's col_idx / values loads have been ISSUED and before the
   /// x gathers wait for them -- the caller's row-offset loads + mark_row_end() go there, so that their latency
   /// overlaps the stream's instead of preceding it.  The mask must have been cleared (clear_marks + barrier).
@@ -579,13 +644,14 @@ struct merge_tile_engine {
 
   /// The same with the destination of finished rows abstracted: `out(r, v)` stores row r of y (plain_store,
   /// fanout_store).
-  template <typename store_t, typename mark_t = no_marks>
+  template <typename store_t, typename mark_t = no_marks, typename pipe_t = no_pipe>
   static __device__ __forceinline__ type_t run_to(storage_t& s, const offset_t* re, const int row0, const int nz0,
                                                   const int nrows, const int natoms, const int nnz,
                                                   const index_t* __restrict__ indices,
                                                   const type_t* __restrict__ values, const type_t* __restrict__ x,
                                                   const store_t out, const type_t carry_in,
-                                                  mark_t mark = mark_t{}, const detail::phase_args phase = {}) {
+                                                  mark_t mark = mark_t{}, const detail::phase_args phase = {},
+                                                  const pipe_t pipe = pipe_t{}) {
     const int tid = threadIdx.x;
     const int nz1 = nz0 + natoms;
     // ---- 1. STREAM ------------------------------------------------------------------------
@@ -593,7 +659,10 @@ struct merge_tile_engine {
     const int shift = nz0 - abase;             // 0..3 leading elements owned by the previous tile
     if constexpr (VEC) {
       // every vector load of the tile in-bounds?  (uniform; false only for the last tile(s) of the matrix)
-      if (abase + KV * 4 * TPB <= nnz) {
+      if constexpr (pipe_t::active) {
+        // (measurement kernels; nnz % 4 == 0 required: every vector the clamp of issue_streams leaves alone is whole)
+        stream_vectors_pipelined(s, nnz, indices, values, x, mark, pipe);
+      } else if (abase + KV * 4 * TPB <= nnz) {
         if constexpr (WINDOW > 0) {
           // the window: WINDOW columns around the column of the tile's middle row, 16-byte aligned, inside [0, cols)
           detail::phase_args ph = phase;

@@ -88,6 +88,64 @@ windowed_tile_kernel(const coord_t* __restrict__ coords, const int rows, const i
       carry_val, nullptr, phase);
 }
 
+// Ordering experiment (round-4 review, item 8): a PERSISTENT workgroup walks a contiguous share of the merge tiles (the product's
+// work_oriented_spmv_fused) and, pipelined, issues a tile's x gathers BEFORE the stream loads of its next tile.  Two register
+// sets: `cur` (dead once the tile's products are in LDS) and `next` (in flight during the walk), copied at the end of the tile.
+template <bool LATE>
+__global__ void __launch_bounds__(TPB)
+persistent_pipelined_kernel(const coord_t* __restrict__ coords, const int num_tiles, const int tiles_per_group, const int rows,
+                            const int nnz, const int* __restrict__ offsets, const int* __restrict__ indices,
+                            const float* __restrict__ values, const float* __restrict__ x, float* __restrict__ y,
+                            int* __restrict__ carry_row, float* __restrict__ carry_val) {
+  using engine_t = kernels::merge_tile_engine<TPB, IPT, true, 0, true, int, int, float, true>;
+  __shared__ typename engine_t::storage_t s_engine;
+  const int tid = threadIdx.x;
+  const int g = kernels::detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int t_begin = g * tiles_per_group;
+  int t_end = t_begin + tiles_per_group;
+  t_end = t_end < num_tiles ? t_end : num_tiles;
+  if (t_begin >= t_end) return;
+  float carry = 0.f;
+  int open_row = 0;
+  typename engine_t::tile_regs cur, next;
+  engine_t::issue_streams(cur, static_cast<int>(coords[t_begin].y) & ~3, static_cast<int>(coords[t_begin + 1].y), indices, values);
+  for (int t = t_begin; t < t_end; ++t) {
+    const coord_t c0 = coords[t];
+    const coord_t c1 = coords[t + 1];
+    const int tn = t + 1 < t_end ? t + 1 : t;
+    const int next_abase = static_cast<int>(coords[tn].y) & ~3;
+    const int next_nz1 = static_cast<int>(coords[tn + 1].y);
+    const int row0 = static_cast<int>(c0.x);
+    const int nz0 = static_cast<int>(c0.y);
+    const int nrows = static_cast<int>(c1.x) - row0;
+    const int natoms = static_cast<int>(c1.y) - nz0;
+    engine_t::clear_marks(s_engine);
+    __syncthreads();
+    carry = engine_t::run_to(
+        s_engine, static_cast<const int*>(nullptr), row0, nz0, nrows, natoms, nnz, indices, values, x, kernels::plain_store<float>{y},
+        carry,
+        [&]() {
+          for (int i = tid; i < nrows; i += TPB) engine_t::mark_row_end(s_engine, i, offsets[row0 + i + 1], nz0);
+        },
+        kernels::detail::phase_args{}, typename engine_t::template tile_pipe<LATE>{cur, next, next_abase, next_nz1});
+    open_row = row0 + nrows;
+    // (the copy stays HERE, behind the walk: an opaque use keeps the compiler from waiting for the next tile's streams any earlier)
+#pragma unroll
+    for (int k = 0; k < engine_t::KV; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        asm volatile("" : "+v"(next.col[k][j]), "+v"(next.val[k][j]));
+        cur.col[k][j] = next.col[k][j];
+        cur.val[k][j] = next.val[k][j];
+      }
+    }
+  }
+  if (tid == 0) {
+    carry_row[g] = open_row;
+    carry_val[g] = carry;
+  }
+}
+
 template <int P>
 void launch_policy(const scratch_view& v, int rows, int cols, int nnz, const int* off, const int* idx, const float* val,
                    const float* x, float* y, hipStream_t stream) {
@@ -203,6 +261,37 @@ int loops_row_gather_f32(const float* table, const int* idx, size_t count, int r
 size_t loops_probe_merge_path_scratch_bytes(int rows, int nnz) {
   const size_t m = static_cast<size_t>(math::ceil_div(static_cast<long long>(rows) + nnz, static_cast<long long>(TPB) * IPT));
   return (m + 1) * sizeof(coord_t) + (m + 2) * (sizeof(double) + sizeof(int)) + 64;
+}
+
+int loops_probe_persistent_f32(int pipelined, int groups, int stages, int rows, int cols, int nnz, const int* offsets,
+                               const int* indices, const float* values, const float* x, float* y, void* scratch, void* stream) {
+  (void)cols;
+  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz < 8 || (nnz & 3) || groups <= 0) return E_BADARG;
+  if ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) return E_BADARG;
+  hipStream_t st = as_stream(stream);
+  const scratch_view v = carve(scratch, rows, nnz);
+  if (v.m < 2 || groups > v.m) return E_CONFIG;
+  if (stages & 4) {
+    const int err = kernels::launch_merge_path_coordinates(st, offsets, rows, nnz, TPB * IPT, v.m, v.coords);
+    if (err) return err;
+  }
+  const int per = math::ceil_div(v.m, groups);
+  const int grid = math::ceil_div(v.m, per);
+  if (stages & 1) {
+    if (pipelined == 2)
+      hipLaunchKernelGGL(persistent_pipelined_kernel<true>, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets,
+                         indices, values, x, y, v.carry_row, v.carry_val);
+    else if (pipelined)
+      hipLaunchKernelGGL(persistent_pipelined_kernel<false>, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets, indices,
+                         values, x, y, v.carry_row, v.carry_val);
+    else
+      hipLaunchKernelGGL((kernels::work_oriented_spmv_fused<TPB, IPT, true, 0, true, int, int, float, true>), dim3(grid), dim3(TPB), 0,
+                         st, v.coords, v.m, per, rows, nnz, offsets, indices, values, x, y, v.carry_row, v.carry_val);
+  }
+  if (stages & 2)
+    hipLaunchKernelGGL(kernels::merge_path_spmv_fixup<float>, dim3(math::ceil_div(grid, 256)), dim3(256), 0, st, v.carry_row,
+                       v.carry_val, grid, rows, y);
+  return static_cast<int>(hipGetLastError());
 }
 
 int loops_probe_policy_count(void) { return kNumPolicies; }

@@ -36,6 +36,7 @@ def lib() -> C.CDLL:
         P.loops_probe_policy_name.restype = C.c_char_p
         P.loops_probe_merge_path_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
         P.loops_probe_merge_path_shape_f32.argtypes = [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
+        P.loops_probe_persistent_f32.argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
         _probes = P
     return _probes
 
@@ -105,6 +106,27 @@ class PolicyRunner:
         L.check(lib().loops_probe_merge_path_f32(policy, stages, c.rows, c.cols, c.nnzs, _ptr(c.offsets), _ptr(c.indices),
                                                  _ptr(c.values), _ptr(x), _ptr(y), _ptr(self.scratch), _stream()),
                 "loops_probe_merge_path_f32")
+        return y
+
+
+class PersistentRunner:
+    """The merge tiles walked by `groups` persistent workgroups (work_oriented_spmv_fused<512, 8>), plain or with each tile's
+    gathers issued before the stream loads of the next tile (loops_probe_persistent_f32)."""
+
+    def __init__(self, csr):
+        self.csr = csr
+        n = lib().loops_probe_merge_path_scratch_bytes(csr.rows, csr.nnzs)
+        self.scratch = torch.empty(n, dtype=torch.uint8, device=csr.values.device)
+        self.built = False
+
+    def run(self, pipelined: int, groups: int, x, y, stages: int = 3):
+        c = self.csr
+        if not self.built:
+            stages |= 4
+            self.built = True
+        L.check(lib().loops_probe_persistent_f32(int(pipelined), groups, stages, c.rows, c.cols, c.nnzs, _ptr(c.offsets),
+                                                 _ptr(c.indices), _ptr(c.values), _ptr(x), _ptr(y), _ptr(self.scratch), _stream()),
+                "loops_probe_persistent_f32")
         return y
 
 

@@ -24,6 +24,8 @@ ap.add_argument("--rows", type=int, default=0, help="exact row count (C3 stand-i
 ap.add_argument("--nnz", type=int, default=0, help="exact nonzero count (C3 stand-ins: 194109311)")
 ap.add_argument("--cap", type=int, default=1 << 14)
 ap.add_argument("--no-shapes", action="store_true", help="skip the tile-shape instantiations")
+ap.add_argument("--persistent", default="", help="comma-separated workgroup counts: the tiles walked by persistent workgroups, "
+                "plain and with each tile's gathers issued before the next tile's stream loads (loops_probe_persistent_f32)")
 args = ap.parse_args()
 
 # --window: 0 = uniform columns, W > 0 = a band of W columns, -4 (generate.HOST_BLOCKED) = the host-blocked stand-in
@@ -73,5 +75,23 @@ for i, name in enumerate([] if args.no_shapes else PR.SHAPES):
     us = a.elapsed_time(b) / args.iters * 1e3
     out[f"shape {name}"] = {"name": "tile " + name, "us": round(us, 2), "exact": ok}
     print(f"tile shape {name:8s} {us:8.2f} us  exact={ok}", flush=True)
+pers = PR.PersistentRunner(csr) if args.persistent else None
+for groups in [int(t) for t in args.persistent.split(",") if t]:
+    for pipelined in (0, 1, 2):
+        y.zero_()
+        pers.run(pipelined, groups, x, y)
+        ok = bool(torch.equal(y, ref))
+        for _ in range(3):
+            pers.run(pipelined, groups, x, y, stages=1)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(args.iters):
+            pers.run(pipelined, groups, x, y, stages=1)
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) / args.iters * 1e3
+        name = f"persistent {groups} workgroups, " + ["plain", "next tile's streams behind the gathers", "next tile's streams once the gathers returned"][pipelined]
+        out[name] = {"name": name, "us": round(us, 2), "exact": ok}
+        print(f"{name:70s} {us:8.2f} us  exact={ok}", flush=True)
 if args.json:
     json.dump(out, open(args.json, "w"), indent=1)
