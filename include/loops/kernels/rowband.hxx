@@ -86,6 +86,7 @@ struct rowband_view {
   const unsigned short* hubs;  ///< [B * (max_hubs + 1)] per band: the number of hubs, then their rows inside the band
   type_t* partial;             ///< [num_partials * H]
   int waves;                   ///< wavefronts per workgroup of kernel A: 8 or 16
+  int max_pieces;              ///< most chunks any band is cut into (picks the form of kernel B)
 };
 
 namespace rowband {
@@ -229,6 +230,50 @@ rowband_combine(const int* __restrict__ multi, const type_t* __restrict__ partia
     detail::load4<type_t, false>(partial + static_cast<long long>(first + k) * H + j, p);
 #pragma unroll
     for (int e = 0; e < 4; ++e) sum[e] += static_cast<double>(p[e]);
+  }
+  const long long row0 = static_cast<long long>(band) * H + j;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (row0 + e < rows) out(static_cast<int>(row0 + e), static_cast<type_t>(sum[e]));
+}
+
+/// Kernel B for bands cut into MANY chunks (a few bands hold most nonzeros: R-MAT graphs in generator or degree order cut one band
+/// into 50-150 chunks, and one load in flight per thread makes the loop above the longest stage): PL threads share a group of 4
+/// rows, thread p adds the chunks p, p + PL, ... (two loads in flight), the PL sums are added in LDS in the order of p.
+/// grid = (H / (1024 / PL), num_multi), 256 threads.  A fixed order, another one than rowband_combine's: the same bits
+/// wherever the fp64 sums are exact.
+template <int PL, typename type_t, typename store_t>
+__global__ void __launch_bounds__(256)
+rowband_combine_wide(const int* __restrict__ multi, const type_t* __restrict__ partial, const int H, const int rows, const store_t out) {
+  constexpr int QUADS = 256 / PL;  // groups of 4 rows per workgroup
+  __shared__ double part[PL][QUADS][4];
+  const int m = blockIdx.y;
+  const int band = multi[3 * m], first = multi[3 * m + 1], count = multi[3 * m + 2];
+  const int quad = static_cast<int>(threadIdx.x) % QUADS, p = static_cast<int>(threadIdx.x) / QUADS;
+  const int j = (static_cast<int>(blockIdx.x) * QUADS + quad) * 4;
+  double sum[4] = {0.0, 0.0, 0.0, 0.0};
+  if (j < H) {
+    for (int k = p; k < count; k += 2 * PL) {
+      type_t a[4], b[4];
+      const int k2 = k + PL < count ? k + PL : k;  // (branch-free second load; not added when it repeats the first)
+      detail::load4<type_t, false>(partial + static_cast<long long>(first + k) * H + j, a);
+      detail::load4<type_t, false>(partial + static_cast<long long>(first + k2) * H + j, b);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] += static_cast<double>(a[e]);
+      if (k + PL < count) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum[e] += static_cast<double>(b[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[p][quad][e] = sum[e];
+  __syncthreads();
+  if (p != 0 || j >= H) return;
+#pragma unroll
+  for (int q = 1; q < PL; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sum[e] += part[q][quad][e];
   }
   const long long row0 = static_cast<long long>(band) * H + j;
 #pragma unroll
@@ -462,27 +507,21 @@ inline int rowband_rows(int rows, int /*cols*/, int /*nnz*/) {
   return h;
 }
 
-/// Kernel A's work list from the bands' step ranges (B + 1 entries).  The bands are cut into about `target_chunks` chunks in
-/// proportion to their steps (every band with nonzeros at least one; the next cut always goes to the band whose chunks are the
-/// longest), a band's chunks of equal size.  {band, first step, end step, partial slot or -1} per chunk, {band, first slot,
+/// Kernel A's work list from the bands' step ranges (B + 1 entries).  The bands are cut into `target_chunks` chunks (every band at
+/// least one; the next cut always goes to the band whose chunks are the longest), a band's chunks of equal size.  {band, first step, end step, partial slot or -1} per chunk, {band, first slot,
 /// chunks} per cut band.
 inline void rowband_chunk_list(const std::vector<int>& band_step, int B, int target_chunks, std::vector<int>& chunks, std::vector<int>& multi,
                                int& num_partials) {
   chunks.clear();
   multi.clear();
   num_partials = 0;
-  const long long total = B > 0 ? static_cast<long long>(band_step[B]) - band_step[0] : 0;
+  // every band one chunk (a band without nonzeros too: its chunk stores zeros), then cut by cut: the next cut goes to the band whose
+  // chunks are the longest (ties: the lower band) until the list has `target_chunks` entries -- exactly, so that one round of
+  // workgroups covers it (proportional shares rounded per band overshoot when a few bands hold most of the steps: 288 chunks
+  // on 256 CUs for a degree-ordered R-MAT graph)
   std::vector<int> pieces(static_cast<std::size_t>(B), 1);
-  long long sum = 0;
-  for (int b = 0; b < B; ++b) {
-    const long long n = band_step[b + 1] - band_step[b];
-    if (n > 0 && total > 0) {
-      long long p = n * target_chunks / total;
-      pieces[b] = static_cast<int>(p < 1 ? 1 : (p > n ? n : p));
-    }
-    sum += pieces[b];
-  }
-  if (sum < target_chunks) {  // hand the remaining cuts to the bands with the longest chunks
+  long long sum = B;
+  {
     using entry = std::pair<double, int>;
     std::priority_queue<entry> heap;
     for (int b = 0; b < B; ++b) {
@@ -532,7 +571,7 @@ inline void rowband_chunk_list(const std::vector<int>& band_step, int B, int tar
 /// The device arrays of one row-band matrix, OWNED.  Type-erased over the value type (`vbytes`).
 struct rowband_storage {
   int rows = 0, cols = 0, nnz = 0, vbytes = 0;
-  int H = 0, B = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0, waves = 8;
+  int H = 0, B = 0, steps = 0, num_chunks = 0, num_partials = 0, num_multi = 0, target_chunks = 0, cus = 0, waves = 8, max_pieces = 1;
   long long gap_pads = 0;      ///< padding slots that bridge column gaps of more than 255
   void *val = nullptr, *partial = nullptr;
   unsigned short* hubs = nullptr;
@@ -551,7 +590,7 @@ struct rowband_storage {
   template <typename type_t>
   rowband_view<type_t> view() const {
     return rowband_view<type_t>{rows, cols, nnz, H, B, steps, num_chunks, num_partials, num_multi, static_cast<const type_t*>(val), meta,
-                                stepbase, chunks, multi, hubs, static_cast<type_t*>(partial), waves};
+                                stepbase, chunks, multi, hubs, static_cast<type_t*>(partial), waves, max_pieces};
   }
 };
 
@@ -572,6 +611,8 @@ inline int rowband_set_chunks(rowband_storage& out, const std::vector<int>& band
   rowband_chunk_list(band_step_host, out.B, out.target_chunks, chunks, multi, out.num_partials);
   out.num_chunks = static_cast<int>(chunks.size() / 4);
   out.num_multi = static_cast<int>(multi.size() / 3);
+  out.max_pieces = 1;
+  for (std::size_t m = 0; m < multi.size() / 3; ++m) out.max_pieces = std::max(out.max_pieces, multi[3 * m + 2]);
   (void)hipFree(out.chunks); (void)hipFree(out.multi); (void)hipFree(out.partial);
   out.chunks = out.multi = nullptr;
   out.partial = nullptr;
@@ -733,8 +774,16 @@ int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const t
     }
   }
   if ((stages & 2) && m.num_multi > 0) {
-    hipLaunchKernelGGL((rowband::rowband_combine<type_t, store_t>), dim3(math::ceil_div(m.H, 1024), m.num_multi), dim3(256), 0, stream,
-                       m.multi, m.partial, m.H, m.rows, out);
+    // one thread per group of 4 rows while no band is cut into more than a handful of chunks, 4 or 16 threads beyond
+    if (m.max_pieces <= 6)
+      hipLaunchKernelGGL((rowband::rowband_combine<type_t, store_t>), dim3(math::ceil_div(m.H, 1024), m.num_multi), dim3(256), 0, stream,
+                         m.multi, m.partial, m.H, m.rows, out);
+    else if (m.max_pieces <= 48)
+      hipLaunchKernelGGL((rowband::rowband_combine_wide<4, type_t, store_t>), dim3(math::ceil_div(m.H, 256), m.num_multi), dim3(256), 0,
+                         stream, m.multi, m.partial, m.H, m.rows, out);
+    else
+      hipLaunchKernelGGL((rowband::rowband_combine_wide<16, type_t, store_t>), dim3(math::ceil_div(m.H, 64), m.num_multi), dim3(256), 0,
+                         stream, m.multi, m.partial, m.H, m.rows, out);
   }
   return static_cast<int>(hipGetLastError());
 }

@@ -94,23 +94,20 @@ def layout(off, idx, val, rows, cols, H):
 
 def chunk_list(band_step, target_chunks):
     """-> (chunks [n, 4] = {band, first step, end step, partial slot or -1}, multi [m, 3] = {band, first slot, chunks}).
-    Bands are cut in proportion to their steps; surplus cuts go to the band whose chunks are the longest (ties: the lower band)."""
+    Every band one chunk, then cut by cut: the next cut goes to the band whose chunks are the longest (ties: the lower band),
+    until the list has target_chunks entries."""
     B = len(band_step) - 1
     n = np.diff(np.asarray(band_step, np.int64))
-    total = int(n.sum())
     pieces = np.ones(B, np.int64)
-    if total > 0:
-        pieces = np.where(n > 0, np.clip(n * target_chunks // total, 1, np.maximum(n, 1)), 1)
-    s = int(pieces.sum())
-    if s < target_chunks:
-        heap = [(-float(n[b]) / pieces[b], b) for b in range(B) if n[b] > pieces[b]]
-        heapq.heapify(heap)
-        while s < target_chunks and heap:
-            _, b = heapq.heappop(heap)
-            pieces[b] += 1
-            s += 1
-            if n[b] > pieces[b]:
-                heapq.heappush(heap, (-float(n[b]) / pieces[b], b))
+    s = B
+    heap = [(-float(n[b]) / pieces[b], b) for b in range(B) if n[b] > pieces[b]]
+    heapq.heapify(heap)
+    while s < target_chunks and heap:
+        _, b = heapq.heappop(heap)
+        pieces[b] += 1
+        s += 1
+        if n[b] > pieces[b]:
+            heapq.heappush(heap, (-float(n[b]) / pieces[b], b))
     chunks, multi, partials = [], [], 0
     for b in range(B):
         s0, nb = int(band_step[b]), int(n[b])
