@@ -1,25 +1,28 @@
-"""Where the row-band layout loses on the structure sweep: stage times, chunk / piece counts and padding for the inputs
-`tests/perf/sweep_structures.py` shows it behind panel-binned on.  usage: diag_rowband_structures.py [runs|rmat_none|rmat_degree|c2 ...]"""
+"""Where the row-band layout loses: stage times, chunk / piece counts, padding and hub rows for the inputs `sweep_structures.py` /
+`bench_panel.py` show it behind panel-binned on.  usage: diag_rowband_structures.py [runs|rmat_none|rmat_degree|<a case of
+bench_panel_cases.CASES> ...] [--cfg=H,target_chunks ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import json
 import numpy as np, torch
 from loops_amd import generate as G, spmv as S
-from bench_panel_cases import batch_ms  # noqa: E402
+from bench_panel_cases import CASES, batch_ms  # noqa: E402
 
 N = 1 << 24
 def make(name):
     if name == "runs":
         return G.csr_from_degrees(G.powerlaw_degrees(1 << 20, N), 1 << 20, 1, 0, True, -1)
-    if name == "c2":
-        return G.csr_from_degrees(G.powerlaw_degrees(1 << 20, N), 1 << 20, 1, 0, True, None)
+    if name in CASES:
+        rows, cols, nnz, window = CASES[name]
+        deg = G.powerlaw_degrees(rows, nnz, cap=min(1 << 14, cols)) if name != "short_rows_8M" else np.full(rows, 2, np.int64)
+        return G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=G.host_blocks(cols) if window == G.HOST_BLOCKED else None)
     return G.rmat_csr(20, 16, relabel=name[5:])
 
 want = [a for a in sys.argv[1:] if not a.startswith("-")] or ["runs", "rmat_none", "rmat_degree"]
 for name in want:
     off, idx, val = make(name)
-    rows = off.size - 1; cols = 1 << 20; nnz = int(off[-1])
+    rows = off.size - 1; cols = CASES[name][1] if name in CASES else 1 << 20; nnz = int(off[-1])
     csr = S.CSR.from_numpy(rows, cols, off, idx, val)
     x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
     y0, y1 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
