@@ -1077,7 +1077,7 @@ def main():
                               "plan_build_ms": round(rb_build, 2),
                               "break_even_products": None if csr_ms is None else break_even(rb_build, ms_b, csr_ms),
                               "equal_to_csr_result": bool(torch.equal(yb, y_loc)),
-                              "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/rowband.hxx): 8 B per nonzero streamed, the "
+                              "note": "plan-time re-ordered copy of the matrix (include/loops/kernels/rowband.hxx): 7 B per nonzero streamed, the "
                                       "band's y sums in LDS (fp64), x gathered through column-sorted (coalescing) loads; not the headline"}
         rb.close()
 
