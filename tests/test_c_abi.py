@@ -104,7 +104,7 @@ def test_measurement_code_lives_outside_the_product_library():
     L = _lib.load_shared(_lib.build())
     P = _lib.load_shared(_lib.build_probes())
     for name in ("loops_stream_copy_f32", "loops_gather_f32", "loops_address_rate_f32", "loops_row_gather_f32",
-                 "loops_probe_merge_path_f32"):
+                 "loops_probe_merge_path_f32", "loops_probe_persistent_f32"):
         assert hasattr(P, name), name
         assert not hasattr(L, name), name
         assert name not in open(os.path.join(ROOT, "include", "loops_amd.h")).read()
