@@ -164,6 +164,17 @@ def round5():
     rb3.set_waves(16)
     soak("band", "row_band, columns in an 8192-wide band, 16 wavefronts", lambda y: (rb3.spmv(x, y), None)[1], ref3, rows)
     rb3.close()
+    del csr3
+    # a graph whose first band holds most nonzeros (R-MAT relabelled by degree): that band is cut into 100+ chunks and its partial
+    # vectors are added by 16 threads per group of rows (rowband_combine_wide)
+    off4, idx4, val4 = G.rmat_csr(20, 16, relabel="degree")
+    ref4 = torch.from_numpy(O.spmv_f32(off4, idx4, val4, xh, omp=True)).cuda()
+    csr4 = S.CSR.from_numpy(rows, cols, off4, idx4, val4)
+    for target in (0, 90):
+        rb4 = S.RowBandPlan(csr4, 0, target)
+        pieces = int(rb4.arrays()[6][:, 2].max())
+        soak("rmat", f"row_band, R-MAT by degree, {rb4.num_chunks} chunks, up to {pieces} per band", lambda y: (rb4.spmv(x, y), None)[1], ref4, rows)
+        rb4.close()
 
 
 if len(sys.argv) > 2 and sys.argv[2] == "r5":
