@@ -266,7 +266,7 @@ size_t loops_probe_merge_path_scratch_bytes(int rows, int nnz) {
 int loops_probe_persistent_f32(int pipelined, int groups, int stages, int rows, int cols, int nnz, const int* offsets,
                                const int* indices, const float* values, const float* x, float* y, void* scratch, void* stream) {
   (void)cols;
-  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz < 8 || (nnz & 3) || groups <= 0) return E_BADARG;
+  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz < 8 || (pipelined && (nnz & 3)) || groups <= 0) return E_BADARG;
   if ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) return E_BADARG;
   hipStream_t st = as_stream(stream);
   const scratch_view v = carve(scratch, rows, nnz);
