@@ -59,7 +59,8 @@ int loops_row_gather_f32(const float* table, const int* idx, size_t count, int r
 size_t loops_probe_merge_path_scratch_bytes(int rows, int nnz);
 /* Ordering experiment: the merge tiles walked by `groups` PERSISTENT workgroups (contiguous shares, the product's
  * work_oriented_spmv_fused<512, 8>); pipelined = 1: each tile's x gathers are issued BEFORE the stream loads of the workgroup's
- * next tile (two register sets); 2: the next tile's streams leave once the gathers have returned (in flight during the walk).  stages / scratch as loops_probe_merge_path_f32; nnz % 4 == 0; bit-equal results. */
+ * next tile (two register sets); 2: the next tile's streams leave once the gathers have returned (in flight during the walk); 3: plain order with the
+ * phased gathers of the headline kernel (8 parts).  stages / scratch as loops_probe_merge_path_f32; nnz % 4 == 0; bit-equal results. */
 int loops_probe_persistent_f32(int pipelined, int groups, int stages, int rows, int cols, int nnz, const int* offsets,
                                const int* indices, const float* values, const float* x, float* y, void* scratch, void* stream);
 int loops_probe_policy_count(void);

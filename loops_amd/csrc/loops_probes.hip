@@ -146,6 +146,46 @@ persistent_pipelined_kernel(const coord_t* __restrict__ coords, const int num_ti
   }
 }
 
+// The persistent form with the phased gathers of the headline kernel (policy::phased(8)): does a share of a few tiles per workgroup
+// help there as it helps the plain kernel?
+__global__ void __launch_bounds__(TPB)
+persistent_phased_kernel(const coord_t* __restrict__ coords, const int num_tiles, const int tiles_per_group, const int rows,
+                         const int nnz, const int* __restrict__ offsets, const int* __restrict__ indices,
+                         const float* __restrict__ values, const float* __restrict__ x, float* __restrict__ y,
+                         int* __restrict__ carry_row, float* __restrict__ carry_val, const kernels::detail::phase_args phase) {
+  using engine_t = kernels::merge_tile_engine<TPB, IPT, true, pol::phased(8), true, int, int, float, true>;
+  __shared__ typename engine_t::storage_t s_engine;
+  const int tid = threadIdx.x;
+  const int g = kernels::detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
+  const int t_begin = g * tiles_per_group;
+  int t_end = t_begin + tiles_per_group;
+  t_end = t_end < num_tiles ? t_end : num_tiles;
+  float carry = 0.f;
+  int open_row = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const coord_t c0 = coords[t];
+    const coord_t c1 = coords[t + 1];
+    const int row0 = static_cast<int>(c0.x);
+    const int nz0 = static_cast<int>(c0.y);
+    const int nrows = static_cast<int>(c1.x) - row0;
+    const int natoms = static_cast<int>(c1.y) - nz0;
+    engine_t::clear_marks(s_engine);
+    __syncthreads();
+    carry = engine_t::run_to(
+        s_engine, static_cast<const int*>(nullptr), row0, nz0, nrows, natoms, nnz, indices, values, x, kernels::plain_store<float>{y},
+        carry,
+        [&]() {
+          for (int i = tid; i < nrows; i += TPB) engine_t::mark_row_end(s_engine, i, offsets[row0 + i + 1], nz0);
+        },
+        phase);
+    open_row = row0 + nrows;
+  }
+  if (tid == 0 && t_begin < t_end) {
+    carry_row[g] = open_row;
+    carry_val[g] = carry;
+  }
+}
+
 template <int P>
 void launch_policy(const scratch_view& v, int rows, int cols, int nnz, const int* off, const int* idx, const float* val,
                    const float* x, float* y, hipStream_t stream) {
@@ -265,8 +305,7 @@ size_t loops_probe_merge_path_scratch_bytes(int rows, int nnz) {
 
 int loops_probe_persistent_f32(int pipelined, int groups, int stages, int rows, int cols, int nnz, const int* offsets,
                                const int* indices, const float* values, const float* x, float* y, void* scratch, void* stream) {
-  (void)cols;
-  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz < 8 || (pipelined && (nnz & 3)) || groups <= 0) return E_BADARG;
+  if (!offsets || !indices || !values || !x || !y || !scratch || rows <= 0 || nnz < 8 || ((pipelined == 1 || pipelined == 2) && (nnz & 3)) || groups <= 0) return E_BADARG;
   if ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) return E_BADARG;
   hipStream_t st = as_stream(stream);
   const scratch_view v = carve(scratch, rows, nnz);
@@ -278,7 +317,10 @@ int loops_probe_persistent_f32(int pipelined, int groups, int stages, int rows, 
   const int per = math::ceil_div(v.m, groups);
   const int grid = math::ceil_div(v.m, per);
   if (stages & 1) {
-    if (pipelined == 2)
+    if (pipelined == 3)
+      hipLaunchKernelGGL(persistent_phased_kernel, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets, indices, values, x,
+                         y, v.carry_row, v.carry_val, kernels::phased_config_for(cols, 4).args);
+    else if (pipelined == 2)
       hipLaunchKernelGGL(persistent_pipelined_kernel<true>, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets,
                          indices, values, x, y, v.carry_row, v.carry_val);
     else if (pipelined)

@@ -77,7 +77,7 @@ for i, name in enumerate([] if args.no_shapes else PR.SHAPES):
     print(f"tile shape {name:8s} {us:8.2f} us  exact={ok}", flush=True)
 pers = PR.PersistentRunner(csr) if args.persistent else None
 for groups in [int(t) for t in args.persistent.split(",") if t]:
-    for pipelined in ((0, 1, 2) if csr.nnzs % 4 == 0 else (0,)):
+    for pipelined in ((0, 1, 2, 3) if csr.nnzs % 4 == 0 else (0, 3)):
         y.zero_()
         pers.run(pipelined, groups, x, y)
         ok = bool(torch.equal(y, ref))
@@ -90,7 +90,7 @@ for groups in [int(t) for t in args.persistent.split(",") if t]:
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / args.iters * 1e3
-        name = f"persistent {groups} workgroups, " + ["plain", "next tile's streams behind the gathers", "next tile's streams once the gathers returned"][pipelined]
+        name = f"persistent {groups} workgroups, " + ["plain", "next tile's streams behind the gathers", "next tile's streams once the gathers returned", "phased gathers (8 parts)"][pipelined]
         out[name] = {"name": name, "us": round(us, 2), "exact": ok}
         print(f"{name:70s} {us:8.2f} us  exact={ok}", flush=True)
 if args.json:
