@@ -146,14 +146,15 @@ persistent_pipelined_kernel(const coord_t* __restrict__ coords, const int num_ti
   }
 }
 
-// The persistent form with the phased gathers of the headline kernel (policy::phased(8)): does a share of a few tiles per workgroup
+// The persistent form with the phased gathers of the headline kernel (policy::phased(8 / 16 / 32)): does a share of a few tiles per workgroup
 // help there as it helps the plain kernel?
+template <int PHASES>
 __global__ void __launch_bounds__(TPB)
 persistent_phased_kernel(const coord_t* __restrict__ coords, const int num_tiles, const int tiles_per_group, const int rows,
                          const int nnz, const int* __restrict__ offsets, const int* __restrict__ indices,
                          const float* __restrict__ values, const float* __restrict__ x, float* __restrict__ y,
                          int* __restrict__ carry_row, float* __restrict__ carry_val, const kernels::detail::phase_args phase) {
-  using engine_t = kernels::merge_tile_engine<TPB, IPT, true, pol::phased(8), true, int, int, float, true>;
+  using engine_t = kernels::merge_tile_engine<TPB, IPT, true, pol::phased(PHASES), true, int, int, float, true>;
   __shared__ typename engine_t::storage_t s_engine;
   const int tid = threadIdx.x;
   const int g = kernels::detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
@@ -317,9 +318,12 @@ int loops_probe_persistent_f32(int pipelined, int groups, int stages, int rows, 
   const int per = math::ceil_div(v.m, groups);
   const int grid = math::ceil_div(v.m, per);
   if (stages & 1) {
-    if (pipelined == 3)
-      hipLaunchKernelGGL(persistent_phased_kernel, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets, indices, values, x,
-                         y, v.carry_row, v.carry_val, kernels::phased_config_for(cols, 4).args);
+    if (pipelined == 3) {
+      const kernels::phased_config cfg = kernels::phased_config_for(cols, 4);   // 8 / 16 / 32 parts by the size of x
+      auto k = cfg.parts == 8 ? persistent_phased_kernel<8> : cfg.parts == 16 ? persistent_phased_kernel<16> : persistent_phased_kernel<32>;
+      hipLaunchKernelGGL(k, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets, indices, values, x, y, v.carry_row,
+                         v.carry_val, cfg.args);
+    }
     else if (pipelined == 2)
       hipLaunchKernelGGL(persistent_pipelined_kernel<true>, dim3(grid), dim3(TPB), 0, st, v.coords, v.m, per, rows, nnz, offsets,
                          indices, values, x, y, v.carry_row, v.carry_val);

@@ -90,7 +90,7 @@ for groups in [int(t) for t in args.persistent.split(",") if t]:
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / args.iters * 1e3
-        name = f"persistent {groups} workgroups, " + ["plain", "next tile's streams behind the gathers", "next tile's streams once the gathers returned", "phased gathers (8 parts)"][pipelined]
+        name = f"persistent {groups} workgroups, " + ["plain", "next tile's streams behind the gathers", "next tile's streams once the gathers returned", "phased gathers"][pipelined]
         out[name] = {"name": name, "us": round(us, 2), "exact": ok}
         print(f"{name:70s} {us:8.2f} us  exact={ok}", flush=True)
 if args.json:

@@ -922,9 +922,11 @@ def test_phased_variant_on_the_reference_battery_and_degenerate_inputs(tile):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("window", [None, 4096], ids=["scattered", "banded"])
-def test_planless_device_decided_kernel(window, dtype):
-    """The asynchronous plan-less entry `loops_spmv_csr_*(MERGE_PATH_FLAT)` above its thresholds (x >= 6 MB, nnz >= 2^20): a sample
-    of the columns decides ON THE DEVICE whether the product gathers in phases (kernels::merge_path_spmv_fused_auto).  Both
+@pytest.mark.parametrize("schedule", ["merge_path_flat", "work_oriented"])
+def test_planless_device_decided_kernel(schedule, window, dtype):
+    """The asynchronous plan-less entries `loops_spmv_csr_*(MERGE_PATH_FLAT | WORK_ORIENTED)` above their thresholds (x >= 6 MB, nnz >=
+    2^20): a sample of the columns decides ON THE DEVICE whether the product gathers in phases (kernels::merge_path_spmv_fused_auto,
+    work_oriented_spmv_fused_phased).  Both
     outcomes -- scattered columns (phased) and a 4096-wide band (plain) -- must give the bits of the held 512x8 plan, also from
     two streams at once and from a captured HIP graph (the decision is device-side: nothing host-side may depend on it)."""
     from loops_amd import spmv as S, generate as G
@@ -940,7 +942,7 @@ def test_planless_device_decided_kernel(window, dtype):
         assert S.columns_look_scattered(csr) == (window is None)
     for x, w in zip(xs, want):
         y = torch.full((rows,), 5.0, dtype=x.dtype, device="cuda")
-        assert torch.equal(S.spmv("merge_path_flat", csr, x, y), w)
+        assert torch.equal(S.spmv(schedule, csr, x, y), w)
     # two streams at once: each stream owns its scratch (coordinates, carry-outs, sample statistics)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     ys = [torch.full((rows,), -1.0, dtype=xs[0].dtype, device="cuda") for _ in streams]
@@ -948,7 +950,7 @@ def test_planless_device_decided_kernel(window, dtype):
     for _ in range(5):
         for st, x, y in zip(streams, xs, ys):
             with torch.cuda.stream(st):
-                S.spmv("merge_path_flat", csr, x, y)
+                S.spmv(schedule, csr, x, y)
     torch.cuda.synchronize()
     assert torch.equal(ys[0], want[0]) and torch.equal(ys[1], want[1])
     # graph capture of the plan-less call ON THE STREAM IT WAS WARMED UP ON: the entry keeps its scratch (coordinates, carry-outs,
@@ -957,12 +959,12 @@ def test_planless_device_decided_kernel(window, dtype):
     side.wait_stream(torch.cuda.current_stream())
     x, yg = xs[0].clone(), torch.empty(rows, dtype=xs[0].dtype, device="cuda")
     with torch.cuda.stream(side):
-        S.spmv("merge_path_flat", csr, x, yg)
+        S.spmv(schedule, csr, x, yg)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, stream=side):
-        S.spmv("merge_path_flat", csr, x, yg)
+        S.spmv(schedule, csr, x, yg)
     for xn, w in zip(reversed(xs), reversed(want)):
         x.copy_(xn)
         yg.fill_(-1.0)
