@@ -150,10 +150,12 @@ inline phased_config phased_config_for(long long cols, int elem_bytes) {
 
 /// A STRUCTURAL guess at whether the phased gathers pay on this matrix, for callers that cannot measure (the plan-less
 /// `algorithms::spmv::merge_path_flat(csr, x, y)`, whose set-up is untimed and synchronous anyway): true when x is at least 3 MB
-/// (6 MB for 8-byte values; below that it fits an L2 next to the stream), the matrix has at least 2^20 nonzeros, fewer than
-/// half of 16 384 sampled pairs of nonzeros ONE TO TWO MERGE TILES APART share a part of x and fewer than a quarter of the sampled
-/// ADJACENT pairs share a 128-byte line of x (kernels::column_scatter_sample).  On the nine structures of
-/// tests/perf/sweep_structures.py and the three C3 stand-ins it agrees with the measured choice on all twelve.  Two small kernels,
+/// (6 MB for 8-byte values; below that it fits an L2 next to the stream), the matrix has at least 2^20 nonzeros, of 16 384 sampled
+/// pairs of nonzeros ONE TO TWO MERGE TILES APART fewer than 2 / parts share a part of x (uniform columns: 1 / parts) and fewer than
+/// a quarter of the sampled ADJACENT pairs share a 128-byte line of x (kernels::column_scatter_sample, detail::scatter_counts_say_phase).
+/// On the twelve structures of tests/perf/sweep_structures.py, the three C3 stand-ins and two R-MAT graphs of C3's size it agrees with
+/// the measured choice (scripts/check_scatter_guess.py; until round 5 the threshold was one half whatever the number of parts, and an
+/// R-MAT graph of 2^23 vertices in generator order -- 3.2 / parts -- was sent to the phased kernel, which loses 18 % there).  Two small kernels,
 /// one 16-byte copy, one stream synchronisation; `scratch` = kernels::scatter_scratch_words device words.  Measuring
 /// (loops_autotune_merge_path_variants_f32, LOOPS_PLAN_MEASURE) remains the reliable way.
 /// (the size test alone -- no device work: callers allocate the scratch words only when it passes)
@@ -176,7 +178,7 @@ inline bool columns_look_scattered(hipStream_t stream, const index_t* indices, l
   unsigned int host[4] = {0, 0, 0, 0};
   if (hipMemcpyAsync(host, scratch, sizeof(host), hipMemcpyDeviceToHost, stream) != hipSuccess) return false;
   if (hipStreamSynchronize(stream) != hipSuccess) return false;
-  return host[1] >= 1024 && 2ull * host[0] < host[1] && 4ull * host[2] < host[3];
+  return detail::scatter_counts_say_phase(host[0], host[1], host[2], host[3], static_cast<unsigned int>(cfg.parts));
 }
 
 /// Launches the sample of columns_look_scattered WITHOUT reading it back: `stats` (scatter_scratch_words device words) then holds in [0..3] what

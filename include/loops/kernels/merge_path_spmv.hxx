@@ -114,6 +114,15 @@ struct window_store {
 template <typename T>
 struct window_store<T, 0> {};
 
+/// The rule of kernels::columns_look_scattered on the four counts of column_scatter_sample (far pairs in one part of x / seen, adjacent
+/// pairs in one 128-byte line / seen): the far pairs share a part LESS than twice as often as uniformly scattered columns would
+/// (1 / parts) -- columns that use the parts unevenly (hub columns at neighbouring ids: R-MAT graphs in generator order, 3.2 / parts
+/// at scale 23) leave most passes nearly empty and already hit the L2 -- and fewer than a quarter of the adjacent pairs share a line.
+__host__ __device__ inline bool scatter_counts_say_phase(unsigned int far_same, unsigned int far_seen, unsigned int near_same,
+                                                         unsigned int near_seen, unsigned int parts) {
+  return far_seen >= 1024u && static_cast<unsigned long long>(far_same) * parts < 2ull * far_seen && 4ull * near_same < near_seen;
+}
+
 /// 4 consecutive elements at byte offset `byte_off` of buffer `r` with cache-policy bits AUX (see policy).
 template <typename T, int AUX>
 __device__ __forceinline__ void buffer_load4(const __amdgpu_buffer_rsrc_t r, const int byte_off, T (&out)[4]) {
@@ -1005,7 +1014,7 @@ merge_path_spmv_fused_auto(const coord_t* __restrict__ coords, const int rows, c
                            int* __restrict__ carry_row, type_t* __restrict__ carry_val, const unsigned int* __restrict__ stats,
                            detail::phase_args phase) {
   const unsigned int far_same = stats[0], far_seen = stats[1], near_same = stats[2], near_seen = stats[3];
-  phase.enabled = (far_seen >= 1024u && 2u * far_same < far_seen && 4u * near_same < near_seen) ? 1u : 0u;
+  phase.enabled = detail::scatter_counts_say_phase(far_same, far_seen, near_same, near_seen, PHASES) ? 1u : 0u;
   merge_path_spmv_tile_to<TPB, IPT, true, detail::policy::phased_auto(PHASES), VEC, false, true>(
       coords, rows, nnz, csr_row_end<offset_t>{offsets}, indices, values, x, plain_store<type_t>{y}, carry_row, carry_val, nullptr,
       phase);
@@ -1028,7 +1037,8 @@ merge_path_spmv_fused_self_phased(const coord_t* __restrict__ coords, const int*
 /// i = k * stride of the nonzero stream are looked at twice:
 ///   FAR   the pair (i, i + far + a per-sample offset below 4096), one to two merge tiles apart: do the two columns fall into the same part of x
 ///         (min(col >> shift, parts - 1))?  Uniformly scattered columns: ~1 / parts of the pairs; bands, host blocks, dense hub
-///         rows: most of them (a tile's gathers then stay inside one or two parts whatever the order);
+///         rows: most of them (a tile's gathers then stay inside one or two parts whatever the order); hub COLUMNS at neighbouring
+///         ids (R-MAT in generator order): 2-3 / parts -- the threshold is 2 / parts (detail::scatter_counts_say_phase);
 ///   NEAR  the pair (i, i + 1): do the two columns share a 128-byte line of x (col >> line_shift)?  Runs of consecutive
 ///         columns do -- their gathers coalesce and hit L1, phasing them only adds passes.
 /// (Adjacent nonzeros say nothing about scatter: columns are sorted inside a row, so a row of 16 uniformly random columns
@@ -1174,7 +1184,7 @@ work_oriented_spmv_fused_phased(const coord_t* __restrict__ coords, const int nu
   __shared__ typename engine_t::storage_t s_engine;
   if (stats != nullptr) {  // (uniform: scalar loads)
     const unsigned int far_same = stats[0], far_seen = stats[1], near_same = stats[2], near_seen = stats[3];
-    phase.enabled = (far_seen >= 1024u && 2u * far_same < far_seen && 4u * near_same < near_seen) ? 1u : 0u;
+    phase.enabled = detail::scatter_counts_say_phase(far_same, far_seen, near_same, near_seen, PHASES) ? 1u : 0u;
   } else {
     phase.enabled = 1u;
   }

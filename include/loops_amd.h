@@ -426,8 +426,9 @@ int loops_autotune_merge_path_f32(int rows, int cols, int nnz, const int* offset
  * shapes that have one (plans of more than one tile).  best_variant = 0 or LOOPS_VARIANT_PHASED, to be passed to
  * loops_spmv_merge_path_*; ms_per_config (optional, 12 entries): [cfg] = plain, [6 + cfg] = phased, -1 where not timed. */
 /* A STRUCTURAL guess at the same question, for callers that cannot measure: *scattered = 1 when x (cols x value_bytes) is at
- * least 3 MB (6 MB for 8-byte values), the matrix holds at least 2^20 nonzeros, fewer than half of 16 384 sampled pairs of
- * nonzeros one merge tile apart share a part of x (uniformly random columns: ~1 in 8; bands, host blocks, dense hub rows: most)
+ * least 3 MB (6 MB for 8-byte values), the matrix holds at least 2^20 nonzeros, of 16 384 sampled pairs of nonzeros one merge tile
+ * apart fewer than 2 / parts share a part of x (parts = 8 / 16 / 32 by the size of x; uniformly random columns: 1 / parts; hub columns
+ * at neighbouring ids: 2-3 / parts; bands, host blocks, dense hub rows: most)
  * and fewer than a quarter of the adjacent pairs share a 128-byte line of x (runs of consecutive columns gather cheaply).  What the
  * plan-less C++ wrapper algorithms::spmv::merge_path_flat(csr, x, y) consults in its untimed set-up.  Synchronous. */
 int loops_columns_look_scattered(int cols, int nnz, const int* indices, int value_bytes, void* stream, int* scattered);

@@ -23,3 +23,10 @@ for tag, window in (("uniform", None), ("band_65536", 65536), ("host_blocked", G
     csr = S.CSR.from_numpy(rows, cols, off, idx, val)
     print(f"C3 stand-in {tag:38s} guess_scattered={S.columns_look_scattered(csr)}", flush=True)
     del csr
+# two R-MAT graphs of C3's size (2^23 vertices x 23 edges): measured (tests/perf/bench_schedules.py --rmat 23,23,none|random): generator order
+# plain 1.21 ms / phased 1.43 -> NOT scattered; labels scattered: plain 2.30 / phased 1.73 -> scattered
+for rl in ("none", "random"):
+    off, idx, val = G.rmat_csr(23, 23, relabel=rl)
+    csr = S.CSR.from_numpy(1 << 23, 1 << 23, off, idx, val)
+    print(f"R-MAT scale 23 x 23, labels {rl:27s} guess_scattered={S.columns_look_scattered(csr)}", flush=True)
+    del csr

@@ -28,8 +28,17 @@ ap.add_argument("--mtx", default="", help="Matrix-Market coordinate file to run 
                 "SuiteSparse LAW/indochina-2004, datasets/suitesparse.txt:2052 in the reference; not shipped). Loaded as the "
                 "reference's loader does (container/market.hxx:100-289): pattern entries = 1, symmetric files mirrored, "
                 "duplicates kept, rows sorted by (row, column)")
+ap.add_argument("--rmat", default="", help="SCALE,EDGE_FACTOR,RELABEL (none|random|degree): an R-MAT graph (generate.rmat_csr, Graph500 "
+                "a, b, c) instead of the hashed-column generator, e.g. 23,23,none = 8.4 M vertices / 193 M edges, the size of C3")
 args = ap.parse_args()
-if args.mtx:
+if args.rmat:
+    sc, ef, rl = args.rmat.split(",")
+    off, idx, val = G.rmat_csr(int(sc), int(ef), relabel=rl)
+    rows = cols = 1 << int(sc)
+    nnz = int(off[-1])
+    deg = np.diff(off.astype(np.int64))
+    args.tag = f"rmat scale {sc} x {ef}, labels {rl}"
+elif args.mtx:
     import scipy.io
     m = scipy.io.mmread(args.mtx).tocsr()  # mmread mirrors symmetric files; pattern -> 1
     m.sort_indices()
