@@ -264,10 +264,22 @@ def context_c3_standins(G, S, O, torch, iters=10):
     abytes = algorithmic_bytes(rows, cols, nnz)
     out = {"shape": f"{rows} rows / {nnz} nnz (LAW/indochina-2004's), fp32", "algorithmic_bytes": abytes,
            "note": "generated stand-ins: the SuiteSparse file is not available offline; tests/perf/bench_schedules.py --mtx PATH runs the real one"}
-    for tag, window in (("uniform_columns", None), ("band_65536", 65536), ("host_blocked", G.HOST_BLOCKED)):
+    shape_rows, shape_nnz = rows, nnz
+    for tag, window in (("uniform_columns", None), ("band_65536", 65536), ("host_blocked", G.HOST_BLOCKED), ("rmat_2e23_x23_generator_order", "rmat")):
         # host_blocked: the locality class LAW graphs belong to -- consecutive ids form hosts of power-law size (generate.host_blocks:
         # >= 256 ids, Pareto 1.1, <= 2^17), 3 of 4 links stay inside the row's host, the rest go anywhere
-        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=G.host_blocks(cols) if window == G.HOST_BLOCKED else None)
+        # rmat (round 5): a Graph500 R-MAT graph of the nearest power-of-two size (2^23 vertices x 23 edges = 192.9 M) in the generator's
+        # own order -- hub vertices at the low ids, as a crawl leaves them: the stand-in on which `group_mapped` falls behind
+        # `work_oriented` the way the reference's published C3 row does (11.87 against 2.33 ms on its GPU, plots/data/*.csv)
+        if window == "rmat":
+            off, idx, val = G.rmat_csr(23, 23, relabel="none")
+            rows = cols = 1 << 23
+            nnz = int(off[-1])
+            xh = G.uniform_distribution_int(cols)
+            x = torch.from_numpy(xh).cuda()
+            abytes = algorithmic_bytes(rows, cols, nnz)
+        else:
+            off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=G.host_blocks(cols) if window == G.HOST_BLOCKED else None)
         csr = S.CSR.from_numpy(rows, cols, off, idx, val)
         ref = O.spmv_f32(off, idx, val, xh, omp=True)
         y = torch.empty(rows, device="cuda")
@@ -294,6 +306,9 @@ def context_c3_standins(G, S, O, torch, iters=10):
                                  "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "choice": sp.info,
                                  "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
         sp.close()
+        if (rows, nnz) != (shape_rows, shape_nnz):
+            res["shape"] = f"{rows} rows / {nnz} nnz, fp32"
+            res["algorithmic_bytes"] = abytes
         out[tag] = res
         del csr, off, idx, val, y
     return out
