@@ -294,7 +294,7 @@ def test_row_range_shards_reassemble_on_one_gpu():
         assert np.array_equal(y_full.cpu().numpy(), ref), world
 
 
-@pytest.mark.parametrize("window", [None, 65536, -4], ids=["uniform", "band65536", "host_blocked"])
+@pytest.mark.parametrize("window", [None, 65536, -4, "rmat"], ids=["uniform", "band65536", "host_blocked", "rmat_2e23_generator_order"])
 def test_c3_standin_group_mapped_vs_work_oriented(window):
     """BASELINE config C3 (indochina-2004: 7 414 866 rows / 194 109 311 nnz, group_mapped vs work_oriented): the
     SuiteSparse file is not shipped (datasets/suitesparse.txt:2052), so the two schedules -- and merge_path_flat --
@@ -305,12 +305,19 @@ def test_c3_standin_group_mapped_vs_work_oriented(window):
     when supplied."""
     from loops_amd import spmv as S, generate as G
     from oracle import oracle as O
-    rows = cols = 7_414_866
-    nnz = 194_109_311
-    deg = G.powerlaw_degrees(rows, nnz, native=True)
-    hosts = G.host_blocks(cols) if window == G.HOST_BLOCKED else None
-    off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, native=True, hosts=hosts)
-    assert off[-1] == nnz and off.size == rows + 1
+    if window == "rmat":   # round 5: a Graph500 R-MAT graph of the nearest power-of-two size, hub vertices at the low ids (max degree 348 957:
+        # the workgroup that owns rows 0-255 under group_mapped owns 5 % of the matrix)
+        rows = cols = 1 << 23
+        off, idx, val = G.rmat_csr(23, 23, relabel="none")
+        nnz = int(off[-1])
+        assert nnz > 190_000_000 and int(np.diff(off.astype(np.int64)).max()) > 300_000
+    else:
+        rows = cols = 7_414_866
+        nnz = 194_109_311
+        deg = G.powerlaw_degrees(rows, nnz, native=True)
+        hosts = G.host_blocks(cols) if window == G.HOST_BLOCKED else None
+        off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, native=True, hosts=hosts)
+        assert off[-1] == nnz and off.size == rows + 1
     x = G.uniform_distribution_int(cols)
     ref = O.spmv_f32(off, idx, val, x, omp=True)
     csr = _dev(off, idx, val, rows, cols)
