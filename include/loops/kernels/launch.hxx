@@ -376,6 +376,17 @@ int launch_thread_mapped_spmm(hipStream_t stream, int rows, const offset_t* offs
   return launch_status();
 }
 
+/// Merge tiles per workgroup of the persistent `work_oriented` kernels: min(4, ceil(tiles / (8 x resident workgroups))), at least 1.
+/// Shares of a few tiles, not one share per resident workgroup: with one long share each, the workgroups of a CU run in step
+/// (their stream and gather phases coincide) and the launch ends when the slowest share does; short shares are balanced by the
+/// dispatcher and still chain their carries in registers.  C3 stand-ins (47 K tiles of 512 x 8; profiles/
+/// r05_work_oriented_shares_experiment.txt): 1 024 / 2 048 / 8 192 / 16 384 shares = 1 332 / 1 176 / 1 068 / 1 062 us (host-blocked),
+/// 936 / 814 / 748 / 741 us (65 536-wide band; one tile per workgroup: 787); C2: 1 024 / 2 048 / 4 352 shares = 115 / 102 / 94 us.
+inline int work_oriented_share(int tiles, int resident) {
+  const int per_resident = math::ceil_div(tiles, 8 * (resident < 1 ? 1 : resident));
+  return per_resident < 1 ? 1 : (per_resident > 4 ? 4 : per_resident);
+}
+
 /// Tuned work_oriented: contiguous shares of 1-4 plan tiles per workgroup (at least eight shares per resident workgroup).
 template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_work_oriented_fused(hipStream_t stream, const merge_plan_view& plan, int rows, int nnz,
@@ -387,13 +398,7 @@ int launch_work_oriented_fused(hipStream_t stream, const merge_plan_view& plan, 
   auto k_vec = work_oriented_spmv_fused<TPB, IPT, PAD, false, true, index_t, offset_t, T, MASK>;
   auto k_scl = work_oriented_spmv_fused<TPB, IPT, PAD, false, false, index_t, offset_t, T, MASK>;
   static const int resident = static_cast<int>(launch_box::occupancy_grid(k_vec, TPB));  // blocks per CU x CUs
-  // Shares of a few tiles, not one share per resident workgroup: with one long share each, the workgroups of a CU run in step
-  // (their stream and gather phases coincide) and the launch ends when the slowest share does; short shares are balanced by the
-  // dispatcher and still chain their carries in registers.  C3 stand-ins (47 K tiles of 512 x 8; profiles/
-  // r05_work_oriented_shares_experiment.txt): 1 024 / 2 048 / 8 192 / 16 384 shares = 1 332 / 1 176 / 1 068 / 1 062 us (host-blocked),
-  // 936 / 814 / 748 / 741 us (65 536-wide band; one tile per workgroup: 787); C2: 1 024 / 2 048 / 4 352 shares = 115 / 102 / 94 us.
-  const int per_resident = math::ceil_div(m, 8 * (resident < 1 ? 1 : resident));
-  const int tiles_per_group = per_resident < 1 ? 1 : (per_resident > 4 ? 4 : per_resident);
+  const int tiles_per_group = work_oriented_share(m, resident);
   const int groups = math::ceil_div(m, tiles_per_group);
   if (aligned)
     hipLaunchKernelGGL(k_vec, dim3(groups), dim3(TPB), 0, stream, plan.coords, m, tiles_per_group, rows, nnz, offsets,
@@ -429,8 +434,7 @@ int launch_work_oriented_fused_phased(hipStream_t stream, const merge_plan_view&
            : cfg.parts == 16 ? work_oriented_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>
                              : work_oriented_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>;
   static const int resident = static_cast<int>(launch_box::occupancy_grid(work_oriented_spmv_fused_phased<TPB, IPT, 8, true, index_t, offset_t, T>, TPB));
-  const int per_resident = math::ceil_div(m, 8 * (resident < 1 ? 1 : resident));   // (the share rule of launch_work_oriented_fused)
-  const int tiles_per_group = per_resident < 1 ? 1 : (per_resident > 4 ? 4 : per_resident);
+  const int tiles_per_group = work_oriented_share(m, resident);
   const int groups = math::ceil_div(m, tiles_per_group);
   T* carry_val = static_cast<T*>(plan.carry_val);
   hipLaunchKernelGGL(k, dim3(groups), dim3(TPB), 0, stream, plan.coords, m, tiles_per_group, rows, nnz, offsets, indices, values, x, y,

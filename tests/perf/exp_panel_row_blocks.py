@@ -1,7 +1,7 @@
 """Experiment: the panel-binned copy of a LARGE matrix built as R independent copies over contiguous row blocks, run back to
 back on one stream (y ranges are disjoint), against the one copy over all rows.  Question: does the whole-matrix copy of C5
 (2 GB of products between its two kernels, 512 KB between a panel's store runs) pay for its size?
-usage: exp_panel_row_blocks.py [c5|c5_shard|c3_uniform] [R ...]"""
+usage: exp_panel_row_blocks.py [c5|c5_shard|c3_uniform] [R ...] [--hw=H]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,7 @@ from bench_panel_cases import CASES, batch_ms  # noqa: E402
 cases = dict(CASES, c5=(1 << 24, 1 << 24, 1 << 29, None))
 name = next((a for a in sys.argv[1:] if a in cases), "c5")
 Rs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [1, 2, 4, 8, 16]
+HW = next((int(a[5:]) for a in sys.argv[1:] if a.startswith("--hw=")), 0)   # force the sub-band height of every copy (0 = automatic)
 rows, cols, nnz, window = cases[name]
 deg = G.powerlaw_degrees(rows, nnz, cap=min(1 << 14, cols))
 off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
@@ -26,7 +27,7 @@ for R in Rs:
         b, e = int(bounds[r]), int(bounds[r + 1])
         o, i, v = P.slice_csr(off, idx, val, b, e)
         c = S.CSR.from_numpy(e - b, cols, o, i, v)
-        plans.append((c, S.PanelBinnedPlan(c)))
+        plans.append((c, S.PanelBinnedPlan(c, HW)))
         ys.append(y[b:e])
     def run():
         for (c, p), yy in zip(plans, ys):
