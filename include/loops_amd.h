@@ -275,6 +275,12 @@ int loops_panel_plan_create_layout_f64(int rows, int cols, int nnz, const int* o
 int loops_panel_plan_layout(const loops_panel_plan_t* plan, long long* info4);
 void loops_panel_plan_destroy(loops_panel_plan_t* plan);
 int loops_panel_plan_info(const loops_panel_plan_t* plan, int* info7);
+/* Row blocks (round 5): with automatic parameters a matrix of 2^28 nonzeros or more is held as independent copies over contiguous row
+ * blocks of ~2^26 nonzeros, run back to back, so that kernel B reads a block's products while they are still in the 256 MB Infinity
+ * Cache (C5 on one GPU: 2.10 -> 1.91 ms; smaller inputs are best as one copy and stay one).  count = the number of blocks (1 = one
+ * copy); row_bounds (optional, count + 1 entries) = their first rows.  For a blocked plan the info calls describe the whole (sums
+ * over the blocks, W / Hw of the first) and loops_panel_plan_arrays / _windows return LOOPS_E_CONFIG. */
+int loops_panel_plan_row_blocks(const loops_panel_plan_t* plan, int* count, int* row_bounds);
 int loops_panel_plan_arrays(const loops_panel_plan_t* plan, void* values, unsigned short* col16, int* dst4, unsigned short* row16,
                             int* perm, int* subband_start);
 /* Kernel B's work list (synchronous copies): window_start[subbands + 1]; windows[2 * window_start[subbands]] = {first item,

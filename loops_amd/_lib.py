@@ -47,7 +47,7 @@ SYMBOLS = [
     "loops_panel_plan_arrays", "loops_panel_plan_windows", "loops_panel_plan_refresh_values_f32", "loops_panel_plan_refresh_values_f64",
     "loops_csc_plan_create_f32", "loops_csc_plan_create_f64", "loops_coo_plan_create_f32", "loops_coo_plan_create_f64", "loops_csc_plan_destroy", "loops_csc_plan_info",
     "loops_csc_plan_refresh_values_f32", "loops_csc_plan_refresh_values_f64", "loops_spmv_csc_planned_f32", "loops_spmv_csc_planned_f64",
-    "loops_panel_plan_create_layout_f32", "loops_panel_plan_create_layout_f64", "loops_panel_plan_layout",
+    "loops_panel_plan_create_layout_f32", "loops_panel_plan_create_layout_f64", "loops_panel_plan_layout", "loops_panel_plan_row_blocks",
     "loops_row_ranges", "loops_comm_unique_id", "loops_comm_init", "loops_comm_destroy", "loops_comm_error_string",
     "loops_allgatherv_f32", "loops_allgatherv_f64",
     "loops_autotune_merge_path_variants_f32", "loops_spmv_plan_variant", "loops_columns_look_scattered",
@@ -204,6 +204,7 @@ def lib() -> C.CDLL:
         L.loops_panel_plan_destroy.restype = None
         L.loops_panel_plan_info.argtypes = [vp, vp]
         L.loops_panel_plan_layout.argtypes = [vp, vp]
+        L.loops_panel_plan_row_blocks.argtypes = [vp, vp, vp]
         L.loops_rowband_plan_create_f32.argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
         L.loops_rowband_plan_destroy.argtypes = [vp]
         L.loops_rowband_plan_destroy.restype = None

@@ -237,6 +237,12 @@ class PanelBinnedPlan:
         lay = (C.c_longlong * 4)()
         L.check(L.lib().loops_panel_plan_layout(self._h, lay), "loops_panel_plan_layout")
         self.compact, self.runs, self.padded_b, self.a_window = bool(lay[0]), int(lay[1]), int(lay[2]), int(lay[3])
+        # row blocks (matrices of 2^28 nonzeros or more, automatic parameters): independent copies run back to back
+        n = C.c_int(0)
+        L.check(L.lib().loops_panel_plan_row_blocks(self._h, C.byref(n), None), "loops_panel_plan_row_blocks")
+        bounds = (C.c_int * (n.value + 1))()
+        L.check(L.lib().loops_panel_plan_row_blocks(self._h, C.byref(n), bounds), "loops_panel_plan_row_blocks")
+        self.row_blocks, self.row_block_bounds = n.value, list(bounds)
 
     @property
     def handle(self):

@@ -358,3 +358,65 @@ def test_out_of_range_column_index_is_refused():
         csr = _dev(off, idx, np.ones(3, np.float32), 2, 5)
         with pytest.raises(L.LoopsError, match="BADARG"):
             S.PanelBinnedPlan(csr)
+
+
+_ROW_BLOCK_SCRIPT = r'''
+import numpy as np, torch, sys
+from loops_amd import spmv as S, generate as G
+from oracle import oracle as O
+rows, cols = 6000, 70000
+rng = np.random.default_rng(5)
+deg = rng.integers(0, 60, rows).astype(np.int64)
+deg[1234] = 50000                      # one row longer than a block: a boundary that cannot move
+deg[-40:] = 0                          # trailing empty rows belong to the last block
+off, idx, val = G.csr_from_degrees(deg, cols, 3)
+nnz = int(off[-1])
+assert nnz >= 4 * 20000
+xh = G.uniform_distribution_int(cols)
+ref = O.spmv_f32(off, idx, val, xh)
+for dtype in (np.float32, np.float64):
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val.astype(dtype))
+    x = torch.from_numpy(xh.astype(dtype)).cuda()
+    pb = S.PanelBinnedPlan(csr)
+    assert pb.row_blocks > 4, pb.row_blocks
+    b = pb.row_block_bounds
+    assert b[0] == 0 and b[-1] == rows and all(b[i] < b[i + 1] for i in range(len(b) - 1)), b
+    y = torch.full((rows,), 7.0, dtype=x.dtype, device="cuda")
+    pb.spmv(x, y)
+    assert np.array_equal(y.cpu().numpy(), ref.astype(dtype)), dtype
+    y.fill_(-1.0)                      # the two kernels of every block, stage by stage
+    pb.spmv_stage(0, x, y); pb.spmv_stage(1, x, y)
+    assert np.array_equal(y.cpu().numpy(), ref.astype(dtype))
+    peers = [torch.full((rows,), -3.0, dtype=x.dtype, device="cuda") for _ in range(2)]
+    y.fill_(-1.0)
+    pb.spmv_fanout(x, y, peers)
+    torch.cuda.synchronize()
+    assert all(np.array_equal(p.cpu().numpy(), ref.astype(dtype)) for p in peers) and np.array_equal(y.cpu().numpy(), ref.astype(dtype))
+    pb.refresh_values(csr.values * 2)
+    assert np.array_equal(pb.spmv(x).cpu().numpy(), 2 * ref.astype(dtype))
+    try:
+        pb.arrays()
+        raise SystemExit("a row-blocked plan has no single set of arrays")
+    except Exception as e:
+        assert "loops_panel_plan_arrays" in str(e), e
+    # a named geometry is one copy, whatever the size
+    one = S.PanelBinnedPlan(csr, pb.Hw)
+    assert one.row_blocks == 1 and np.array_equal(one.spmv(x).cpu().numpy(), ref.astype(dtype))
+    one.close(); pb.close()
+    # the held SpMV plan over the same matrix may adopt the blocked copy: same bits either way
+    sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=2)
+    assert np.array_equal(sp.spmv(x).cpu().numpy(), ref.astype(dtype)), sp.layout
+    sp.close()
+print("row blocks ok")
+'''
+
+
+def test_row_blocked_plan_equals_one_copy():
+    """Matrices of 2^28 nonzeros or more are held as independent panel-binned copies over row blocks (abi_panel.inc); the block
+    size is a plan-time knob read once per process (LOOPS_PANEL_BLOCK_NNZ), so the small-scale check runs in its own process:
+    product, stage calls, fan-out, value refresh, a row longer than a block, trailing empty rows, f32 / f64."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LOOPS_PANEL_BLOCK_NNZ="20000", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", _ROW_BLOCK_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "row blocks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
