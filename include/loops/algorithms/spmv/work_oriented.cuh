@@ -4,7 +4,7 @@
  * per thread of an occupancy-sized grid (reference include/loops/algorithms/spmv/work_oriented.cuh:33-121).
  * Runs the fused persistent kernel (loops/kernels/merge_path_spmv.hxx: work_oriented_spmv_fused): each
  * workgroup walks an even contiguous share of 1-4 merge tiles with the open row carried in registers
- * (phased x gathers over 512 x 8 tiles where the columns look scattered over a large x).  No atomics;
+ * (one 512 x 8 tile per workgroup with phased x gathers -- merge_path_flat's launch -- where the columns look scattered over a large x).  No atomics;
  * y does not have to be zero-filled.
  */
 #pragma once
@@ -18,6 +18,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/kernels/launch.hxx>
+#include <loops/algorithms/spmv/merge_path_flat.cuh>
 #include <loops/error.hxx>
 #include <loops/memory.hxx>
 
@@ -54,21 +55,18 @@ void work_oriented(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, v
   constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
   using plan_t = schedule::merge_path::preprocess_t<block_size, items_per_thread, index_t, offset_t, std::size_t,
                                                     std::size_t>;
-  // Columns scattered over an x of 3 MB or more (kernels::columns_look_scattered, the guess `merge_path_flat` goes by): shares of
-  // 512 x 8 tiles with PHASED x gathers (work_oriented_spmv_fused_phased; same bits).
+  // Columns scattered over an x of 3 MB or more (kernels::columns_look_scattered, the guess `merge_path_flat` goes by): the share is
+  // one 512 x 8 tile per workgroup and the launch is merge_path_flat's phased kernel (a persistent form with phased gathers was
+  // measured 10 % behind it: 74 VGPRs, three resident workgroups; profiles/r05_work_oriented_shares_experiment.txt).
   if (kernels::columns_worth_sampling(static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t)))) {
     vector_t<unsigned int> scratch(kernels::scatter_scratch_words);
     if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                         static_cast<int>(sizeof(type_t)), scratch.data().get())) {
-      using wide_t = schedule::merge_path::preprocess_t<512, 8, index_t, offset_t, std::size_t, std::size_t>;
+      using wide_t = merge_path_plan_of_t<512, 8, index_t, offset_t>;
       wide_t wide(typename wide_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows), static_cast<offset_t>(csr.nnzs)),
                   stream, wide_t::prepass_always);
-      kernels::merge_plan_view view{wide.data(), wide.carry_rows(), wide.template carry_values<type_t>(),
-                                    static_cast<int>(wide.merge_tiles())};
-      kernels::launch_work_oriented_fused_phased(stream, view, static_cast<int>(csr.rows), static_cast<int>(csr.cols),
-                                                 static_cast<int>(csr.nnzs), csr.offsets.data().get(), csr.indices.data().get(),
-                                                 csr.values.data().get(), x.data().get(), y.data().get(),
-                                                 static_cast<unsigned int*>(nullptr));
+      wide.classify(stream);
+      merge_path_flat_phased_async_with<512, 8>(wide, csr, x, y, stream);
       (void)xpu::stream_synchronize(stream);
       return;
     }

@@ -411,39 +411,6 @@ int launch_work_oriented_fused(hipStream_t stream, const merge_plan_view& plan, 
   return launch_status();
 }
 
-/// work_oriented with phased x gathers over a plan of 512 x 8 tiles (work_oriented_spmv_fused_phased).  `stats` (scatter_scratch_words
-/// device words) != nullptr: the sample of the columns is launched in front and the DEVICE decides per product whether the gathers
-/// are phased (asynchronous: the plan-less C-ABI entry); nullptr: always phased (the caller asked columns_look_scattered).
-/// Unaligned arrays run the plain kernel.
-template <typename index_t, typename offset_t, typename T>
-int launch_work_oriented_fused_phased(hipStream_t stream, const merge_plan_view& plan, int rows, int cols, int nnz,
-                                      const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
-                                      unsigned int* stats) {
-  constexpr int TPB = 512, IPT = 8;
-  const int m = plan.num_merge_tiles;
-  if (m == 0) return 0;
-  const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-  if (!aligned) return launch_work_oriented_fused<TPB, IPT, true>(stream, plan, rows, nnz, offsets, indices, values, x, y);
-  if (stats) {
-    const int err = launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols),
-                                                 static_cast<int>(sizeof(T)), stats);
-    if (err) return err;
-  }
-  const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
-  auto k = cfg.parts == 8    ? work_oriented_spmv_fused_phased<TPB, IPT, 8, true, index_t, offset_t, T>
-           : cfg.parts == 16 ? work_oriented_spmv_fused_phased<TPB, IPT, 16, true, index_t, offset_t, T>
-                             : work_oriented_spmv_fused_phased<TPB, IPT, 32, true, index_t, offset_t, T>;
-  static const int resident = static_cast<int>(launch_box::occupancy_grid(work_oriented_spmv_fused_phased<TPB, IPT, 8, true, index_t, offset_t, T>, TPB));
-  const int tiles_per_group = work_oriented_share(m, resident);
-  const int groups = math::ceil_div(m, tiles_per_group);
-  T* carry_val = static_cast<T*>(plan.carry_val);
-  hipLaunchKernelGGL(k, dim3(groups), dim3(TPB), 0, stream, plan.coords, m, tiles_per_group, rows, nnz, offsets, indices, values, x, y,
-                     plan.carry_row, carry_val, static_cast<const unsigned int*>(stats), cfg.args);
-  hipLaunchKernelGGL(merge_path_spmv_fixup<T>, dim3(math::ceil_div(groups, 256)), dim3(256), 0, stream, plan.carry_row, carry_val,
-                     groups, rows, y);
-  return launch_status();
-}
-
 /// Tuned group_mapped: one workgroup per TPB consecutive rows, no plan, no atomics.
 template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_group_mapped_fused(hipStream_t stream, int rows, int nnz, const offset_t* offsets, const index_t* indices,

@@ -1168,55 +1168,6 @@ work_oriented_spmv_fused(const coord_t* __restrict__ coords, const int num_merge
   }
 }
 
-/// work_oriented with the PHASED x gathers of merge_path_spmv_fused_phased: the same shares of tiles, every tile's
-/// gathers in PHASES clock-aligned passes by column range.  `stats` == nullptr: always phased (callers that decided on the host);
-/// otherwise the device decides per launch by what column_scatter_sample wrote there (the rule of merge_path_spmv_fused_auto).
-/// 512 x 8 tiles: with 2 048-item tiles a pass holds too few gathers (round 4: 9 % at best); C3 stand-in with uniform columns
-/// 3.01 -> 2.52 ms, C2 94 -> 90 us (profiles/r05_work_oriented_shares_experiment.txt).  Same bits as the plain kernel.
-template <int TPB, int IPT, int PHASES, bool VEC, typename index_t, typename offset_t, typename type_t>
-__global__ void __launch_bounds__(TPB)
-work_oriented_spmv_fused_phased(const coord_t* __restrict__ coords, const int num_merge_tiles, const int tiles_per_group,
-                                const int rows, const int nnz, const offset_t* __restrict__ offsets,
-                                const index_t* __restrict__ indices, const type_t* __restrict__ values,
-                                const type_t* __restrict__ x, type_t* __restrict__ y, int* __restrict__ carry_row,
-                                type_t* __restrict__ carry_val, const unsigned int* __restrict__ stats, detail::phase_args phase) {
-  using engine_t = merge_tile_engine<TPB, IPT, true, detail::policy::phased_auto(PHASES), VEC, index_t, offset_t, type_t, true>;
-  __shared__ typename engine_t::storage_t s_engine;
-  if (stats != nullptr) {  // (uniform: scalar loads)
-    const unsigned int far_same = stats[0], far_seen = stats[1], near_same = stats[2], near_seen = stats[3];
-    phase.enabled = detail::scatter_counts_say_phase(far_same, far_seen, near_same, near_seen, PHASES) ? 1u : 0u;
-  } else {
-    phase.enabled = 1u;
-  }
-  const int tid = threadIdx.x;
-  const int g = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
-  const int t_begin = g * tiles_per_group;
-  int t_end = t_begin + tiles_per_group;
-  t_end = t_end < num_merge_tiles ? t_end : num_merge_tiles;
-  type_t carry = type_t(0);
-  int open_row = 0;
-  for (int t = t_begin; t < t_end; ++t) {
-    const coord_t c0 = coords[t];
-    const coord_t c1 = coords[t + 1];
-    const int row0 = static_cast<int>(c0.x);
-    const int nz0 = static_cast<int>(c0.y);
-    const int nrows = static_cast<int>(c1.x) - row0;
-    const int natoms = static_cast<int>(c1.y) - nz0;
-    engine_t::clear_marks(s_engine);
-    __syncthreads();
-    carry = engine_t::run_to(s_engine, static_cast<const offset_t*>(nullptr), row0, nz0, nrows, natoms, nnz, indices, values, x,
-                             plain_store<type_t>{y}, carry, [&]() {
-      for (int i = tid; i < nrows; i += TPB)
-        engine_t::mark_row_end(s_engine, i, static_cast<int>(offsets[row0 + i + 1]), nz0);
-    }, phase);
-    open_row = row0 + nrows;
-  }
-  if (tid == 0 && t_begin < t_end) {
-    carry_row[g] = open_row;
-    carry_val[g] = carry;
-  }
-}
-
 /**
  * group_mapped: workgroup b owns the TPB consecutive rows [b * TPB, (b + 1) * TPB) and sweeps the
  * concatenation of their nonzeros cooperatively (semantics of schedule::setup<group_mapped, TPB, TPB>,

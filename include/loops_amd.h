@@ -110,7 +110,7 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  * kernels, ~5 us -- and its tile kernel gathers in phases when they are scattered, loops_columns_look_scattered's rule evaluated on
  * the device: the call stays asynchronous; |x| = 8 / 16 MB, scattered columns: 1.5 / 1.7 x.
  * LOOPS_WORK_ORIENTED, round 5: workgroups walk shares of 1-4 merge tiles (one long share per resident workgroup kept them in step);
- * above the same thresholds the entry takes 512 x 8 tiles and the same device-side choice of phased gathers.) */
+ * above the same thresholds the share is one 512 x 8 tile and the launch is LOOPS_MERGE_PATH_FLAT's, device-side choice included.) */
 int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
                        const float* values, const float* x, float* y, void* stream);
 int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,

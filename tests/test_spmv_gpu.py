@@ -932,8 +932,8 @@ def test_phased_variant_on_the_reference_battery_and_degenerate_inputs(tile):
 @pytest.mark.parametrize("schedule", ["merge_path_flat", "work_oriented"])
 def test_planless_device_decided_kernel(schedule, window, dtype):
     """The asynchronous plan-less entries `loops_spmv_csr_*(MERGE_PATH_FLAT | WORK_ORIENTED)` above their thresholds (x >= 6 MB, nnz >=
-    2^20): a sample of the columns decides ON THE DEVICE whether the product gathers in phases (kernels::merge_path_spmv_fused_auto,
-    work_oriented_spmv_fused_phased).  Both
+    2^20; WORK_ORIENTED takes MERGE_PATH_FLAT's launch there -- shares of one 512 x 8 tile): a sample of the columns decides ON THE DEVICE
+    whether the product gathers in phases (kernels::merge_path_spmv_fused_auto).  Both
     outcomes -- scattered columns (phased) and a 4096-wide band (plain) -- must give the bits of the held 512x8 plan, also from
     two streams at once and from a captured HIP graph (the decision is device-side: nothing host-side may depend on it)."""
     from loops_amd import spmv as S, generate as G
