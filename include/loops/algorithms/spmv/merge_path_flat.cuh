@@ -121,8 +121,8 @@ util::timer_t merge_path_flat(csr_t<index_t, offset_t, type_t>& csr, vector_t<ty
     vector_t<unsigned int> scratch(kernels::scatter_scratch_words);
     if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                         static_cast<int>(sizeof(type_t)), scratch.data().get())) {
-      // (x beyond 24 MB -- 32 parts: 256 x 16 tiles, twice the gathers per lane and pass; uniform C3 stand-in 2.29 -> 2.10 ms)
-      if (kernels::phased_config_for(static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t))).parts == 32) {
+      // (16 or 32 parts -- x beyond 6 MB, 12 MB for 8-byte values: 256 x 16 tiles, twice the gathers per lane and pass; 3-11 % faster)
+      if (kernels::phased_config_for(static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t))).parts >= 16) {
         using tall_t = merge_path_plan_of_t<256, 16, index_t, offset_t>;
         tall_t tall(lay, stream, tall_t::prepass_always);
         tall.classify(stream);

@@ -62,7 +62,7 @@ void work_oriented(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, v
     vector_t<unsigned int> scratch(kernels::scatter_scratch_words);
     if (kernels::columns_look_scattered(stream, csr.indices.data().get(), static_cast<long long>(csr.nnzs), static_cast<long long>(csr.cols),
                                         static_cast<int>(sizeof(type_t)), scratch.data().get())) {
-      if (kernels::phased_config_for(static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t))).parts == 32) {  // (as merge_path_flat)
+      if (kernels::phased_config_for(static_cast<long long>(csr.cols), static_cast<int>(sizeof(type_t))).parts >= 16) {  // (as merge_path_flat)
         using tall_t = merge_path_plan_of_t<256, 16, index_t, offset_t>;
         tall_t tall(typename tall_t::layout_t(csr.offsets.data().get(), static_cast<index_t>(csr.rows), static_cast<offset_t>(csr.nnzs)),
                     stream, tall_t::prepass_always);
