@@ -38,8 +38,8 @@ def test_spmv_plan_picks_tile_and_layout():
     assert S.MergePathPlan(csr, "auto").tile == "512x8"
     p = S.SpmvPlan(csr, allow_copy=False, measure=False)
     # (round 4: hashed columns over an x of 32 MB LOOK scattered -- loops_columns_look_scattered -- so the unmeasured plan that
-    # stays on the CSR takes the phased-gather twin of 512 x 8)
-    assert p.info["layout"] == "csr" and p.info["tile"] == "512x8+phased"
+    # stays on the CSR takes a phased-gather kernel; round 5: over 256 x 16 tiles from 16 parts of x on)
+    assert p.info["layout"] == "csr" and p.info["tile"] == "256x16+phased"
     assert np.array_equal(p.spmv(x).cpu().numpy(), ref)
     p.close()
     p = S.SpmvPlan(csr, allow_copy=True, measure=False)
