@@ -354,7 +354,7 @@ int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float*
  *                                  row-band (4-byte values, mean row >= 8 nonzeros) from 2 MB.  (Structure does not show
  *                                  column locality -- a narrow band is faster from the CSR as given, a wide one from the
  *                                  row-band copy whatever the size of x: MEASURE finds out.)
- *                                  A plan that stays on the CSR takes 512 x 8 tiles with phased x gathers (LOOPS_VARIANT_PHASED) when
+ *                                  A plan that stays on the CSR takes 512 x 8 (from 16 parts of x on: 256 x 16) tiles with phased x gathers (LOOPS_VARIANT_PHASED) when
  *                                  the columns LOOK scattered over an x of 3 MB or more (loops_columns_look_scattered).
  * Without ALLOW_COPY the product always runs on the caller's arrays.  Creation is synchronous.  One product in flight per plan.
  * loops_spmv_planned_*: y = A x; offsets / indices / values are the arrays the plan was created from (ignored -- may be NULL
