@@ -246,7 +246,37 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
     S.bcsr_thread_mapped(b, x, y, mfma=1)
     out["mfma"]["kernel"] = "loops::kernels::bcsr4x4_mfma_spmv"
-    out["parity_vs_oracle_bit_exact"] = bool(np.array_equal(y.cpu().numpy(), O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)))
+    want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)
+    out["parity_vs_oracle_bit_exact"] = bool(np.array_equal(y.cpu().numpy(), want))
+    # the held plan for this matrix: the block-band copy (kernels/bcsr_band.hxx) -- blocks sorted by block column inside bands whose
+    # row sums live in LDS, MFMA block products; what it costs to build and after how many products it has paid for itself
+    try:
+        S.BCSRBandPlan(b).close()                                       # (first build in the process: allocator warm-up)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        plan = S.BCSRBandPlan(b)
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        shapes = plan.tune(10)
+        tune_ms = (time.perf_counter() - t0) * 1e3
+        ms = timed_ms(torch, lambda: plan.spmv(x, y), iters)
+        y.fill_(-1.0)
+        plan.spmv(x, y)
+        saved = out["mfma"]["avg_launch_ms"] - ms
+        out["block_band_plan"] = {
+            "kernel": "loops::kernels::bcsr_band::bcsr_band_accumulate", "avg_launch_ms": round(ms, 5), "GFLOPs": round(2 * 16 * nb / ms / 1e6, 1),
+            "achieved_GBps": round(abytes / ms / 1e6, 1), "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+            "band_block_rows": plan.HB, "bands": plan.num_bands, "chunks": plan.num_chunks, "partial_vectors": plan.num_partials,
+            "shape": {"waves": plan.waves, "steps_per_batch": plan.unroll, "non_temporal": plan.nt},
+            "plan_build_ms": round(build_ms, 3), "plan_tune_ms": round(tune_ms, 3),
+            "break_even_products": (int(np.ceil(build_ms / saved)) if saved > 0 else None),
+            "break_even_products_incl_tune": (int(np.ceil((build_ms + tune_ms) / saved)) if saved > 0 else None),
+            "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), want)),
+            "note": "held plan (a re-ordered copy of the blocks); the one-shot bcsr_thread_mapped<4, 4> wrapper launches the MFMA kernel above"}
+        plan.close()
+    except Exception as e:  # noqa: BLE001
+        out["block_band_plan"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

@@ -45,6 +45,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <queue>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -217,7 +218,8 @@ rowband_accumulate(const int* __restrict__ chunks, const type_t* __restrict__ va
 }
 
 /// Kernel B: rows of the bands that were cut into several chunks.  grid = (H / 1024, num_multi), 256 threads x 4 rows.
-template <typename type_t, typename store_t>
+/// DEPTH = partial vectors a thread has in flight (4 or 8: the launcher takes the smallest that covers the longest cut).
+template <int DEPTH, typename type_t, typename store_t>
 __global__ void __launch_bounds__(256)
 rowband_combine(const int* __restrict__ multi, const type_t* __restrict__ partial, const int H, const int rows, const store_t out) {
   const int m = blockIdx.y;
@@ -225,11 +227,21 @@ rowband_combine(const int* __restrict__ multi, const type_t* __restrict__ partia
   const int j = (static_cast<int>(blockIdx.x) * 256 + static_cast<int>(threadIdx.x)) * 4;
   if (j >= H) return;
   double sum[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int k = 0; k < count; ++k) {
-    type_t p[4];
-    detail::load4<type_t, false>(partial + static_cast<long long>(first + k) * H + j, p);
+  // DEPTH partial vectors in flight per thread (branch-free: a surplus load repeats the band's last vector and is not added) --
+  // with one load in flight the kernel was a chain of `count` memory round trips (C2 / C4, 4 chunks per band: 6.8 us for 21 MB)
+  for (int k0 = 0; k0 < count; k0 += DEPTH) {
+    type_t p[DEPTH][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sum[e] += static_cast<double>(p[e]);
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = k0 + d < count ? k0 + d : count - 1;
+      detail::load4<type_t, false>(partial + static_cast<long long>(first + k) * H + j, p[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const bool live = k0 + d < count;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[e] += live ? static_cast<double>(p[d][e]) : 0.0;
+    }
   }
   const long long row0 = static_cast<long long>(band) * H + j;
 #pragma unroll
@@ -594,13 +606,14 @@ struct rowband_storage {
   }
 };
 
-/// Default number of chunks: one per band where there are at least as many bands as compute units (the dispatcher balances
-/// them; only a band with twice the mean's items is cut), else one round of equal chunks (C2: 64 bands of 16384 rows -> 256
-/// chunks).  Measured (profiles/r05_rowband_experiments.txt, the 8-byte layout): band C3 stand-in, 453 bands, uncut 268 us, 512 /
-/// 1024 chunks 275 / 305; C2 256 chunks 37 us, 512 chunks 44-54 (two workgroups per CU, twice the partial vectors).
+/// Default number of chunks: one per band where there are more than half as many bands as compute units (the dispatcher
+/// balances them; cutting ONE band of 255 on 256 CUs would buy a partial-vector round trip and a second launch for nothing),
+/// else one round of equal chunks (C2: 64 bands of 16384 rows -> 256 chunks).  Measured (profiles/r05_rowband_experiments.txt,
+/// the 8-byte layout): band C3 stand-in, 453 bands, uncut 268 us, 512 / 1024 chunks 275 / 305; C2 256 chunks 37 us, 512 chunks
+/// 44-54 (two workgroups per CU, twice the partial vectors).
 inline int rowband_target_chunks(int B, int cus) {
   const int c = cus > 0 ? cus : 256;
-  return B >= c ? B : c;
+  return 2 * B > c ? B : c;
 }
 
 /// (Re)builds the work lists of a built layout for about `target_chunks` chunks (0 = automatic); `band_step_host` = the B + 1 step
@@ -746,6 +759,29 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   return 0;
 }
 
+/// Kernel B's launch: the rows of `num_multi` cut bands of H rows each (`multi` = {band, first partial slot, chunks} per band).
+/// One thread per group of 4 rows while no band is cut into more than a handful of chunks, 4 or 16 threads beyond.  The band
+/// index is the grid's y dimension (at most 65 535 per launch: longer lists go out in slabs).
+template <typename type_t, typename store_t>
+void launch_rowband_combine(hipStream_t stream, const int* multi, int num_multi, int max_pieces, const type_t* partial, int H, int rows,
+                            const store_t out) {
+  constexpr int max_y = 65535;
+  for (int m0 = 0; m0 < num_multi; m0 += max_y) {
+    const int my = num_multi - m0 < max_y ? num_multi - m0 : max_y;
+    const int* mm = multi + 3 * static_cast<std::size_t>(m0);
+    if (max_pieces <= 4)
+      hipLaunchKernelGGL((rowband::rowband_combine<4, type_t, store_t>), dim3(math::ceil_div(H, 1024), my), dim3(256), 0, stream, mm, partial, H, rows, out);
+    else if (max_pieces <= 8)
+      hipLaunchKernelGGL((rowband::rowband_combine<8, type_t, store_t>), dim3(math::ceil_div(H, 1024), my), dim3(256), 0, stream, mm, partial, H, rows, out);
+    else if (max_pieces <= 48)
+      hipLaunchKernelGGL((rowband::rowband_combine_wide<4, type_t, store_t>), dim3(math::ceil_div(H, 256), my), dim3(256), 0, stream, mm, partial, H,
+                         rows, out);
+    else
+      hipLaunchKernelGGL((rowband::rowband_combine_wide<16, type_t, store_t>), dim3(math::ceil_div(H, 64), my), dim3(256), 0, stream, mm, partial, H,
+                         rows, out);
+  }
+}
+
 /// y = A x over a row-band matrix: kernel A, then kernel B if some band was cut.  stages: bit 0 = accumulate, bit 1 = combine.
 /// Kernel A runs 8 or 16 wavefronts per workgroup (`m.waves`), one step per wavefront and batch.  Measured on MI355X
 /// (tests/perf/bench_rowband.py, profiles/r05_rowband_experiments.txt): C2 32.6 / 35.7 us with 8 / 16 wavefronts (more wavefronts
@@ -760,31 +796,28 @@ int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const t
   const bool nt = items * (sizeof(type_t) + 3.0) + (static_cast<double>(m.rows) + m.cols + 2.0 * m.num_partials * m.H) * sizeof(type_t) > 240e6;
   if ((stages & 1) && m.num_chunks > 0) {
     const std::size_t lds = static_cast<std::size_t>(rowband::lds_words(m.H)) * sizeof(double);
-    auto go = [&](auto kernel, int waves) {
-      if (lds > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(waves * wave::size), lds, stream, m.chunks, m.val, m.meta, m.stepbase, m.hubs, x, m.H,
-                         m.rows, m.partial, out);
+    auto go = [&](auto w_tag, auto nt_tag) {
+      constexpr int W = decltype(w_tag)::value;
+      constexpr bool NT = decltype(nt_tag)::value;
+      auto* kernel = rowband::rowband_accumulate<W, 1, NT, type_t, store_t>;
+      if (lds > 65536) {  // opt into the large LDS once per instantiation (this lambda body is instantiated per <W, NT>), not per launch
+        static const hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)opted;
+      }
+      hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(W * wave::size), lds, stream, m.chunks, m.val, m.meta, m.stepbase, m.hubs, x, m.H, m.rows,
+                         m.partial, out);
     };
+    using w8 = std::integral_constant<int, 8>;
+    using w16 = std::integral_constant<int, 16>;
     if (m.waves == 16) {
-      if (nt) go(rowband::rowband_accumulate<16, 1, true, type_t, store_t>, 16);
-      else go(rowband::rowband_accumulate<16, 1, false, type_t, store_t>, 16);
+      if (nt) go(w16{}, std::true_type{});
+      else go(w16{}, std::false_type{});
     } else {
-      if (nt) go(rowband::rowband_accumulate<8, 1, true, type_t, store_t>, 8);
-      else go(rowband::rowband_accumulate<8, 1, false, type_t, store_t>, 8);
+      if (nt) go(w8{}, std::true_type{});
+      else go(w8{}, std::false_type{});
     }
   }
-  if ((stages & 2) && m.num_multi > 0) {
-    // one thread per group of 4 rows while no band is cut into more than a handful of chunks, 4 or 16 threads beyond
-    if (m.max_pieces <= 6)
-      hipLaunchKernelGGL((rowband::rowband_combine<type_t, store_t>), dim3(math::ceil_div(m.H, 1024), m.num_multi), dim3(256), 0, stream,
-                         m.multi, m.partial, m.H, m.rows, out);
-    else if (m.max_pieces <= 48)
-      hipLaunchKernelGGL((rowband::rowband_combine_wide<4, type_t, store_t>), dim3(math::ceil_div(m.H, 256), m.num_multi), dim3(256), 0,
-                         stream, m.multi, m.partial, m.H, m.rows, out);
-    else
-      hipLaunchKernelGGL((rowband::rowband_combine_wide<16, type_t, store_t>), dim3(math::ceil_div(m.H, 64), m.num_multi), dim3(256), 0,
-                         stream, m.multi, m.partial, m.H, m.rows, out);
-  }
+  if ((stages & 2) && m.num_multi > 0) launch_rowband_combine<type_t>(stream, m.multi, m.num_multi, m.max_pieces, m.partial, m.H, m.rows, out);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -217,6 +217,41 @@ int loops_spmv_bcsr_f64(int R, int C, int mode, int rows, int num_block_rows, in
                         const int* block_offsets, const int* block_cols, const double* block_values,
                         const double* x_padded, double* y, void* stream);
 
+/* ---- Block-band plan for 4 x 4 fp32 BCSR (include/loops/kernels/bcsr_band.hxx) ------------------------------------------------
+ * A held plan for algorithms::spmv::bcsr_thread_mapped<4, 4> (algorithms/spmv/bcsr_thread_mapped.cuh:36-123) products over ONE
+ * matrix: a re-ordered COPY of the blocks (container/bcsr.hxx:13-17 cells, row-major) -- bands of `band_block_rows` block-rows
+ * (0 = automatic; else a power of two in [16, 4096]), the blocks of a band sorted by block column so that the 16-byte x
+ * gathers of a wavefront share 128-byte lines; the band's 4 HB row sums live in LDS as fp64 words (ds_add_f64), the block
+ * inner product runs on v_mfma_f32_4x4x1.  Bands are cut into about `target_chunks` workgroups (0 = automatic: the CU count
+ * when there are fewer bands); cut bands go through fp32 partial vectors and a second kernel.  y needs no zero-fill, rows of
+ * y >= `rows` are not written, x must be padded to 4 * num_block_cols.  SUMMATION ORDER: the fp64 LDS atomics of different
+ * wavefronts arrive in no fixed order -- results are bit-identical to bcsr_thread_mapped (and between runs) whenever the
+ * fp64 sums of a row's fp32 block products are exact (the exactly-summable inputs of the tests; in general the last bit of a
+ * row may differ from run to run).  Callers that need run-to-run determinism on arbitrary values use loops_spmv_bcsr_f32.
+ * Returns LOOPS_E_BADARG for a block column outside [0, num_block_cols), LOOPS_E_RANGE when row code + block column do not
+ * fit one 32-bit word at the band height asked for.
+ * loops_bcsr_band_plan_info: info10 = {HB, bands, column bits, steps of 16 blocks, chunks, partial vectors, cut bands,
+ * wavefronts per workgroup, steps per batch, non-temporal streams}.  loops_bcsr_band_plan_arrays: HOST copies (any pointer may
+ * be NULL): values [steps * 256], words [steps * 16] = (block-row inside the band << column bits) | block column (padding:
+ * row code HB), perm [steps * 16] = BCSR position of the slot's block or -1, chunks [n * 4] = {band, first step, end step,
+ * partial slot or -1}, multi [m * 3] = {band, first partial slot, chunks}.  _set_chunks re-cuts the bands of a built plan;
+ * _tune times every compiled kernel shape (ms12, may be NULL: (waves 8 | 16) x (steps 1 | 2 | 4) x (plain | non-temporal), in ms)
+ * and keeps the fastest; _set_shape sets one.  One plan per stream for concurrent products (the plan owns its partial vectors). */
+typedef struct loops_bcsr_band_plan loops_bcsr_band_plan_t;
+int loops_bcsr_band_plan_create_f32(int rows, int num_block_rows, int num_block_cols, int num_blocks, const int* block_offsets,
+                                    const int* block_cols, const float* block_values, int band_block_rows, int target_chunks,
+                                    void* stream, loops_bcsr_band_plan_t** out);
+void loops_bcsr_band_plan_destroy(loops_bcsr_band_plan_t* plan);
+int loops_bcsr_band_plan_info(const loops_bcsr_band_plan_t* plan, int* info10);
+int loops_bcsr_band_plan_arrays(const loops_bcsr_band_plan_t* plan, float* values, unsigned int* words, int* perm, int* chunks, int* multi);
+int loops_bcsr_band_plan_set_chunks(loops_bcsr_band_plan_t* plan, int target_chunks);
+int loops_bcsr_band_plan_tune(loops_bcsr_band_plan_t* plan, int repeats, float* ms12, void* stream);
+int loops_bcsr_band_plan_set_shape(loops_bcsr_band_plan_t* plan, int waves, int unroll, int nt);
+int loops_bcsr_band_plan_refresh_values_f32(loops_bcsr_band_plan_t* plan, const float* block_values, void* stream);
+int loops_spmv_bcsr_band_f32(const loops_bcsr_band_plan_t* plan, const float* x_padded, float* y, void* stream);
+/* stage 0: the accumulate kernel only (partial vectors of cut bands are left in the plan), stage 1: the combine kernel only. */
+int loops_spmv_bcsr_band_stage_f32(const loops_bcsr_band_plan_t* plan, int stage, const float* x_padded, float* y, void* stream);
+
 /* ---- CSR SpMM  C[rows x n] = A[rows x cols] * B[cols x n], dense row-major B and C ------------
  * Replaces algorithms::spmm::thread_mapped (algorithms/spmm/thread_mapped.cuh:28-90; caller:
  * examples/spmm/thread_mapped.cu:30-41).  schedule LOOPS_MERGE_PATH_FLAT = the tuned kernel

@@ -55,6 +55,9 @@ SYMBOLS = [
     "loops_rowband_plan_create_f32", "loops_rowband_plan_destroy", "loops_rowband_plan_info", "loops_rowband_plan_arrays",
     "loops_rowband_plan_set_chunks", "loops_rowband_plan_tune", "loops_rowband_plan_set_waves", "loops_rowband_plan_refresh_values_f32", "loops_spmv_rowband_f32", "loops_spmv_rowband_stage_f32",
     "loops_spmv_rowband_fanout_f32",
+    "loops_bcsr_band_plan_create_f32", "loops_bcsr_band_plan_destroy", "loops_bcsr_band_plan_info", "loops_bcsr_band_plan_arrays",
+    "loops_bcsr_band_plan_set_chunks", "loops_bcsr_band_plan_tune", "loops_bcsr_band_plan_set_shape", "loops_bcsr_band_plan_refresh_values_f32",
+    "loops_spmv_bcsr_band_f32", "loops_spmv_bcsr_band_stage_f32",
 ]
 
 
@@ -217,6 +220,17 @@ def lib() -> C.CDLL:
         L.loops_spmv_rowband_f32.argtypes = [vp, vp, vp, vp]
         L.loops_spmv_rowband_stage_f32.argtypes = [vp, ci, vp, vp, vp]
         L.loops_spmv_rowband_fanout_f32.argtypes = [vp, vp, vp, ci, vp, vp]
+        L.loops_bcsr_band_plan_create_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
+        L.loops_bcsr_band_plan_destroy.argtypes = [vp]
+        L.loops_bcsr_band_plan_destroy.restype = None
+        L.loops_bcsr_band_plan_info.argtypes = [vp, vp]
+        L.loops_bcsr_band_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.loops_bcsr_band_plan_set_chunks.argtypes = [vp, ci]
+        L.loops_bcsr_band_plan_tune.argtypes = [vp, ci, vp, vp]
+        L.loops_bcsr_band_plan_set_shape.argtypes = [vp, ci, ci, ci]
+        L.loops_bcsr_band_plan_refresh_values_f32.argtypes = [vp, vp, vp]
+        L.loops_spmv_bcsr_band_f32.argtypes = [vp, vp, vp, vp]
+        L.loops_spmv_bcsr_band_stage_f32.argtypes = [vp, ci, vp, vp, vp]
         L.loops_row_ranges.argtypes = [ci, vp, ci, vp]
         L.loops_comm_unique_id.argtypes = [vp]
         L.loops_comm_init.argtypes = [ci, ci, vp, C.POINTER(vp)]

@@ -31,6 +31,7 @@
 #include <loops/kernels/dia_spmv.hxx>
 #include <loops/kernels/csc_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
+#include <loops/kernels/bcsr_band.hxx>
 
 using namespace loops;
 using kernels::coord_t;
@@ -73,5 +74,6 @@ inline int check_csr(int rows, int cols, int nnz, const void* off, const void* i
 #include "abi_formats.inc"
 #include "abi_panel.inc"
 #include "abi_rowband.inc"
+#include "abi_bcsr_band.inc"
 #include "abi_plans.inc"
 #include "abi_multi_gpu.inc"

@@ -580,6 +580,81 @@ def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None =
     return y
 
 
+class BCSRBandPlan:
+    """Block-band copy of a 4 x 4 fp32 BCSR (loops_bcsr_band_plan_*; include/loops/kernels/bcsr_band.hxx): bands of HB block-rows
+    whose 4 HB row sums live in LDS as fp64 words, the band's blocks sorted by block column so that the x gathers of a
+    wavefront share lines; block inner products on v_mfma_f32_4x4x1.  A held plan for bcsr_thread_mapped<4, 4> products."""
+
+    STEP = 16
+
+    def __init__(self, b: BCSR, band_block_rows: int = 0, target_chunks: int = 0):
+        assert b.R == 4 and b.C == 4 and b.values.dtype == torch.float32
+        self.rows, self.num_block_rows, self.num_block_cols, self.num_blocks = b.rows, b.num_block_rows, b.num_block_cols, b.num_blocks
+        self._h = C.c_void_p()
+        L.check(L.lib().loops_bcsr_band_plan_create_f32(b.rows, b.num_block_rows, b.num_block_cols, b.num_blocks, _ptr(b.block_offsets),
+                                                        _ptr(b.block_cols), _ptr(b.values), int(band_block_rows), int(target_chunks),
+                                                        _stream(), C.byref(self._h)), "loops_bcsr_band_plan_create_f32")
+        self._read_info()
+
+    def _read_info(self):
+        info = (C.c_int * 10)()
+        L.check(L.lib().loops_bcsr_band_plan_info(self._h, info), "loops_bcsr_band_plan_info")
+        (self.HB, self.num_bands, self.cbits, self.steps, self.num_chunks, self.num_partials, self.num_multi, self.waves, self.unroll,
+         self.nt) = list(info)
+        self.slots = self.steps * self.STEP
+
+    def set_chunks(self, target_chunks: int = 0):
+        L.check(L.lib().loops_bcsr_band_plan_set_chunks(self._h, int(target_chunks)), "loops_bcsr_band_plan_set_chunks")
+        self._read_info()
+
+    def tune(self, repeats: int = 10):
+        """Time every compiled kernel shape and keep the fastest -> {(waves, unroll, nt): ms}."""
+        ms = (C.c_float * 12)()
+        L.check(L.lib().loops_bcsr_band_plan_tune(self._h, int(repeats), ms, _stream()), "loops_bcsr_band_plan_tune")
+        self._read_info()
+        keys = [(w, u, nt) for w in (8, 16) for u in (1, 2, 4) for nt in (0, 1)]
+        return {k: float(v) for k, v in zip(keys, ms)}
+
+    def set_shape(self, waves: int, unroll: int, nt: int):
+        L.check(L.lib().loops_bcsr_band_plan_set_shape(self._h, int(waves), int(unroll), int(nt)), "loops_bcsr_band_plan_set_shape")
+        self._read_info()
+
+    def arrays(self):
+        """(values [slots, 4, 4], words, perm, chunks [n, 4], multi [m, 3]) copied to the host."""
+        val, words, perm = np.zeros((self.slots, 4, 4), np.float32), np.zeros(self.slots, np.uint32), np.zeros(self.slots, np.int32)
+        chunks, multi = np.zeros((self.num_chunks, 4), np.int32), np.zeros((self.num_multi, 3), np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
+        L.check(L.lib().loops_bcsr_band_plan_arrays(self._h, p(val), p(words), p(perm), p(chunks), p(multi)), "loops_bcsr_band_plan_arrays")
+        return val, words, perm, chunks, multi
+
+    def refresh_values(self, values: torch.Tensor):
+        assert values.dtype == torch.float32 and values.numel() == self.num_blocks * 16
+        L.check(L.lib().loops_bcsr_band_plan_refresh_values_f32(self._h, _ptr(values), _stream()), "loops_bcsr_band_plan_refresh_values_f32")
+
+    def spmv(self, x_padded: torch.Tensor, y: torch.Tensor | None = None) -> torch.Tensor:
+        if y is None:
+            y = torch.empty(self.rows, dtype=torch.float32, device=x_padded.device)
+        assert x_padded.dtype == torch.float32 and y.dtype == torch.float32 and x_padded.numel() >= 4 * self.num_block_cols and y.numel() >= self.rows
+        assert x_padded.is_contiguous() and y.is_contiguous()
+        L.check(L.lib().loops_spmv_bcsr_band_f32(self._h, _ptr(x_padded), _ptr(y), _stream()), "loops_spmv_bcsr_band_f32")
+        return y
+
+    def spmv_stage(self, stage: int, x_padded, y):
+        L.check(L.lib().loops_spmv_bcsr_band_stage_f32(self._h, stage, _ptr(x_padded), _ptr(y), _stream()), "loops_spmv_bcsr_band_stage_f32")
+        return y
+
+    def close(self):
+        if self._h:
+            L.lib().loops_bcsr_band_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def coo_spmv(rows: int, cols: int, row_indices, col_indices, values, x, y=None, tuned: bool = True):
     """COO SpMV (loops_spmv_coo_f32 / _f64): ``tuned`` = one atomic per run of equal row indices (y zero-filled
     inside); otherwise the reference shape, one atomic per nonzero into a y zero-filled here."""
