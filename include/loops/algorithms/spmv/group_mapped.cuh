@@ -3,8 +3,9 @@
  * @brief `algorithms::spmv::group_mapped(csr, x, y, stream)`: a workgroup owns 256 consecutive rows
  * and sweeps their concatenated nonzeros lane-strided (reference
  * include/loops/algorithms/spmv/group_mapped.cuh:27-105 -- CUDA-only there; this is the CDNA4
- * implementation: group_mapped_spmv_fused, the merge-tile engine over the workgroup's own rows --
- * no atomics, no plan).  y does not have to be zero-filled by the caller.
+ * implementation: the merge-tile engine over the workgroup's own rows, groups of more than 24 tiles published and swept by a
+ * second launch, one workgroup per 2 tiles (kernels/group_mapped_spmv.hxx) -- no floating-point atomics, no plan).  y does not
+ * have to be zero-filled by the caller.
  */
 #pragma once
 
@@ -17,6 +18,7 @@
 #include <loops/util/timer.hxx>
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/kernels/launch.hxx>
+#include <loops/kernels/group_mapped_spmv.hxx>
 #include <loops/memory.hxx>
 
 namespace loops {
@@ -28,9 +30,12 @@ void group_mapped(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, ve
                   xpu::stream_t stream = 0) {
   constexpr int block_size = launch_t<type_t>::block_size;
   constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
-  kernels::launch_group_mapped_fused<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
-      stream, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(),
-      csr.indices.data().get(), csr.values.data().get(), x.data().get(), y.data().get());
+  // control words + carry-outs of the shared-out groups: zero-filled scratch of this call (thrust value-initialises)
+  vector_t<unsigned char> scratch(kernels::group_share_scratch_bytes<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), block_size,
+                                                                             items_per_thread));
+  kernels::launch_group_mapped_shared<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
+      stream, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(), csr.indices.data().get(),
+      csr.values.data().get(), x.data().get(), y.data().get(), scratch.data().get());
   (void)xpu::stream_synchronize(stream);
 }
 

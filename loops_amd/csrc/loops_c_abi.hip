@@ -23,6 +23,7 @@
 #include <loops/util/launch_box.hxx>
 #include <loops/util/math.hxx>
 #include <loops/kernels/launch.hxx>
+#include <loops/kernels/group_mapped_spmv.hxx>
 #include <loops/kernels/panel_binned.hxx>
 #include <loops/kernels/rowband.hxx>
 #include <loops/multi_gpu/partition.hxx>
