@@ -129,6 +129,9 @@ def pmc_bound(args):
                     "reading": "bound by the CU's outstanding-read capacity (~95 in flight) x round-trip latency, not by the L2 request "
                                "path (16 per clk per XCD) nor by HBM bandwidth; calibration: profiles/r02_inflight_calibration.json",
                     "collected_at": d.get("_kernel_build"),
+                    # (pmc_summary hands the file out only when the digest of the kernel sources it was collected at equals the digest
+                    #  of the sources this process runs: the counters describe THIS kernel even when `collected_at` is an older commit)
+                    "digest_matches_head": True, "kernel_sources_sha256": d.get("_kernel_sources_sha256"),
                     "source": src}
     return None
 
@@ -413,8 +416,10 @@ def main():
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for functional tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="functional test: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--ref-gpu", action="store_true",
-                    help="also time the reference's own HIP kernels on this GPU (oracle/_ref/libloops_ref_gpu.so)")
+    ap.add_argument("--ref-gpu", dest="ref_gpu", action="store_true", default=True,
+                    help="N = 1 (default: on): also time the reference's own HIP kernels on this GPU, outside the timed region "
+                         "(oracle/_ref/libloops_ref_gpu.so, the reference compiled by oracle/Makefile: three launches)")
+    ap.add_argument("--no-ref-gpu", dest="ref_gpu", action="store_false", help="skip the reference-HIP-backend leg")
     ap.add_argument("--sweep", action="store_true", help="also time every compiled tile/variant (stderr)")
     ap.add_argument("--overlap-chunks", default="2,4",
                     help="N > 1: also try the step with the SpMV cut into this many row chunks whose exchanges overlap "
@@ -510,6 +515,7 @@ def main():
     blocked = None      # the shard's re-ordered copy, if any: a RowBandPlan or a PanelBinnedPlan
     shard_kind = "csr"  # "csr" | "rowband" | "panel"
     layout_probe = None
+    csr_same_shards = None
 
     def make_shard_plan(kind, sub=None):
         """The re-ordered copy of a CSR (this rank's shard, or a row chunk of it) in layout `kind`."""
@@ -551,6 +557,16 @@ def main():
             elif args.layout == kind:
                 raise RuntimeError(f"--layout {kind} cannot be built on every rank")
         layout_probe = {k: round(v, 5) for k, v in times.items()}
+        # the metric BASELINE.json names -- merge_path_flat on the unmodified CSR -- on the same shards, same probe (10 products,
+        # worst rank): the record carries it beside whatever layout the timed region runs
+        ms = timed_ms(torch, lambda: S.merge_path_flat(csr, x, y_loc, plan=plan, variant=args.variant), 10)
+        if world > 1:
+            t = torch.tensor([ms], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms = float(t[0])
+        csr_same_shards = {"ms_per_spmv_worst_rank": round(ms, 5), "GFLOPs": round(2.0 * nnz / (ms * 1e-3) / 1e9, 2),
+                           "kernel": "loops::kernels::merge_path_spmv_fused" + ("_phased" if args.variant == VARIANT_PHASED else ""),
+                           "tile": args.tile, "note": "SpMV only (no exchange), start-up probe outside the timed region"}
         if times:
             shard_kind = min(times, key=times.get)
             blocked = built.pop(shard_kind)
@@ -809,7 +825,10 @@ def main():
                 step_includes += f", {chunked[mode]['chunks']} chunks overlapping the SpMV"
             step_includes += "]"
         return {
-            "metric": "CSR SpMV GFLOP/s, merge_path_flat", "value": round(gflops, 2), "unit": "GFLOP/s",
+            # what the timed region runs: merge_path_flat on the unmodified CSR, or a held plan over a re-ordered copy of the shards (then
+            # config.merge_path_flat_csr_same_shards holds the merge_path_flat figure of the same shards)
+            "metric": {"csr": "CSR SpMV GFLOP/s, merge_path_flat", "rowband": "CSR SpMV GFLOP/s, row-band held plan",
+                       "panel": "CSR SpMV GFLOP/s, panel-binned held plan"}[shard_kind], "value": round(gflops, 2), "unit": "GFLOP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong" if strong else (None if world == 1 else "weak"), "vs_baseline": None,
             # the scaling curve's own figures at the top level: which matrix, what the step holds, the ratio to the SAME matrix on
@@ -838,6 +857,7 @@ def main():
                                         f"panel-binned{' (compact)' if blocked.compact else ''}, {blocked.num_panels} panels of {blocked.W} columns x "
                                         f"{blocked.num_subbands} sub-bands of {blocked.Hw} rows (x per GPU {cols * 4 >> 20} MB)"),
                        "shard_layout_probe_ms": layout_probe,
+                       "merge_path_flat_csr_same_shards": csr_same_shards,
                        "step_includes": step_includes,
                        "ms_per_step_with_prepass": None if R_["ms_with_prepass"] is None else round(R_["ms_with_prepass"], 5),
                        "timed_regions_ms_per_step": regions["ms_per_step"],
@@ -1217,7 +1237,7 @@ def main():
 
     # ------------------------------------------------------------------ the reference's own HIP path on this GPU
     so = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
-    if args.ref_gpu and rank == 0 and world == 1 and os.path.exists(so):
+    if args.ref_gpu and rank == 0 and world == 1 and not strong and not args.window and os.path.exists(so):
         import ctypes as C
         from loops_amd import _lib
         R = _lib.load_shared(so)
@@ -1230,7 +1250,13 @@ def main():
                                    p(x_h), p(yr), 10, C.byref(ms))
             ref_gpu[name] = {"rc": rc, "best_kernel_ms": round(ms.value, 5),
                              "GFLOPs": round(2.0 * csr.nnzs / (ms.value * 1e-3) / 1e9, 2) if ms.value > 0 else None}
+        ref_gpu["what"] = ("the reference's own kernels (include/loops/algorithms/spmv/{merge_path_flat,thread_mapped,work_oriented}.cuh, its HIP "
+                           "backend) compiled from /root/reference by oracle/Makefile and run on this GPU on the same matrix: kernel-only time of "
+                           "the wrapper's util::timer_t (merge_path_flat.cuh:111-136), best of 10, y zero-filled outside")
         R_["ref_gpu"] = ref_gpu
+    elif args.ref_gpu and rank == 0 and world == 1 and not strong and not args.window:
+        R_["ref_gpu"] = {"error": "oracle/_ref/libloops_ref_gpu.so is not built (python -c 'import __graft_entry__ as g; g.build_checker()' where "
+                                  "/root/reference is mounted)"}
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
     if rank == 0 and world == 1 and not strong and not args.no_cpu_baseline:

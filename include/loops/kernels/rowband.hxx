@@ -27,7 +27,8 @@
  *                           acc[row] += double(val * x[column]), then store the H sums -- straight to y when the band is
  *                           one chunk, else as an fp32 partial vector;
  *   B  rowband_combine      bands cut into several chunks (few, long bands: the chunk is the unit of parallelism): y[r] = the
- *                           partial vectors of r's band added in chunk order (fp64, rounded once).  8 H / chunk_items bytes
+ *                           partial vectors of r's band (each a chunk's fp64 sums rounded to the value type) added in chunk
+ *                           order in fp64 and rounded to the value type again.  8 H / chunk_items bytes
  *                           per nonzero of extra traffic; not launched when every band is one chunk.
  * y needs no zero-fill; no global atomics.  Products are fp32 (one rounding each, as in every other kernel here), all sums
  * fp64: exactly summable inputs give the CSR kernels' bits; the LDS atomics of different wavefronts arrive in no fixed order,
@@ -35,7 +36,9 @@
  *
  * When it pays: nonzeros per band / columns spanned >= ~1/8, i.e. x of a few MB (C2) or column locality at band scale
  * (web graphs in crawl order, FEM bands).  With scattered columns over an x of tens of MB every gather is its own line
- * again (C5 shards, uniform C3 stand-in): panel-binned territory.  The SpMV plan adopts it by measurement only.
+ * again (C5 shards, uniform C3 stand-in): panel-binned territory.  The SpMV plan adopts it by measurement (LOOPS_PLAN_MEASURE) or,
+ * unmeasured, by size (x of 2-6 MB under rows of >= 8 nonzeros) -- never under LOOPS_PLAN_DETERMINISTIC: the LDS atomics of
+ * different wavefronts arrive in no fixed order (see "y needs no zero-fill" above for when that cannot matter).
  * No reference counterpart (the reference's merge_path_flat.cuh:71-82 pays one global atomic per nonzero).
  */
 #pragma once
@@ -512,9 +515,10 @@ refresh_values(const int* __restrict__ perm, const type_t* __restrict__ values, 
 constexpr int rowband_e_badarg = -1, rowband_e_range = -2;
 
 /// Rows per band: 16384 (the tallest band the LDS holds: the taller the band, the denser its column-sorted nonzeros and the fewer
-/// lines a wavefront's 64 gathers touch), halved while the matrix would be left with fewer than 64 bands.
-inline int rowband_rows(int rows, int /*cols*/, int /*nnz*/) {
-  int h = rowband::max_band_rows;
+/// lines a wavefront's 64 gathers touch), halved while the matrix would be left with fewer than 64 bands; 8192 at most for
+/// 8-byte values (C2 in fp64, tests/perf/bench_rowband.py --f64: 56.4 us with 8192 rows, 82.4 with 16384; CSR fp64 189).
+inline int rowband_rows(int rows, int /*cols*/, int /*nnz*/, int vbytes = 4) {
+  int h = vbytes > 4 ? rowband::max_band_rows / 2 : rowband::max_band_rows;
   while (h > 256 && rows / h < 64) h /= 2;
   return h;
 }
@@ -648,7 +652,7 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   if (!offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values)) || target_chunks < 0) return rowband_e_badarg;
   out.release();
   out.rows = rows; out.cols = cols; out.nnz = nnz; out.vbytes = static_cast<int>(sizeof(type_t));
-  out.H = band_rows != 0 ? band_rows : rowband_rows(rows, cols, nnz);
+  out.H = band_rows != 0 ? band_rows : rowband_rows(rows, cols, nnz, static_cast<int>(sizeof(type_t)));
   if (out.H < 64 || out.H > rowband::max_band_rows || (out.H & (out.H - 1))) return rowband_e_badarg;
   int hshift = 0;
   while ((1 << hshift) < out.H) ++hshift;

@@ -362,6 +362,9 @@ int loops_spmv_panel_fanout_f64(const loops_panel_plan_t* plan, const double* x,
 typedef struct loops_rowband_plan loops_rowband_plan_t;
 int loops_rowband_plan_create_f32(int rows, int cols, int nnz, const int* offsets, const int* indices, const float* values,
                                   int band_rows, int target_chunks, void* stream, loops_rowband_plan_t** out);
+/* 8-byte values: the same record per slot (3 bytes of row code + column delta), fp64 products, fp64 LDS sums, fp64 partial vectors. */
+int loops_rowband_plan_create_f64(int rows, int cols, int nnz, const int* offsets, const int* indices, const double* values,
+                                  int band_rows, int target_chunks, void* stream, loops_rowband_plan_t** out);
 void loops_rowband_plan_destroy(loops_rowband_plan_t* plan);
 int loops_rowband_plan_info(const loops_rowband_plan_t* plan, int* info8);
 int loops_rowband_plan_arrays(const loops_rowband_plan_t* plan, void* values, unsigned short* row16, unsigned char* delta8, int* perm,
@@ -370,7 +373,10 @@ int loops_rowband_plan_set_chunks(loops_rowband_plan_t* plan, int target_chunks)
 int loops_rowband_plan_tune(loops_rowband_plan_t* plan, int repeats, float* ms2, void* stream);
 int loops_rowband_plan_set_waves(loops_rowband_plan_t* plan, int waves);
 int loops_rowband_plan_refresh_values_f32(loops_rowband_plan_t* plan, const float* values, void* stream);
+int loops_rowband_plan_refresh_values_f64(loops_rowband_plan_t* plan, const double* values, void* stream);
 int loops_spmv_rowband_f32(const loops_rowband_plan_t* plan, const float* x, float* y, void* stream);
+int loops_spmv_rowband_f64(const loops_rowband_plan_t* plan, const double* x, double* y, void* stream);
+int loops_spmv_rowband_stage_f64(const loops_rowband_plan_t* plan, int stage, const double* x, double* y, void* stream);
 /* one kernel at a time for timing: stage 0 = accumulate, 1 = combine */
 int loops_spmv_rowband_stage_f32(const loops_rowband_plan_t* plan, int stage, const float* x, float* y, void* stream);
 int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float* x, float* y, int num_peers, float* const* h_peer_y,
@@ -382,11 +388,11 @@ int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float*
  *   flags & LOOPS_PLAN_MEASURE     time the candidates on the device at creation (256 x 8 and 512 x 8 merge tiles over the
  *                                  unmodified CSR; `repeats` launches each, <= 0: 10) instead of choosing by structure alone;
  *   flags & LOOPS_PLAN_ALLOW_COPY  the plan may keep a re-ordered COPY of the matrix (about another nnz * (4 + sizeof(T)) bytes + tables):
- *                                  the row-band copy (4-byte values; "row-band layout" above) or the panel-binned copy
+ *                                  the row-band copy ("row-band layout" above; not under LOOPS_PLAN_DETERMINISTIC) or the panel-binned copy
  *                                  ("panel-binned layout" above).  With MEASURE both are built and timed (x of at least 1 MB /
  *                                  2 MB) and one is adopted only if >= 5 % faster than the best CSR shape (and than the other);
  *                                  without MEASURE a copy is taken by size alone: panel-binned when cols * sizeof(T) > 6 MB,
- *                                  row-band (4-byte values, mean row >= 8 nonzeros) from 2 MB.  (Structure does not show
+ *                                  row-band (mean row >= 8 nonzeros) from 2 MB.  (Structure does not show
  *                                  column locality -- a narrow band is faster from the CSR as given, a wide one from the
  *                                  row-band copy whatever the size of x: MEASURE finds out.)
  *                                  A plan that stays on the CSR takes 512 x 8 (from 16 parts of x on: 256 x 16) tiles with phased x gathers (LOOPS_VARIANT_PHASED) when
@@ -398,6 +404,11 @@ int loops_spmv_rowband_fanout_f32(const loops_rowband_plan_t* plan, const float*
  * ms per product of {CSR 256 x 8, CSR 512 x 8, row-band, panel-binned}, -1 where not timed.  Any output pointer may be NULL. */
 #define LOOPS_PLAN_MEASURE 1
 #define LOOPS_PLAN_ALLOW_COPY 2
+/* Only layouts whose summation order is fixed (the CSR kernels, the panel-binned copy): the row-band copy adds a row's products
+ * with fp64 LDS atomics that arrive in no fixed order -- exact, hence reproducible, whenever the fp64 sum of a row's products is
+ * exact (fp32 products spanning < 53 - 24 - log2 n binary orders of magnitude per row; the exactly summable inputs of the
+ * tests), otherwise the last bit of a row may differ from run to run and between devices. */
+#define LOOPS_PLAN_DETERMINISTIC 4
 #define LOOPS_LAYOUT_CSR 0
 /* (1 was the column-blocked layout, retired in round 5: never returned) */
 #define LOOPS_LAYOUT_PANEL_BINNED 2

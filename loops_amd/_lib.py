@@ -55,6 +55,7 @@ SYMBOLS = [
     "loops_rowband_plan_create_f32", "loops_rowband_plan_destroy", "loops_rowband_plan_info", "loops_rowband_plan_arrays",
     "loops_rowband_plan_set_chunks", "loops_rowband_plan_tune", "loops_rowband_plan_set_waves", "loops_rowband_plan_refresh_values_f32", "loops_spmv_rowband_f32", "loops_spmv_rowband_stage_f32",
     "loops_spmv_rowband_fanout_f32",
+    "loops_rowband_plan_create_f64", "loops_rowband_plan_refresh_values_f64", "loops_spmv_rowband_f64", "loops_spmv_rowband_stage_f64",
     "loops_bcsr_band_plan_create_f32", "loops_bcsr_band_plan_destroy", "loops_bcsr_band_plan_info", "loops_bcsr_band_plan_arrays",
     "loops_bcsr_band_plan_set_chunks", "loops_bcsr_band_plan_tune", "loops_bcsr_band_plan_set_shape", "loops_bcsr_band_plan_refresh_values_f32",
     "loops_spmv_bcsr_band_f32", "loops_spmv_bcsr_band_stage_f32",
@@ -209,6 +210,10 @@ def lib() -> C.CDLL:
         L.loops_panel_plan_layout.argtypes = [vp, vp]
         L.loops_panel_plan_row_blocks.argtypes = [vp, vp, vp]
         L.loops_rowband_plan_create_f32.argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
+        L.loops_rowband_plan_create_f64.argtypes = [ci, ci, ci, vp, vp, vp, ci, ci, vp, C.POINTER(vp)]
+        L.loops_rowband_plan_refresh_values_f64.argtypes = [vp, vp, vp]
+        L.loops_spmv_rowband_f64.argtypes = [vp, vp, vp, vp]
+        L.loops_spmv_rowband_stage_f64.argtypes = [vp, ci, vp, vp, vp]
         L.loops_rowband_plan_destroy.argtypes = [vp]
         L.loops_rowband_plan_destroy.restype = None
         L.loops_rowband_plan_info.argtypes = [vp, vp]

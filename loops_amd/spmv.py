@@ -314,18 +314,20 @@ class PanelBinnedPlan:
 class RowBandPlan:
     """Row-band copy of a CSR (loops_rowband_plan_*; include/loops/kernels/rowband.hxx): the y accumulators of a band of H rows
     live in LDS as fp64 words, the band's nonzeros are sorted by column so that a wavefront's 64 x gathers fall on a few
-    neighbouring lines; 7 bytes per nonzero streamed (columns as one-byte deltas).  For x of a few MB, or column locality at band scale.  fp32 only."""
+    neighbouring lines; 3 bytes of row code + column delta per nonzero next to the value.  For x of a few MB, or column locality
+    at band scale.  fp32 and fp64 values."""
 
     STEP = 256
 
     def __init__(self, csr: CSR, band_rows: int = 0, target_chunks: int = 0):
-        assert csr.values.dtype == torch.float32
+        assert csr.values.dtype in (torch.float32, torch.float64)
         self.dtype = csr.values.dtype
+        self._sfx = _suffix(csr.values)
         self.rows, self.cols, self.nnz = csr.rows, csr.cols, csr.nnzs
         self._h = C.c_void_p()
-        L.check(L.lib().loops_rowband_plan_create_f32(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values),
-                                                      int(band_rows), int(target_chunks), _stream(), C.byref(self._h)),
-                "loops_rowband_plan_create_f32")
+        L.check(getattr(L.lib(), "loops_rowband_plan_create_" + self._sfx)(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices),
+                                                                            _ptr(csr.values), int(band_rows), int(target_chunks), _stream(),
+                                                                            C.byref(self._h)), "loops_rowband_plan_create")
         self._read_info()
 
     def _read_info(self):
@@ -357,7 +359,8 @@ class RowBandPlan:
 
     def arrays(self):
         """(values, row16, delta8, perm, stepbase [steps, 4], chunks [n, 4], multi [m, 3], hubs [bands, 33]) copied to the host."""
-        val, row16, delta8 = np.zeros(self.padded, np.float32), np.zeros(self.padded, np.uint16), np.zeros(self.padded, np.uint8)
+        val = np.zeros(self.padded, np.float32 if self.dtype == torch.float32 else np.float64)
+        row16, delta8 = np.zeros(self.padded, np.uint16), np.zeros(self.padded, np.uint8)
         perm, stepbase = np.zeros(self.padded, np.int32), np.zeros((self.steps, 4), np.int32)
         chunks, multi = np.zeros((self.num_chunks, 4), np.int32), np.zeros((self.num_multi, 3), np.int32)
         hubs = np.zeros((self.num_bands, 33), np.uint16)
@@ -368,7 +371,7 @@ class RowBandPlan:
 
     def refresh_values(self, values: torch.Tensor):
         assert values.dtype == self.dtype and values.numel() == self.nnz
-        L.check(L.lib().loops_rowband_plan_refresh_values_f32(self._h, _ptr(values), _stream()), "loops_rowband_plan_refresh_values_f32")
+        L.check(getattr(L.lib(), "loops_rowband_plan_refresh_values_" + self._sfx)(self._h, _ptr(values), _stream()), "loops_rowband_plan_refresh_values")
 
     def _check(self, x, y):
         assert x.dtype == self.dtype and y.dtype == self.dtype and x.numel() >= self.cols and y.numel() >= self.rows
@@ -378,16 +381,17 @@ class RowBandPlan:
         if y is None:
             y = torch.empty(self.rows, dtype=self.dtype, device=x.device)
         self._check(x, y)
-        L.check(L.lib().loops_spmv_rowband_f32(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_rowband_f32")
+        L.check(getattr(L.lib(), "loops_spmv_rowband_" + self._sfx)(self._h, _ptr(x), _ptr(y), _stream()), "loops_spmv_rowband")
         return y
 
     def spmv_stage(self, stage: int, x, y):
-        L.check(L.lib().loops_spmv_rowband_stage_f32(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_rowband_stage_f32")
+        L.check(getattr(L.lib(), "loops_spmv_rowband_stage_" + self._sfx)(self._h, stage, _ptr(x), _ptr(y), _stream()), "loops_spmv_rowband_stage")
         return y
 
     def spmv_fanout(self, x, y, peers):
         """``spmv`` whose row stores also go to ``peers`` (loops_spmv_rowband_fanout_f32; see merge_path_flat_fanout)."""
         self._check(x, y)
+        assert self.dtype == torch.float32, "the fan-out form is compiled for fp32"
         arr, n = _peer_array(peers)
         L.check(L.lib().loops_spmv_rowband_fanout_f32(self._h, _ptr(x), _ptr(y), n, arr, _stream()), "loops_spmv_rowband_fanout_f32")
         return y
@@ -406,16 +410,17 @@ class RowBandPlan:
 
 class SpmvPlan:
     """loops_spmv_plan_*: tile shape AND layout of one matrix chosen at plan time.  ``measure``: time the candidates on the
-    device; ``allow_copy``: the plan may hold a column-blocked copy of the matrix when that is faster (x larger than the
-    per-XCD L2).  ``spmv(x, y)`` runs whatever was chosen; ``info`` says what that is."""
+    device; ``allow_copy``: the plan may hold a re-ordered copy of the matrix (row-band, panel-binned) when that is faster;
+    ``deterministic``: only layouts whose summation order is fixed (no row-band copy).  ``spmv(x, y)`` runs whatever was chosen;
+    ``info`` says what that is."""
 
     LAYOUTS = {0: "csr", 2: "panel_binned", 3: "row_band"}
 
-    def __init__(self, csr: CSR, allow_copy: bool = True, measure: bool = True, repeats: int = 10):
+    def __init__(self, csr: CSR, allow_copy: bool = True, measure: bool = True, repeats: int = 10, deterministic: bool = False):
         self.csr = csr
         self._sfx = _suffix(csr.values)
         self._h = C.c_void_p()
-        flags = (1 if measure else 0) | (2 if allow_copy else 0)
+        flags = (1 if measure else 0) | (2 if allow_copy else 0) | (4 if deterministic else 0)  # LOOPS_PLAN_MEASURE | _ALLOW_COPY | _DETERMINISTIC
         create = getattr(L.lib(), "loops_spmv_plan_create_" + self._sfx)
         L.check(create(csr.rows, csr.cols, csr.nnzs, _ptr(csr.offsets), _ptr(csr.indices), _ptr(csr.values), flags, repeats,
                        _stream(), C.byref(self._h)), "loops_spmv_plan_create")

@@ -1,5 +1,5 @@
 """Row-band layout (loops_rowband_plan_*): layout check against the numpy specification, equality with the CSR product, and a
-sweep of band height x chunk size x kernel shape on one case.  usage: bench_rowband.py [case] [--quick]
+sweep of band height x chunk size x kernel shape on one case.  usage: bench_rowband.py [case] [--f64] [--nocheck]
 env: RB_H=4096,8192,16384  RB_G=0,256,512 (target chunks)  RB_CFG=162,164,82,84  RB_DIAG=1,2,3  (comma lists)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -17,10 +17,14 @@ if "--uniform-degrees" in sys.argv:
     deg = np.full(rows, nnz // rows, np.int64)
 hosts = G.host_blocks(cols) if window == G.HOST_BLOCKED else None
 off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=hosts)
+F64 = "--f64" in sys.argv   # 8-byte values: the CSR kernel of the same precision beside the row-band copy
+VB = 8 if F64 else 4
+if F64:
+    val = val.astype(np.float64)
 csr = S.CSR.from_numpy(rows, cols, off, idx, val)
-x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda()
-y0, y1 = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
-abytes = nnz * 8 + (rows + 1) * 4 + rows * 4 + cols * 4
+x = torch.from_numpy(G.uniform_distribution_int(cols).astype(val.dtype)).cuda()
+y0, y1 = torch.empty(rows, dtype=x.dtype, device="cuda"), torch.empty(rows, dtype=x.dtype, device="cuda")
+abytes = nnz * (4 + VB) + (rows + 1) * 4 + rows * VB + cols * VB
 mp = S.MergePathPlan(csr, "512x8")
 S.merge_path_flat(csr, x, y0, plan=mp)
 t_csr = batch_ms(lambda: S.merge_path_flat(csr, x, y0, plan=mp))
@@ -29,7 +33,7 @@ print(name, "csr 512x8 %.1f us" % (t_csr * 1e3), file=sys.stderr, flush=True)
 def ints(key, default):
     return [int(t) for t in os.environ.get(key, default).split(",") if t]
 
-out = {"case": name, "csr_512x8_us": round(t_csr * 1e3, 2), "runs": []}
+out = {"case": name, "value_bytes": VB, "csr_512x8_us": round(t_csr * 1e3, 2), "csr_frac": round(abytes / t_csr / 1e6 / 8000, 4), "runs": []}
 checked = False
 for H in ints("RB_H", "8192"):
     plan, b_ms = build_ms(lambda: S.RowBandPlan(csr, H, 0))

@@ -276,3 +276,76 @@ def test_spmv_plan_adopts_the_row_band_copy_where_it_wins_and_refreshes_it():
         p.refresh_values()
         assert torch.equal(p.spmv(x), 2 * want)
         p.close()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# 8-byte values (the reference builds every example as .f32 and .f64, examples/spmv/CMakeLists.txt:29-50): the same layout
+# arrays (the record per slot does not depend on the value type), fp64 products and sums, fp64 partial vectors.
+@pytest.mark.parametrize("band_rows,target", [(0, 0), (8192, 700), (256, 1000)])
+def test_f64_many_bands_bit_exact(band_rows, target):
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows, cols = 70_001, 150_001
+    deg = G.powerlaw_degrees(rows, 1 << 21, cap=1 << 13)
+    deg[::7] = 0
+    off, idx, val32 = G.csr_from_degrees(deg, cols, 1)
+    val = val32.astype(np.float64)
+    xh = G.uniform_distribution_int(cols).astype(np.float64)
+    ref = O.spmv_f64(off, idx, val, xh)
+    csr = _dev(off, idx, val, rows, cols)
+    x = torch.from_numpy(xh).cuda()
+    plan = S.RowBandPlan(csr, band_rows, target)
+    assert plan.dtype == torch.float64 and plan.num_bands == -(-rows // plan.H)
+    _check_layout(plan, off, idx, val, target)
+    if target:
+        assert plan.num_partials > 0
+    for waves in (8, 16):
+        plan.set_waves(waves)
+        y = torch.full((rows,), 7.0, dtype=torch.float64, device="cuda")
+        plan.spmv(x, y)
+        assert np.array_equal(y.cpu().numpy(), ref), waves
+    csr.values.mul_(2.0)
+    plan.refresh_values(csr.values)
+    assert np.array_equal(plan.spmv(x).cpu().numpy(), 2 * ref)
+    ms8, ms16 = plan.tune(3)
+    assert ms8 > 0 and ms16 > 0
+    plan.close()
+
+
+def test_f64_battery_and_real_values():
+    """The battery in fp64 (golden y of the f64 reference build) and realistic values: within 1e-13 of the exact product."""
+    from loops_amd import spmv as S
+    g = load_golden("battery.npz")
+    for name, (r, c, off, idx, val) in battery().items():
+        csr = _dev(off, idx, val.astype(np.float64), r, c)
+        plan = S.RowBandPlan(csr, 64, 7)
+        for tag in ("int", "real"):
+            xh = g[f"{name}.x_{tag}"].astype(np.float64)
+            y = plan.spmv(torch.from_numpy(xh).cuda()).cpu().numpy()
+            prod = val.astype(np.float64) * xh[idx]
+            want = np.zeros(r)
+            np.add.at(want, np.repeat(np.arange(r), np.diff(off)), prod)
+            l1 = np.zeros(r)
+            np.add.at(l1, np.repeat(np.arange(r), np.diff(off)), np.abs(prod))
+            assert np.all(np.abs(y - want) <= 1e-13 * l1 + 1e-300), (name, tag)
+        plan.close()
+
+
+def test_f64_spmv_plan_can_hold_the_row_band_copy():
+    """An f64 SpMV plan may now choose the row-band copy (unmeasured: by size; LOOPS_PLAN_DETERMINISTIC rules it out)."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    rows = cols = 1 << 18                                                  # x = 2 MB in fp64
+    deg = G.powerlaw_degrees(rows, 1 << 22, cap=1 << 12)
+    off, idx, val32 = G.csr_from_degrees(deg, cols, 1)
+    val = val32.astype(np.float64)
+    xh = G.uniform_distribution_int(cols).astype(np.float64)
+    ref = O.spmv_f64(off, idx, val, xh)
+    csr = _dev(off, idx, val, rows, cols)
+    x = torch.from_numpy(xh).cuda()
+    plan = S.SpmvPlan(csr, measure=False, allow_copy=True)
+    assert plan.layout == "row_band", plan.layout
+    assert np.array_equal(plan.spmv(x).cpu().numpy(), ref)
+    det = S.SpmvPlan(csr, measure=False, allow_copy=True, deterministic=True)
+    assert det.layout == "csr", det.layout
+    assert np.array_equal(det.spmv(x).cpu().numpy(), ref)

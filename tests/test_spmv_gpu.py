@@ -444,6 +444,11 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     assert d["scaling"] == "strong" and sd["workload"] == "c5" and sd["rows"] == 1 << 17 and sd["nnz"] == 1 << 21
     assert sd["exchange"] in d["config"]["allgatherv_probe_ms_per_step"] and sd["shard_layout"] in ("rowband", "panel")
     assert sd["spmv_only_ms_per_step"] > 0 and sd["like_for_like_first_point"] == "python bench.py --gpus 1 --scaling strong"
+    # the record says what ran: the metric names the held plan of the shards, and the metric BASELINE.json quotes -- merge_path_flat on
+    # the unmodified CSR -- sits beside it, measured on the same shards in the same start-up probe
+    assert d["metric"] == {"rowband": "CSR SpMV GFLOP/s, row-band held plan", "panel": "CSR SpMV GFLOP/s, panel-binned held plan"}[sd["shard_layout"]]
+    same = d["config"]["merge_path_flat_csr_same_shards"]
+    assert same["GFLOPs"] > 0 and same["ms_per_spmv_worst_rank"] > 0 and "merge_path_spmv_fused" in same["kernel"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong", "--steps", "5", "--warmup", "2",
                           "--c5-log2-rows", "17", "--c5-log2-nnz", "21"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert one.returncode == 0, one.stderr[-3000:]
@@ -459,6 +464,19 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     dc = json.loads([ln for ln in c2.stdout.splitlines() if ln.startswith("{")][0])
     assert dc["scaling"] == "strong" and dc["scaling_detail"]["workload"] == "c2" and dc["scaling_detail"]["rows"] == 1 << 16
     assert "configs[1] (C2)" in dc["config"]["baseline_config"] and dc["config"]["parity_vs_oracle_bit_exact"] is True
+    # N = 1, the driver's command: merge_path_flat on the unmodified CSR, the reference's own HIP kernels timed on this GPU beside it
+    # (three launches of oracle/_ref/libloops_ref_gpu.so outside the timed region), the counters' digest check spelled out
+    n1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-context", "--log2-rows", "16",
+                         "--log2-nnz", "20"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert n1.returncode == 0, n1.stderr[-3000:]
+    d0 = json.loads([ln for ln in n1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d0["metric"] == "CSR SpMV GFLOP/s, merge_path_flat" and d0["n_gpus"] == 1 and d0["config"]["merge_path_flat_csr_same_shards"] is None
+    ref = d0["config"]["reference_hip_backend_on_this_gpu"]
+    assert ref is not None
+    if "error" not in ref:  # (oracle/_ref is built where /root/reference is mounted and travels with the tree)
+        assert all(ref[k]["rc"] == 0 and ref[k]["best_kernel_ms"] > 0 for k in ("merge_path_flat", "thread_mapped", "work_oriented"))
+    counters = (d0.get("roofline") or {}).get("counters")
+    assert counters is None or counters["digest_matches_head"] is True          # (None: not the profiled configuration)
     # a rank that dies takes the job down with a non-zero status (an unknown exchange name fails on every rank)
     r = subprocess.run(cmd + ["--exchange", "no-such-exchange"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

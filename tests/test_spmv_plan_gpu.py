@@ -77,11 +77,11 @@ def test_spmv_plan_picks_tile_and_layout():
 
 
 def test_spmv_plan_structural_rule_with_8_byte_values():
-    """Without LOOPS_PLAN_MEASURE a copy is chosen by size: from 6 MB of x the panel-binned copy, whatever the value type (the
-    row-band copy holds 4-byte values only); products equal the oracle's."""
+    """Without LOOPS_PLAN_MEASURE a copy is chosen by size, whatever the value type: the row-band copy for an x of 2-6 MB under rows
+    of >= 8 nonzeros (8-byte values too, since round 6), the panel-binned copy beyond; products equal the oracle's."""
     from loops_amd import spmv as S, generate as G
     from oracle import oracle as O
-    for cols, want in ((1 << 19, "csr"), (1 << 21, "panel_binned"), (1 << 22, "panel_binned")):       # x = 4 / 16 / 32 MB
+    for cols, want in ((1 << 17, "csr"), (1 << 19, "row_band"), (1 << 21, "panel_binned"), (1 << 22, "panel_binned")):  # x = 1 / 4 / 16 / 32 MB
         rows = 1 << 15
         deg = G.powerlaw_degrees(rows, 1 << 20, cap=1 << 12)
         off, idx, val = G.csr_from_degrees(deg, cols, seed=3)
