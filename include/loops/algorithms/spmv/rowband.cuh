@@ -1,15 +1,16 @@
 /**
  * @file rowband.cuh
- * @brief `algorithms::spmv::rowband_t<index_t, offset_t, float>`: a CSR held in the row-band layout (loops/kernels/rowband.hxx)
+ * @brief `algorithms::spmv::rowband_t<index_t, offset_t, float | double>`: a CSR held in the row-band layout (loops/kernels/rowband.hxx)
  * -- the y accumulators of a band of rows live in LDS, the band's nonzeros are sorted by column so that a wavefront's x gathers
- * fall on a few neighbouring lines; 7 bytes per nonzero streamed (columns as one-byte deltas).  For an x of a few MB or column locality at band scale.  The
+ * fall on a few neighbouring lines; 3 bytes per nonzero streamed next to the value (row code, column as a one-byte delta).  For an x of a few MB or column locality at band scale.  The
  * header-API twin of loops_rowband_plan_* (include/loops_amd.h).  No reference counterpart (its merge_path_flat.cuh:71-82 pays
  * one global atomic per nonzero, its CSR kernels one scattered gather).
  *
  *   algorithms::spmv::rowband_t<int, int, float> A(csr);
  *   A.spmv(x, y);                                                       // y = csr * x
  *
- * One product in flight per object (it owns the partial-vector scratch).  4-byte values only.
+ * One product in flight per object (it owns the partial-vector scratch).  4- and 8-byte values.  The band sums are fp64 LDS
+ * atomics that arrive in no fixed order: see include/loops_amd.h (LOOPS_PLAN_DETERMINISTIC) for when that cannot matter.
  */
 #pragma once
 
@@ -26,7 +27,7 @@ namespace spmv {
 template <typename index_t, typename offset_t, typename type_t>
 struct rowband_t {
   static_assert(sizeof(index_t) == 4 && sizeof(offset_t) == 4, "rowband_t: 32-bit indices and offsets");
-  static_assert(sizeof(type_t) == 4, "rowband_t: 4-byte values");
+  static_assert(sizeof(type_t) == 4 || sizeof(type_t) == 8, "rowband_t: 4- or 8-byte values");
   std::size_t rows, cols, nnzs;
   kernels::rowband_storage arrays;   ///< H, B, steps, chunks, waves and the owned device arrays
 
@@ -45,7 +46,7 @@ struct rowband_t {
 
   /// Whether rowband_create can take the matrix at all (the bounds it checks before it sorts).
   static bool fits(const csr_t<index_t, offset_t, type_t>& csr) {
-    const int h = kernels::rowband_rows(static_cast<int>(csr.rows), static_cast<int>(csr.cols), static_cast<int>(csr.nnzs));
+    const int h = kernels::rowband_rows(static_cast<int>(csr.rows), static_cast<int>(csr.cols), static_cast<int>(csr.nnzs), static_cast<int>(sizeof(type_t)));
     const long long bands = (static_cast<long long>(csr.rows) + h - 1) / h;
     return bands <= (1ll << 26) &&
            static_cast<long long>(csr.nnzs) + bands * (static_cast<long long>(csr.cols) / kernels::rowband::max_delta + kernels::rowband::step_items) < (1ll << 31) - 4096;

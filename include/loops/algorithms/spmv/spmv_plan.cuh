@@ -30,7 +30,7 @@ struct spmv_plan_t {
   enum layout_kind { csr_layout = 0, panel_binned_layout = 2, row_band_layout = 3 };  // (LOOPS_LAYOUT_* of include/loops_amd.h)
   using small_t = merge_path_small_plan_t<index_t, offset_t, type_t>;  // 256 x 8 (256 x 4 for 8-byte values)
   using large_t = merge_path_plan_t<index_t, offset_t, type_t>;        // 512 x 8 (512 x 4)
-  using band_t = rowband_t<index_t, offset_t, float>;  ///< (4-byte values only: never built for other value types)
+  using band_t = rowband_t<index_t, offset_t, type_t>;
   using panel_t = panel_binned_t<index_t, offset_t, type_t>;
   static constexpr std::size_t large_block = merge_path_launch_t<type_t>::block_size, large_items = merge_path_launch_t<type_t>::items_per_thread;
 
@@ -44,11 +44,11 @@ struct spmv_plan_t {
   std::unique_ptr<panel_t> panel;
 
   /// @param allow_copy the plan may keep a re-ordered copy of `csr` (adopted when >= 5 % faster than the best CSR shape;
-  ///        without `measure`: panel-binned when cols * sizeof(type_t) > 6 MB, row-band from 2 MB for 4-byte values under a mean
-  ///        row of >= 8 nonzeros)
+  ///        without `measure`: panel-binned when cols * sizeof(type_t) > 6 MB, row-band from 2 MB under a mean row of >= 8 nonzeros)
   /// @param measure time the candidates (`repeats` products each) instead of choosing by structure alone
+  /// @param deterministic only layouts whose summation order is fixed: no row-band copy (LOOPS_PLAN_DETERMINISTIC of the C ABI)
   explicit spmv_plan_t(csr_t<index_t, offset_t, type_t>& csr, bool allow_copy = true, bool measure = true, int repeats = 10,
-                       xpu::stream_t stream = 0) {
+                       xpu::stream_t stream = 0, bool deterministic = false) {
     const typename small_t::layout_t lay(csr.offsets.data().get(), static_cast<index_t>(csr.rows), static_cast<offset_t>(csr.nnzs));
     small = std::make_unique<small_t>(lay, stream, small_t::prepass_always);
     const bool short_rows = small->classify(stream) || small->merge_tiles() <= 1;
@@ -68,11 +68,9 @@ struct spmv_plan_t {
               panel = std::make_unique<panel_t>(csr, 0, stream);
               layout = panel_binned_layout;
             }
-          } else if constexpr (sizeof(type_t) == 4) {
-            if (csr.nnzs / csr.rows >= 8 && band_t::fits(csr)) {
-              band = std::make_unique<band_t>(csr, 0, 0, stream);
-              layout = row_band_layout;
-            }
+          } else if (!deterministic && csr.nnzs / csr.rows >= 8 && band_t::fits(csr)) {
+            band = std::make_unique<band_t>(csr, 0, 0, stream);
+            layout = row_band_layout;
           }
         } catch (const std::exception&) {
           (void)hipGetLastError();  // clear the sticky error of the failed allocation
@@ -133,8 +131,8 @@ struct spmv_plan_t {
     }
     if (keep_small && !phased) large.reset();
     else small.reset();
-    if constexpr (sizeof(type_t) == 4) {
-      if (allow_copy && x_bytes >= (std::size_t(1) << 20) && band_t::fits(csr)) {  // second candidate: the row-band copy, its shape tuned
+    {
+      if (allow_copy && !deterministic && x_bytes >= (std::size_t(1) << 20) && band_t::fits(csr)) {  // second candidate: the row-band copy, its shape tuned
         auto rb = std::make_unique<band_t>(csr, 0, 0, stream);
         rb->tune(repeats, stream);
         ms_band = time_ms(repeats, stream, [&] { rb->spmv_async(x, y, stream); });
@@ -165,9 +163,7 @@ struct spmv_plan_t {
   /// y = csr * x on `stream` (asynchronous).  `csr` must be the matrix the plan was built from.
   void spmv_async(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, vector_t<type_t>& y, xpu::stream_t stream = 0) {
     if (panel) panel->spmv_async(x, y, stream);
-    else if (band) {
-      if constexpr (sizeof(type_t) == 4) band->spmv_async(x, y, stream);
-    }
+    else if (band) band->spmv_async(x, y, stream);
     else if (small)
       merge_path_flat_async_with<launch_t<type_t>::block_size, launch_t<type_t>::items_per_thread>(*small, csr, x, y, stream, true);
     else if (phased) {

@@ -340,43 +340,72 @@ find_hubs(const offset_t* __restrict__ offsets, const int rows, const int H, sho
 }
 
 /// key[i] = band << cbits | column, item[i] = i, rin[i] = row inside the band, or 0x8000 | hub number for the rows of hubs.
-/// Lane per IPT consecutive nonzeros: one search for the row of the first, then a walk along the offsets (as panel::make_keys).
-template <int IPT, typename index_t, typename offset_t>
+/// One workgroup per TILE consecutive nonzeros: the rows they belong to are found ONCE per workgroup (two searches over the
+/// offsets), their offsets staged in LDS, and every lane then handles nonzeros i, i + 256, ... -- coalesced reads of the columns,
+/// coalesced writes of the three outputs, the row of a nonzero by a search in LDS.  (The first version gave a lane 8 CONSECUTIVE
+/// nonzeros and walked the offsets: every access of a wavefront instruction 32 bytes apart, 0.32 ms of C2's 2.1 ms build.)
+/// A tile that spans more rows than the stage holds (runs of empty rows) searches the offsets in memory instead.
+template <int TILE, typename key_t, typename index_t, typename offset_t>
 __global__ void __launch_bounds__(256)
 make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indices, const short* __restrict__ hubidx, const int rows,
-          const int nnz, const int hshift, const int cbits, const int cols, unsigned long long* __restrict__ keys, int* __restrict__ item,
+          const int nnz, const int hshift, const int cbits, const int cols, key_t* __restrict__ keys, int* __restrict__ item,
           unsigned short* __restrict__ rin, int* __restrict__ bad) {
-  const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
+  constexpr int STAGE = 2 * TILE;  // row starts of the tile's rows
+  __shared__ offset_t s_off[STAGE + 1];
+  __shared__ int s_row0, s_rows;
+  const long long base_ll = static_cast<long long>(blockIdx.x) * TILE;
   if (base_ll >= nnz) return;
   const int base = static_cast<int>(base_ll);
-  int row = 0, count = rows;
-  while (count > 0) {
-    const int half = count >> 1;
-    const int mid = row + half;
-    if (offsets[mid + 1] <= base) {
-      row = mid + 1;
-      count -= half + 1;
-    } else {
-      count = half;
+  const int end = nnz - base < TILE ? nnz : base + TILE;
+  auto row_of = [&](const int i, int lo, int count) {  // last row in [lo, lo + count) that starts at or before nonzero i
+    while (count > 1) {
+      const int half = count >> 1;
+      if (offsets[lo + half] <= i) {
+        lo += half;
+        count -= half;
+      } else {
+        count = half;
+      }
     }
+    return lo;
+  };
+  if (threadIdx.x == 0) {
+    const int r0 = row_of(base, 0, rows), r1 = row_of(end - 1, r0, rows - r0);
+    s_row0 = r0;
+    s_rows = r1 - r0 + 1;
   }
-  offset_t row_end = offsets[row + 1];
-  int hub = hubidx[row];
-#pragma unroll
-  for (int j = 0; j < IPT; ++j) {
-    const int i = base + j;
-    if (i >= nnz) break;
-    if (i >= row_end) {
-      while (i >= row_end) row_end = offsets[++row + 1];  // skip empty rows
-      hub = hubidx[row];
+  __syncthreads();
+  const int row0 = s_row0, nrows = s_rows;
+  const bool staged = nrows <= STAGE;
+  if (staged) {
+    for (int j = threadIdx.x; j <= nrows; j += 256) s_off[j] = offsets[row0 + j];
+    __syncthreads();
+  }
+  for (int i = base + static_cast<int>(threadIdx.x); i < end; i += 256) {
+    int row;
+    if (staged) {
+      int lo = 0, count = nrows;
+      while (count > 1) {
+        const int half = count >> 1;
+        if (s_off[lo + half] <= i) {
+          lo += half;
+          count -= half;
+        } else {
+          count = half;
+        }
+      }
+      row = row0 + lo;
+    } else {
+      row = row_of(i, row0, nrows);
     }
+    const int hub = hubidx[row];
     unsigned int col = static_cast<unsigned int>(indices[i]);
     if (col >= static_cast<unsigned int>(cols)) {  // (also a negative index) flagged, then clamped
       *bad = 1;
       col = 0;
     }
     const unsigned int b = static_cast<unsigned int>(row) >> hshift;
-    keys[i] = (static_cast<unsigned long long>(b) << cbits) | col;
+    keys[i] = (static_cast<key_t>(b) << cbits) | static_cast<key_t>(col);
     item[i] = i;
     rin[i] = hub >= 0 ? static_cast<unsigned short>(0x8000u | static_cast<unsigned int>(hub))
                       : static_cast<unsigned short>(static_cast<unsigned int>(row) - (b << hshift));
@@ -384,12 +413,14 @@ make_keys(const offset_t* __restrict__ offsets, const index_t* __restrict__ indi
 }
 
 /// band_start[b] = the first sorted position whose band is >= b (b <= B: band_start[B] = nnz).
+template <typename key_t>
 __global__ void __launch_bounds__(256)
-band_starts(const unsigned long long* __restrict__ sorted, const int nnz, const int B, const int cbits, int* __restrict__ band_start) {
+band_starts(const key_t* __restrict__ sorted, const int nnz, const int B, const int cbits, int* __restrict__ band_start) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b > B) return;
-  const unsigned long long want = static_cast<unsigned long long>(b) << cbits;
+  const key_t want = static_cast<key_t>(static_cast<unsigned int>(b)) << cbits;
   int lo = 0, count = nnz;
+  if (b == B) lo = nnz, count = 0;  // (B << cbits may not fit a 32-bit key)
   while (count > 0) {
     const int half = count >> 1;
     if (sorted[lo + half] < want) {
@@ -403,24 +434,35 @@ band_starts(const unsigned long long* __restrict__ sorted, const int nnz, const 
 }
 
 /// Column gap of sorted item j to its predecessor in the band (0 for a band's first item) and the padding slots that bridge it.
-__device__ __forceinline__ void gap_of(const unsigned long long* __restrict__ sorted, const int j, const int cbits, unsigned int& gap,
+template <typename key_t>
+__device__ __forceinline__ void gap_of(const key_t* __restrict__ sorted, const int j, const int cbits, unsigned int& gap,
                                        unsigned int& pads) {
   gap = 0;
   if (j > 0) {
-    const unsigned long long key = sorted[j], prev = sorted[j - 1];
+    const key_t key = sorted[j], prev = sorted[j - 1];
     if ((key >> cbits) == (prev >> cbits)) gap = static_cast<unsigned int>(key - prev);  // same band: the keys differ in the column only
   }
   pads = gap > static_cast<unsigned int>(max_delta) ? (gap - 1u) / static_cast<unsigned int>(max_delta) : 0u;
 }
 
 /// slots[j] = 1 + the padding slots in front of sorted item j (j < nnz), slots[nnz] = 0: the exclusive scan numbers the slots.
+/// *any_pads is set when some gap needs padding slots at all (rare: a column gap of more than 255 inside a band).
+template <typename key_t>
 __global__ void __launch_bounds__(256)
-count_slots(const unsigned long long* __restrict__ sorted, const int nnz, const int cbits, int* __restrict__ slots) {
+count_slots(const key_t* __restrict__ sorted, const int nnz, const int cbits, int* __restrict__ slots, int* __restrict__ any_pads) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j > nnz) return;
   unsigned int gap = 0, pads = 0;
   if (j < nnz) gap_of(sorted, j, cbits, gap, pads);
   slots[j] = j < nnz ? static_cast<int>(1u + pads) : 0;
+  if (pads) *any_pads = 1;
+}
+
+/// steps[b] of a layout WITHOUT gap padding: the band's items rounded up to whole steps, steps[B] = 0.
+__global__ void __launch_bounds__(256)
+band_step_counts_dense(const int* __restrict__ band_start, const int B, int* __restrict__ steps) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= B) steps[b] = b < B ? (band_start[b + 1] - band_start[b] + step_items - 1) / step_items : 0;
 }
 
 /// steps[b] = whole steps of band b (its slots rounded up to 256), steps[B] = 0.
@@ -469,16 +511,16 @@ __device__ __forceinline__ long long slot_at(const long long s) {
 
 /// Sorted item j -> its slot (and the padding slots in front of it that bridge a long column gap).
 /// Row code: the row inside the band, or -- for a hub's item -- H + 1 + hub * hub_replicas + q % hub_replicas (q = slot in the step).
-template <typename type_t>
+template <typename key_t, typename type_t>
 __global__ void __launch_bounds__(256)
-place(const unsigned long long* __restrict__ sorted, const int* __restrict__ item, const unsigned short* __restrict__ rin,
+place(const key_t* __restrict__ sorted, const int* __restrict__ item, const unsigned short* __restrict__ rin,
       const int* __restrict__ band_start, const int* __restrict__ slot_pos, const int* __restrict__ band_step,
       const type_t* __restrict__ values, const int nnz, const int cbits, const int H, type_t* __restrict__ val,
       unsigned int* __restrict__ meta, int* __restrict__ perm, int* __restrict__ stepbase) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nnz) return;
-  const unsigned long long key = sorted[j];
-  const unsigned int col = static_cast<unsigned int>(key & ((1ull << cbits) - 1));
+  const key_t key = sorted[j];
+  const unsigned int col = static_cast<unsigned int>(key & ((static_cast<key_t>(1) << cbits) - 1));
   const int b = static_cast<int>(key >> cbits);
   unsigned int gap, pads;
   gap_of(sorted, j, cbits, gap, pads);
@@ -498,6 +540,68 @@ place(const unsigned long long* __restrict__ sorted, const int* __restrict__ ite
   set_meta(meta, at, row, (s & 63) == 0 ? 0u : gap - static_cast<unsigned int>(max_delta) * pads, true, static_cast<unsigned int>(H));
   perm[at] = i;
   if ((s & 63) == 0) stepbase[s >> 6] = static_cast<int>(col);
+}
+
+/// The layout WITHOUT gap padding (no column gap of more than 255 inside a band: the common case), written lane record by lane
+/// record: slot s of band b is sorted item band_start[b] + (s - 256 band_step[b]), so the thread of (step, lane) fetches its four
+/// items itself and writes its 16 bytes of values, 12 bytes of codes + deltas and 16 bytes of CSR positions whole -- no atomics on
+/// the packed words, no padding pre-fill, and no scan over the nonzeros in front of it (`place` needs all three: C2 368 + 28 +
+/// 110 us of a 1.6 ms build).  Same arrays as fill_padding + place produce.
+template <typename key_t, typename type_t>
+__global__ void __launch_bounds__(256)
+place_dense(const key_t* __restrict__ sorted, const int* __restrict__ item, const unsigned short* __restrict__ rin,
+            const int* __restrict__ band_start, const int* __restrict__ band_step, const type_t* __restrict__ values, const int steps, const int B,
+            const int cbits, const int H, type_t* __restrict__ val, unsigned int* __restrict__ meta, int* __restrict__ perm, int* __restrict__ stepbase) {
+  const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int step = static_cast<int>(t >> 6), lane = static_cast<int>(t & 63);
+  if (step >= steps) return;
+  int b = 0, count = B;  // the band of the step: the last b with band_step[b] <= step (bands without steps share a start: the last one owns it)
+  while (count > 1) {
+    const int half = count >> 1;
+    if (band_step[b + half] <= step) {
+      b += half;
+      count -= half;
+    } else {
+      count = half;
+    }
+  }
+  const int j0 = band_start[b] + (step - band_step[b]) * step_items, jend = band_start[b + 1];
+  const key_t cmask = (static_cast<key_t>(1) << cbits) - 1;
+  type_t v[4];
+  int at[4];
+  unsigned int code[4], delta[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int q = 64 * e + lane;
+    const int j = j0 + q;
+    v[e] = type_t(0);
+    at[e] = -1;
+    code[e] = static_cast<unsigned int>(H);
+    delta[e] = 0u;
+    unsigned int col = 0u;
+    if (j < jend) {
+      col = static_cast<unsigned int>(sorted[j] & cmask);
+      const int i = item[j];
+      const unsigned int c = rin[i];
+      v[e] = values[i];
+      at[e] = i;
+      code[e] = (c & 0x8000u) ? static_cast<unsigned int>(H) + 1u + (c & 0x7FFFu) * hub_replicas + static_cast<unsigned int>(q % hub_replicas) : c;
+      if (lane != 0) delta[e] = col - static_cast<unsigned int>(sorted[j - 1] & cmask);  // (same band: j - 1 >= j0; <= 255 here)
+    }
+    if (lane == 0) stepbase[static_cast<long long>(step) * 4 + e] = static_cast<int>(col);
+  }
+  const long long rec = static_cast<long long>(step) * wave::size + lane;
+  type_t* vp = val + rec * 4;
+  int* pp = perm + rec * 4;
+  unsigned int* mp = meta + rec * 3;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    vp[e] = v[e];
+    pp[e] = at[e];
+  }
+  mp[0] = code[0] | (code[1] << 16);
+  mp[1] = code[2] | (code[3] << 16);
+  mp[2] = delta[0] | (delta[1] << 8) | (delta[2] << 16) | (delta[3] << 24);
 }
 
 template <typename type_t>
@@ -645,8 +749,8 @@ inline int rowband_set_chunks(rowband_storage& out, const std::vector<int>& band
 /// Builds the row-band copy of a CSR on the device.  band_rows: 0 = automatic, else a power of two in [64, 16384];
 /// target_chunks: 0 = automatic.  Returns 0, a hipError_t, rowband_e_badarg (also: a column index outside [0, cols)) or
 /// rowband_e_range (the padded layout may not fit 32-bit positions).
-template <typename index_t, typename offset_t, typename type_t>
-int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset_t* offsets, const index_t* indices, const type_t* values,
+template <typename key_t, typename index_t, typename offset_t, typename type_t>
+int rowband_create_keyed(hipStream_t stream, int rows, int cols, int nnz, const offset_t* offsets, const index_t* indices, const type_t* values,
                    int band_rows, int target_chunks, rowband_storage& out) {
   static_assert(sizeof(index_t) == 4 && sizeof(offset_t) == 4, "rowband_create: 32-bit indices and offsets");
   if (!offsets || rows < 0 || cols < 0 || nnz < 0 || (nnz > 0 && (!indices || !values)) || target_chunks < 0) return rowband_e_badarg;
@@ -678,13 +782,13 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   auto up = [](std::size_t v) { return (v + 255) & ~std::size_t(255); };
   std::size_t sort_bytes = 0, scan_bytes = 0;
   {
-    unsigned long long* k = nullptr;
+    key_t* k = nullptr;
     int* ci = nullptr;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k, k, ci, ci, nnz, 0, cbits + bbits);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, ci, ci, (nnz > B ? nnz : B) + 1);
   }
   const std::size_t cub_bytes_total = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
-  const std::size_t key_bytes = up((static_cast<std::size_t>(nnz) + 1) * 8), item_bytes = up((static_cast<std::size_t>(nnz) + 1) * 4);
+  const std::size_t key_bytes = up((static_cast<std::size_t>(nnz) + 1) * sizeof(key_t)), item_bytes = up((static_cast<std::size_t>(nnz) + 1) * 4);
   const std::size_t rin_bytes = up((static_cast<std::size_t>(nnz) + 1) * 2), band_bytes = up((static_cast<std::size_t>(B) + 1) * 4);
   const std::size_t hub_bytes = up((static_cast<std::size_t>(rows) + 1) * 2);
   const std::size_t temp_bytes = 2 * key_bytes + 2 * item_bytes + rin_bytes + hub_bytes + 2 * band_bytes + 256 + cub_bytes_total;
@@ -697,8 +801,8 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   if (e != hipSuccess) return static_cast<int>(e);
   char* at = base;
   auto carve = [&](std::size_t bytes) { char* p = at; at += bytes; return p; };
-  auto* keys_in = reinterpret_cast<unsigned long long*>(carve(key_bytes));
-  auto* keys_out = reinterpret_cast<unsigned long long*>(carve(key_bytes));
+  auto* keys_in = reinterpret_cast<key_t*>(carve(key_bytes));
+  auto* keys_out = reinterpret_cast<key_t*>(carve(key_bytes));
   int* item_in = reinterpret_cast<int*>(carve(item_bytes));
   int* item_out = reinterpret_cast<int*>(carve(item_bytes));
   auto* rin = reinterpret_cast<unsigned short*>(carve(rin_bytes));
@@ -717,30 +821,44 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   hipLaunchKernelGGL((rowband::find_hubs<offset_t>), dim3(B), dim3(256), 0, stream, offsets, rows, out.H, hubidx, out.hubs);
-  constexpr int KEYS_PER_LANE = 8;
+  constexpr int KEY_TILE = 2048;
   if (nnz > 0) {
-    hipLaunchKernelGGL((rowband::make_keys<KEYS_PER_LANE, index_t, offset_t>), dim3(math::ceil_div(nnz, 256 * KEYS_PER_LANE)), dim3(256), 0,
-                       stream, offsets, indices, hubidx, rows, nnz, hshift, cbits, cols, keys_in, item_in, rin, bad);
+    hipLaunchKernelGGL((rowband::make_keys<KEY_TILE, key_t, index_t, offset_t>), dim3(math::ceil_div(nnz, KEY_TILE)), dim3(256), 0, stream, offsets,
+                       indices, hubidx, rows, nnz, hshift, cbits, cols, keys_in, item_in, rin, bad);
     e = hipcub::DeviceRadixSort::SortPairs(cub_temp, cub_bytes, keys_in, keys_out, item_in, item_out, nnz, 0, cbits + bbits, stream);
     if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   }
-  hipLaunchKernelGGL(rowband::band_starts, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, keys_out, nnz, B, cbits, band_start);
-  hipLaunchKernelGGL(rowband::count_slots, dim3(math::ceil_div(nnz + 1, 256)), dim3(256), 0, stream, keys_out, nnz, cbits, slots);
-  cub_bytes = cub_bytes_total;
-  e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, slots, slot_pos, nnz + 1, stream);
+  hipLaunchKernelGGL((rowband::band_starts<key_t>), dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, keys_out, nnz, B, cbits, band_start);
+  // First the layout WITHOUT gap padding (no column gap of more than 255 inside a band: the common case) -- its band steps follow
+  // from the band starts alone; only when count_slots finds a gap that needs padding slots is the scan over the nonzeros run.
+  int* any_pads = bad + 1;
+  e = hipMemsetAsync(any_pads, 0, sizeof(int), stream);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&out.band_step), sizeof(int) * (static_cast<std::size_t>(B) + 1));
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
-  hipLaunchKernelGGL(rowband::band_step_counts, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, band_start, slot_pos, B, steps_of);
+  hipLaunchKernelGGL((rowband::count_slots<key_t>), dim3(math::ceil_div(nnz + 1, 256)), dim3(256), 0, stream, keys_out, nnz, cbits, slots, any_pads);
+  hipLaunchKernelGGL(rowband::band_step_counts_dense, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, band_start, B, steps_of);
   cub_bytes = cub_bytes_total;
   e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, steps_of, out.band_step, B + 1, stream);
   std::vector<int> bs(static_cast<std::size_t>(B) + 1, 0);
-  int h_bad = 0, h_slots = 0;
+  int h_bad = 0, h_pads = 0, h_slots = nnz;
   if (e == hipSuccess) e = hipMemcpyAsync(bs.data(), out.band_step, sizeof(int) * bs.size(), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&h_bad, bad, sizeof(int), hipMemcpyDeviceToHost, stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&h_slots, slot_pos + nnz, sizeof(int), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h_pads, any_pads, sizeof(int), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   if (h_bad != 0) { out.release(); return rowband_e_badarg; }
+  if (h_pads != 0) {  // gaps to bridge: number the slots by a scan, redo the band steps from it
+    cub_bytes = cub_bytes_total;
+    e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, slots, slot_pos, nnz + 1, stream);
+    if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+    hipLaunchKernelGGL(rowband::band_step_counts, dim3(math::ceil_div(B + 1, 256)), dim3(256), 0, stream, band_start, slot_pos, B, steps_of);
+    cub_bytes = cub_bytes_total;
+    e = hipcub::DeviceScan::ExclusiveSum(cub_temp, cub_bytes, steps_of, out.band_step, B + 1, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(bs.data(), out.band_step, sizeof(int) * bs.size(), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_slots, slot_pos + nnz, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  }
   out.steps = bs[B];
   out.gap_pads = static_cast<long long>(h_slots) - nnz;
   const std::size_t n = static_cast<std::size_t>(out.steps > 0 ? out.steps : 1) * rowband::step_items;
@@ -750,17 +868,42 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
   alloc(&out.perm, sizeof(int) * n);
   alloc(&out.stepbase, sizeof(int) * (n / 64));
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
-  hipLaunchKernelGGL((rowband::fill_padding<type_t>), dim3(static_cast<unsigned int>((n + 255) / 256)), dim3(256), 0, stream,
-                     static_cast<long long>(n), out.H, static_cast<type_t*>(out.val), out.meta, out.perm, out.stepbase);
-  if (nnz > 0)
-    hipLaunchKernelGGL((rowband::place<type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, item_out, rin, band_start,
-                       slot_pos, out.band_step, values, nnz, cbits, out.H, static_cast<type_t*>(out.val), out.meta, out.perm,
-                       out.stepbase);
+  if (h_pads == 0 && out.steps > 0) {
+    hipLaunchKernelGGL((rowband::place_dense<key_t, type_t>), dim3(static_cast<unsigned int>((static_cast<long long>(out.steps) * wave::size + 255) / 256)),
+                       dim3(256), 0, stream, keys_out, item_out, rin, band_start, out.band_step, values, out.steps, B, cbits, out.H,
+                       static_cast<type_t*>(out.val), out.meta, out.perm, out.stepbase);
+  } else {
+    hipLaunchKernelGGL((rowband::fill_padding<type_t>), dim3(static_cast<unsigned int>((n + 255) / 256)), dim3(256), 0, stream,
+                       static_cast<long long>(n), out.H, static_cast<type_t*>(out.val), out.meta, out.perm, out.stepbase);
+    if (nnz > 0)
+      hipLaunchKernelGGL((rowband::place<key_t, type_t>), dim3(math::ceil_div(nnz, 256)), dim3(256), 0, stream, keys_out, item_out, rin, band_start,
+                         slot_pos, out.band_step, values, nnz, cbits, out.H, static_cast<type_t*>(out.val), out.meta, out.perm,
+                         out.stepbase);
+  }
   e = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = static_cast<hipError_t>(rowband_set_chunks(out, bs, target_chunks));
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
   return 0;
+}
+
+/// The builder with the narrowest sort key that holds band and column: 32 bits wherever they fit (C2: 6 + 20 bits -- half the
+/// radix passes of the 64-bit key the first version always sorted), 64 otherwise.  Same layout arrays either way (the sort is
+/// stable, the key order the same).
+template <typename index_t, typename offset_t, typename type_t>
+int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset_t* offsets, const index_t* indices, const type_t* values,
+                   int band_rows, int target_chunks, rowband_storage& out) {
+  int H = band_rows != 0 ? band_rows : rowband_rows(rows, cols, nnz, static_cast<int>(sizeof(type_t)));
+  if (H < 64) H = 64;  // (the keyed builder refuses it; only the key width is decided here)
+  const long long B = rows > 0 ? (static_cast<long long>(rows) + H - 1) / H : 0;
+  int cbits = 1;
+  while (cbits < 31 && (static_cast<long long>(cols) >> cbits) != 0) ++cbits;
+  int bbits = 1;
+  while (bbits < 31 && (B >> bbits) != 0) ++bbits;
+  if (cbits + bbits <= 32)
+    return rowband_create_keyed<unsigned int, index_t, offset_t, type_t>(stream, rows, cols, nnz, offsets, indices, values, band_rows, target_chunks, out);
+  return rowband_create_keyed<unsigned long long, index_t, offset_t, type_t>(stream, rows, cols, nnz, offsets, indices, values, band_rows, target_chunks,
+                                                                            out);
 }
 
 /// Kernel B's launch: the rows of `num_multi` cut bands of H rows each (`multi` = {band, first partial slot, chunks} per band).
