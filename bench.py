@@ -42,342 +42,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s measured float4 copy
-
-
-def algorithmic_bytes(rows, cols, nnz, vbytes=4):
-    # nnz * (4 + 4) + (rows + 1) * 4 + rows * 4 + cols * 4 for fp32
-    return nnz * (4 + vbytes) + (rows + 1) * 4 + rows * vbytes + cols * vbytes
-
-
-KERNEL_SOURCES = ("include/loops/kernels/merge_path_spmv.hxx", "include/loops/util/wave.hxx")
-VARIANT_PHASED = 8  # include/loops_amd.h LOOPS_VARIANT_PHASED: the default kernel with phased x gathers (same CSR, same bits)
-
-
-def headline_kernel(args):
-    """Name prefix (incl. the tile shape's template arguments) of the dominant kernel of the N = 1 run in rocprofv3's tables."""
-    tpb, ipt = args.tile.split("x")
-    base = "merge_path_spmv_fused_phased" if args.variant == VARIANT_PHASED else "merge_path_spmv_fused"
-    return f"{base}<{tpb}, {ipt},"
-
-
-def kernel_sources_digest():
-    """sha256 of the files the headline kernel is compiled from: what ties a committed counter summary to the code that runs."""
-    import hashlib
-    h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
-    return h.hexdigest()
-
-
-def pmc_summary(args):
-    """(summary dict, path, note) of the committed rocprofv3 PMC passes of THIS command (profiles/rNN_c2_pmc_summary_<tile>.json,
-    scripts/pmc_c2.sh: separate --pmc runs) -- only when the configuration is the profiled one AND the summary was collected
-    at the kernel sources as they are now (`_kernel_sources_sha256`, written by scripts/pmc_summarize.py); otherwise
-    (None, None, why)."""
-    if args.gpus != 1 or args.window or args.log2_rows != 20 or args.log2_nnz != 24 or args.variant not in (0, VARIANT_PHASED) \
-            or args.layout in ("rowband", "panel") or args.scaling == "strong":
-        return None, None, "configuration differs from the profiled one (C2, N = 1, unmodified CSR)"
-    import glob
-    tag = args.tile + ("_phased" if args.variant == VARIANT_PHASED else "")
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_c2_pmc_summary_{tag}.json")), reverse=True)
-    if not paths:
-        return None, None, f"no committed counter summary for tile {tag}"
-    d = json.load(open(paths[0]))
-    rel = os.path.relpath(paths[0], ROOT)
-    if d.get("_kernel_sources_sha256") != kernel_sources_digest():
-        return None, None, (f"{rel} was collected at other kernel sources than the ones loaded now (digest of {', '.join(KERNEL_SOURCES)} "
-                            "differs or is absent): re-run scripts/pmc_c2.sh")
-    return d, rel, None
-
-
-def pmc_traffic(args):
-    """HBM-side bytes per launch of the dominant kernel from the committed counters: TCC_EA0_RDREQ x 128 B (every fabric read
-    of this kernel is a 128-B line: TCC_EA0_RDREQ_32B = 0; FETCH_SIZE tallies them at 64 B on gfx950, MI355X_MICROARCH.md HBM
-    section) + WRITE_SIZE.  Returns (bytes, source file, note); bytes is None -- with the reason in note -- when no summary
-    matches this configuration and these kernel sources."""
-    d, rel, why = pmc_summary(args)
-    if d is None:
-        return None, None, why
-    for k, v in d.items():
-        if headline_kernel(args) not in k or not isinstance(v, dict):
-            continue
-        wr = v.get("WRITE_SIZE", {}).get("mean")
-        if "TCC_EA0_RDREQ_sum" in v and wr is not None:
-            return int(v["TCC_EA0_RDREQ_sum"]["mean"] * 128 + wr * 1024), rel, None
-        if "FETCH_SIZE" in v and wr is not None:
-            return int((2 * v["FETCH_SIZE"]["mean"] + wr) * 1024), rel, None
-    return None, rel, "the summary holds no fabric-read counters for the headline kernel"
-
-
-def pmc_bound(args):
-    """What the committed counters of the dominant kernel say bounds it (same summary file as pmc_traffic):
-    L2 requests per launch, L2 hit rate, average L1 -> L2 round trip, reads in flight per CU, share of its active time the
-    vector L1 waits for data, L2 requests per clock and XCD.  None when the configuration differs from the profiled one."""
-    d, src, _ = pmc_summary(args)
-    if d is None:
-        return None
-    for k, v in d.items():
-        if headline_kernel(args) in k and isinstance(v, dict) and "TCP_TCC_READ_REQ_LATENCY_sum" in v:
-            m = {c: x["mean"] for c, x in v.items()}
-            cyc = m["GRBM_GUI_ACTIVE"] / 8
-            return {"l2_requests_per_launch": int(m["TCC_REQ_sum"]), "l2_hit_rate": round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4),
-                    "avg_l1_to_l2_round_trip_clks": round(m["TCP_TCC_READ_REQ_LATENCY_sum"] / m["TCP_TCC_READ_REQ_sum"], 1),
-                    "reads_in_flight_per_cu": round(m["TCP_TCC_READ_REQ_LATENCY_sum"] / cyc / 256, 1),
-                    "l1_waiting_for_data_frac": round(m["TCP_PENDING_STALL_CYCLES_sum"] / m["TCP_GATE_EN1_sum"], 3),
-                    "l2_requests_per_clk_per_xcd": round(m["TCC_REQ_sum"] / 8 / cyc, 2),
-                    "reading": "bound by the CU's outstanding-read capacity (~95 in flight) x round-trip latency, not by the L2 request "
-                               "path (16 per clk per XCD) nor by HBM bandwidth; calibration: profiles/r02_inflight_calibration.json",
-                    "collected_at": d.get("_kernel_build"),
-                    # (pmc_summary hands the file out only when the digest of the kernel sources it was collected at equals the digest
-                    #  of the sources this process runs: the counters describe THIS kernel even when `collected_at` is an older commit)
-                    "digest_matches_head": True, "kernel_sources_sha256": d.get("_kernel_sources_sha256"),
-                    "source": src}
-    return None
-
-
-def full_matrix_on_device(G, S, torch, degrees, cols, chunks=8):
-    """The whole synthetic matrix as one device CSR, generated and uploaded in row chunks (host memory stays at one
-    chunk: C5 is 4.3 GB of indices + values)."""
-    rows = degrees.size
-    off = np.zeros(rows + 1, np.int64)
-    np.cumsum(degrees, out=off[1:])
-    nnz = int(off[-1])
-    idx_d = torch.empty(nnz, dtype=torch.int32, device="cuda")
-    val_d = torch.empty(nnz, dtype=torch.float32, device="cuda")
-    cut = np.linspace(0, rows, chunks + 1).astype(np.int64)
-    for a, b in zip(cut[:-1], cut[1:]):
-        _, i, v = G.csr_from_degrees(degrees[a:b], cols, seed=1, row_begin=int(a))
-        idx_d[int(off[a]):int(off[b])].copy_(torch.from_numpy(i))
-        val_d[int(off[a]):int(off[b])].copy_(torch.from_numpy(v))
-    return S.CSR(rows, cols, torch.from_numpy(off.astype(np.int32)).cuda(), idx_d, val_d)
-
-
-class Watchdog:
-    """Host-side deadline around the parts of an N > 1 run that could hang (a candidate exchange of the start-up probe
-    that never completes on some rank).  A hung collective cannot be cancelled from inside the process, so the run is built
-    measure-first: the step is timed with the safe exchange BEFORE any other candidate is tried, and when a deadline
-    passes every rank's own watchdog ends its process -- rank 0 after printing the record it already holds, with the
-    reason in config.watchdog.  A hung candidate therefore costs that candidate, not the run."""
-
-    def __init__(self, rank):
-        import threading
-        self.rank, self.what, self.deadline, self.fallback = rank, None, None, None
-        self.record_printed = False  # the record is out: a deadline missed afterwards (teardown) must not fail the run
-        self._lock = threading.Lock()
-        t = threading.Thread(target=self._run, daemon=True)
-        t.start()
-
-    def arm(self, what, seconds):
-        with self._lock:
-            self.what, self.deadline = what, time.monotonic() + seconds
-
-    def disarm(self):
-        with self._lock:
-            self.what, self.deadline = None, None
-
-    def _run(self):
-        while True:
-            time.sleep(0.5)
-            with self._lock:
-                expired = self.deadline is not None and time.monotonic() > self.deadline
-                what = self.what
-            if expired:
-                print(f"[rank {self.rank}] watchdog: '{what}' did not finish in time", file=sys.stderr, flush=True)
-                if self.rank == 0 and self.fallback is not None:
-                    rec = self.fallback(f"'{what}' did not finish within its deadline; reporting the measurement taken before it")
-                    if rec is not None:
-                        print(json.dumps(rec), flush=True)
-                        os._exit(0)
-                os._exit(0 if self.rank != 0 or self.record_printed else 3)
-
-
-def timed_ms(torch, fn, iters, warm=3):
-    """ms per call: `iters` back-to-back calls between one pair of HIP events on the launch stream."""
-    for _ in range(warm):
-        fn()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(iters):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / iters
-
-
-def one_gpu_same_matrix(G, S, torch, degrees, cols, x, y_gathered, iters=20):
-    """BASELINE C5's denominator: the SAME matrix on ONE GPU (rank 0's, outside the timed region) -- the planned
-    merge_path_flat SpMV on the unmodified CSR and the product of the held SpMV plan (layout by measurement),
-    each y compared bit for bit with the vector the N ranks gathered (SURVEY 8e parity)."""
-    t0 = time.time()
-    csr = full_matrix_on_device(G, S, torch, degrees, cols)
-    gen_s = time.time() - t0
-    y = torch.empty(csr.rows, dtype=torch.float32, device="cuda")
-    plan = S.MergePathPlan(csr, "512x8")
-    ms_csr = timed_ms(torch, lambda: S.merge_path_flat(csr, x, y, plan=plan), iters)
-    eq_csr = bool(torch.equal(y, y_gathered))
-    out = {"workload": f"{csr.rows} rows / {csr.nnzs} nnz on rank 0's GPU alone (x {cols * 4 >> 20} MB)",
-           "csr_ms_per_spmv": round(ms_csr, 5), "csr_equals_gathered_y_bit_for_bit": eq_csr, "generate_upload_seconds": round(gen_s, 1)}
-    plan.close()
-    try:  # what a caller gets by default from a held plan: loops_spmv_plan_* picks tile shape and layout by measurement
-        sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
-        ms_p = timed_ms(torch, lambda: sp.spmv(x, y), iters)
-        out.update({"planned_ms_per_spmv": round(ms_p, 5), "planned_choice": sp.info,
-                    "planned_equals_gathered_y_bit_for_bit": bool(torch.equal(y, y_gathered))})
-        sp.close()
-    except Exception as e:  # noqa: BLE001
-        out["planned_error"] = f"{type(e).__name__}: {e}"
-    out["best_ms_per_spmv"] = min(v for k, v in out.items() if k.endswith("_ms_per_spmv"))
-    out["GFLOPs"] = round(2.0 * csr.nnzs / out["best_ms_per_spmv"] / 1e6, 2)  # the N = 1 `value` of THIS matrix (bench.py --gpus 1 runs C2)
-    return out
-
-
-def context_c4_bcsr(G, S, O, torch, iters=50):
-    """BASELINE config C4 at full size next to the headline (context line of the N = 1 record): BCSR 4x4, 2^18 block
-    rows x 16 blocks, bcsr_thread_mapped with the MFMA block inner product, bit-exact against the oracle."""
-    nbr, per = 1 << 18, 16
-    boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, per)
-    xh = G.uniform_distribution_int(nbr * 4)
-    b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
-    x, y = torch.from_numpy(xh).cuda(), torch.empty(nbr * 4, device="cuda")
-    nb = int(bcols.size)
-    abytes = nb * (16 * 4 + 4) + (nbr + 1) * 4 + nbr * 4 * 4 + nbr * 4 * 4  # SURVEY 8d B_bcsr: 294 649 860
-    out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks, fp32 (BASELINE configs[3])", "algorithmic_bytes": abytes}
-    for name, mode in (("mfma", 1), ("thread_per_block_row", 0)):
-        ms = timed_ms(torch, lambda: S.bcsr_thread_mapped(b, x, y, mfma=mode), iters)
-        out[name] = {"avg_launch_ms": round(ms, 5), "GFLOPs": round(2 * 16 * nb / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
-                     "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
-    S.bcsr_thread_mapped(b, x, y, mfma=1)
-    out["mfma"]["kernel"] = "loops::kernels::bcsr4x4_mfma_spmv"
-    want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)
-    out["parity_vs_oracle_bit_exact"] = bool(np.array_equal(y.cpu().numpy(), want))
-    # the held plan for this matrix: the block-band copy (kernels/bcsr_band.hxx) -- blocks sorted by block column inside bands whose
-    # row sums live in LDS, MFMA block products; what it costs to build and after how many products it has paid for itself
-    try:
-        S.BCSRBandPlan(b).close()                                       # (first build in the process: allocator warm-up)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        plan = S.BCSRBandPlan(b)
-        torch.cuda.synchronize()
-        build_ms = (time.perf_counter() - t0) * 1e3
-        t0 = time.perf_counter()
-        shapes = plan.tune(10)
-        tune_ms = (time.perf_counter() - t0) * 1e3
-        ms = timed_ms(torch, lambda: plan.spmv(x, y), iters)
-        y.fill_(-1.0)
-        plan.spmv(x, y)
-        saved = out["mfma"]["avg_launch_ms"] - ms
-        out["block_band_plan"] = {
-            "kernel": "loops::kernels::bcsr_band::bcsr_band_accumulate", "avg_launch_ms": round(ms, 5), "GFLOPs": round(2 * 16 * nb / ms / 1e6, 1),
-            "achieved_GBps": round(abytes / ms / 1e6, 1), "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
-            "band_block_rows": plan.HB, "bands": plan.num_bands, "chunks": plan.num_chunks, "partial_vectors": plan.num_partials,
-            "shape": {"waves": plan.waves, "steps_per_batch": plan.unroll, "non_temporal": plan.nt},
-            "plan_build_ms": round(build_ms, 3), "plan_tune_ms": round(tune_ms, 3),
-            "break_even_products": (int(np.ceil(build_ms / saved)) if saved > 0 else None),
-            "break_even_products_incl_tune": (int(np.ceil((build_ms + tune_ms) / saved)) if saved > 0 else None),
-            "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), want)),
-            "note": "held plan (a re-ordered copy of the blocks); the one-shot bcsr_thread_mapped<4, 4> wrapper launches the MFMA kernel above"}
-        plan.close()
-    except Exception as e:  # noqa: BLE001
-        out["block_band_plan"] = {"error": f"{type(e).__name__}: {e}"}
-    return out
-
-
-def context_c3_standins(G, S, O, torch, iters=10):
-    """BASELINE config C3 next to the headline (context): `group_mapped` vs `work_oriented` (+ merge_path_flat) on generated
-    stand-ins of indochina-2004's exact shape -- 7 414 866 rows / 194 109 311 nnz; the SuiteSparse file is not shipped
-    (datasets/suitesparse.txt:2052 in the reference): scale-free degrees with uniformly random columns (no locality: a lower
-    bound for a crawl-ordered web graph), with columns in a 65 536-wide band, and host-blocked (how LAW graphs are laid out).  Whole calls through loops_spmv_csr_f32,
-    bit-exact against the oracle."""
-    rows = cols = 7_414_866
-    nnz = 194_109_311
-    deg = G.powerlaw_degrees(rows, nnz)
-    xh = G.uniform_distribution_int(cols)
-    x = torch.from_numpy(xh).cuda()
-    abytes = algorithmic_bytes(rows, cols, nnz)
-    out = {"shape": f"{rows} rows / {nnz} nnz (LAW/indochina-2004's), fp32", "algorithmic_bytes": abytes,
-           "note": "generated stand-ins: the SuiteSparse file is not available offline; tests/perf/bench_schedules.py --mtx PATH runs the real one"}
-    shape_rows, shape_nnz = rows, nnz
-    for tag, window in (("uniform_columns", None), ("band_65536", 65536), ("host_blocked", G.HOST_BLOCKED), ("rmat_2e23_x23_generator_order", "rmat")):
-        # host_blocked: the locality class LAW graphs belong to -- consecutive ids form hosts of power-law size (generate.host_blocks:
-        # >= 256 ids, Pareto 1.1, <= 2^17), 3 of 4 links stay inside the row's host, the rest go anywhere
-        # rmat (round 5): a Graph500 R-MAT graph of the nearest power-of-two size (2^23 vertices x 23 edges = 192.9 M) in the generator's
-        # own order -- hub vertices at the low ids, as a crawl leaves them: the stand-in on which `group_mapped` falls behind
-        # `work_oriented` the way the reference's published C3 row does (11.87 against 2.33 ms on its GPU, plots/data/*.csv)
-        if window == "rmat":
-            off, idx, val = G.rmat_csr(23, 23, relabel="none")
-            rows = cols = 1 << 23
-            nnz = int(off[-1])
-            xh = G.uniform_distribution_int(cols)
-            x = torch.from_numpy(xh).cuda()
-            abytes = algorithmic_bytes(rows, cols, nnz)
-        else:
-            off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window, hosts=G.host_blocks(cols) if window == G.HOST_BLOCKED else None)
-        csr = S.CSR.from_numpy(rows, cols, off, idx, val)
-        ref = O.spmv_f32(off, idx, val, xh, omp=True)
-        y = torch.empty(rows, device="cuda")
-        res = {}
-        # merge_path_flat runs over a held 256 x 8 plan here: the headline's kernel symbol (merge_path_spmv_fused<512, 8>) must
-        # stay exclusive to the C2 matrix in this process, so that rocprofv3's per-kernel average of this command is the headline's
-        mplan = S.MergePathPlan(csr, "256x8")
-        # (and the phased-gather twin over 256 x 16 tiles -- 32 parts at this |x| -- a measured choice only: it gains where the
-        # columns are scattered and LOSES where they are local; another template instantiation than the headline's, 512 x 8 / 8 parts)
-        pplan = S.MergePathPlan(csr, "256x16")
-        runs = {"group_mapped": lambda: S.spmv("group_mapped", csr, x, y), "work_oriented": lambda: S.spmv("work_oriented", csr, x, y),
-                "merge_path_flat": lambda: S.merge_path_flat(csr, x, y, plan=mplan),
-                "merge_path_flat_phased_gathers": lambda: S.merge_path_flat(csr, x, y, plan=pplan, variant=VARIANT_PHASED)}
-        for sched, fn in runs.items():
-            ms = timed_ms(torch, fn, iters)
-            res[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
-                          "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
-        mplan.close()
-        pplan.close()
-        # what a caller gets by default from a held plan (loops_spmv_plan_*: tile shape + layout picked by measurement)
-        sp = S.SpmvPlan(csr, allow_copy=True, measure=True, repeats=5)
-        ms = timed_ms(torch, lambda: sp.spmv(x, y), iters)
-        res["held_spmv_plan"] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
-                                 "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "choice": sp.info,
-                                 "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
-        sp.close()
-        if (rows, nnz) != (shape_rows, shape_nnz):
-            res["shape"] = f"{rows} rows / {nnz} nnz, fp32"
-            res["algorithmic_bytes"] = abytes
-        out[tag] = res
-        del csr, off, idx, val, y
-    return out
-
-
-def context_schedules(S, torch, csr, x, ref_y, abytes, iters=50):
-    """The other tuned schedules on the headline matrix (work_oriented and group_mapped are BASELINE C3's pair):
-    whole call through loops_spmv_csr_f32 (work_oriented includes its coordinate pre-pass), bit-exact vs the headline y."""
-    y = torch.empty_like(ref_y)
-    out = {}
-    wplan = S.MergePathPlan(csr, "256x8")  # work_oriented with a held plan: the region the reference's timer brackets
-    ms = timed_ms(torch, lambda: S.work_oriented(csr, x, y, plan=wplan), iters)
-    out["work_oriented_held_plan"] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
-                                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
-    for sched in ("work_oriented", "group_mapped"):
-        ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
-        out[sched] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
-                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
-    return out
-
-
-def self_launch(n):
-    """`python bench.py --gpus N ...` started WITHOUT a launcher (N > 1, no WORLD_SIZE in the environment): start the N ranks
-    ourselves -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>
-    bench.py <the same arguments>` -- and pass rank 0's JSON line (the children inherit stdout / stderr) and the job's exit
-    code through.  A rank that fails makes torchrun stop the others and exit non-zero; its traceback is on stderr."""
-    import socket
-    import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
-    print("[bench] no launcher in the environment: " + " ".join(cmd), file=sys.stderr, flush=True)
-    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
-    return subprocess.call(cmd, env=env)
+# (re-exported: scripts/pmc_summarize.py, tests/test_bench_watchdog.py and tests/perf use these names off `bench`)
+from benchlib.counters import (HBM_PEAK_GBPS, KERNEL_SOURCES, VARIANT_PHASED, algorithmic_bytes, headline_kernel, kernel_sources_digest,  # noqa: E402,F401
+                               pmc_bound, pmc_summary, pmc_traffic)
+from benchlib.context import (context_c3_standins, context_c4_bcsr, context_schedules, full_matrix_on_device, one_gpu_same_matrix,  # noqa: E402,F401
+                              timed_ms)
+from benchlib.launch import Watchdog, self_launch  # noqa: E402,F401
 
 
 def main():
