@@ -183,11 +183,7 @@ bcsr_band_accumulate(const int* __restrict__ chunks, const float* __restrict__ v
     for (int j = threadIdx.x; j < H && row0 + j < rows; j += TPB) out(static_cast<int>(row0 + j), static_cast<float>(acc[j]));
   } else {  // the chunk's partial vector; rowband_combine adds the band's up
     float* to = partial + static_cast<long long>(slot) * H;
-#ifdef LOOPS_EXP_NT_PARTIAL
-    for (int j = threadIdx.x; j < H; j += TPB) __builtin_nontemporal_store(static_cast<float>(acc[j]), to + j);
-#else
     for (int j = threadIdx.x; j < H; j += TPB) to[j] = static_cast<float>(acc[j]);
-#endif
   }
 }
 
