@@ -98,7 +98,7 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
         torch.cuda.synchronize()
         build_ms = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
-        shapes = plan.tune(10)
+        shapes = plan.tune(30)
         tune_ms = (time.perf_counter() - t0) * 1e3
         ms = timed_ms(torch, lambda: plan.spmv(x, y), iters)
         y.fill_(-1.0)
@@ -163,10 +163,18 @@ def context_c3_standins(G, S, O, torch, iters=10):
         runs = {"group_mapped": lambda: S.spmv("group_mapped", csr, x, y), "work_oriented": lambda: S.spmv("work_oriented", csr, x, y),
                 "merge_path_flat": lambda: S.merge_path_flat(csr, x, y, plan=mplan),
                 "merge_path_flat_phased_gathers": lambda: S.merge_path_flat(csr, x, y, plan=pplan, variant=VARIANT_PHASED)}
+        # which kernels an entry launches on a matrix of this size (the one-shot entries decide by size: abi_csr.inc)
+        launches = {"group_mapped": "group_mapped_spmv_publish + group_mapped_spmv_claims + group_mapped_fixup (one-kernel group_mapped_spmv_fused once "
+                                    "the entry's memo says nothing was published)",
+                    "work_oriented": "shares of ONE tile through merge_path_flat's one-shot launch (sampled columns, merge_path_spmv_fused_auto: plain or "
+                                     "phased gathers decided on the device) -- the persistent work_oriented_spmv_fused only below the sampling thresholds",
+                    "merge_path_flat": "merge_path_spmv_fused_planned<256, 8> (held plan) + fix-up",
+                    "merge_path_flat_phased_gathers": "merge_path_spmv_fused_phased_planned<256, 16, 32> (held plan) + fix-up"}
         for sched, fn in runs.items():
             ms = timed_ms(torch, fn, iters)
             res[sched] = {"ms_per_spmv": round(ms, 4), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
-                          "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref))}
+                          "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "parity_vs_oracle_bit_exact": bool(np.array_equal(y.cpu().numpy(), ref)),
+                          "launches": launches[sched]}
         mplan.close()
         pplan.close()
         # what a caller gets by default from a held plan (loops_spmv_plan_*: tile shape + layout picked by measurement)

@@ -34,8 +34,9 @@
  *
  * Steps 1-4 are the `merge_tile_engine`; the three tuned CSR kernels differ only in how they
  * cut the merge path into tiles: merge_path_flat (one plan tile per workgroup), work_oriented
- * (a fixed grid, an even contiguous share of plan tiles per workgroup, carried in registers) and
- * group_mapped (the tiles of the workgroup's own 256 rows, found in LDS -- no plan, no fix-up).
+ * (an even contiguous share of 1-4 plan tiles per workgroup, eight shares per resident workgroup,
+ * the open row carried in a register) and group_mapped (the tiles of the workgroup's own 256 rows,
+ * found in LDS -- no plan; heavy groups shared out: group_mapped_spmv.hxx).
  *
  * y needs NO zero-fill: every row is stored exactly once by the thread that consumes its
  * row-end item; the summation order is deterministic (no floating-point atomics).
@@ -1111,9 +1112,11 @@ merge_path_spmv_fused_phased_planned(const coord_t* __restrict__ coords, const i
 }
 
 /**
- * work_oriented: a FIXED, occupancy-sized grid; every workgroup owns an even, contiguous share
- * of the merge tiles (hence of rows + nonzeros) and walks it tile after tile, carrying the open
- * row's partial sum in a register -- one carry-out per workgroup instead of one per tile.
+ * work_oriented: every workgroup owns an even, contiguous share of the merge tiles (hence of rows +
+ * nonzeros; the launcher sizes the shares at 1-4 tiles -- eight shares per resident workgroup --
+ * instead of one long share per workgroup of an occupancy-sized grid: launch.hxx) and walks it tile
+ * after tile, carrying the open row's partial sum in a register -- one carry-out per share instead
+ * of one per tile.
  * (Even-share semantics of schedule::setup<work_oriented>, reference work_oriented.hxx:79-91,
  * at merge-tile granularity.)
  */

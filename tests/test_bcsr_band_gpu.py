@@ -116,7 +116,8 @@ def test_refresh_values_and_tune():
     plan = S.BCSRBandPlan(b)
     times = plan.tune(3)
     assert len(times) == 12 and all(t > 0 for t in times.values())
-    assert (plan.waves, plan.unroll, plan.nt) == min(times, key=times.get)
+    fastest = min(times, key=times.get)                               # (the shape the plan came with stays unless another is 2 % faster)
+    assert times[(plan.waves, plan.unroll, plan.nt)] <= 1.03 * times[fastest]
     assert np.array_equal(plan.spmv(xd).cpu().numpy(), _numpy_product(nbr * 4, boff, bcols, bvals, x))
     new_vals = (np.random.default_rng(9).integers(-8, 9, size=bvals.size) / 8.0).astype(np.float32)
     plan.refresh_values(torch.from_numpy(new_vals).cuda())
