@@ -117,6 +117,24 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
         plan.close()
     except Exception as e:  # noqa: BLE001
         out["block_band_plan"] = {"error": f"{type(e).__name__}: {e}"}
+    # the reference's own bcsr_thread_mapped<4, 4> (algorithms/spmv/bcsr_thread_mapped.cuh:36-123, its HIP backend) on this GPU and matrix:
+    # oracle/_ref/libloops_ref_gpu.so, built by oracle/Makefile where /root/reference is mounted; kernel-only time, best of 10
+    so = os.path.join(ROOT, "oracle", "_ref", "libloops_ref_gpu.so")
+    if os.path.exists(so):
+        try:
+            import ctypes as C
+            from loops_amd import _lib
+            R = _lib.load_shared(so)
+            yr = np.zeros(nbr * 4, np.float32)
+            ms = C.c_float()
+            p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            rc = R.refgpu_bcsr_spmv(4, 0, C.c_long(nbr * 4), C.c_long(nbr * 4), C.c_long(nbr), C.c_long(nbr), C.c_long(nb), p(boff), p(bcols), p(bvals),
+                                    p(xh), p(yr), 10, C.byref(ms))
+            out["reference_hip_backend_on_this_gpu"] = {
+                "rc": rc, "best_kernel_ms": round(ms.value, 5), "frac": round(abytes / ms.value / 1e6 / HBM_PEAK_GBPS, 4) if ms.value > 0 else None,
+                "equals_oracle": bool(np.array_equal(yr, want)), "kernel": "the reference's __bcsr_thread_mapped<4, 4> (thread per block-row)"}
+        except Exception as e:  # noqa: BLE001
+            out["reference_hip_backend_on_this_gpu"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

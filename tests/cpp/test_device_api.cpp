@@ -21,6 +21,7 @@
 #include <loops/algorithms/spmv/merge_path_flat.cuh>
 #include <loops/algorithms/spmv/flat_partitioned.cuh>
 #include <loops/algorithms/spmv/bcsr_thread_mapped.cuh>
+#include <loops/algorithms/spmv/bcsr_band.cuh>
 #include <loops/algorithms/spmv/coo_thread_mapped.cuh>
 #include <loops/algorithms/spmv/csc_thread_mapped.cuh>
 #include <loops/algorithms/spmv/dia_thread_mapped.cuh>
@@ -142,6 +143,19 @@ static void run_battery() {
       bcsr_case(bcsr_t<2, 2, int, int, T>(csr), "bcsr<2,2>");
       bcsr_case(bcsr_t<3, 3, int, int, T>(csr), "bcsr<3,3>");
       bcsr_case(bcsr_t<4, 4, int, int, T>(csr), "bcsr<4,4> (MFMA for f32)");
+      if constexpr (sizeof(T) == 4) {  // the held block-band plan for 4 x 4 fp32 blocks: automatic and smallest bands, bands cut into chunks
+        bcsr_t<4, 4, int, int, T> b4(csr);
+        vector_t<T, H> xp(b4.num_block_cols * 4, T(0));
+        for (std::size_t i = 0; i < h.cols; ++i) xp[i] = xh[i];
+        vector_t<T> xpd(xp);
+        for (int cfg : {0, 1, 2}) {
+          algorithms::spmv::bcsr_band_t<int, int> plan(b4, cfg == 0 ? 0 : 16, cfg == 2 ? 5 : 0);
+          if (cfg == 2) plan.arrays.waves = 8, plan.arrays.unroll = 4;
+          auto y = vector_t<T>(h.rows, T(7));  // (y needs no zero-fill)
+          plan.spmv(xpd, y);
+          check_y("bcsr_band_t", m, y, ref);
+        }
+      }
     }
     // plan reuse: one preprocess_t, several x (what an iterative solver does)
     if (h.rows) {
