@@ -1,6 +1,6 @@
 """Soak: the tuned kernels launched back to back for a fixed wall time on C2 and on a self-completing band matrix; every
 result compared ON THE GPU with the first one (bit-equal) -- races / ordering bugs show up as a mismatch count > 0.
-usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3|r4|r5]     (rN = only the kernels added in that round)"""
+usage: python tests/perf/soak.py [seconds per case, default 20] [r2|r3|r4|r5|r6]     (rN = only the kernels added in that round)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -126,6 +126,57 @@ def round4_planless():
 
 # ---- round 5: the row-band layout -- LDS fp64 atomics from 8 / 16 wavefronts, hub replicas, partial vectors + combine, DPP prefix
 # sums of the column deltas; exactly summable inputs (any order gives the same bits) and real values (run-to-run identity)
+def round6():
+    """Round 6: the block-band BCSR plan (uncut and cut bands, several kernel shapes), group_mapped with shared-out groups (R-MAT in
+    generator order, hub rows on group boundaries; the one-shot entry's memo flips between the two forms on the way), the row-band
+    layout with 8-byte values and its dense placement path."""
+    nbr = 1 << 18
+    boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, 16)
+    xh4 = G.uniform_distribution_int(nbr * 4)
+    ref4 = torch.from_numpy(O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh4)).cuda()
+    b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    x4 = torch.from_numpy(xh4).cuda()
+    for label, hb, chunks, shape in (("automatic (HB 1024 uncut), 16 x 1", 0, 0, (16, 1, 0)), ("HB 4096 cut in 4, 16 x 1 nt", 4096, 0, (16, 1, 1)),
+                                     ("HB 1024, 8 x 4", 1024, 0, (8, 4, 0)), ("HB 2048, 600 chunks, 16 x 2", 2048, 600, (16, 2, 1))):
+        plan = S.BCSRBandPlan(b, hb, chunks)
+        plan.set_shape(*shape)
+        soak("c4", "block_band " + label, lambda y: (plan.spmv(x4, y), None)[1], ref4, nbr * 4)
+        plan.close()
+    del b
+    off, idx, val = G.rmat_csr(20, 16, relabel="none")
+    xh = G.uniform_distribution_int(cols)
+    x = torch.from_numpy(xh).cuda()
+    ref = torch.from_numpy(O.spmv_f32(off, idx, val, xh, omp=True)).cuda()
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    soak("rmat20", "group_mapped, heavy groups shared out", lambda y: (S.spmv("group_mapped", csr, x, y), None)[1], ref, rows)
+    deg = G.powerlaw_degrees(rows, 1 << 24)
+    deg[255] = deg[256] = deg[1 << 19] = 70_000                       # hub rows on both sides of a group boundary and mid-matrix
+    off2, idx2, val2 = G.csr_from_degrees(deg, cols, 1)
+    ref2 = torch.from_numpy(O.spmv_f32(off2, idx2, val2, xh, omp=True)).cuda()
+    csr2 = S.CSR.from_numpy(rows, cols, off2, idx2, val2)
+    soak("c2hubs", "group_mapped, three heavy groups among 4 096", lambda y: (S.spmv("group_mapped", csr2, x, y), None)[1], ref2, rows)
+    del csr, csr2
+    off3, idx3, val3 = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
+    csr3 = S.CSR.from_numpy(rows, cols, off3, idx3, val3.astype(np.float64))
+    x64 = torch.from_numpy(xh.astype(np.float64)).cuda()
+    ref3 = torch.from_numpy(O.spmv_f64(off3, idx3, val3.astype(np.float64), xh.astype(np.float64))).cuda()
+    for waves in (8, 16):
+        rb = S.RowBandPlan(csr3)
+        rb.set_waves(waves)
+        y64 = torch.empty(rows, dtype=torch.float64, device="cuda")
+        bad = torch.zeros((), dtype=torch.int64, device="cuda")
+        n, t0 = 0, time.time()
+        while time.time() - t0 < secs:
+            for _ in range(200):
+                y64.fill_(float("nan"))
+                rb.spmv(x64, y64)
+                bad += (y64 != ref3).any()
+            n += 200
+            torch.cuda.synchronize()
+        print(f"{'c2f64':7s} {'row_band, 8-byte values, %d wavefronts' % waves:46s} rounds {n:7d} mismatching rounds {int(bad.item())}", flush=True)
+        rb.close()
+
+
 def round5():
     off, idx, val = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
     xh = G.uniform_distribution_int(cols)
@@ -177,6 +228,9 @@ def round5():
         rb4.close()
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "r6":
+    round6()
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == "r5":
     round5()
     sys.exit(0)
