@@ -17,8 +17,10 @@
  * Layout (a re-ordered COPY, built once on the device: one radix sort of (band, block column) keys over the blocks):
  *   blocks sorted by (band = block-row / HB, block column, BCSR position); every band padded to whole STEPS of 16 blocks (one
  *   MFMA batch = one 1 KB wavefront load).  Per block 68 bytes, as in BCSR: the 16 cells (row-major, container/bcsr.hxx:13-17)
- *   and ONE 32-bit word (block-row inside the band << cbits) | block column; a padding block has zero cells, row code HB (a
- *   dump accumulator) and column 0.
+ *   and ONE 32-bit word (row code << cbits) | block column; the row code is the block-row inside the band, HB for a padding block
+ *   (zero cells, column 0: a dump accumulator), or -- for the blocks of a HUB block-row (>= 1 / 32 of its band's blocks) -- one of
+ *   the hub's 16 replicated accumulator groups, picked by the block's place in its step, so that the lanes of one ds_add
+ *   instruction never meet in one LDS word (rowband.hxx: hub rows).
  *
  * y = A x:
  *   A  bcsr_band_accumulate  one workgroup per CHUNK = a run of steps of one band: zero 4 (HB + 1) fp64 words of LDS, stream
@@ -55,7 +57,17 @@ constexpr int step_blocks = 16;            ///< blocks per step: one MFMA batch,
 constexpr int block_cells = 16;            ///< 4 x 4
 constexpr int max_band_block_rows = 4096;  ///< 4 (HB + 1) fp64 accumulators in the 160 KB LDS of a CU
 constexpr int min_band_block_rows = 16;
-constexpr int lds_words(int HB) { return 4 * (HB + 1); }
+constexpr int max_hubs = rowband::max_hubs;          ///< block-rows per band that get replicated accumulators ("hubs")
+constexpr int hub_replicas = rowband::hub_replicas;  ///< accumulator groups per hub: the 16 blocks of a step spread over them
+constexpr int hub_share_div = 32;                    ///< a block-row is a hub from 1 / 32 of its band's blocks (at least 64 blocks) on
+/// LDS fp64 words of a workgroup of kernel A: the band's block-rows, the dump block-row, the hubs' replicas (4 rows each).
+constexpr int lds_words(int HB) { return 4 * (HB + 1 + max_hubs * hub_replicas); }
+/// Bits of a row code: block-row inside the band, HB = padding, above HB a hub's replica.
+constexpr int row_code_bits(int HB) {
+  int b = 0;
+  while ((1 << b) <= HB + max_hubs * hub_replicas) ++b;
+  return b;
+}
 }  // namespace bcsr_band
 
 /// Device arrays of a block-band matrix (owned by bcsr_band_storage).
@@ -69,6 +81,7 @@ struct bcsr_band_view {
   const unsigned int* meta;  ///< [steps * 16] (row code << cbits) | block column
   const int* chunks;         ///< [4 * num_chunks] {band, first step, end step, partial slot or -1}
   const int* multi;          ///< [3 * num_multi] {band, first partial slot, chunks}
+  const unsigned short* hubs;  ///< [B * (max_hubs + 1)] per band: the number of hubs, then their block-rows inside the band
   float* partial;            ///< [num_partials * 4 HB]
   int waves, unroll, nt;     ///< kernel A's shape: wavefronts per workgroup (8 | 16), steps per batch (1 | 2 | 4), non-temporal streams
   int max_pieces;
@@ -84,9 +97,10 @@ using f32x4 = float __attribute__((ext_vector_type(4)));
 template <int WAVES, int U, bool NT, typename store_t>
 __global__ void __launch_bounds__(WAVES * wave::size)
 bcsr_band_accumulate(const int* __restrict__ chunks, const float* __restrict__ val, const unsigned int* __restrict__ meta,
-                     const float* __restrict__ x, const int HB, const int cbits, const int rows, float* __restrict__ partial, const store_t out) {
+                     const unsigned short* __restrict__ hubs, const float* __restrict__ x, const int HB, const int cbits, const int rows,
+                     float* __restrict__ partial, const store_t out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bcsr_band_lds[];
-  double* acc = reinterpret_cast<double*>(bcsr_band_lds);  // [4 (HB + 1)]: the band's rows, then the dump block-row
+  double* acc = reinterpret_cast<double*>(bcsr_band_lds);  // [lds_words(HB)]: the band's rows, the dump block-row, the hubs' replicas
   constexpr int TPB = WAVES * wave::size;
   const int lane = wave::lane();
   const int q = lane >> 2;  // block of the step
@@ -177,6 +191,18 @@ bcsr_band_accumulate(const int* __restrict__ chunks, const float* __restrict__ v
     }
   }
   __syncthreads();
+  // hubs: replicas -> the block-row's own four words (one thread per (hub, row of the block), fixed order)
+  const unsigned short* hb = hubs + static_cast<long long>(band) * (max_hubs + 1);
+  const int nh = hb[0];
+  if (static_cast<int>(threadIdx.x) < 4 * nh) {
+    const int h = static_cast<int>(threadIdx.x) >> 2, r4 = static_cast<int>(threadIdx.x) & 3;
+    const double* rep = acc + 4 * (HB + 1 + h * hub_replicas) + r4;
+    double sum = 0.0;
+#pragma unroll
+    for (int r = 0; r < hub_replicas; ++r) sum += rep[4 * r];
+    acc[4 * hb[1 + h] + r4] += sum;
+  }
+  if (nh > 0) __syncthreads();  // (workgroup-uniform)
   const int H = 4 * HB;
   if (slot < 0) {
     const long long row0 = static_cast<long long>(band) * H;
@@ -189,12 +215,13 @@ bcsr_band_accumulate(const int* __restrict__ chunks, const float* __restrict__ v
 
 // ------------------------------------------------------------------------------------------------ plan-time kernels
 
-/// key[b] = band << cbits | block column, item[b] = b, rin[b] = block-row inside the band (one lane per block; its block-row by
-/// binary search over the offsets).
+/// key[b] = band << cbits | block column, item[b] = b, rin[b] = block-row inside the band, or 0x8000 | hub number for the blocks of a
+/// hub block-row (one lane per block; its block-row by binary search over the offsets).
 template <typename key_t>
 __global__ void __launch_bounds__(256)
-make_keys(const int* __restrict__ block_offsets, const int* __restrict__ block_cols, const int nbr, const int nb, const int hshift,
-          const int cbits, const int nbc, key_t* __restrict__ keys, int* __restrict__ item, unsigned short* __restrict__ rin, int* __restrict__ bad) {
+make_keys(const int* __restrict__ block_offsets, const int* __restrict__ block_cols, const short* __restrict__ hubidx, const int nbr, const int nb,
+          const int hshift, const int cbits, const int nbc, key_t* __restrict__ keys, int* __restrict__ item, unsigned short* __restrict__ rin,
+          int* __restrict__ bad) {
   const long long b_ll = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (b_ll >= nb) return;
   const int b = static_cast<int>(b_ll);
@@ -218,7 +245,9 @@ make_keys(const int* __restrict__ block_offsets, const int* __restrict__ block_c
   const unsigned int band = static_cast<unsigned int>(br) >> hshift;
   keys[b] = (static_cast<key_t>(band) << cbits) | static_cast<key_t>(col);
   item[b] = b;
-  rin[b] = static_cast<unsigned short>(static_cast<unsigned int>(br) - (band << hshift));
+  const int hub = hubidx[br];
+  rin[b] = hub >= 0 ? static_cast<unsigned short>(0x8000u | static_cast<unsigned int>(hub))
+                    : static_cast<unsigned short>(static_cast<unsigned int>(br) - (band << hshift));
 }
 
 /// band_start[b] = the first sorted position whose band is >= b (b <= B: band_start[B] = nb).
@@ -265,7 +294,7 @@ fill_padding(const long long slots, const unsigned int pad_word, float* __restri
 template <typename key_t>
 __global__ void __launch_bounds__(256)
 place(const key_t* __restrict__ sorted, const int* __restrict__ item, const unsigned short* __restrict__ rin, const int* __restrict__ band_start,
-      const int* __restrict__ band_step, const float* __restrict__ values, const int nb, const int cbits, float* __restrict__ val,
+      const int* __restrict__ band_step, const float* __restrict__ values, const int nb, const int cbits, const int HB, float* __restrict__ val,
       unsigned int* __restrict__ meta, int* __restrict__ perm) {
   const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
   const long long j = t >> 2;
@@ -278,7 +307,11 @@ place(const key_t* __restrict__ sorted, const int* __restrict__ item, const unsi
   const int src = item[j];
   *reinterpret_cast<f32x4*>(val + s * block_cells + part * 4) = *reinterpret_cast<const f32x4*>(values + static_cast<long long>(src) * block_cells + part * 4);
   if (part == 0) {
-    meta[s] = (static_cast<unsigned int>(rin[src]) << cbits) | col;
+    // row code: the block-row inside the band, or -- a hub's block -- one of the hub's replicas, picked by the block's place in its
+    // step (the 16 blocks of one ds_add instruction go to 16 different accumulator groups)
+    const unsigned int c = rin[src];
+    const unsigned int code = (c & 0x8000u) ? static_cast<unsigned int>(HB) + 1u + (c & 0x7FFFu) * hub_replicas + static_cast<unsigned int>(s % step_blocks) : c;
+    meta[s] = (code << cbits) | col;
     perm[s] = src;
   }
 }
@@ -303,6 +336,7 @@ struct bcsr_band_storage {
   int waves = 16, unroll = 1, nt = 0, max_pieces = 1;  ///< (16 wavefronts x 1 step: best or within 2 % of the best shape on every size measured)
   float *val = nullptr, *partial = nullptr;
   unsigned int* meta = nullptr;
+  unsigned short* hubs = nullptr;
   int *perm = nullptr, *chunks = nullptr, *multi = nullptr, *band_step = nullptr;
 
   bcsr_band_storage() = default;
@@ -311,12 +345,12 @@ struct bcsr_band_storage {
   ~bcsr_band_storage() { release(); }
   void release() {
     (void)hipFree(val); (void)hipFree(partial); (void)hipFree(meta); (void)hipFree(perm); (void)hipFree(chunks); (void)hipFree(multi);
-    (void)hipFree(band_step);
-    val = partial = nullptr; meta = nullptr; perm = chunks = multi = band_step = nullptr;
+    (void)hipFree(band_step); (void)hipFree(hubs);
+    val = partial = nullptr; meta = nullptr; hubs = nullptr; perm = chunks = multi = band_step = nullptr;
   }
   bcsr_band_view view() const {
     return bcsr_band_view{rows, num_block_rows, num_block_cols, num_blocks, HB, B, cbits, steps, num_chunks, num_partials, num_multi,
-                          val, meta, chunks, multi, partial, waves, unroll, nt, max_pieces};
+                          val, meta, chunks, multi, hubs, partial, waves, unroll, nt, max_pieces};
   }
   /// bytes one product streams (cells + words + partial vectors both ways)
   double stream_bytes() const {
@@ -333,13 +367,25 @@ inline int bcsr_band_block_rows(int num_block_rows, int cbits, int cus) {
   const int c = cus > 0 ? cus : 256;
   int h = bcsr_band::max_band_block_rows;
   while (h > 64 && num_block_rows / h < c) h /= 2;
-  auto bits = [](int v) { int b = 0; while ((1 << b) < v) ++b; return b; };
-  while (h > bcsr_band::min_band_block_rows && bits(h) + 1 + cbits > 32) h /= 2;
+  while (h > bcsr_band::min_band_block_rows && bcsr_band::row_code_bits(h) + cbits > 32) h /= 2;
   return h;
 }
 
 inline int bcsr_band_set_chunks(bcsr_band_storage& out, const std::vector<int>& band_step_host, int target_chunks) {
   out.target_chunks = target_chunks > 0 ? target_chunks : rowband_target_chunks(out.B, out.cus);
+  if (target_chunks <= 0 && out.target_chunks == out.B && out.B > 0) {
+    // one chunk per band is right while the bands are about equally long; a band of more than twice the mean (hub block-rows) is
+    // cut into pieces of at most that: 64 hub block-rows of 16 384 blocks among 2^17 of 8 -- 56 us uncut (the bands that hold a hub
+    // run five times as long as the others), 32 us with equal chunks (tests/perf/exp_bcsr_band_hubs.py)
+    const long long total = band_step_host[static_cast<std::size_t>(out.B)];
+    const long long cap = std::max<long long>(2 * ((total + out.B - 1) / out.B), 1);
+    long long extra = 0;
+    for (int b = 0; b < out.B; ++b) {
+      const long long n = band_step_host[static_cast<std::size_t>(b) + 1] - band_step_host[static_cast<std::size_t>(b)];
+      if (n > cap) extra += (n + cap - 1) / cap - 1;
+    }
+    out.target_chunks += static_cast<int>(std::min<long long>(extra, 1 << 20));
+  }
   std::vector<int> chunks, multi;
   rowband_chunk_list(band_step_host, out.B, out.target_chunks, chunks, multi, out.num_partials);
   out.num_chunks = static_cast<int>(chunks.size() / 4);
@@ -383,7 +429,7 @@ inline int bcsr_band_create(hipStream_t stream, int rows, int num_block_rows, in
   if (out.HB < bb::min_band_block_rows || out.HB > bb::max_band_block_rows || (out.HB & (out.HB - 1))) return rowband_e_badarg;
   int hshift = 0;
   while ((1 << hshift) < out.HB) ++hshift;
-  if (hshift + 1 + cbits > 32) return rowband_e_range;
+  if (bb::row_code_bits(out.HB) + cbits > 32) return rowband_e_range;
   out.B = num_block_rows > 0 ? (num_block_rows + out.HB - 1) / out.HB : 0;
   out.steps = out.num_chunks = out.num_partials = out.num_multi = 0;
   if (num_block_rows == 0) return 0;
@@ -406,7 +452,8 @@ inline int bcsr_band_create(hipStream_t stream, int rows, int num_block_rows, in
   const std::size_t cub_bytes_total = up(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
   const std::size_t key_bytes = up((static_cast<std::size_t>(nb) + 1) * (wide ? 8 : 4)), item_bytes = up((static_cast<std::size_t>(nb) + 1) * 4);
   const std::size_t rin_bytes = up((static_cast<std::size_t>(nb) + 1) * 2), band_bytes = up((static_cast<std::size_t>(B) + 1) * 4);
-  const std::size_t temp_bytes = 2 * key_bytes + 2 * item_bytes + rin_bytes + 2 * band_bytes + 256 + cub_bytes_total;
+  const std::size_t hub_bytes = up((static_cast<std::size_t>(num_block_rows) + 1) * 2);
+  const std::size_t temp_bytes = 2 * key_bytes + 2 * item_bytes + rin_bytes + hub_bytes + 2 * band_bytes + 256 + cub_bytes_total;
   char* base = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), temp_bytes);
   struct guard_t {
@@ -421,21 +468,27 @@ inline int bcsr_band_create(hipStream_t stream, int rows, int num_block_rows, in
   int* item_in = reinterpret_cast<int*>(carve(item_bytes));
   int* item_out = reinterpret_cast<int*>(carve(item_bytes));
   auto* rin = reinterpret_cast<unsigned short*>(carve(rin_bytes));
+  auto* hubidx = reinterpret_cast<short*>(carve(hub_bytes));
   int* band_start = reinterpret_cast<int*>(carve(band_bytes));
   int* steps_of = reinterpret_cast<int*>(carve(band_bytes));
   int* bad = reinterpret_cast<int*>(carve(256));
   void* cub_temp = carve(cub_bytes_total);
   std::size_t cub_bytes = cub_bytes_total;
 
-  e = hipMemsetAsync(bad, 0, sizeof(int), stream);
+  const std::size_t hubs_n = static_cast<std::size_t>(B) * (bb::max_hubs + 1);
+  e = hipMalloc(reinterpret_cast<void**>(&out.hubs), sizeof(unsigned short) * hubs_n);
+  if (e == hipSuccess) e = hipMemsetAsync(out.hubs, 0, sizeof(unsigned short) * hubs_n, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int), stream);
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  // hub block-rows per band (rowband's kernel over the block offsets: a block-row holding >= 1 / 32 of its band's blocks)
+  hipLaunchKernelGGL((rowband::find_hubs<int>), dim3(B), dim3(256), 0, stream, block_offsets, num_block_rows, out.HB, hubidx, out.hubs, bb::hub_share_div);
   auto sorted_phase = [&](auto key_tag) -> hipError_t {
     using key_t = decltype(key_tag);
     auto* kin = static_cast<key_t*>(keys_in);
     auto* kout = static_cast<key_t*>(keys_out);
     if (nb > 0) {
-      hipLaunchKernelGGL((bb::make_keys<key_t>), dim3(math::ceil_div(nb, 256)), dim3(256), 0, stream, block_offsets, block_cols, num_block_rows, nb,
-                         hshift, cbits, num_block_cols, kin, item_in, rin, bad);
+      hipLaunchKernelGGL((bb::make_keys<key_t>), dim3(math::ceil_div(nb, 256)), dim3(256), 0, stream, block_offsets, block_cols, hubidx, num_block_rows,
+                         nb, hshift, cbits, num_block_cols, kin, item_in, rin, bad);
       const hipError_t se = hipcub::DeviceRadixSort::SortPairs(cub_temp, cub_bytes, kin, kout, item_in, item_out, nb, 0, cbits + bbits, stream);
       if (se != hipSuccess) return se;
     }
@@ -468,15 +521,27 @@ inline int bcsr_band_create(hipStream_t stream, int rows, int num_block_rows, in
     const dim3 grid(static_cast<unsigned int>((static_cast<long long>(nb) * 4 + 255) / 256));
     if (wide)
       hipLaunchKernelGGL((bb::place<unsigned long long>), grid, dim3(256), 0, stream, static_cast<const unsigned long long*>(keys_out), item_out, rin,
-                         band_start, out.band_step, values, nb, cbits, out.val, out.meta, out.perm);
+                         band_start, out.band_step, values, nb, cbits, out.HB, out.val, out.meta, out.perm);
     else
       hipLaunchKernelGGL((bb::place<unsigned int>), grid, dim3(256), 0, stream, static_cast<const unsigned int*>(keys_out), item_out, rin, band_start,
-                         out.band_step, values, nb, cbits, out.val, out.meta, out.perm);
+                         out.band_step, values, nb, cbits, out.HB, out.val, out.meta, out.perm);
   }
   e = hipStreamSynchronize(stream);
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = static_cast<hipError_t>(bcsr_band_set_chunks(out, bs, target_chunks));
   if (e != hipSuccess) { out.release(); return static_cast<int>(e); }
+  if (band_block_rows == 0 && target_chunks == 0 && out.B > 0) {
+    // Automatic height, one band per CU -- right while the bands are about equally long.  When some band is more than twice the
+    // mean (hub block-rows), equal CHUNKS of the tallest band balance better than whole bands of unequal length: the same matrix
+    // again at the tallest height the words allow, cut into one round of chunks (64 hubs of 16 384 blocks among 2^17 block-rows
+    // of 8: 47.8 us at the uncut height with its long bands cut, 31.4 us tall; tests/perf/exp_bcsr_band_hubs.py)
+    long long longest = 0;
+    for (int b = 0; b < out.B; ++b) longest = std::max<long long>(longest, bs[static_cast<std::size_t>(b) + 1] - bs[static_cast<std::size_t>(b)]);
+    int tall = bb::max_band_block_rows;
+    while (tall > bb::min_band_block_rows && bb::row_code_bits(tall) + cbits > 32) tall /= 2;
+    if (longest * out.B > 2 * static_cast<long long>(bs[static_cast<std::size_t>(B)]) && tall > out.HB)
+      return bcsr_band_create(stream, rows, num_block_rows, num_block_cols, num_blocks, block_offsets, block_cols, values, tall, 0, out);
+  }
   return 0;
 }
 
@@ -491,7 +556,8 @@ inline void launch_accumulate(hipStream_t stream, const bcsr_band_view& m, const
     static const hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)opted;
   }
-  hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(WAVES * wave::size), lds, stream, m.chunks, m.val, m.meta, x, m.HB, m.cbits, m.rows, m.partial, out);
+  hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(WAVES * wave::size), lds, stream, m.chunks, m.val, m.meta, m.hubs, x, m.HB, m.cbits, m.rows, m.partial,
+                     out);
 }
 }  // namespace bcsr_band
 

@@ -301,22 +301,23 @@ rowband_combine_wide(const int* __restrict__ multi, const type_t* __restrict__ p
 /// A row is a HUB of its band when it holds at least hub_threshold(items of the band) nonzeros: with a share p of the band's
 /// items, 64 p lanes of every update instruction meet in its accumulator and the LDS serialises them (C2: stream + updates
 /// 25-30 us with uniform row lengths, 37-40 us with its power-law rows).
-__host__ __device__ constexpr int hub_threshold(long long band_items) {
-  return band_items / 128 > 64 ? static_cast<int>(band_items / 128) : 64;
+__host__ __device__ constexpr int hub_threshold(long long band_items, int share_div = 128) {
+  return band_items / share_div > 64 ? static_cast<int>(band_items / share_div) : 64;
 }
 
 /// One workgroup per band: the first max_hubs rows (in row order) that reach the band's hub threshold.
 /// hubidx[row] = the row's hub number inside its band, or -1; hubs[b * (max_hubs + 1)] = count, then the rows inside the band.
 template <typename offset_t>
 __global__ void __launch_bounds__(256)
-find_hubs(const offset_t* __restrict__ offsets, const int rows, const int H, short* __restrict__ hubidx, unsigned short* __restrict__ hubs) {
+find_hubs(const offset_t* __restrict__ offsets, const int rows, const int H, short* __restrict__ hubidx, unsigned short* __restrict__ hubs,
+          const int share_div = 128) {
   using scan_t = hipcub::BlockScan<int, 256>;
   __shared__ typename scan_t::TempStorage temp;
   __shared__ int carry;
   const int b = blockIdx.x;
   const long long row0 = static_cast<long long>(b) * H;
   const int n = rows - row0 < H ? static_cast<int>(rows - row0) : H;
-  const int threshold = hub_threshold(static_cast<long long>(offsets[row0 + n]) - static_cast<long long>(offsets[row0]));
+  const int threshold = hub_threshold(static_cast<long long>(offsets[row0 + n]) - static_cast<long long>(offsets[row0]), share_div);
   unsigned short* hb = hubs + static_cast<long long>(b) * (max_hubs + 1);
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();

@@ -232,9 +232,11 @@ int loops_spmv_bcsr_f64(int R, int C, int mode, int rows, int num_block_rows, in
  * fit one 32-bit word at the band height asked for.
  * loops_bcsr_band_plan_info: info10 = {HB, bands, column bits, steps of 16 blocks, chunks, partial vectors, cut bands,
  * wavefronts per workgroup, steps per batch, non-temporal streams}.  loops_bcsr_band_plan_arrays: HOST copies (any pointer may
- * be NULL): values [steps * 256], words [steps * 16] = (block-row inside the band << column bits) | block column (padding:
- * row code HB), perm [steps * 16] = BCSR position of the slot's block or -1, chunks [n * 4] = {band, first step, end step,
- * partial slot or -1}, multi [m * 3] = {band, first partial slot, chunks}.  _set_chunks re-cuts the bands of a built plan;
+ * be NULL): values [steps * 256], words [steps * 16] = (row code << column bits) | block column -- row code = the block-row inside
+ * the band; HB for padding; HB + 1 + 16 hub + (slot mod 16) for a block of the band's hub number `hub` (a block-row holding >= 1 / 32
+ * of its band's blocks, at least 64: its blocks are spread over 16 replicated accumulator groups) --, perm [steps * 16] = BCSR
+ * position of the slot's block or -1, chunks [n * 4] = {band, first step, end step, partial slot or -1}, multi [m * 3] = {band,
+ * first partial slot, chunks}, hubs [bands * 33] = per band the number of hubs (<= 32), then their block-rows inside the band.  _set_chunks re-cuts the bands of a built plan;
  * _tune times every compiled kernel shape (ms12, may be NULL: (waves 8 | 16) x (steps 1 | 2 | 4) x (plain | non-temporal), in ms)
  * and keeps the fastest; _set_shape sets one.  One plan per stream for concurrent products (the plan owns its partial vectors). */
 typedef struct loops_bcsr_band_plan loops_bcsr_band_plan_t;
@@ -243,7 +245,8 @@ int loops_bcsr_band_plan_create_f32(int rows, int num_block_rows, int num_block_
                                     void* stream, loops_bcsr_band_plan_t** out);
 void loops_bcsr_band_plan_destroy(loops_bcsr_band_plan_t* plan);
 int loops_bcsr_band_plan_info(const loops_bcsr_band_plan_t* plan, int* info10);
-int loops_bcsr_band_plan_arrays(const loops_bcsr_band_plan_t* plan, float* values, unsigned int* words, int* perm, int* chunks, int* multi);
+int loops_bcsr_band_plan_arrays(const loops_bcsr_band_plan_t* plan, float* values, unsigned int* words, int* perm, int* chunks, int* multi,
+                                unsigned short* hubs);
 int loops_bcsr_band_plan_set_chunks(loops_bcsr_band_plan_t* plan, int target_chunks);
 int loops_bcsr_band_plan_tune(loops_bcsr_band_plan_t* plan, int repeats, float* ms12, void* stream);
 int loops_bcsr_band_plan_set_shape(loops_bcsr_band_plan_t* plan, int waves, int unroll, int nt);

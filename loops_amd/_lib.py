@@ -229,7 +229,7 @@ def lib() -> C.CDLL:
         L.loops_bcsr_band_plan_destroy.argtypes = [vp]
         L.loops_bcsr_band_plan_destroy.restype = None
         L.loops_bcsr_band_plan_info.argtypes = [vp, vp]
-        L.loops_bcsr_band_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.loops_bcsr_band_plan_arrays.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.loops_bcsr_band_plan_set_chunks.argtypes = [vp, ci]
         L.loops_bcsr_band_plan_tune.argtypes = [vp, ci, vp, vp]
         L.loops_bcsr_band_plan_set_shape.argtypes = [vp, ci, ci, ci]

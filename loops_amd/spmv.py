@@ -625,12 +625,13 @@ class BCSRBandPlan:
         self._read_info()
 
     def arrays(self):
-        """(values [slots, 4, 4], words, perm, chunks [n, 4], multi [m, 3]) copied to the host."""
+        """(values [slots, 4, 4], words, perm, chunks [n, 4], multi [m, 3], hubs [bands, 33]) copied to the host."""
         val, words, perm = np.zeros((self.slots, 4, 4), np.float32), np.zeros(self.slots, np.uint32), np.zeros(self.slots, np.int32)
         chunks, multi = np.zeros((self.num_chunks, 4), np.int32), np.zeros((self.num_multi, 3), np.int32)
+        hubs = np.zeros((self.num_bands, 33), np.uint16)
         p = lambda a: a.ctypes.data_as(C.c_void_p) if a.size else None  # noqa: E731
-        L.check(L.lib().loops_bcsr_band_plan_arrays(self._h, p(val), p(words), p(perm), p(chunks), p(multi)), "loops_bcsr_band_plan_arrays")
-        return val, words, perm, chunks, multi
+        L.check(L.lib().loops_bcsr_band_plan_arrays(self._h, p(val), p(words), p(perm), p(chunks), p(multi), p(hubs)), "loops_bcsr_band_plan_arrays")
+        return val, words, perm, chunks, multi, hubs
 
     def refresh_values(self, values: torch.Tensor):
         assert values.dtype == torch.float32 and values.numel() == self.num_blocks * 16

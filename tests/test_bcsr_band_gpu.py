@@ -35,6 +35,7 @@ CASES = {
     "one_long_row": (65, 4096, lambda r: np.concatenate([[3000], r.integers(0, 5, size=64)])),
     "empty_bands": (400, 300, lambda r: np.concatenate([np.zeros(130, np.int64), r.integers(1, 9, size=70), np.zeros(200, np.int64)])),
     "one_block_row": (1, 64, lambda r: np.array([40])),
+    "hub_block_rows": (600, 2000, lambda r: np.concatenate([[1900, 3, 1500], r.integers(0, 6, size=296), [1200], r.integers(0, 6, size=300)])),
 }
 
 
@@ -68,27 +69,48 @@ def test_product_matches_oracle_and_block_product(name):
         plan.close()
 
 
+def _hubs_of(lens, hb):
+    """numpy restatement of the hub rule: per band the first 32 block-rows (in order) holding >= max(64, band blocks // 32) blocks."""
+    nbr = lens.size
+    out = {}
+    for band in range(-(-nbr // hb)):
+        mine = lens[band * hb:(band + 1) * hb]
+        threshold = max(64, int(mine.sum()) // 32)
+        out[band] = [int(r) for r in np.nonzero(mine >= threshold)[0][:32]]
+    return out
+
+
 def test_layout_arrays_follow_the_documented_order():
-    """values / words / perm against a numpy restatement: blocks sorted by (band, block column, BCSR position), every band padded
-    to whole steps of 16 blocks with zero cells, row code HB, column 0, perm -1; the work list covers every step once."""
+    """values / words / perm / hubs against a numpy restatement: blocks sorted by (band, block column, BCSR position), every band
+    padded to whole steps of 16 blocks with zero cells, row code HB, column 0, perm -1; hub block-rows coded as replicas picked by the
+    slot's place in its step; the work list covers every step once."""
     from loops_amd import spmv as S
     nbr, nbc = 500, 700
     lens = np.random.default_rng(5).integers(0, 30, size=nbr)
+    lens[[3, 130, 131, 499]] = [400, 300, 90, 250]                                # hub block-rows (and one just below a band's threshold)
     boff, bcols, bvals, _ = _blocks(nbr, nbc, lens, seed=11)
     b = _device(boff, bcols, bvals, nbr * 4, nbc)
     for hb, chunks in ((64, 0), (16, 40), (128, 300)):
         plan = S.BCSRBandPlan(b, band_block_rows=hb, target_chunks=chunks)
-        val, words, perm, chunk_list, multi = plan.arrays()
+        val, words, perm, chunk_list, multi, hubs = plan.arrays()
+        want_hubs = _hubs_of(lens, hb)
+        assert any(want_hubs.values())
         br_of = np.repeat(np.arange(nbr), np.diff(boff))
         order = np.lexsort((np.arange(bcols.size), bcols, br_of // hb))
         cmask = (1 << plan.cbits) - 1
         at = 0
         for band in range(plan.num_bands):
+            assert hubs[band, 0] == len(want_hubs[band]) and list(hubs[band, 1:1 + hubs[band, 0]]) == want_hubs[band], band
             mine = order[br_of[order] // hb == band]
             n = mine.size
             assert np.array_equal(perm[at:at + n], mine)
             assert np.array_equal(words[at:at + n] & cmask, bcols[mine])
-            assert np.array_equal(words[at:at + n] >> plan.cbits, br_of[mine] % hb)
+            rows_in = br_of[mine] % hb
+            code = rows_in.copy()
+            for k, hub_row in enumerate(want_hubs[band]):
+                sel = rows_in == hub_row
+                code[sel] = hb + 1 + 16 * k + (at + np.nonzero(sel)[0]) % 16
+            assert np.array_equal(words[at:at + n] >> plan.cbits, code)
             assert np.array_equal(val[at:at + n].reshape(n, 16), bvals.reshape(-1, 16)[mine])
             padded = -(-n // 16) * 16
             assert np.all(perm[at + n:at + padded] == -1) and np.all(words[at + n:at + padded] == (hb << plan.cbits))
