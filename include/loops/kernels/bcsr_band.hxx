@@ -547,14 +547,14 @@ inline int bcsr_band_create(hipStream_t stream, int rows, int num_block_rows, in
 
 namespace bcsr_band {
 /// One launch of kernel A in shape <WAVES, U, NT>.  Bands taller than 64 KB of accumulators need the kernel opted into the
-/// large LDS: once per instantiation, not per launch.
+/// large LDS: once per instantiation and device, not per launch.
 template <int WAVES, int U, bool NT, typename store_t>
 inline void launch_accumulate(hipStream_t stream, const bcsr_band_view& m, const float* x, const store_t out) {
   const std::size_t lds = static_cast<std::size_t>(lds_words(m.HB)) * sizeof(double);
   auto* kernel = bcsr_band_accumulate<WAVES, U, NT, store_t>;
   if (lds > 65536) {
-    static const hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)opted;
+    static unsigned long long opted_devices = 0;  // (one per instantiation of this function template)
+    kernels::detail::allow_large_lds(reinterpret_cast<const void*>(kernel), opted_devices);
   }
   hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(WAVES * wave::size), lds, stream, m.chunks, m.val, m.meta, m.hubs, x, m.HB, m.cbits, m.rows, m.partial,
                      out);

@@ -907,6 +907,19 @@ int rowband_create(hipStream_t stream, int rows, int cols, int nnz, const offset
                                                                             out);
 }
 
+namespace detail {
+/// Opts `kernel` into the 160 KB LDS of a CU once per device: `done` is the calling instantiation's own static mask of the devices
+/// already served (function attributes are per device; a process may drive several).  Not synchronised: two host threads may both
+/// set the attribute, which is harmless.
+inline void allow_large_lds(const void* kernel, unsigned long long& done) {
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  if (known && ((done >> dev) & 1ull)) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (known) done |= 1ull << dev;
+}
+}  // namespace detail
+
 /// Kernel B's launch: the rows of `num_multi` cut bands of H rows each (`multi` = {band, first partial slot, chunks} per band).
 /// One thread per group of 4 rows while no band is cut into more than a handful of chunks, 4 or 16 threads beyond.  The band
 /// index is the grid's y dimension (at most 65 535 per launch: longer lists go out in slabs).
@@ -948,9 +961,9 @@ int launch_rowband_to(hipStream_t stream, const rowband_view<type_t>& m, const t
       constexpr int W = decltype(w_tag)::value;
       constexpr bool NT = decltype(nt_tag)::value;
       auto* kernel = rowband::rowband_accumulate<W, 1, NT, type_t, store_t>;
-      if (lds > 65536) {  // opt into the large LDS once per instantiation (this lambda body is instantiated per <W, NT>), not per launch
-        static const hipError_t opted = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)opted;
+      if (lds > 65536) {  // opt into the large LDS once per instantiation (this lambda body is instantiated per <W, NT>) and device, not per launch
+        static unsigned long long opted_devices = 0;
+        detail::allow_large_lds(reinterpret_cast<const void*>(kernel), opted_devices);
       }
       hipLaunchKernelGGL(kernel, dim3(m.num_chunks), dim3(W * wave::size), lds, stream, m.chunks, m.val, m.meta, m.stepbase, m.hubs, x, m.H, m.rows,
                          m.partial, out);
