@@ -388,6 +388,22 @@ inline int bcsr_band_set_chunks(bcsr_band_storage& out, const std::vector<int>& 
   }
   std::vector<int> chunks, multi;
   rowband_chunk_list(band_step_host, out.B, out.target_chunks, chunks, multi, out.num_partials);
+  {
+    // kernel A addresses a chunk's streams with 32-bit byte offsets (1 KB per step): no chunk may pass 2^21 steps.  A cut that
+    // leaves one (an explicit target on an enormous, skewed matrix) is refined until none does.
+    constexpr long long max_chunk_steps = (1ll << 21) - 1;
+    auto longest = [&]() {
+      long long m = 0;
+      for (std::size_t c = 0; c + 3 < chunks.size(); c += 4) m = std::max<long long>(m, static_cast<long long>(chunks[c + 2]) - chunks[c + 1]);
+      return m;
+    };
+    for (int round = 0; round < 8 && longest() > max_chunk_steps; ++round) {
+      const long long total = out.B > 0 ? band_step_host[static_cast<std::size_t>(out.B)] : 0;
+      out.target_chunks = static_cast<int>(std::min<long long>(std::max<long long>(2ll * out.target_chunks, total / (max_chunk_steps / 2) + out.B), 1 << 24));
+      rowband_chunk_list(band_step_host, out.B, out.target_chunks, chunks, multi, out.num_partials);
+    }
+    if (longest() > max_chunk_steps) return rowband_e_range;
+  }
   out.num_chunks = static_cast<int>(chunks.size() / 4);
   out.num_multi = static_cast<int>(multi.size() / 3);
   out.max_pieces = 1;

@@ -43,7 +43,7 @@ for H in ints("RB_H", "8192"):
         assert plan.steps == base.shape[0], (plan.steps, base.shape)
         assert np.array_equal(dhubs, hubs), (dhubs[:2], hubs[:2])
         assert np.array_equal(dv, v) and np.array_equal(dr16, r16) and np.array_equal(dd8, d8) and np.array_equal(dperm, perm) and np.array_equal(dbase, base)
-        ch, mu = spec.chunk_list(bs, plan.num_bands if plan.num_bands >= 256 else 256)
+        ch, mu = spec.chunk_list(bs, plan.num_bands if 2 * plan.num_bands > 256 else 256)
         assert np.array_equal(dchunks[:, :4], ch) and np.array_equal(dmulti, mu), (dchunks[:4], ch[:4])
         checked = True
         print("layout == specification (H %d, steps %d, padding %.2f %%)" % (H, plan.steps, 100.0 * (plan.padded - nnz) / max(nnz, 1)), file=sys.stderr, flush=True)

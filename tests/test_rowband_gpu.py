@@ -46,7 +46,7 @@ def _check_layout(plan, off, idx, val, target_chunks=0):
     assert np.all(v[~real] == 0) and np.all(r16[~real] == plan.H)                                 # inert padding
     assert plan.gap_pads >= int((d8[~real] == 255).sum())                                         # the slots that bridge column gaps (a group's first slot stores delta 0)
     B = plan.num_bands
-    target = target_chunks or (B if B >= _cus() else _cus())
+    target = target_chunks or (B if 2 * B > _cus() else _cus())       # (kernels::rowband_target_chunks)
     ch, mu = spec.chunk_list(bs, target)
     assert np.array_equal(dchunks, ch) and np.array_equal(dmulti, mu)
     assert plan.num_partials == (int(mu[:, 2].sum()) if mu.size else 0)
@@ -349,3 +349,24 @@ def test_f64_spmv_plan_can_hold_the_row_band_copy():
     det = S.SpmvPlan(csr, measure=False, allow_copy=True, deterministic=True)
     assert det.layout == "csr", det.layout
     assert np.array_equal(det.spmv(x).cpu().numpy(), ref)
+
+
+def test_band_count_just_under_the_cu_count_is_left_uncut():
+    """More than half as many bands as compute units: one chunk per band (cutting ONE band of 255 on 256 CUs would buy a partial-vector
+    round trip and a second launch for nothing); half as many or fewer: one round of equal chunks.  The layout still equals the
+    specification and the product the oracle's."""
+    from loops_amd import spmv as S, generate as G
+    from oracle import oracle as O
+    cus = _cus()
+    for bands in (cus - 1, cus // 2 + 1, cus // 2, 3):
+        rows = bands * 64 - 5
+        deg = np.random.default_rng(bands).integers(0, 9, size=rows)
+        off, idx, val = G.csr_from_degrees(deg.astype(np.int64), 5000, seed=bands)
+        csr = _dev(off, idx, val, rows, 5000)
+        plan = S.RowBandPlan(csr, 64, 0)
+        assert plan.num_bands == bands
+        assert (plan.num_chunks == bands and plan.num_partials == 0) if 2 * bands > cus else plan.num_chunks >= min(cus, plan.steps)
+        _check_layout(plan, off, idx, val, 0)
+        xh = G.uniform_distribution_int(5000)
+        assert np.array_equal(plan.spmv(torch.from_numpy(xh).cuda()).cpu().numpy(), O.spmv_f32(off, idx, val, xh))
+        plan.close()
