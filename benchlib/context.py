@@ -80,10 +80,13 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
     nb = int(bcols.size)
     abytes = nb * (16 * 4 + 4) + (nbr + 1) * 4 + nbr * 4 * 4 + nbr * 4 * 4  # SURVEY 8d B_bcsr: 294 649 860
     out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks, fp32 (BASELINE configs[3])", "algorithmic_bytes": abytes}
-    for name, mode in (("mfma", 1), ("thread_per_block_row", 0)):
+    for name, mode in (("mfma", 1), ("thread_per_block_row", 0), ("merge_path_one_shot", 4)):
         ms = timed_ms(torch, lambda: S.bcsr_thread_mapped(b, x, y, mfma=mode), iters)
         out[name] = {"avg_launch_ms": round(ms, 5), "GFLOPs": round(2 * 16 * nb / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
+    out["merge_path_one_shot"]["note"] = ("loops::kernels::bcsr4x4_mfma_merge_path + coordinates + fix-up: the load-balanced one-shot form (equal tiles "
+                                          "of block-row ends + blocks) -- nothing to balance on C4's uniform block-rows; 44 x the MFMA kernel on skewed lengths "
+                                          "(profiles/r06_bcsr_band_c4_experiments.txt, section 7)")
     S.bcsr_thread_mapped(b, x, y, mfma=1)
     out["mfma"]["kernel"] = "loops::kernels::bcsr4x4_mfma_spmv"
     want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)

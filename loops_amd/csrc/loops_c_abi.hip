@@ -33,6 +33,7 @@
 #include <loops/kernels/csc_spmv.hxx>
 #include <loops/kernels/bcsr_spmv.hxx>
 #include <loops/kernels/bcsr_band.hxx>
+#include <loops/kernels/bcsr_merge_path.hxx>
 
 using namespace loops;
 using kernels::coord_t;

@@ -566,7 +566,7 @@ class BCSR:
         return (self.cols + self.C - 1) // self.C
 
 
-BCSR_MODES = {"thread": 0, "mfma": 1, "coalesced": 2, "tuned": 3}
+BCSR_MODES = {"thread": 0, "mfma": 1, "coalesced": 2, "tuned": 3, "merge_path": 4}
 
 
 def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool | int | str = False):

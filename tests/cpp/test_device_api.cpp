@@ -22,6 +22,7 @@
 #include <loops/algorithms/spmv/flat_partitioned.cuh>
 #include <loops/algorithms/spmv/bcsr_thread_mapped.cuh>
 #include <loops/algorithms/spmv/bcsr_band.cuh>
+#include <loops/algorithms/spmv/bcsr_merge_path.cuh>
 #include <loops/algorithms/spmv/coo_thread_mapped.cuh>
 #include <loops/algorithms/spmv/csc_thread_mapped.cuh>
 #include <loops/algorithms/spmv/dia_thread_mapped.cuh>
@@ -148,6 +149,7 @@ static void run_battery() {
         vector_t<T, H> xp(b4.num_block_cols * 4, T(0));
         for (std::size_t i = 0; i < h.cols; ++i) xp[i] = xh[i];
         vector_t<T> xpd(xp);
+        { auto y = vector_t<T>(h.rows, T(7)); algorithms::spmv::bcsr_merge_path(b4, xpd, y); check_y("bcsr_merge_path", m, y, ref); }
         for (int cfg : {0, 1, 2}) {
           algorithms::spmv::bcsr_band_t<int, int> plan(b4, cfg == 0 ? 0 : 16, cfg == 2 ? 5 : 0);
           if (cfg == 2) plan.arrays.waves = 8, plan.arrays.unroll = 4;

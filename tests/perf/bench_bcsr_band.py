@@ -32,6 +32,10 @@ out = {"workload": f"BCSR 4x4, {nbr} block-rows x {per} blocks", "algorithmic_by
 ms = per_launch_ms(lambda: S.bcsr_thread_mapped(b, x, y, mfma=1))
 print(f"bcsr4x4_mfma_spmv (shipped)                     {ms*1e3:7.1f} us  frac {abytes/ms/1e6/8000:.3f}", file=sys.stderr)
 out["mfma_us"] = round(ms * 1e3, 2)
+ms = per_launch_ms(lambda: S.bcsr_thread_mapped(b, x, y, mfma="merge_path"))
+ok = bool(np.array_equal(y.cpu().numpy(), want))
+print(f"bcsr4x4_mfma_merge_path (one-shot, balanced)        {ms*1e3:7.1f} us  frac {abytes/ms/1e6/8000:.3f} exact={ok}", file=sys.stderr)
+out["merge_path_us"] = round(ms * 1e3, 2)
 hbs = [int(t) for t in os.environ.get("BB_HB", "0").split(",")]
 cuts = [int(t) for t in os.environ.get("BB_CHUNKS", "0").split(",")]
 for hb in hbs:

@@ -24,6 +24,9 @@ def ms(fn, iters=30):
     e.record(); torch.cuda.synchronize()
     return a.elapsed_time(e) / iters * 1e3
 print("blocks", bcols.size, "mfma kernel %.1f us" % ms(lambda: S.bcsr_thread_mapped(b, x, y, mfma=1)))
+t = ms(lambda: S.bcsr_thread_mapped(b, x, y, mfma="merge_path"))
+S.bcsr_thread_mapped(b, x, y, mfma="merge_path")
+print("merge-path one-shot kernel %.1f us exact=%s" % (t, bool(np.array_equal(y.cpu().numpy(), want))))
 for hb in (0, 4096):
     plan = S.BCSRBandPlan(b, band_block_rows=hb)
     t = ms(lambda: plan.spmv(x, y))

@@ -58,7 +58,7 @@ def test_every_mode_matches_the_block_product(R, dtype):
             assert np.array_equal(want, O.bcsr_spmv_f32(R, R, rows, boff, bcols, bvals, x)), (name, "oracle")
         b = S.BCSR(R, R, rows, nbc * R, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
         xd = torch.from_numpy(x).cuda()
-        modes = ("thread", "coalesced", "tuned") + EXPLICIT + (("mfma",) if R == 4 and dtype == np.float32 else ())
+        modes = ("thread", "coalesced", "tuned") + EXPLICIT + (("mfma", "merge_path") if R == 4 and dtype == np.float32 else ())
         for mode in modes:
             y = torch.full((rows + R,), 7.0, dtype=xd.dtype, device="cuda")   # rows >= `rows` must stay untouched
             S.bcsr_thread_mapped(b, xd, y, mfma=mode)
@@ -130,3 +130,30 @@ def test_real_valued_blocks_within_the_fp32_bound():
         for mode in ("thread", "tuned"):
             got = S.bcsr_thread_mapped(b, torch.from_numpy(x).cuda(), mfma=mode).cpu().numpy().astype(np.float64)
             assert np.all(np.abs(got - y64.ravel()) <= 2e-6 * l1.ravel() + 1e-30), (R, mode)
+
+
+def test_merge_path_bcsr_on_skewed_block_rows():
+    """The merge-path form of the 4 x 4 fp32 product (loops_spmv_bcsr_f32 mode 4, kernels/bcsr_merge_path.hxx): block-rows of several
+    tiles (carry-outs across many tiles), hub block-rows next to empty ones, tiles that hold a thousand short block-rows, a matrix
+    that ends in a hub; bit-exact against the block product; rows past `rows` untouched; repeated calls share the per-stream scratch."""
+    from loops_amd import spmv as S
+    rng = np.random.default_rng(12)
+    cases = {
+        "hubs": np.concatenate([[5000], rng.integers(0, 4, size=300), [0] * 40, [9000, 2500], rng.integers(0, 9, size=2000), [7000]]),
+        "short": rng.integers(0, 2, size=6000),
+        "empty_front": np.concatenate([np.zeros(1500, np.int64), [3000], np.zeros(1500, np.int64)]),
+        "one_tile": np.array([3, 0, 5]),
+    }
+    for name, lens in cases.items():
+        nbr, nbc = lens.size, 12000
+        boff, bcols, bvals, x = _blocks(4, nbr, nbc, lens, seed=len(name), dtype=np.float32)
+        rows = nbr * 4 - 2
+        want = _numpy_product(4, rows, boff, bcols, bvals, x)
+        b = S.BCSR(4, 4, rows, nbc * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+        xd = torch.from_numpy(x).cuda()
+        for _ in range(3):
+            y = torch.full((rows + 4,), 7.0, device="cuda")
+            S.bcsr_thread_mapped(b, xd, y, mfma="merge_path")
+            got = y.cpu().numpy()
+            assert np.array_equal(got[:rows], want), name
+            assert np.all(got[rows:] == 7.0), name
