@@ -142,7 +142,24 @@ def round6():
         plan.set_shape(*shape)
         soak("c4", "block_band " + label, lambda y: (plan.spmv(x4, y), None)[1], ref4, nbr * 4)
         plan.close()
+    soak("c4", "bcsr merge-path one-shot (mode 4)", lambda y: (S.bcsr_thread_mapped(b, x4, y, mfma="merge_path"), None)[1], ref4, nbr * 4)
     del b
+    rng = np.random.default_rng(3)                                       # 64 hub block-rows of 16 384 blocks among 2^17 of 8
+    nbh = 1 << 17
+    lens = np.full(nbh, 8, np.int64)
+    lens[rng.choice(nbh, size=64, replace=False)] = 16384
+    boffh = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    bcolsh = np.concatenate([np.sort(rng.choice(nbh, size=int(n), replace=False)) for n in lens]).astype(np.int32)
+    bvalsh = (rng.integers(1, 9, size=bcolsh.size * 16) / 8.0).astype(np.float32)
+    xhh = G.uniform_distribution_int(nbh * 4)
+    refh = torch.from_numpy(O.bcsr_spmv_f32(4, 4, nbh * 4, boffh, bcolsh, bvalsh, xhh)).cuda()
+    bh = S.BCSR(4, 4, nbh * 4, nbh * 4, torch.from_numpy(boffh).cuda(), torch.from_numpy(bcolsh).cuda(), torch.from_numpy(bvalsh).cuda())
+    xh4 = torch.from_numpy(xhh).cuda()
+    soak("hubs", "bcsr merge-path one-shot, hub block-rows", lambda y: (S.bcsr_thread_mapped(bh, xh4, y, mfma="merge_path"), None)[1], refh, nbh * 4)
+    planh = S.BCSRBandPlan(bh)
+    soak("hubs", f"block_band automatic (HB {planh.HB}, {planh.num_chunks} chunks, replicas)", lambda y: (planh.spmv(xh4, y), None)[1], refh, nbh * 4)
+    planh.close()
+    del bh
     off, idx, val = G.rmat_csr(20, 16, relabel="none")
     xh = G.uniform_distribution_int(cols)
     x = torch.from_numpy(xh).cuda()
