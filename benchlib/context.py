@@ -84,8 +84,8 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
         ms = timed_ms(torch, lambda: S.bcsr_thread_mapped(b, x, y, mfma=mode), iters)
         out[name] = {"avg_launch_ms": round(ms, 5), "GFLOPs": round(2 * 16 * nb / ms / 1e6, 1), "achieved_GBps": round(abytes / ms / 1e6, 1),
                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4)}
-    out["merge_path_one_shot"]["note"] = ("loops::kernels::bcsr4x4_mfma_merge_path + coordinates + fix-up: the load-balanced one-shot form (equal tiles "
-                                          "of block-row ends + blocks) -- nothing to balance on C4's uniform block-rows; 44 x the MFMA kernel on skewed lengths "
+    out["merge_path_one_shot"]["note"] = ("loops::kernels::bcsr4x4_mfma_merge_path + fix-up: the load-balanced one-shot form (equal tiles "
+                                          "of block-row ends + blocks) -- nothing to balance on C4's uniform block-rows; 47 x the MFMA kernel on skewed lengths "
                                           "(profiles/r06_bcsr_band_c4_experiments.txt, section 7)")
     S.bcsr_thread_mapped(b, x, y, mfma=1)
     out["mfma"]["kernel"] = "loops::kernels::bcsr4x4_mfma_spmv"

@@ -3,7 +3,7 @@
  * @brief `algorithms::spmv::bcsr_merge_path(bcsr, x, y, stream) -> util::timer_t`: the product of
  * `bcsr_thread_mapped<4, 4>` (reference algorithms/spmv/bcsr_thread_mapped.cuh:36-123) on the merge-path schedule -- equal tiles
  * of (block-row ends, blocks), so that a block-row of any length is shared among workgroups (kernels/bcsr_merge_path.hxx).  For
- * BCSR matrices whose block-row lengths are skewed (64 block-rows of 16 384 blocks among 2^17 short ones: 42 us against 1.8 ms
+ * BCSR matrices whose block-row lengths are skewed (64 block-rows of 16 384 blocks among 2^17 short ones: 39 us against 1.8 ms
  * from the thread_mapped kernels); where the lengths are uniform `bcsr_thread_mapped` is ~20 % faster.  4 x 4 fp32 blocks, int
  * indices; x padded to 4 * num_block_cols; y needs no zero-fill.  No reference counterpart.
  */

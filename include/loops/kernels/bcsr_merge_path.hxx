@@ -7,8 +7,8 @@
  * `bcsr4x4_mfma_spmv` -- so a block-row of 16 384 blocks is walked by that owner alone: 64 such block-rows among 2^17 short ones
  * cost 1.83 ms (tests/perf/exp_bcsr_band_hubs.py), a cliff of the kind merge_path_flat exists to remove for CSR.  Here the merge
  * path of (block-row ends, blocks) is cut into equal tiles exactly as merge_path_flat cuts (row ends, nonzeros)
- * (schedule/merge_path_flat.hxx:45-76; the same coordinate pre-pass, `merge_path_coordinates_of` over `block_offsets`), one
- * workgroup per tile:
+ * (schedule/merge_path_flat.hxx:45-76; the same split of diagonal t * TILE over `block_offsets`, found inside the tile kernel by a
+ * 64-ary search per wavefront instead of a pre-pass launch), one workgroup per tile:
  *   - the tile's block-row ends go to LDS, 4 fp64 sums per block-row of the tile are zeroed in LDS;
  *   - the tile's blocks are streamed 16 at a time per wavefront (1 KB contiguous: lane (q, i) loads row i of block q); the
  *     block-row of a block is found by a halving search over the LDS row ends (<= 11 probes); x[4] is gathered per block;
@@ -21,9 +21,9 @@
  * fixed order, rounded to fp32 per tile, carry-outs added in tile order: bit-identical to bcsr_thread_mapped on exactly summable
  * inputs (what the tests pin).
  *
- * Measured (MI355X): 64 hub block-rows of 16 384 blocks among 2^17 of 8 -- 41.6 us against 1 836 us for `bcsr4x4_mfma_spmv`; BASELINE
- * C4 (every block-row 16 blocks: nothing to balance) 84.8 us against 66-70 us -- the search, the LDS sums and two more launches
- * (coordinates, fix-up) cost 20 % where the lengths are uniform.  Hence an explicit entry (`loops_spmv_bcsr_f32` mode 4,
+ * Measured (MI355X): 64 hub block-rows of 16 384 blocks among 2^17 of 8 -- 39 us against 1 840 us for `bcsr4x4_mfma_spmv`; BASELINE
+ * C4 (every block-row 16 blocks: nothing to balance) 81.5 us against 66-70 us -- the search, the LDS sums and the tile set-up (its coordinates by a 64-ary
+ * search, row ends, zeroing) and the fix-up launch cost 20 % where the lengths are uniform.  Hence an explicit entry (`loops_spmv_bcsr_f32` mode 4,
  * `algorithms::spmv::bcsr_merge_path`), not what the thread_mapped wrapper launches; callers that multiply one matrix many times
  * hold a block-band plan (bcsr_band.hxx: 56 us on C4, 31 us on the hub case).
  */
@@ -43,7 +43,8 @@ namespace kernels {
 
 /// Merge items (block-row ends + blocks) per tile.  A tile may hold that many block-rows: 4 fp64 sums each + the row ends live in
 /// LDS (36 bytes per item: 1024 -> 37 KB, four workgroups of 8 wavefronts per CU).  Measured on MI355X (C4 / the hub case of
-/// tests/perf/exp_bcsr_band_hubs.py, us): 1024 x 8 wavefronts 84.8 / 41.6, 2048 x 16 86.6 / 42.2, 4096 x 16 103.4 / 51.8; two steps
+/// tests/perf/exp_bcsr_band_hubs.py, us; with the coordinate pre-pass still a launch of its own): 1024 x 8 wavefronts 84.8 / 41.6,
+/// 2048 x 16 86.6 / 42.2, 4096 x 16 103.4 / 51.8; two steps
 /// per batch 10 % slower; without the software pipeline 86.4 / 43.3.
 #ifndef LOOPS_BCSR_MERGE_TILE  // (tuning builds only)
 #define LOOPS_BCSR_MERGE_TILE 1024
@@ -59,10 +60,10 @@ constexpr int bcsr_merge_tile = LOOPS_BCSR_MERGE_TILE;
 inline int bcsr_merge_tiles(int num_block_rows, int num_blocks) {
   return static_cast<int>((static_cast<long long>(num_block_rows) + num_blocks + bcsr_merge_tile - 1) / bcsr_merge_tile);
 }
-/// Scratch of one product: coordinates [M + 1], carry rows [M], carry values [4 M].
+/// Scratch of one product: carry values [4 M], carry rows [M].
 inline std::size_t bcsr_merge_scratch_bytes(int num_block_rows, int num_blocks) {
   const std::size_t m = static_cast<std::size_t>(bcsr_merge_tiles(num_block_rows, num_blocks));
-  return sizeof(coord_t) * (m + 1) + sizeof(int) * m + sizeof(float) * 4 * m + 64;
+  return sizeof(int) * m + sizeof(float) * 4 * m + 64;
 }
 /// Dynamic LDS of the tile kernel: the row ends, then the sums of the tile's block-rows, of the open one and a dump group.
 constexpr std::size_t bcsr_merge_lds_bytes(int tile) { return sizeof(double) * 4 * (static_cast<std::size_t>(tile) + 2) + sizeof(int) * static_cast<std::size_t>(tile); }
@@ -72,12 +73,13 @@ constexpr std::size_t bcsr_merge_lds_bytes(int tile) { return sizeof(double) * 4
 /// reads zeros: buffer semantics) -- the block-band kernel with the block-row of a block found by a search instead of read off a word.
 template <int TILE, int WAVES, int U>
 __global__ void __launch_bounds__(WAVES * wave::size)
-bcsr4x4_mfma_merge_path(const coord_t* __restrict__ coords, const int rows, const int num_block_rows, const int* __restrict__ block_offsets,
+bcsr4x4_mfma_merge_path(const int rows, const int num_block_rows, const int num_blocks, const int* __restrict__ block_offsets,
                         const int* __restrict__ block_cols, const float* __restrict__ values, const float* __restrict__ x, float* __restrict__ y,
                         int* __restrict__ carry_row, float* __restrict__ carry_val) {
   using f32x4 = float __attribute__((ext_vector_type(4)));
   using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
   constexpr int TPB = WAVES * wave::size;
+  static_assert(WAVES >= 2, "two wavefronts split the tile's two diagonals");
   extern __shared__ __attribute__((aligned(16))) unsigned char bcsr_merge_lds[];
   double* s_acc = reinterpret_cast<double*>(bcsr_merge_lds);                   // [4 (TILE + 2)]
   int* s_re = reinterpret_cast<int*>(bcsr_merge_lds + sizeof(double) * 4 * (TILE + 2));  // [TILE] end (block index) of block-row row0 + r
@@ -86,9 +88,36 @@ bcsr4x4_mfma_merge_path(const coord_t* __restrict__ coords, const int rows, cons
   const int q = lane >> 2, i = lane & 3;
   const int w = __builtin_amdgcn_readfirstlane(tid / wave::size);
   const int t = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
-  const coord_t c0 = coords[t], c1 = coords[t + 1];
-  const int row0 = static_cast<int>(c0.x), blk0 = static_cast<int>(c0.y);
-  const int nrows = static_cast<int>(c1.x) - row0, nblocks = static_cast<int>(c1.y) - blk0;
+  // The tile's two merge-path coordinates, found HERE: wavefront 0 splits diagonal t * TILE, wavefront 1 diagonal (t + 1) * TILE, each
+  // with a 64-ary search (every lane probes one block-row end, a ballot narrows the range 64-fold: three dependent rounds for 2^18
+  // block-rows instead of eighteen) -- no coordinate pre-pass launch.  Same split as search.hxx / merge_path_coordinates_of.
+  __shared__ int s_split[2];
+  if (w < 2) {
+    const long long dl = static_cast<long long>(t + w) * TILE;
+    const long long total = static_cast<long long>(num_block_rows) + num_blocks;
+    const int d = static_cast<int>(dl < total ? dl : total);
+    int lo = d - num_blocks > 0 ? d - num_blocks : 0;       // the first m in [lo, hi) with block_offsets[m + 1] > d - m - 1, or hi
+    int hi = d < num_block_rows ? d : num_block_rows;
+    while (hi > lo) {
+      const int span = hi - lo;
+      const int step = (span + wave::size - 1) / wave::size;
+      const int m = lo + lane * step;
+      const bool before = m < hi && block_offsets[m + 1] <= d - m - 1;  // (true: the split lies behind m)
+      const unsigned long long votes = __ballot(before);
+      const int trues = __popcll(votes);                               // the predicate is monotone: the trues are lanes 0 .. trues - 1
+      const int new_lo = trues > 0 ? lo + (trues - 1) * step + 1 : lo;
+      const int new_hi = trues < wave::size && lo + trues * step < hi ? lo + trues * step : hi;
+      lo = new_lo;
+      hi = step == 1 ? new_lo : new_hi;                                 // (step 1: every candidate was probed)
+    }
+    if (lane == 0) s_split[w] = lo;
+  }
+  __syncthreads();
+  const long long total_items = static_cast<long long>(num_block_rows) + num_blocks;
+  const long long dl0 = static_cast<long long>(t) * TILE, dl1 = dl0 + TILE;
+  const int d0 = static_cast<int>(dl0 < total_items ? dl0 : total_items), d1 = static_cast<int>(dl1 < total_items ? dl1 : total_items);
+  const int row0 = s_split[0], blk0 = d0 - row0;
+  const int nrows = s_split[1] - row0, nblocks = (d1 - s_split[1]) - blk0;
   for (int r = tid; r < nrows; r += TPB) s_re[r] = block_offsets[row0 + r + 1];
   for (int j = tid; j < 4 * (nrows + 1); j += TPB) s_acc[j] = 0.0;
   if (tid < 4) s_acc[4 * (TILE + 1) + tid] = 0.0;
@@ -196,12 +225,8 @@ inline int launch_bcsr4x4_merge_path(hipStream_t stream, int rows, int num_block
   if (num_blocks == 0) return rows > 0 ? static_cast<int>(hipMemsetAsync(y, 0, sizeof(float) * static_cast<std::size_t>(rows), stream)) : 0;
   const int m = bcsr_merge_tiles(num_block_rows, num_blocks);
   char* p = static_cast<char*>(scratch);
-  coord_t* coords = reinterpret_cast<coord_t*>(p);
-  float* carry_val = reinterpret_cast<float*>(p + sizeof(coord_t) * (static_cast<std::size_t>(m) + 1));
+  float* carry_val = reinterpret_cast<float*>(p);
   int* carry_row = reinterpret_cast<int*>(reinterpret_cast<char*>(carry_val) + sizeof(float) * 4 * static_cast<std::size_t>(m));
-  const int n = m + 1;
-  hipLaunchKernelGGL(merge_path_coordinates_of<csr_row_end<int>>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream, csr_row_end<int>{block_offsets},
-                     num_block_rows, num_blocks, bcsr_merge_tile, m, coords);
   {
     constexpr int W = LOOPS_BCSR_MERGE_WAVES, UU = LOOPS_BCSR_MERGE_U;
     auto* kernel = bcsr4x4_mfma_merge_path<bcsr_merge_tile, W, UU>;
@@ -215,8 +240,8 @@ inline int launch_bcsr4x4_merge_path(hipStream_t stream, int rows, int num_block
         if (known) opted_devices |= 1ull << dev;
       }
     }
-    hipLaunchKernelGGL(kernel, dim3(m), dim3(W * wave::size), lds, stream, coords, rows, num_block_rows, block_offsets, block_cols, values, x, y, carry_row,
-                       carry_val);
+    hipLaunchKernelGGL(kernel, dim3(m), dim3(W * wave::size), lds, stream, rows, num_block_rows, num_blocks, block_offsets, block_cols, values, x, y,
+                       carry_row, carry_val);
   }
   if (m > 1)
     hipLaunchKernelGGL(bcsr_merge_path_fixup, dim3(math::ceil_div(4 * m, 256)), dim3(256), 0, stream, carry_row, carry_val, m, num_block_rows, rows, y);

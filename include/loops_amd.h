@@ -205,8 +205,8 @@ int loops_work_oriented_grid(int* out_blocks);
  * steps in flight.
  * mode 4 (4x4 fp32 only): the MERGE-PATH form (include/loops/kernels/bcsr_merge_path.hxx) -- equal tiles of (block-row ends,
  * blocks), block-row sums in LDS, MFMA block products, 4-wide carry-outs + a fix-up launch; no reference counterpart.  For BCSR
- * with skewed block-row lengths (64 block-rows of 16 384 blocks among 2^17 of 8: 42 us, against 1.8 ms for modes 0-3, which give
- * a block-row to one owner as the reference does); ~20 % slower than mode 1 where the lengths are uniform (C4: 85 against
+ * with skewed block-row lengths (64 block-rows of 16 384 blocks among 2^17 of 8: 39 us, against 1.8 ms for modes 0-3, which give
+ * a block-row to one owner as the reference does); ~20 % slower than mode 1 where the lengths are uniform (C4: 81.5 against
  * 66-70 us).  Uses a per-stream scratch block (loops_release_scratch frees it).
  * mode 0: register accumulation, thread per block-row (the reference's kernel shape); mode 1: MFMA 4x4x1 block inner product
  * (4x4 only), kernel shape picked from the mean blocks per block-row.  Tuning aids: mode 1u = one block
