@@ -30,12 +30,15 @@ void group_mapped(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, ve
                   xpu::stream_t stream = 0) {
   constexpr int block_size = launch_t<type_t>::block_size;
   constexpr int items_per_thread = launch_t<type_t>::items_per_thread;
-  // control words + carry-outs of the shared-out groups: zero-filled scratch of this call (thrust value-initialises)
-  vector_t<unsigned char> scratch(kernels::group_share_scratch_bytes<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), block_size,
-                                                                             items_per_thread));
+  // control words + carry-outs of the shared-out groups: zero-filled scratch of this call (thrust value-initialises), the words of
+  // the column sample behind them (an x of 6 MB or more: plain or phased gathers decided on the device)
+  const std::size_t share_bytes = (kernels::group_share_scratch_bytes<type_t>(static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), block_size,
+                                                                              items_per_thread) + 255) & ~std::size_t(255);
+  vector_t<unsigned char> scratch(share_bytes + kernels::scatter_scratch_words * sizeof(unsigned int));
+  unsigned int* stats = reinterpret_cast<unsigned int*>(scratch.data().get() + share_bytes);
   kernels::launch_group_mapped_shared<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
       stream, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(), csr.indices.data().get(),
-      csr.values.data().get(), x.data().get(), y.data().get(), scratch.data().get());
+      csr.values.data().get(), x.data().get(), y.data().get(), scratch.data().get(), nullptr, static_cast<int>(csr.cols), stats);
   (void)xpu::stream_synchronize(stream);
 }
 

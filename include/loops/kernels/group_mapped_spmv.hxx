@@ -25,6 +25,11 @@
  * Launches 2 and 3 cost ~3 us each when nothing was published; callers that run the same matrix repeatedly can skip them with
  * the reported count (the C ABI's one-shot entry does: abi_csr.inc).
  *
+ * Gather order.  Over an x of 6 MB or more (kernels::columns_worth_sampling, the plan-less merge_path_flat entry's rule) the
+ * launcher puts column_scatter_sample in front and runs the `policy::phased_auto` builds of the same kernels: where the sampled
+ * columns are scattered every workgroup gathers x part by part off the shared clock (merge_tile_engine), otherwise
+ * exactly as before -- decided on the device, same loads in another order, same bits.
+ *
  * Deterministic: a claim's result does not depend on which workgroup ran it, carry-outs are added in claim order.
  * Bit-identical to group_mapped_spmv_fused wherever fp32 sums are exact; otherwise the two differ as merge_path_flat and
  * work_oriented do (a hub row is summed per claim, then across claims).
@@ -33,10 +38,12 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
 #include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/kernels/launch.hxx>
 #include <loops/util/math.hxx>
 
 namespace loops {
@@ -51,14 +58,17 @@ namespace kernels {
 #ifndef LOOPS_GROUP_HEAVY_TILES  // (tuning builds only: tests/perf/bench_group_mapped.py with LOOPS_AMD_LIB)
 #define LOOPS_GROUP_HEAVY_TILES 24
 #endif
-constexpr int group_heavy_tiles = LOOPS_GROUP_HEAVY_TILES;
+constexpr int group_heavy_tiles = LOOPS_GROUP_HEAVY_TILES;  ///< (in tiles of 2 048 items)
 /// Tiles per claim: the open row is carried in a register through `group_claim_tiles` consecutive tiles (one carry-out and one
 /// load of the group's row ends per claim).  A claim is a serial chain of ~5 us per tile: with few claims it IS the second
 /// kernel's duration (4 tiles: 25 us on a matrix that publishes a handful of groups), hence 2.
 #ifndef LOOPS_GROUP_CLAIM_TILES
 #define LOOPS_GROUP_CLAIM_TILES 2
 #endif
-constexpr int group_claim_tiles = LOOPS_GROUP_CLAIM_TILES;
+constexpr int group_claim_tiles = LOOPS_GROUP_CLAIM_TILES;  ///< (in tiles of 2 048 items)
+/// The two thresholds for a tile of `tile` items: the same ITEM counts (and the same scratch layout) whatever the tile shape.
+constexpr int group_heavy_tiles_of(int tile) { return group_heavy_tiles * 2048 / tile > 1 ? group_heavy_tiles * 2048 / tile : 1; }
+constexpr int group_claim_tiles_of(int tile) { return group_claim_tiles * 2048 / tile > 1 ? group_claim_tiles * 2048 / tile : 1; }
 
 /// Control words of one group_mapped call (zero between calls: the fix-up kernel leaves them so).
 struct group_share_ctl {
@@ -78,8 +88,8 @@ struct group_share_layout {
 inline group_share_layout group_share_layout_of(int rows, int nnz, int TPB, int IPT, std::size_t vbytes) {
   group_share_layout l;
   const std::size_t items = static_cast<std::size_t>(rows) + static_cast<std::size_t>(nnz), tile = static_cast<std::size_t>(TPB) * IPT;
-  l.G = items / (tile * group_heavy_tiles) + 1;  // groups that can be heavy
-  l.U = items / (tile * group_claim_tiles) + 2 * l.G + 1;  // (sum of ceil(tiles / claim) over the heavy groups)
+  l.G = items / (tile * group_heavy_tiles_of(static_cast<int>(tile))) + 1;  // groups that can be heavy
+  l.U = items / (tile * group_claim_tiles_of(static_cast<int>(tile))) + 2 * l.G + 1;  // (sum of ceil(tiles / claim) over the heavy groups)
   l.off_rec = 256;
   l.off_val = l.off_rec + sizeof(group_share_rec) * l.G;
   l.off_row = l.off_val + ((vbytes * l.U + 15) & ~std::size_t(15));
@@ -183,7 +193,8 @@ struct group_tiles {
   /// The tiles of diagonals [d_begin, d_end) in sequence, the open row carried in a register.  Returns the partial sum of the
   /// row open at d_end and leaves that row (inside the group; == group_rows when nothing is open) in `open_row`.
   __device__ __forceinline__ type_t run(const int d_begin, const int d_end, const int nnz, const index_t* __restrict__ indices,
-                                        const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y, int& open_row) {
+                                        const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y, int& open_row,
+                                        const detail::phase_args phase = {}) {
     const offset_t* row_end = s.off + 1;
     type_t carry = type_t(0);
     int tx0 = split(d_begin);
@@ -196,7 +207,8 @@ struct group_tiles {
         __syncthreads();
         for (int i = threadIdx.x; i < tx1 - tx0; i += TPB) engine_t::mark_row_end(s.engine, i, static_cast<int>(row_end[tx0 + i]), nz_begin + ty0);
       }
-      carry = engine_t::run(s.engine, row_end + tx0, group_row0 + tx0, nz_begin + ty0, tx1 - tx0, ty1 - ty0, nnz, indices, values, x, y, carry);
+      carry = engine_t::run_to(s.engine, row_end + tx0, group_row0 + tx0, nz_begin + ty0, tx1 - tx0, ty1 - ty0, nnz, indices, values, x,
+                               plain_store<type_t>{y}, carry, typename engine_t::no_marks{}, phase);
       tx0 = tx1;
     }
     open_row = tx0;
@@ -204,14 +216,29 @@ struct group_tiles {
   }
 };
 
-template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t, bool MASK = false>
-__global__ void __launch_bounds__(TPB, (TPB == 256 && sizeof(type_t) == 4 ? 8 : 1))  // (fp32: 64 VGPRs, 8 workgroups per CU, as group_mapped_spmv_fused compiles)
+namespace detail {
+/// policy::phased_auto builds: plain or phased gathers by what column_scatter_sample left in `stats` (merge_path_spmv_fused_auto's rule).
+template <int NT>
+__device__ __forceinline__ phase_args group_phase(const unsigned int* __restrict__ stats, phase_args phase) {
+  if constexpr (policy::phased_is_auto(NT)) {
+    const unsigned int far_same = stats[0], far_seen = stats[1], near_same = stats[2], near_seen = stats[3];
+    phase.enabled = scatter_counts_say_phase(far_same, far_seen, near_same, near_seen, policy::phases(NT)) ? 1u : 0u;
+  }
+  return phase;
+}
+}  // namespace detail
+
+/// SHARE = false: every group swept by its owner (what the one-shot entry launches alone once its memo says the matrix has no
+/// heavy group -- group_mapped_spmv_fused with a choice of gather order).
+template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t, bool MASK = false, bool SHARE = true>
+__global__ void __launch_bounds__(TPB, (TPB == 256 && sizeof(type_t) == 4 && NT == 0 ? 8 : 1))  // (fp32: 64 VGPRs, 8 workgroups per CU, as group_mapped_spmv_fused compiles)
 group_mapped_spmv_publish(const int rows, const int nnz, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                           const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
-                          const group_share_view<type_t> sc) {
+                          const group_share_view<type_t> sc, const unsigned int* __restrict__ stats, detail::phase_args phase) {
   using tiles_t = group_tiles<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t, MASK>;
   __shared__ typename tiles_t::storage_t storage;
   tiles_t gt(storage);
+  phase = detail::group_phase<NT>(stats, phase);
 #ifdef LOOPS_GROUP_CONTIGUOUS  // (tuning builds only)
   const int g = detail::xcd_contiguous(static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x));
 #else
@@ -219,12 +246,13 @@ group_mapped_spmv_publish(const int rows, const int nnz, const offset_t* __restr
 #endif
   gt.load_group(g, rows, offsets);
   const int tiles = gt.tiles();
-  if (tiles <= group_heavy_tiles) {
+  if (!SHARE || tiles <= group_heavy_tiles_of(tiles_t::TILE)) {
     int open_row;
-    (void)gt.run(0, gt.total, nnz, indices, values, x, y, open_row);
+    (void)gt.run(0, gt.total, nnz, indices, values, x, y, open_row, phase);
   } else {
     __shared__ unsigned long long s_got;
-    const int claims = (tiles + group_claim_tiles - 1) / group_claim_tiles;
+    constexpr int per_claim = group_claim_tiles_of(tiles_t::TILE);
+    const int claims = (tiles + per_claim - 1) / per_claim;
     if (threadIdx.x == 0) {
       s_got = atomicAdd(&sc.ctl->packed, (1ull << 32) | static_cast<unsigned long long>(claims));
       sc.rec[s_got >> 32] = group_share_rec{g, static_cast<int>(s_got & 0xFFFFFFFFull), claims, 0};
@@ -236,16 +264,17 @@ group_mapped_spmv_publish(const int rows, const int nnz, const offset_t* __restr
 }
 
 template <int TPB, int IPT, bool PAD, int NT, bool VEC, typename index_t, typename offset_t, typename type_t, bool MASK = false>
-__global__ void __launch_bounds__(TPB, (TPB == 256 && sizeof(type_t) == 4 ? 8 : 1))
+__global__ void __launch_bounds__(TPB, (TPB == 256 && sizeof(type_t) == 4 && NT == 0 ? 8 : 1))
 group_mapped_spmv_claims(const int rows, const int nnz, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
                          const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y,
-                         const group_share_view<type_t> sc) {
+                         const group_share_view<type_t> sc, const unsigned int* __restrict__ stats, detail::phase_args phase) {
   using tiles_t = group_tiles<TPB, IPT, PAD, NT, VEC, index_t, offset_t, type_t, MASK>;
-  constexpr int CLAIM_ITEMS = group_claim_tiles * tiles_t::TILE;
+  constexpr int CLAIM_ITEMS = group_claim_tiles_of(tiles_t::TILE) * tiles_t::TILE;
   __shared__ typename tiles_t::storage_t storage;
   const unsigned long long packed = sc.ctl->packed;
   const int total_claims = static_cast<int>(packed & 0xFFFFFFFFull);
   tiles_t gt(storage);
+  phase = detail::group_phase<NT>(stats, phase);
   int loaded = -1;
   // (a fixed grid strides over the claim numbers: the host does not know how many were handed out, and an upper-bound grid of
   //  workgroups that exit at once still costs ~0.5 us per thousand)
@@ -266,7 +295,7 @@ group_mapped_spmv_claims(const int rows, const int nnz, const offset_t* __restri
     const int d0 = c * CLAIM_ITEMS;
     const int d1 = d0 + CLAIM_ITEMS < gt.total ? d0 + CLAIM_ITEMS : gt.total;
     int open_row;
-    const type_t carry = gt.run(d0, d1, nnz, indices, values, x, y, open_row);
+    const type_t carry = gt.run(d0, d1, nnz, indices, values, x, y, open_row, phase);
     if (threadIdx.x == 0) {
       sc.carry_row[b] = open_row < gt.group_rows ? gt.group_row0 + open_row : rows;  // (`rows`: nothing open -- the group ends with this claim)
       sc.carry_val[b] = carry;
@@ -312,26 +341,51 @@ group_mapped_fixup(const int rows, type_t* __restrict__ y, const group_share_vie
 
 /// Tuned group_mapped with heavy groups shared out (file comment).  `scratch`: group_share_scratch_bytes<T>(rows, nnz, TPB, IPT)
 /// bytes whose first 256 are zero before the first call.  `report` (may be null; device-visible): receives 1 + the number of
-/// groups the call published when its last kernel ends.
+/// groups the call published when its last kernel ends.  `stats` (may be null: plain gathers): kernels::scatter_scratch_words
+/// device words -- with them, and `cols` columns worth asking about, the gather order is decided on the device (file comment).
+/// `share` = false: the publish kernel alone with every group swept by its owner (callers that KNOW the matrix has no heavy group).
 template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_group_mapped_shared(hipStream_t stream, int rows, int nnz, const offset_t* offsets, const index_t* indices, const T* values, const T* x,
-                               T* y, void* scratch, unsigned int* report = nullptr) {
+                               T* y, void* scratch, unsigned int* report = nullptr, int cols = 0, unsigned int* stats = nullptr, bool share = true) {
   if (rows == 0) return 0;
-  const auto sc = group_share_view<T>::carve(scratch, rows, nnz, TPB, IPT);
+  const auto sc = share ? group_share_view<T>::carve(scratch, rows, nnz, TPB, IPT) : group_share_view<T>{};
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
   const dim3 groups(math::ceil_div(rows, TPB)), claims(sc.max_claims < 8192 ? sc.max_claims : 8192), block(TPB);
-  if (aligned) {
-    hipLaunchKernelGGL((group_mapped_spmv_publish<TPB, IPT, PAD, false, true, index_t, offset_t, T, MASK>), groups, block, 0, stream, rows, nnz, offsets,
-                       indices, values, x, y, sc);
-    hipLaunchKernelGGL((group_mapped_spmv_claims<TPB, IPT, PAD, false, true, index_t, offset_t, T, MASK>), claims, block, 0, stream, rows, nnz, offsets,
-                       indices, values, x, y, sc);
+  const bool sampled = aligned && stats && columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), true);
+  auto go = [&](auto publish, auto owner, auto claim, const detail::phase_args ph) {
+    if (!share) {
+      hipLaunchKernelGGL(owner, groups, block, 0, stream, rows, nnz, offsets, indices, values, x, y, sc, stats, ph);
+      return;
+    }
+    hipLaunchKernelGGL(publish, groups, block, 0, stream, rows, nnz, offsets, indices, values, x, y, sc, stats, ph);
+    hipLaunchKernelGGL(claim, claims, block, 0, stream, rows, nnz, offsets, indices, values, x, y, sc, stats, ph);
+  };
+  if (sampled) {
+    const int err = launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), stats);
+    if (err) return err;
+    const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
+    // (tiles of 16 items per lane for 16 / 32 parts, the plan-less merge_path_flat entry's shape, measured here: uniform C3 stand-in
+    //  2.65 against 2.78 ms, but R-MAT 2^23 -- whose sample says "plain" -- 1.44 against 1.385: a group of 256 rows is 1.6 such tiles,
+    //  the second one mostly empty and as many passes long.  One shape, then.)
+    auto with = [&](auto parts) {
+      constexpr int NT = detail::policy::phased_auto(decltype(parts)::value);
+      go(group_mapped_spmv_publish<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK, true>,
+         group_mapped_spmv_publish<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK, false>,
+         group_mapped_spmv_claims<TPB, IPT, PAD, NT, true, index_t, offset_t, T, MASK>, cfg.args);
+    };
+    if (cfg.parts == 8) with(std::integral_constant<int, 8>{});
+    else if (cfg.parts == 16) with(std::integral_constant<int, 16>{});
+    else with(std::integral_constant<int, 32>{});
+  } else if (aligned) {
+    go(group_mapped_spmv_publish<TPB, IPT, PAD, 0, true, index_t, offset_t, T, MASK, true>,
+       group_mapped_spmv_publish<TPB, IPT, PAD, 0, true, index_t, offset_t, T, MASK, false>,
+       group_mapped_spmv_claims<TPB, IPT, PAD, 0, true, index_t, offset_t, T, MASK>, detail::phase_args{});
   } else {
-    hipLaunchKernelGGL((group_mapped_spmv_publish<TPB, IPT, PAD, false, false, index_t, offset_t, T, MASK>), groups, block, 0, stream, rows, nnz, offsets,
-                       indices, values, x, y, sc);
-    hipLaunchKernelGGL((group_mapped_spmv_claims<TPB, IPT, PAD, false, false, index_t, offset_t, T, MASK>), claims, block, 0, stream, rows, nnz, offsets,
-                       indices, values, x, y, sc);
+    go(group_mapped_spmv_publish<TPB, IPT, PAD, 0, false, index_t, offset_t, T, MASK, true>,
+       group_mapped_spmv_publish<TPB, IPT, PAD, 0, false, index_t, offset_t, T, MASK, false>,
+       group_mapped_spmv_claims<TPB, IPT, PAD, 0, false, index_t, offset_t, T, MASK>, detail::phase_args{});
   }
-  hipLaunchKernelGGL((group_mapped_fixup<T>), dim3(64), dim3(256), 0, stream, rows, y, sc, report);
+  if (share) hipLaunchKernelGGL((group_mapped_fixup<T>), dim3(64), dim3(256), 0, stream, rows, y, sc, report);
   return static_cast<int>(hipGetLastError());
 }
 

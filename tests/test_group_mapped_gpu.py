@@ -139,3 +139,34 @@ def test_memo_survives_a_change_of_content_under_the_same_pointers():
             S.spmv("group_mapped", csr, xd, y)
             torch.cuda.synchronize()                                                 # (lets the memo word arrive: the next call reads it)
             assert np.array_equal(y.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("window", [None, 4096])
+@pytest.mark.parametrize("hub", [0, 120_000])
+def test_gather_order_decided_on_the_device(dtype, window, hub):
+    """An x of 6 MB or more and 2^20 nonzeros or more: the launcher samples the columns and runs the builds of the same kernels that
+    gather in phases where the sample says "scattered" (uniform columns) and plainly where it does not (a band of 4 096 columns) --
+    with a heavy group (publish + claims + fix-up) and without (after the first call the memo sends the owner-only launch).
+    Same loads in another order: bit-exact against the oracle either way, call after call."""
+    from loops_amd import generate as G, spmv as S
+    from oracle import oracle as O
+    cols = (1 << 21) + 77 if dtype == np.float32 else (1 << 20) + 77                  # x = 8 MB
+    rows = 60_000
+    rng = np.random.default_rng(5)
+    d = rng.integers(8, 40, size=rows)
+    if hub:
+        d[257] = hub
+    off, idx, val = G.csr_from_degrees(d.astype(np.int64), cols, 11, 0, True, window)
+    assert off[-1] >= 1 << 20
+    val = val.astype(dtype)
+    x = G.uniform_distribution_int(cols).astype(dtype)
+    want = O.spmv_f32(off, idx, val.astype(np.float32), x.astype(np.float32)).astype(dtype)   # (exactly summable: the same in both precisions)
+    csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty(rows, dtype=xd.dtype, device="cuda")
+    for _ in range(4):
+        y.fill_(-1.0)
+        S.spmv("group_mapped", csr, xd, y)
+        torch.cuda.synchronize()                                                     # (the memo word arrives: later calls may take the owner-only launch)
+        assert np.array_equal(y.cpu().numpy(), want)
