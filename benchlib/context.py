@@ -87,6 +87,14 @@ def context_c4_bcsr(G, S, O, torch, iters=50):
     out["merge_path_one_shot"]["note"] = ("loops::kernels::bcsr4x4_mfma_merge_path + fix-up: the load-balanced one-shot form (equal tiles "
                                           "of block-row ends + blocks) -- nothing to balance on C4's uniform block-rows; 47 x the MFMA kernel on skewed lengths "
                                           "(profiles/r06_bcsr_band_c4_experiments.txt, section 7)")
+    # mode "tuned" (what the drop-in wrapper bcsr_thread_mapped<4, 4> launches): the kernel is chosen by the class of the block-row lengths,
+    # found by a probe on the first call and remembered -- C4's are even, so after the first call this IS the MFMA kernel
+    S.bcsr_thread_mapped(b, x, y, mfma="tuned")
+    torch.cuda.synchronize()
+    ms = timed_ms(torch, lambda: S.bcsr_thread_mapped(b, x, y, mfma="tuned"), iters)
+    out["tuned_mode"] = {"avg_launch_ms": round(ms, 5), "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                         "block_row_lengths": S.bcsr_row_length_class(b),
+                         "note": "even lengths -> bcsr4x4_mfma_spmv, skewed -> bcsr4x4_mfma_merge_path (kernels::bcsr_row_length_class)"}
     S.bcsr_thread_mapped(b, x, y, mfma=1)
     out["mfma"]["kernel"] = "loops::kernels::bcsr4x4_mfma_spmv"
     want = O.bcsr_spmv_f32(4, 4, nbr * 4, boff, bcols, bvals, xh)
@@ -188,7 +196,7 @@ def context_c3_standins(G, S, O, torch, iters=10):
         launches = {"group_mapped": "group_mapped_spmv_publish + group_mapped_spmv_claims + group_mapped_fixup (one-kernel group_mapped_spmv_fused once "
                                     "the entry's memo says nothing was published)",
                     "work_oriented": "shares of ONE tile through merge_path_flat's one-shot launch (sampled columns, merge_path_spmv_fused_auto: plain or "
-                                     "phased gathers decided on the device) -- the persistent work_oriented_spmv_fused only below the sampling thresholds",
+                                     "phased gathers decided on the device) -- the persistent work_oriented_spmv_fused only below the sampling threshold (x < 3 MB)",
                     "merge_path_flat": "merge_path_spmv_fused_planned<256, 8> (held plan) + fix-up",
                     "merge_path_flat_phased_gathers": "merge_path_spmv_fused_phased_planned<256, 16, 32> (held plan) + fix-up"}
         for sched, fn in runs.items():
@@ -222,10 +230,12 @@ def context_schedules(S, torch, csr, x, ref_y, abytes, iters=50):
     ms = timed_ms(torch, lambda: S.work_oriented(csr, x, y, plan=wplan), iters)
     out["work_oriented_held_plan"] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
                                       "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
-    for sched in ("work_oriented", "group_mapped"):
+    # the plan-less entries, whole calls (coordinates rebuilt per call as the reference's wrappers do; the column sample behind the choice
+    # of gather order is remembered per matrix) -- "merge_path_flat_one_shot" is what a caller of the reference's API gets without a plan
+    for key, sched in (("merge_path_flat_one_shot", "merge_path_flat"), ("work_oriented", "work_oriented"), ("group_mapped", "group_mapped")):
         ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
-        out[sched] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
-                      "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
+        out[key] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
+                    "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
     return out
 
 

@@ -38,7 +38,8 @@ void group_mapped(csr_t<index_t, offset_t, type_t>& csr, vector_t<type_t>& x, ve
   unsigned int* stats = reinterpret_cast<unsigned int*>(scratch.data().get() + share_bytes);
   kernels::launch_group_mapped_shared<block_size, items_per_thread, (items_per_thread % 2 == 0)>(
       stream, static_cast<int>(csr.rows), static_cast<int>(csr.nnzs), csr.offsets.data().get(), csr.indices.data().get(),
-      csr.values.data().get(), x.data().get(), y.data().get(), scratch.data().get(), nullptr, static_cast<int>(csr.cols), stats);
+      csr.values.data().get(), x.data().get(), y.data().get(), scratch.data().get(), nullptr, static_cast<int>(csr.cols), stats, /*share=*/true,
+      /*resample=*/true, /*timed_path=*/true);  // (from 6 MB on: below, a group's partly empty last tile makes the phased order a loss)
   (void)xpu::stream_synchronize(stream);
 }
 

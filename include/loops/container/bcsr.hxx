@@ -35,6 +35,10 @@ struct bcsr_t {
   vector_t<offset_t, space> block_offsets;     ///< num_block_rows + 1
   vector_t<index_t, space> block_col_indices;  ///< num_blocks
   vector_t<value_t, space> values;             ///< num_blocks * R * C
+  /// What algorithms::spmv::bcsr_thread_mapped<4, 4> found out about the block-row lengths on its first call on this matrix
+  /// (kernels::bcsr_rows_even / bcsr_rows_skewed; 0 = not looked at yet): which of its two kernels later calls launch.  A hint
+  /// only -- offsets edited in place afterwards keep the old choice, the product stays right.  Reset it to 0 to have them looked at again.
+  mutable int row_length_class = 0;
 
   bcsr_t() : rows(0), cols(0), nnzs(0), num_block_rows(0), num_block_cols(0), num_blocks(0) {}
 
@@ -42,7 +46,7 @@ struct bcsr_t {
   bcsr_t(const bcsr_t<R, C, index_t, offset_t, value_t, rhs_space>& rhs)
       : rows(rhs.rows), cols(rhs.cols), nnzs(rhs.nnzs), num_block_rows(rhs.num_block_rows),
         num_block_cols(rhs.num_block_cols), num_blocks(rhs.num_blocks), block_offsets(rhs.block_offsets),
-        block_col_indices(rhs.block_col_indices), values(rhs.values) {}
+        block_col_indices(rhs.block_col_indices), values(rhs.values), row_length_class(rhs.row_length_class) {}
 
   template <auto rhs_space, typename csr_offset_t>
   bcsr_t(const csr_t<index_t, csr_offset_t, value_t, rhs_space>& csr) : rows(csr.rows), cols(csr.cols), nnzs(csr.nnzs) {

@@ -248,5 +248,85 @@ inline int launch_bcsr4x4_merge_path(hipStream_t stream, int rows, int num_block
   return static_cast<int>(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Which of the two plan-less 4 x 4 fp32 products a matrix should get (callers that cannot measure: the
+// bcsr_thread_mapped<4, 4> wrapper, loops_spmv_bcsr_f32 mode "tuned").  The thread_mapped MFMA kernel (bcsr_spmv.hxx) walks the
+// block-rows of a wavefront in lockstep, a few blocks of each per step: 17 % faster than the merge-path tiles where the
+// lengths are even (2^18 block-rows of 16 blocks, scattered columns: 70 against 84 us), but a block-row of L blocks is a serial
+// chain of 0.043 us x L, and a wavefront's 4 block-rows cost 4 x the longest of them.  Measured (tests/perf/exp_bcsr_skew_rule.py,
+// profiles/r06_bcsr_skew_rule.txt; MFMA / tiles in us): lengths uniform in 16 +- 4 / 8 / 16: 84 / 83, 89 / 83, 99 / 82 (lockstep
+// blocks 1.17 / 1.32 / 1.62 x the blocks); geometric 122 / 81; Pareto tails capped at 64 / 4 096: 84 / 43, 469 / 54; ONE block-row
+// of 256 / 512 / 2 048 blocks among even ones: 70 / 83, 75 / 82, 156 / 81 in the middle of the matrix, 79 / 82, 92 / 81 (512) as the
+// last block-row; 64 block-rows of 16 384: 1 830 / 39.  Rule: SKEWED when the lockstep walk (sum over groups of 4 consecutive
+// block-rows of 4 x the group's longest) touches more than 1.2 x the blocks, or the longest block-row exceeds
+// max(64, blocks / 14 000) blocks (its chain alone then costs what the tiles cost extra, should it come last).
+constexpr int bcsr_rows_even = 1, bcsr_rows_skewed = 2;  ///< (0 = not known yet)
+__host__ __device__ inline int bcsr_row_length_class(unsigned long long lockstep_blocks, unsigned int longest, unsigned long long num_blocks) {
+  const unsigned long long cap = num_blocks / 14000ull > 64ull ? num_blocks / 14000ull : 64ull;
+  return (longest > cap || 10ull * lockstep_blocks > 12ull * num_blocks) ? bcsr_rows_skewed : bcsr_rows_even;
+}
+/// Host form over a host copy of the offsets (container/bcsr.hxx builds them on the host anyway).
+template <typename offset_t>
+inline int bcsr_row_length_class_of(const offset_t* block_offsets, std::size_t num_block_rows) {
+  unsigned long long lockstep = 0;
+  unsigned int longest = 0;
+  for (std::size_t g = 0; g < num_block_rows; g += 4) {
+    unsigned int m = 0;
+    for (std::size_t r = g; r < g + 4 && r < num_block_rows; ++r) {
+      const unsigned int len = static_cast<unsigned int>(block_offsets[r + 1] - block_offsets[r]);
+      m = len > m ? len : m;
+    }
+    lockstep += 4ull * m;
+    longest = m > longest ? m : longest;
+  }
+  return bcsr_row_length_class(lockstep, longest, num_block_rows ? static_cast<unsigned long long>(block_offsets[num_block_rows]) : 0ull);
+}
+struct bcsr_skew_ctl {
+  unsigned long long lockstep;
+  unsigned int longest, done;
+};
+/// Device form: a thread per block-row; the last workgroup through stores the class to `report` (may be host memory mapped into
+/// the device) and leaves `ctl` (ZERO before the first launch) zero again.
+__global__ void __launch_bounds__(256)
+bcsr_skew_probe(const int num_block_rows, const int num_blocks, const int* __restrict__ block_offsets, bcsr_skew_ctl* __restrict__ ctl,
+                unsigned int* __restrict__ report) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  unsigned int len = r < num_block_rows ? static_cast<unsigned int>(block_offsets[r + 1] - block_offsets[r]) : 0u;
+  unsigned int m = len;
+  m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), 1)));
+  m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), 2)));  // longest of the group of 4 (every lane of the group)
+  unsigned long long sum = m;  // 4 lanes x the group's longest = the group's lockstep blocks
+  unsigned int top = m;
+  for (int d = 1; d < wave::size; d <<= 1) {
+    sum += static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(sum), d));
+    top = max(top, static_cast<unsigned int>(__shfl_xor(static_cast<int>(top), d)));
+  }
+  if (wave::lane() == 0) {
+    atomicAdd(&ctl->lockstep, sum);
+    atomicMax(&ctl->longest, top);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&ctl->done, 1u) == gridDim.x - 1) {
+      __threadfence();
+      const unsigned long long lockstep = __hip_atomic_load(&ctl->lockstep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int longest = __hip_atomic_load(&ctl->longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(report, static_cast<unsigned int>(bcsr_row_length_class(lockstep, longest, static_cast<unsigned long long>(num_blocks))),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ctl->lockstep = 0ull;
+      ctl->longest = 0u;
+      ctl->done = 0u;
+    }
+  }
+}
+inline int launch_bcsr_skew_probe(hipStream_t stream, int num_block_rows, int num_blocks, const int* block_offsets, bcsr_skew_ctl* ctl,
+                                  unsigned int* report) {
+  if (num_block_rows <= 0) return 0;
+  hipLaunchKernelGGL(bcsr_skew_probe, dim3(math::ceil_div(num_block_rows, 256)), dim3(256), 0, stream, num_block_rows, num_blocks, block_offsets, ctl,
+                     report);
+  return static_cast<int>(hipGetLastError());
+}
+
 }  // namespace kernels
 }  // namespace loops

@@ -344,14 +344,17 @@ group_mapped_fixup(const int rows, type_t* __restrict__ y, const group_share_vie
 /// groups the call published when its last kernel ends.  `stats` (may be null: plain gathers): kernels::scatter_scratch_words
 /// device words -- with them, and `cols` columns worth asking about, the gather order is decided on the device (file comment).
 /// `share` = false: the publish kernel alone with every group swept by its owner (callers that KNOW the matrix has no heavy group).
+/// `resample` = false: `stats` still hold the sample of this matrix; `timed_path`: columns_worth_sampling's (false for callers
+/// that pay the sample once per matrix).
 template <int TPB, int IPT, bool PAD, typename index_t, typename offset_t, typename T, bool MASK = true>
 int launch_group_mapped_shared(hipStream_t stream, int rows, int nnz, const offset_t* offsets, const index_t* indices, const T* values, const T* x,
-                               T* y, void* scratch, unsigned int* report = nullptr, int cols = 0, unsigned int* stats = nullptr, bool share = true) {
+                               T* y, void* scratch, unsigned int* report = nullptr, int cols = 0, unsigned int* stats = nullptr, bool share = true,
+                               bool resample = true, bool timed_path = true) {
   if (rows == 0) return 0;
   const auto sc = share ? group_share_view<T>::carve(scratch, rows, nnz, TPB, IPT) : group_share_view<T>{};
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
   const dim3 groups(math::ceil_div(rows, TPB)), claims(sc.max_claims < 8192 ? sc.max_claims : 8192), block(TPB);
-  const bool sampled = aligned && stats && columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), true);
+  const bool sampled = aligned && stats && columns_worth_sampling(static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), timed_path);
   auto go = [&](auto publish, auto owner, auto claim, const detail::phase_args ph) {
     if (!share) {
       hipLaunchKernelGGL(owner, groups, block, 0, stream, rows, nnz, offsets, indices, values, x, y, sc, stats, ph);
@@ -361,7 +364,7 @@ int launch_group_mapped_shared(hipStream_t stream, int rows, int nnz, const offs
     hipLaunchKernelGGL(claim, claims, block, 0, stream, rows, nnz, offsets, indices, values, x, y, sc, stats, ph);
   };
   if (sampled) {
-    const int err = launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), stats);
+    const int err = resample ? launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), stats) : 0;
     if (err) return err;
     const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));
     // (tiles of 16 items per lane for 16 / 32 parts, the plan-less merge_path_flat entry's shape, measured here: uniform C3 stand-in

@@ -197,16 +197,17 @@ inline int launch_column_scatter_sample(hipStream_t stream, const index_t* indic
 
 /// The plan-less product on a matrix worth asking about: sample (async) -> merge_path_spmv_fused_auto (plain or phased gathers,
 /// decided on the device) -> fix-up.  Two-kernel form only (plan-less plans are never classified); unaligned arrays or a single
-/// tile run the plain kernel.
+/// tile run the plain kernel.  `resample` = false: `stats` still hold the sample of THIS matrix (callers that remember which
+/// matrix they sampled last: the sample is then paid once per matrix and `timed_path` = false -- ask from 3 MB on -- is the right rule).
 template <int TPB, int IPT, typename index_t, typename offset_t, typename T>
 int launch_merge_path_fused_auto(hipStream_t stream, const merge_plan_view& plan, int rows, int cols, int nnz,
                                  const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
-                                 unsigned int* stats) {
+                                 unsigned int* stats, bool resample = true, bool timed_path = true) {
   const int m = plan.num_merge_tiles;
   const bool aligned = ((reinterpret_cast<std::uintptr_t>(indices) | reinterpret_cast<std::uintptr_t>(values)) & 15u) == 0;
-  if (m <= 1 || !aligned || !stats || !columns_worth_sampling(nnz, cols, static_cast<int>(sizeof(T)), true))
+  if (m <= 1 || !aligned || !stats || !columns_worth_sampling(nnz, cols, static_cast<int>(sizeof(T)), timed_path))
     return launch_merge_path_fused<TPB, IPT, true, 0, index_t, offset_t, T, true>(stream, plan, rows, nnz, offsets, indices, values, x, y);
-  int err = launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), stats);
+  int err = resample ? launch_column_scatter_sample(stream, indices, static_cast<long long>(nnz), static_cast<long long>(cols), static_cast<int>(sizeof(T)), stats) : 0;
   if (err) return err;
   T* carry_val = static_cast<T*>(plan.carry_val);
   const phased_config cfg = phased_config_for(cols, static_cast<int>(sizeof(T)));

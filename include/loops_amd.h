@@ -198,14 +198,19 @@ int loops_work_oriented_grid(int* out_blocks);
  * x must be padded to num_block_cols * C; rows of y >= `rows` are not written.
  * Block shapes compiled into the library: 2x2, 3x3, 4x4, 8x8 (fp32 and fp64); anything else returns LOOPS_E_CONFIG (the
  * header API instantiates any <R, C>).
- * mode 3: the tuned kernel of the shape (what algorithms::spmv::bcsr_thread_mapped<R, C> launches): mode 1 for 4x4 fp32,
- * mode 2 otherwise.  mode 2: coalesced lane-group kernel, any shape, fp32 / fp64 -- a slot of lanes reads whole lines of
+ * mode 3: the tuned kernel of the shape (what algorithms::spmv::bcsr_thread_mapped<R, C> launches): mode 2 for every shape but
+ * 4x4 fp32; there mode 1 where the block-row lengths are even and mode 4 where they are skewed (longest block-row beyond
+ * max(64, blocks / 14 000) blocks, or a lockstep walk of groups of 4 block-rows touching more than 1.2 x the blocks).  The class
+ * of a matrix is found by a probe the FIRST mode-3 call on it launches (remembered per host thread by block_offsets pointer and
+ * sizes, up to 8 matrices; reported through mapped host memory, no synchronisation): that call, and any until the report has
+ * arrived, run mode 4, which is safe on any lengths.  A matrix edited in place keeps its class (the product stays right).
+ * mode 2: coalesced lane-group kernel, any shape, fp32 / fp64 -- a slot of lanes reads whole lines of
  * consecutive blocks of one block-row, 16 bytes per lane (36-byte 3x3 blocks: lane per block), block inner product on the
  * VALU, log2 cross-lane reduce; tuning aid 100000 + 100 h + u = h in {1,4,16} blocks of a block-row per step, u in {1,2,4}
  * steps in flight.
  * mode 4 (4x4 fp32 only): the MERGE-PATH form (include/loops/kernels/bcsr_merge_path.hxx) -- equal tiles of (block-row ends,
  * blocks), block-row sums in LDS, MFMA block products, 4-wide carry-outs + a fix-up launch; no reference counterpart.  For BCSR
- * with skewed block-row lengths (64 block-rows of 16 384 blocks among 2^17 of 8: 39 us, against 1.8 ms for modes 0-3, which give
+ * with skewed block-row lengths (64 block-rows of 16 384 blocks among 2^17 of 8: 39 us, against 1.8 ms for modes 0-2, which give
  * a block-row to one owner as the reference does); ~20 % slower than mode 1 where the lengths are uniform (C4: 81.5 against
  * 66-70 us).  Uses a per-stream scratch block (loops_release_scratch frees it).
  * mode 0: register accumulation, thread per block-row (the reference's kernel shape); mode 1: MFMA 4x4x1 block inner product
@@ -221,6 +226,10 @@ int loops_spmv_bcsr_f32(int R, int C, int mode, int rows, int num_block_rows, in
 int loops_spmv_bcsr_f64(int R, int C, int mode, int rows, int num_block_rows, int num_blocks,
                         const int* block_offsets, const int* block_cols, const double* block_values,
                         const double* x_padded, double* y, void* stream);
+
+/* The class of a BCSR's block-row lengths by mode 3's rule, computed now (one small kernel + a 4-byte copy; SYNCHRONISES the
+ * stream): *out_class = 1 even (mode 3 -> mode 1), 2 skewed (mode 3 -> mode 4).  For callers that pick the mode themselves. */
+int loops_bcsr_row_length_class(int num_block_rows, int num_blocks, const int* block_offsets, int* out_class, void* stream);
 
 /* ---- Block-band plan for 4 x 4 fp32 BCSR (include/loops/kernels/bcsr_band.hxx) ------------------------------------------------
  * A held plan for algorithms::spmv::bcsr_thread_mapped<4, 4> (algorithms/spmv/bcsr_thread_mapped.cuh:36-123) products over ONE

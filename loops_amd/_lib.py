@@ -36,7 +36,7 @@ SYMBOLS = [
     "loops_spmv_csr_f32", "loops_spmv_csr_f64", "loops_spmv_merge_path_f32", "loops_spmv_merge_path_f64",
     "loops_spmv_merge_path_stage_f32", "loops_spmv_csr_schedule_api_f32",
     "loops_schedule_dump_merge_path", "loops_schedule_dump_work_oriented", "loops_schedule_dump_group_mapped",
-    "loops_work_oriented_grid", "loops_spmv_bcsr_f32",
+    "loops_work_oriented_grid", "loops_spmv_bcsr_f32", "loops_bcsr_row_length_class",
     "loops_spmm_csr_f32", "loops_spmm_csr_f64", "loops_spmm_merge_path_f32", "loops_spmv_coo_f32", "loops_spmv_ell_f32", "loops_spmv_csc_f32", "loops_autotune_merge_path_f32",
         "loops_spmv_bcsr_f64", "loops_spmm_merge_path_f64", "loops_spmv_coo_f64", "loops_spmv_ell_f64", "loops_spmv_csc_f64",
     "loops_spmv_dia_f32", "loops_spmv_dia_f64",
@@ -185,6 +185,7 @@ def lib() -> C.CDLL:
         L.loops_device_compute_units.argtypes = [C.POINTER(ci)]
         for name in ("loops_spmv_bcsr_f32", "loops_spmv_bcsr_f64"):
             getattr(L, name).argtypes = [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp]
+        L.loops_bcsr_row_length_class.argtypes = [ci, ci, vp, C.POINTER(ci), vp]
         L.loops_spmm_csr_f32.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmm_csr_f64.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]
         L.loops_spmm_merge_path_f32.argtypes = [vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp]

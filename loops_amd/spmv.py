@@ -569,11 +569,19 @@ class BCSR:
 BCSR_MODES = {"thread": 0, "mfma": 1, "coalesced": 2, "tuned": 3, "merge_path": 4}
 
 
+def bcsr_row_length_class(b: BCSR) -> str:
+    """loops_bcsr_row_length_class: "even" / "skewed" block-row lengths by the rule of loops_spmv_bcsr_f32's mode "tuned" (synchronises)."""
+    out = C.c_int(0)
+    L.check(L.lib().loops_bcsr_row_length_class(b.num_block_rows, b.num_blocks, _ptr(b.block_offsets), C.byref(out), _stream()),
+            "loops_bcsr_row_length_class")
+    return {1: "even", 2: "skewed"}[out.value]
+
+
 def bcsr_thread_mapped(b: BCSR, x_padded: torch.Tensor, y: torch.Tensor | None = None, mfma: bool | int | str = False):
     """algorithms::spmv::bcsr_thread_mapped<R, C>.  ``mfma`` is the `mode` of loops_spmv_bcsr_*: False / "thread" =
     thread per block-row (the reference's kernel shape), True / "mfma" = the 4x4 fp32 MFMA kernel, "coalesced" = the
-    lane-group kernel of any shape / precision, "tuned" = what the C++ wrapper launches (MFMA for 4x4 fp32, coalesced
-    otherwise); integers pass through (tuning shapes, include/loops_amd.h)."""
+    lane-group kernel of any shape / precision, "tuned" = what the C++ wrapper launches (4x4 fp32: MFMA on even block-row lengths, merge-path tiles on
+    skewed ones and until the matrix's class is known; coalesced otherwise), "merge_path" = those tiles; integers pass through (tuning shapes, include/loops_amd.h)."""
     if isinstance(mfma, str):
         mfma = BCSR_MODES[mfma]
     if y is None:

@@ -140,6 +140,17 @@ static void run_battery() {
         auto y = fresh();
         algorithms::spmv::bcsr_thread_mapped(b, xpd, y);
         check_y(what, m, y, ref);
+        if constexpr (decltype(b)::kBlockRows == 4 && decltype(b)::kBlockCols == 4 && sizeof(T) == 4) {
+          // 4 x 4 fp32: the first call looked at the block-row lengths and remembered their class in the matrix object; both
+          // kernels the wrapper chooses from, by forcing the class
+          CHECK(b.num_blocks == 0 || b.row_length_class == kernels::bcsr_rows_even || b.row_length_class == kernels::bcsr_rows_skewed);
+          for (int cls : {kernels::bcsr_rows_even, kernels::bcsr_rows_skewed}) {
+            b.row_length_class = cls;
+            auto y2 = fresh();
+            algorithms::spmv::bcsr_thread_mapped(b, xpd, y2);
+            check_y(cls == kernels::bcsr_rows_skewed ? "bcsr<4,4> on merge-path tiles" : "bcsr<4,4> MFMA", m, y2, ref);
+          }
+        }
       };
       bcsr_case(bcsr_t<2, 2, int, int, T>(csr), "bcsr<2,2>");
       bcsr_case(bcsr_t<3, 3, int, int, T>(csr), "bcsr<3,3>");

@@ -1,6 +1,6 @@
 """group_mapped next to work_oriented / merge_path_flat (whole one-shot calls through loops_spmv_csr_f32) on the structures the
 round-5 review names: R-MAT 2^23 x 23 in generator order (hub rows first), the host-blocked and band C3 stand-ins, C2.
-usage: bench_group_mapped.py [rmat|host|band|c2|uniform ...]"""
+usage: bench_group_mapped.py [rmat|host|band|c2|c2x8|c2x16|uniform ...]"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -24,8 +24,9 @@ def matrix(name):
     if name == "rmat":
         off, idx, val = G.rmat_csr(23, 23, relabel="none")
         return off, idx, val, 1 << 23, 1 << 23
-    if name == "c2":
-        rows = cols = 1 << 20
+    if name in ("c2", "c2x8", "c2x16"):   # C2, and C2's rows over an x of 8 / 16 MB
+        rows = 1 << 20
+        cols = rows * {"c2": 1, "c2x8": 2, "c2x16": 4}[name]
         off, idx, val = G.powerlaw_csr(rows, cols, 1 << 24)
         return off, idx, val, rows, cols
     rows = cols = 7_414_866
@@ -45,7 +46,7 @@ for name in (sys.argv[1:] or ["rmat", "host", "band", "c2"]):
     xd = torch.from_numpy(x).cuda(); y = torch.empty(rows, device="cuda")
     row = {}
     for sched in ("group_mapped", "work_oriented", "merge_path_flat"):
-        iters = 50 if name == "c2" else 10
+        iters = 50 if name.startswith("c2") else 10
         ms = per_call_ms(lambda: S.spmv(sched, csr, xd, y), iters=iters)
         y.fill_(-1.0); S.spmv(sched, csr, xd, y)
         row[sched] = {"ms": round(ms, 4), "bit_exact": bool(np.array_equal(y.cpu().numpy(), want))}

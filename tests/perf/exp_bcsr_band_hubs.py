@@ -27,6 +27,10 @@ print("blocks", bcols.size, "mfma kernel %.1f us" % ms(lambda: S.bcsr_thread_map
 t = ms(lambda: S.bcsr_thread_mapped(b, x, y, mfma="merge_path"))
 S.bcsr_thread_mapped(b, x, y, mfma="merge_path")
 print("merge-path one-shot kernel %.1f us exact=%s" % (t, bool(np.array_equal(y.cpu().numpy(), want))))
+S.bcsr_thread_mapped(b, x, y, mfma="tuned"); torch.cuda.synchronize()    # (first call: merge-path tiles + the probe of the block-row lengths)
+t = ms(lambda: S.bcsr_thread_mapped(b, x, y, mfma="tuned"))
+S.bcsr_thread_mapped(b, x, y, mfma="tuned")
+print("mode 'tuned' (class %s) %.1f us exact=%s" % (S.bcsr_row_length_class(b), t, bool(np.array_equal(y.cpu().numpy(), want))))
 for hb in (0, 4096):
     plan = S.BCSRBandPlan(b, band_block_rows=hb)
     t = ms(lambda: plan.spmv(x, y))

@@ -157,3 +157,52 @@ def test_merge_path_bcsr_on_skewed_block_rows():
             got = y.cpu().numpy()
             assert np.array_equal(got[:rows], want), name
             assert np.all(got[rows:] == 7.0), name
+
+
+def _class_by_the_rule(lens):
+    """numpy restatement of kernels::bcsr_row_length_class (bcsr_merge_path.hxx): skewed when the longest block-row exceeds
+    max(64, blocks / 14 000) or groups of 4 consecutive block-rows walked in lockstep touch more than 1.2 x the blocks."""
+    lens = np.asarray(lens, np.int64)
+    nb = int(lens.sum())
+    if lens.size == 0 or nb == 0:
+        return "even"
+    pad = np.concatenate([lens, np.zeros((-lens.size) % 4, np.int64)]).reshape(-1, 4)
+    lockstep = int(4 * pad.max(axis=1).sum())
+    return "skewed" if (int(lens.max()) > max(64, nb // 14000) or 10 * lockstep > 12 * nb) else "even"
+
+
+def test_tuned_mode_picks_the_kernel_by_the_block_row_lengths():
+    """loops_spmv_bcsr_f32 mode "tuned" on 4 x 4 fp32: the first call on a matrix runs the merge-path tiles and launches the probe of
+    the block-row lengths; once its report has arrived later calls run the MFMA kernel on even lengths and stay on the tiles on
+    skewed ones (include/loops_amd.h).  Whatever ran: bit-exact against the block product, call after call, matrices alternating;
+    loops_bcsr_row_length_class agrees with the numpy restatement of the rule."""
+    from loops_amd import spmv as S
+    rng = np.random.default_rng(21)
+    cases = {
+        "even16": np.full(5000, 16),
+        "mild": rng.integers(14, 19, size=5000),                 # lockstep ~1.1 x
+        "spread": rng.integers(8, 25, size=5000),                # lockstep ~1.3 x
+        "hub": np.concatenate([rng.integers(0, 9, size=3000), [6000], rng.integers(0, 9, size=3000)]),
+        "alternating": np.tile([0, 0, 0, 40], 1500),            # lockstep groups of 4 touch 4 x the blocks
+        "row_of_65": np.concatenate([np.full(4000, 12), [65]]),
+        "row_of_64": np.concatenate([np.full(4000, 12), [64]]),
+    }
+    built = {}
+    for name, lens in cases.items():
+        nbr, nbc = lens.size, 8000
+        boff, bcols, bvals, x = _blocks(4, nbr, nbc, lens, seed=len(name) + 3, dtype=np.float32)
+        rows = nbr * 4 - 1
+        b = S.BCSR(4, 4, rows, nbc * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+        built[name] = (b, torch.from_numpy(x).cuda(), _numpy_product(4, rows, boff, bcols, bvals, x), rows)
+        assert S.bcsr_row_length_class(b) == _class_by_the_rule(lens), name
+    assert [_class_by_the_rule(cases[n]) for n in ("even16", "mild", "spread", "hub", "alternating", "row_of_65", "row_of_64")] == \
+        ["even", "even", "skewed", "skewed", "skewed", "skewed", "even"]
+    for _ in range(3):
+        for name, (b, xd, want, rows) in built.items():
+            for _ in range(2):
+                y = torch.full((rows + 4,), 7.0, device="cuda")
+                S.bcsr_thread_mapped(b, xd, y, mfma="tuned")
+                torch.cuda.synchronize()                                       # (the probe's report arrives: the next call may change kernel)
+                got = y.cpu().numpy()
+                assert np.array_equal(got[:rows], want), name
+                assert np.all(got[rows:] == 7.0), name
