@@ -948,14 +948,16 @@ def test_phased_variant_on_the_reference_battery_and_degenerate_inputs(tile):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("window", [None, 4096], ids=["scattered", "banded"])
 @pytest.mark.parametrize("schedule", ["merge_path_flat", "work_oriented"])
-def test_planless_device_decided_kernel(schedule, window, dtype):
-    """The asynchronous plan-less entries `loops_spmv_csr_*(MERGE_PATH_FLAT | WORK_ORIENTED)` above their thresholds (x >= 6 MB, nnz >=
-    2^20; WORK_ORIENTED takes MERGE_PATH_FLAT's launch there -- shares of one 512 x 8 tile): a sample of the columns decides ON THE DEVICE
+@pytest.mark.parametrize("log2_cols", [20, 21], ids=["x4MB", "x8MB"])
+def test_planless_device_decided_kernel(schedule, window, dtype, log2_cols):
+    """The asynchronous plan-less entries `loops_spmv_csr_*(MERGE_PATH_FLAT | WORK_ORIENTED)` above their thresholds (x >= 3 MB -- 8-byte
+    values: 6 MB --, nnz >= 2^20; WORK_ORIENTED takes MERGE_PATH_FLAT's launch there -- shares of one tile; 512 x 8 tiles up to x = 6 MB,
+    256 x 16 beyond): a sample of the columns -- taken on the first call on a matrix, remembered by the stream's scratch plan -- decides ON THE DEVICE
     whether the product gathers in phases (kernels::merge_path_spmv_fused_auto).  Both
     outcomes -- scattered columns (phased) and a 4096-wide band (plain) -- must give the bits of the held 512x8 plan, also from
     two streams at once and from a captured HIP graph (the decision is device-side: nothing host-side may depend on it)."""
     from loops_amd import spmv as S, generate as G
-    rows, cols = 1 << 18, 1 << 21                                   # x = 8 MB (f32) / 16 MB (f64)
+    rows, cols = 1 << 18, 1 << log2_cols                            # x = 4 / 8 MB (f32), 8 / 16 MB (f64)
     deg = G.powerlaw_degrees(rows, 1 << 21, cap=1 << 12)
     off, idx, val = G.csr_from_degrees(deg, cols, 1, 0, True, window)
     assert idx.size >= 1 << 20
