@@ -285,28 +285,42 @@ struct bcsr_skew_ctl {
   unsigned long long lockstep;
   unsigned int longest, done;
 };
-/// Device form: a thread per block-row; the last workgroup through stores the class to `report` (may be host memory mapped into
-/// the device) and leaves `ctl` (ZERO before the first launch) zero again.
+/// Device form: a few workgroups stride over the block-rows (a thread per block-row and step), sum up inside the workgroup and
+/// post ONE set of atomics each (a wavefront per set was 87 us on 2^18 block-rows: ~9 000 atomics on two words, ~88 per us); the
+/// last workgroup through stores the class to `report` (may be host memory mapped into the device) and leaves `ctl` (ZERO before
+/// the first launch) zero again.
 __global__ void __launch_bounds__(256)
 bcsr_skew_probe(const int num_block_rows, const int num_blocks, const int* __restrict__ block_offsets, bcsr_skew_ctl* __restrict__ ctl,
                 unsigned int* __restrict__ report) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  unsigned int len = r < num_block_rows ? static_cast<unsigned int>(block_offsets[r + 1] - block_offsets[r]) : 0u;
-  unsigned int m = len;
-  m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), 1)));
-  m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), 2)));  // longest of the group of 4 (every lane of the group)
-  unsigned long long sum = m;  // 4 lanes x the group's longest = the group's lockstep blocks
-  unsigned int top = m;
+  unsigned long long sum = 0;
+  unsigned int top = 0;
+  // (the stride is a multiple of 4: the groups of 4 consecutive block-rows stay with 4 neighbouring lanes)
+  for (long long r0 = static_cast<long long>(blockIdx.x) * 256; r0 < num_block_rows; r0 += static_cast<long long>(gridDim.x) * 256) {
+    const long long r = r0 + threadIdx.x;
+    unsigned int m = r < num_block_rows ? static_cast<unsigned int>(block_offsets[r + 1] - block_offsets[r]) : 0u;
+    m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), 1)));
+    m = max(m, static_cast<unsigned int>(__shfl_xor(static_cast<int>(m), 2)));  // longest of the group of 4 (in every lane of the group)
+    sum += m;  // 4 lanes x the group's longest = the group's lockstep blocks
+    top = max(top, m);
+  }
   for (int d = 1; d < wave::size; d <<= 1) {
     sum += static_cast<unsigned long long>(__shfl_xor(static_cast<long long>(sum), d));
     top = max(top, static_cast<unsigned int>(__shfl_xor(static_cast<int>(top), d)));
   }
+  __shared__ unsigned long long s_sum[256 / wave::size];
+  __shared__ unsigned int s_top[256 / wave::size];
   if (wave::lane() == 0) {
-    atomicAdd(&ctl->lockstep, sum);
-    atomicMax(&ctl->longest, top);
+    s_sum[threadIdx.x / wave::size] = sum;
+    s_top[threadIdx.x / wave::size] = top;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    for (int w = 1; w < 256 / wave::size; ++w) {
+      sum += s_sum[w];
+      top = max(top, s_top[w]);
+    }
+    atomicAdd(&ctl->lockstep, sum);
+    atomicMax(&ctl->longest, top);
     __threadfence();
     if (atomicAdd(&ctl->done, 1u) == gridDim.x - 1) {
       __threadfence();
@@ -323,8 +337,8 @@ bcsr_skew_probe(const int num_block_rows, const int num_blocks, const int* __res
 inline int launch_bcsr_skew_probe(hipStream_t stream, int num_block_rows, int num_blocks, const int* block_offsets, bcsr_skew_ctl* ctl,
                                   unsigned int* report) {
   if (num_block_rows <= 0) return 0;
-  hipLaunchKernelGGL(bcsr_skew_probe, dim3(math::ceil_div(num_block_rows, 256)), dim3(256), 0, stream, num_block_rows, num_blocks, block_offsets, ctl,
-                     report);
+  const int blocks = math::ceil_div(num_block_rows, 256);
+  hipLaunchKernelGGL(bcsr_skew_probe, dim3(blocks < 128 ? blocks : 128), dim3(256), 0, stream, num_block_rows, num_blocks, block_offsets, ctl, report);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -19,6 +19,7 @@
 #include <loops/algorithms/spmv/launch_box.hxx>
 #include <loops/kernels/csr_spmv.hxx>
 #include <loops/kernels/merge_path_spmv.hxx>
+#include <loops/util/wave.hxx>
 #include <loops/kernels/merge_path_spmm.hxx>
 #include <loops/util/launch.hxx>
 #include <loops/util/launch_box.hxx>
@@ -51,13 +52,44 @@ int launch_merge_path_head_check(hipStream_t stream, const coord_t* coords, int 
   return launch_status();
 }
 
+/// merge_path_coordinates_of with a WAVEFRONT per coordinate: a 64-ary search -- every lane probes one row end, a ballot narrows
+/// the range 64-fold -- so a table over 2^20 rows costs 4 dependent memory round trips instead of 20 (the pre-pass of every
+/// plan-less call: 7.2 -> ~3 us on C2, profiles/r06_oneshot_kernel_stats.csv).  Same split, same coordinates (search.hxx).
+template <typename row_end_t>
+__global__ void __launch_bounds__(256)
+merge_path_coordinates_wide(const row_end_t row_end, const int rows, const int nnz, const int tile_items, const int num_merge_tiles,
+                            coord_t* __restrict__ coords) {
+  const int i = blockIdx.x * (256 / wave::size) + static_cast<int>(threadIdx.x) / wave::size;  // (wavefront-uniform)
+  if (i > num_merge_tiles) return;
+  const int lane = wave::lane();
+  const int d = static_cast<int>(static_cast<long long>(i) * tile_items);  // int, like the reference (search.hxx:46-47)
+  int lo = d - nnz > 0 ? d - nnz : 0;  // the first m in [lo, hi) with row_end(m) > d - m - 1, or hi
+  int hi = d < rows ? d : rows;
+  while (hi > lo) {
+    const int span = hi - lo;
+    const int step = (span + wave::size - 1) / wave::size;
+    const int m = lo + lane * step;
+    const bool before = m < hi && static_cast<int>(row_end(m)) <= d - m - 1;  // (true: the split lies behind m)
+    const int trues = __popcll(__ballot(before));                             // monotone predicate: the trues are lanes 0 .. trues - 1
+    const int new_lo = trues > 0 ? lo + (trues - 1) * step + 1 : lo;
+    const int new_hi = trues < wave::size && lo + trues * step < hi ? lo + trues * step : hi;
+    lo = new_lo;
+    hi = step == 1 ? new_lo : new_hi;  // (step 1: every candidate was probed)
+  }
+  if (lane == 0) coords[i] = coord_t{static_cast<unsigned int>(lo < rows ? lo : rows), static_cast<unsigned int>(d - lo)};
+}
+
 /// coords[i] = merge-path split at diagonal i * tpb * ipt, i in [0, M].
 template <typename offset_t>
 int launch_merge_path_coordinates(hipStream_t stream, const offset_t* offsets, int rows, int nnz, int tile_items,
                                   int num_merge_tiles, coord_t* coords) {
   const int n = num_merge_tiles + 1;
-  hipLaunchKernelGGL(merge_path_coordinates_of<csr_row_end<offset_t>>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream,
-                     csr_row_end<offset_t>{offsets}, rows, nnz, tile_items, num_merge_tiles, coords);
+  if (rows >= 4096)  // (a wavefront per coordinate pays once the lane-per-coordinate search is more than ~12 round trips deep)
+    hipLaunchKernelGGL(merge_path_coordinates_wide<csr_row_end<offset_t>>, dim3(math::ceil_div(n, 256 / wave::size)), dim3(256), 0, stream,
+                       csr_row_end<offset_t>{offsets}, rows, nnz, tile_items, num_merge_tiles, coords);
+  else
+    hipLaunchKernelGGL(merge_path_coordinates_of<csr_row_end<offset_t>>, dim3(math::ceil_div(n, 256)), dim3(256), 0, stream,
+                       csr_row_end<offset_t>{offsets}, rows, nnz, tile_items, num_merge_tiles, coords);
   return launch_status();
 }
 

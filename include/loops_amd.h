@@ -106,11 +106,15 @@ int loops_merge_plan_coords(const loops_merge_plan_t* plan, unsigned* h_coords);
  * plan-less call works on a stream the same call has run on before -- the scratch exists then; the first call on a stream allocates.)  A held plan (loops_merge_plan_t, loops_rowband_plan_t, loops_panel_plan_t) owns ONE set of
  * scratch buffers and is passed as const only because its coordinates are read-only: it serves one product at a
  * time -- do not run the same plan on two streams or from two threads concurrently; create one plan per stream. */
-/* (LOOPS_MERGE_PATH_FLAT, round 4: from an x of 6 MB on and 2^20 nonzeros the call samples the columns on the device -- two small
- * kernels, ~5 us -- and its tile kernel gathers in phases when they are scattered, loops_columns_look_scattered's rule evaluated on
- * the device: the call stays asynchronous; |x| = 8 / 16 MB, scattered columns: 1.5 / 1.7 x.
- * LOOPS_WORK_ORIENTED, round 5: workgroups walk shares of 1-4 merge tiles (one long share per resident workgroup kept them in step);
- * above the same thresholds the share is one 512 x 8 tile and the launch is LOOPS_MERGE_PATH_FLAT's, device-side choice included.) */
+/* (LOOPS_MERGE_PATH_FLAT: from an x of 3 MB on (8-byte values: 6 MB) and 2^20 nonzeros the call samples the columns on the device --
+ * two small kernels, ~5 us, on the FIRST call on a matrix: the stream's scratch remembers (indices pointer, nnz, columns) -- and its
+ * tile kernel gathers in phases when they are scattered, loops_columns_look_scattered's rule evaluated on the device: the call stays
+ * asynchronous; |x| = 4 / 8 / 16 MB, scattered columns: 1.12 / 1.5 / 1.7 x (C2: 106 -> 94 us per call).  A matrix edited in place under
+ * the same pointer keeps its sample: the gather ORDER only, never the result.
+ * LOOPS_WORK_ORIENTED: workgroups walk shares of 1-4 merge tiles (one long share per resident workgroup kept them in step);
+ * above the same thresholds the share is one tile and the launch is LOOPS_MERGE_PATH_FLAT's, device-side choice included.
+ * LOOPS_GROUP_MAPPED: groups of more than 24 tiles are shared out (kernels/group_mapped_spmv.hxx); from an x of 6 MB on the same
+ * device-side choice of gather order.) */
 int loops_spmv_csr_f32(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,
                        const float* values, const float* x, float* y, void* stream);
 int loops_spmv_csr_f64(int schedule, int rows, int cols, int nnz, const int* offsets, const int* indices,

@@ -1,0 +1,34 @@
+"""The plan-less entries as a profiler sees them (scripts/prof_r06_oneshot.sh: rocprofv3 --kernel-trace --stats of this file):
+50 whole calls each of merge_path_flat / work_oriented / group_mapped on C2, of BCSR mode "tuned" on C4 and on the hub case."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from loops_amd import generate as G, spmv as S
+
+rows = cols = 1 << 20
+off, idx, val = G.powerlaw_csr(rows, cols, 1 << 24)
+csr = S.CSR.from_numpy(rows, cols, off, idx, val)
+x = torch.from_numpy(G.uniform_distribution_int(cols)).cuda(); y = torch.empty(rows, device="cuda")
+for sched in ("merge_path_flat", "work_oriented", "group_mapped"):
+    for _ in range(50):
+        S.spmv(sched, csr, x, y)
+    torch.cuda.synchronize()
+
+rng = np.random.default_rng(3)
+for name in ("c4", "hubs"):
+    if name == "c4":
+        nbr = 1 << 18
+        boff, bcols, bvals = G.uniform_bcsr(nbr, nbr, 16)
+    else:
+        nbr = 1 << 17
+        lens = np.full(nbr, 8, np.int64); lens[rng.choice(nbr, size=64, replace=False)] = 16384
+        boff = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        bcols = np.concatenate([np.sort(rng.choice(nbr, size=int(n), replace=False)) for n in lens]).astype(np.int32)
+        bvals = (rng.integers(1, 9, size=bcols.size * 16) / 8.0).astype(np.float32)
+    b = S.BCSR(4, 4, nbr * 4, nbr * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    xb = torch.from_numpy(G.uniform_distribution_int(nbr * 4)).cuda(); yb = torch.empty(nbr * 4, device="cuda")
+    S.bcsr_thread_mapped(b, xb, yb, mfma="tuned"); torch.cuda.synchronize()   # first call: tiles + probe
+    for _ in range(50):
+        S.bcsr_thread_mapped(b, xb, yb, mfma="tuned")
+    torch.cuda.synchronize()
+    print(name, S.bcsr_row_length_class(b))

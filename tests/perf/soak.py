@@ -143,6 +143,7 @@ def round6():
         soak("c4", "block_band " + label, lambda y: (plan.spmv(x4, y), None)[1], ref4, nbr * 4)
         plan.close()
     soak("c4", "bcsr merge-path one-shot (mode 4)", lambda y: (S.bcsr_thread_mapped(b, x4, y, mfma="merge_path"), None)[1], ref4, nbr * 4)
+    soak("c4", "bcsr mode 3 (probe -> MFMA kernel)", lambda y: (S.bcsr_thread_mapped(b, x4, y, mfma="tuned"), None)[1], ref4, nbr * 4)
     del b
     rng = np.random.default_rng(3)                                       # 64 hub block-rows of 16 384 blocks among 2^17 of 8
     nbh = 1 << 17
@@ -156,6 +157,7 @@ def round6():
     bh = S.BCSR(4, 4, nbh * 4, nbh * 4, torch.from_numpy(boffh).cuda(), torch.from_numpy(bcolsh).cuda(), torch.from_numpy(bvalsh).cuda())
     xh4 = torch.from_numpy(xhh).cuda()
     soak("hubs", "bcsr merge-path one-shot, hub block-rows", lambda y: (S.bcsr_thread_mapped(bh, xh4, y, mfma="merge_path"), None)[1], refh, nbh * 4)
+    soak("hubs", "bcsr mode 3 (probe -> merge-path tiles)", lambda y: (S.bcsr_thread_mapped(bh, xh4, y, mfma="tuned"), None)[1], refh, nbh * 4)
     planh = S.BCSRBandPlan(bh)
     soak("hubs", f"block_band automatic (HB {planh.HB}, {planh.num_chunks} chunks, replicas)", lambda y: (planh.spmv(xh4, y), None)[1], refh, nbh * 4)
     planh.close()
@@ -173,6 +175,24 @@ def round6():
     csr2 = S.CSR.from_numpy(rows, cols, off2, idx2, val2)
     soak("c2hubs", "group_mapped, three heavy groups among 4 096", lambda y: (S.spmv("group_mapped", csr2, x, y), None)[1], ref2, rows)
     del csr, csr2
+    # the plan-less entries with the gather order decided on the device from a remembered sample: C2 (x = 4 MB: merge_path_flat /
+    # work_oriented ask, group_mapped does not) and C2's rows over x = 8 MB with a hub row (group_mapped asks too, and shares out)
+    offc, idxc, valc = G.powerlaw_csr(rows, cols, 1 << 24)
+    refc = torch.from_numpy(O.spmv_f32(offc, idxc, valc, xh, omp=True)).cuda()
+    csrc = S.CSR.from_numpy(rows, cols, offc, idxc, valc)
+    for sched in ("merge_path_flat", "work_oriented"):
+        soak("c2", sched + " plan-less (sample remembered)", lambda y, sched=sched: (S.spmv(sched, csrc, x, y), None)[1], refc, rows)
+    del csrc
+    deg8 = G.powerlaw_degrees(rows, 1 << 24)
+    deg8[1000] = 90_000
+    off8, idx8, val8 = G.csr_from_degrees(deg8, 2 * cols, 1)
+    xh8 = G.uniform_distribution_int(2 * cols)
+    x8 = torch.from_numpy(xh8).cuda()
+    ref8 = torch.from_numpy(O.spmv_f32(off8, idx8, val8, xh8, omp=True)).cuda()
+    csr8 = S.CSR.from_numpy(rows, 2 * cols, off8, idx8, val8)
+    for sched in ("group_mapped", "merge_path_flat"):
+        soak("c2x8", sched + " plan-less, x = 8 MB, one hub row", lambda y, sched=sched: (S.spmv(sched, csr8, x8, y), None)[1], ref8, rows)
+    del csr8
     off3, idx3, val3 = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
     csr3 = S.CSR.from_numpy(rows, cols, off3, idx3, val3.astype(np.float64))
     x64 = torch.from_numpy(xh.astype(np.float64)).cuda()
