@@ -206,3 +206,36 @@ def test_tuned_mode_picks_the_kernel_by_the_block_row_lengths():
                 got = y.cpu().numpy()
                 assert np.array_equal(got[:rows], want), name
                 assert np.all(got[rows:] == 7.0), name
+
+
+def test_tuned_mode_from_two_streams_and_a_captured_graph():
+    """Mode "tuned" reads its memo on the host when the call is made and launches on the caller's stream only: two streams at once, and
+    a HIP graph captured on a stream the call has run on before (scratch and memo exist then), must give the block product."""
+    from loops_amd import spmv as S
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(0, 9, size=4000), [5000], rng.integers(0, 9, size=4000)])
+    nbr, nbc = lens.size, 9000
+    boff, bcols, bvals, x = _blocks(4, nbr, nbc, lens, seed=2, dtype=np.float32)
+    rows = nbr * 4
+    want = torch.from_numpy(_numpy_product(4, rows, boff, bcols, bvals, x)).cuda()
+    b = S.BCSR(4, 4, rows, nbc * 4, torch.from_numpy(boff).cuda(), torch.from_numpy(bcols).cuda(), torch.from_numpy(bvals).cuda())
+    xd = torch.from_numpy(x).cuda()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ys = [torch.full((rows,), -1.0, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(4):
+        for st, y in zip(streams, ys):
+            with torch.cuda.stream(st):
+                S.bcsr_thread_mapped(b, xd, y, mfma="tuned")
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], want) and torch.equal(ys[1], want)
+    side = streams[0]
+    yg = torch.empty(rows, device="cuda")
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        S.bcsr_thread_mapped(b, xd, yg, mfma="tuned")
+    for _ in range(3):
+        yg.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(yg, want)

@@ -947,7 +947,7 @@ def test_phased_variant_on_the_reference_battery_and_degenerate_inputs(tile):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("window", [None, 4096], ids=["scattered", "banded"])
-@pytest.mark.parametrize("schedule", ["merge_path_flat", "work_oriented"])
+@pytest.mark.parametrize("schedule", ["merge_path_flat", "work_oriented", "group_mapped"])   # (group_mapped: its own kernels, the same sample from 6 MB on)
 @pytest.mark.parametrize("log2_cols", [20, 21], ids=["x4MB", "x8MB"])
 def test_planless_device_decided_kernel(schedule, window, dtype, log2_cols):
     """The asynchronous plan-less entries `loops_spmv_csr_*(MERGE_PATH_FLAT | WORK_ORIENTED)` above their thresholds (x >= 3 MB -- 8-byte
