@@ -59,6 +59,13 @@ __device__ __forceinline__ type_t fused_multiply_add(type_t a, type_t b, type_t 
   else return a * b + c;
 }
 
+/// Lane j's value, in scalar registers (wavefront-uniform).
+__device__ __forceinline__ long long uniform_of_lane(const long long v, const int j) {
+  const int lo = __builtin_amdgcn_readfirstlane(__shfl(static_cast<int>(v), j));
+  const int hi = __builtin_amdgcn_readfirstlane(__shfl(static_cast<int>(v >> 32), j));
+  return (static_cast<long long>(hi) << 32) | static_cast<long long>(static_cast<unsigned int>(lo));
+}
+
 template <int B, typename index_t, typename offset_t, typename type_t>
 __device__ __forceinline__ void row_batches(offset_t& k, const offset_t end, const index_t* __restrict__ indices,
                                             const type_t* __restrict__ values, const type_t* __restrict__ x, type_t& sum) {
@@ -87,6 +94,118 @@ __global__ void thread_mapped_batched_spmv(setup_t config, const offset_t* __res
     detail::row_batches<4>(k, end, indices, values, x, sum);
     for (; k < end; ++k) sum = detail::fused_multiply_add(values[k], x[indices[k]], sum);
     y[row] = sum;
+  }
+}
+
+/// thread_mapped with the MEMORY reads of its long rows shared by the wavefront.  Ownership and arithmetic are the schedule's: a
+/// thread owns whole rows (row = global thread id, + grid size per round: `config.tiles()`), a row's products are added in the
+/// row's order, starting from 0, with the plain loop's fused multiply-adds -- bit for bit the reference loop
+/// (algorithms/spmv/thread_mapped.cuh:27-44).  What changes is who LOADS: a lane walking a 16 384-nonzero row alone has 16 loads
+/// in flight and 63 idle neighbours (C2: the few rows at the degree cap set the whole kernel's 0.64 ms).  Rows of `LONG` nonzeros
+/// or more are therefore read by the whole wavefront, 256 consecutive nonzeros per step (coalesced index / value loads, 256
+/// gathers in flight, the next step's loads issued before this step is summed), handed over through LDS, and summed by every lane
+/// in sequence (the owner keeps the result) -- the chain of dependent fused multiply-adds, 11.5 clocks per nonzero with its LDS
+/// reads, is what remains.  Shorter rows run as before, 16 / 4 / 1 at a time per lane.  Measured against the batched kernel
+/// (tests/perf/exp_thread_mapped_assisted.py, profiles/r06_thread_mapped_assisted.txt): C2 0.645 -> 0.204 ms (fp64 0.34), one row of
+/// 2^19 nonzeros 16.9 -> 2.5 ms, one row of 900 per wavefront 0.096 -> 0.043, rows of 16 / 200 and 16 rows of 400 per wavefront unchanged.
+template <int TPB, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(TPB)
+thread_mapped_assisted_spmv(const int rows, const offset_t* __restrict__ offsets, const index_t* __restrict__ indices,
+                            const type_t* __restrict__ values, const type_t* __restrict__ x, type_t* __restrict__ y) {
+    constexpr int W = wave::size, WAVES = TPB / W, U = 4, CHUNK = U * W, LONG = 128;
+  __shared__ __attribute__((aligned(16))) type_t s_v[WAVES][CHUNK];
+  __shared__ __attribute__((aligned(16))) type_t s_x[WAVES][CHUNK];
+  const int lane = wave::lane();
+  const int w = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / W);
+  const long long stride = static_cast<long long>(gridDim.x) * TPB;
+  for (long long base = static_cast<long long>(blockIdx.x) * TPB + w * W; base < rows; base += stride) {  // (wavefront-uniform)
+    const long long row = base + lane;
+    offset_t k = 0, end = 0;
+    if (row < rows) {
+      k = offsets[row];
+      end = offsets[row + 1];
+    }
+    // Which rows of this wavefront go the assisted way: those of LONG nonzeros or more -- unless there are so many of them that their
+    // start-up (two dependent memory round trips each, one row after the other: ~3 us) outweighs what the lockstep walk of all 64 rows
+    // costs (~37 ns per nonzero of the longest row; the assisted chain: ~4 ns per nonzero).  Rough constants, generous margins:
+    // 64 rows of 200 stay in lockstep (7 us against 250), one row of 900 among short ones is assisted (7 against 33).
+    bool is_long = end - k >= static_cast<offset_t>(LONG);
+    {
+      const unsigned long long longs = __ballot(is_long);
+      if (longs != 0ull) {  // (wavefront-uniform)
+        long long mine = end - k, longest = mine, long_sum = is_long ? mine : 0, short_longest = is_long ? 0 : mine;
+        for (int d = 1; d < W; d <<= 1) {
+          longest = max(longest, __shfl_xor(longest, d));
+          short_longest = max(short_longest, __shfl_xor(short_longest, d));
+          long_sum += __shfl_xor(long_sum, d);
+        }
+        const long long assisted_ns = 3000ll * __popcll(longs) + 4ll * long_sum + 37ll * short_longest, lockstep_ns = 37ll * longest;
+        if (assisted_ns >= lockstep_ns) is_long = false;
+      }
+    }
+    type_t sum = 0;
+    if (!is_long) {
+      detail::row_batches<16>(k, end, indices, values, x, sum);
+      detail::row_batches<4>(k, end, indices, values, x, sum);
+      for (; k < end; ++k) sum = detail::fused_multiply_add(values[k], x[indices[k]], sum);
+    }
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {  // the wavefront's long rows, one after the other
+      const int j = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const long long rk = detail::uniform_of_lane(static_cast<long long>(k), j), rend = detail::uniform_of_lane(static_cast<long long>(end), j);
+      index_t c_next[U];
+      type_t v_next[U], v_cur[U], x_cur[U];
+      auto load = [&](const long long b, index_t (&c)[U], type_t (&v)[U]) {  // nonzeros b + lane + 64 u; past the row: column 0, value 0
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long long at = b + lane + W * u;
+          const bool ok = at < rend;
+          c[u] = ok ? indices[at] : index_t(0);
+          v[u] = ok ? values[at] : type_t(0);
+        }
+      };
+      load(rk, c_next, v_cur);
+#pragma unroll
+      for (int u = 0; u < U; ++u) x_cur[u] = x[c_next[u]];
+      load(rk + CHUNK, c_next, v_next);
+      type_t s = 0;
+      for (long long b = rk; b < rend; b += CHUNK) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {  // (past the row's end: value 0 AND x 0 -- the gather read x[0], which may be anything)
+          s_v[w][lane + W * u] = v_cur[u];
+          s_x[w][lane + W * u] = b + lane + W * u < rend ? x_cur[u] : type_t(0);
+        }
+        // the next step's gathers and the loads of the one after it leave before this step is summed
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          v_cur[u] = v_next[u];
+          x_cur[u] = x[c_next[u]];
+        }
+        load(b + 2 * CHUNK, c_next, v_next);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int n = rend - b < CHUNK ? static_cast<int>(rend - b) : CHUNK;
+        // (32 at a time: the LDS reads of a block leave together, ahead of its chain of dependent fused multiply-adds -- one item at a
+        //  time every step waits out an LDS round trip: 120 clocks per nonzero instead of ~11.5; two register sets with the next block's
+        //  reads behind the current chain spilled and ran slower, the chain on the owner lane alone changed nothing)
+        int t = 0;
+        for (; t + 32 <= n; t += 32) {
+          type_t a[32], b32[32];
+#pragma unroll
+          for (int i = 0; i < 32; ++i) {
+            a[i] = s_v[w][t + i];
+            b32[i] = s_x[w][t + i];
+          }
+#pragma unroll
+          for (int i = 0; i < 32; ++i) s = detail::fused_multiply_add(a[i], b32[i], s);
+        }
+        for (; t < n; ++t) s = detail::fused_multiply_add(s_v[w][t], s_x[w][t], s);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == j) sum = s;
+    }
+    if (row < rows) y[row] = sum;
   }
 }
 

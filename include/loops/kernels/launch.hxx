@@ -461,7 +461,8 @@ int launch_group_mapped_fused(hipStream_t stream, int rows, int nnz, const offse
 }
 
 /// `reference_shape`: the plain loop over `config.atoms(row)` (the reference's kernel, algorithms/spmv/thread_mapped.cuh:27-44)
-/// instead of the batched one (same schedule, same bits, 5-12 x faster on this GPU: see thread_mapped_batched_spmv).
+/// instead of the tuned one (same schedule, same bits; rows 16 / 4 at a time and long rows read by the whole wavefront: 5-25 x faster
+/// on this GPU, see thread_mapped_batched_spmv / thread_mapped_assisted_spmv).
 template <typename index_t, typename offset_t, typename T>
 int launch_thread_mapped(hipStream_t stream, std::size_t rows, std::size_t cols, std::size_t nnz,
                          const offset_t* offsets, const index_t* indices, const T* values, const T* x, T* y,
@@ -474,6 +475,9 @@ int launch_thread_mapped(hipStream_t stream, std::size_t rows, std::size_t cols,
   if (reference_shape)
     launch::non_cooperative(stream, thread_mapped_spmv<setup_t, index_t, offset_t, T>, grid, dim3(block), config, rows, cols, nnz,
                             offsets, indices, values, x, y);
+  else if (rows < (std::size_t(1) << 31))  // the same rows per thread, long rows read by the whole wavefront (thread_mapped_assisted_spmv)
+    hipLaunchKernelGGL((thread_mapped_assisted_spmv<static_cast<int>(block), index_t, offset_t, T>), grid, dim3(block), 0, stream,
+                       static_cast<int>(rows), offsets, indices, values, x, y);
   else
     launch::non_cooperative(stream, thread_mapped_batched_spmv<setup_t, index_t, offset_t, T>, grid, dim3(block), config, offsets,
                             indices, values, x, y);

@@ -112,6 +112,39 @@ def test_merge_path_unaligned_views_and_f64():
         assert np.array_equal(y, ref.astype(np.float64)), sched
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_thread_mapped_with_assisted_long_rows_equals_the_reference_loop_bit_for_bit(dtype):
+    """kernels::thread_mapped_assisted_spmv: rows of 128 nonzeros or more are READ by the whole wavefront (256 per step, through LDS) and
+    summed in the row's order with the plain loop's fused multiply-adds; a wavefront with too many such rows keeps the lockstep walk.
+    Identical bits to the reference-shaped loop on REAL values: rows around the threshold and around the 256- and 32-item steps, one
+    long row per wavefront, several, ALL rows long (the lockstep choice), long rows at the matrix's ends, x[0] = inf behind the padding
+    of a step (a padded pair must contribute nothing: the gather of a lane past the row's end reads x[0])."""
+    from loops_amd import spmv as S, generate as G
+    rng = np.random.default_rng(11)
+    cols = 60_000
+    cases = {
+        "around_the_steps": np.tile(np.array([127, 128, 129, 255, 256, 257, 287, 288, 289, 511, 512, 513, 1000, 3, 0, 40] + [5] * 48, np.int64), 30),
+        "one_per_wavefront": np.where(np.arange(64 * 40) % 64 == 17, 3000, rng.integers(0, 20, size=64 * 40)),
+        "several_per_wavefront": np.where(np.arange(64 * 40) % 8 == 1, rng.integers(128, 700, size=64 * 40), rng.integers(0, 9, size=64 * 40)),
+        "all_long": np.full(64 * 12, 200, np.int64),
+        "ends": np.concatenate([[20_000], rng.integers(0, 30, size=777), [50_000]]),
+    }
+    for name, deg in cases.items():
+        deg = np.asarray(deg, np.int64)
+        off, idx, val = G.csr_from_degrees(deg, cols, len(name), 0, False)       # values U[0.5, 1.5)
+        xh = G.realistic_x(cols).astype(dtype)
+        xh[0] = np.inf                                                          # column 0 is where a lane past a row's end gathers
+        keep = idx != 0                                                         # (no nonzero may USE it)
+        val = np.where(keep, val, 0).astype(dtype); idx = np.where(keep, idx, 1).astype(np.int32)
+        csr = _dev(off, idx, val, deg.size, cols)
+        x = torch.from_numpy(xh).cuda()
+        tuned = S.spmv("thread_mapped", csr, x)
+        if dtype == np.float32:
+            assert torch.equal(tuned, S.spmv_schedule_api("thread_mapped", csr, x)), name
+        assert torch.equal(tuned, S.spmv("original", csr, x)), name          # (the plain loop `sum += values[nz] * x[indices[nz]]`)
+        assert bool(torch.isfinite(tuned).all()), name
+
+
 def test_thread_mapped_batched_equals_the_reference_loop_bit_for_bit():
     """The tuned thread_mapped (rows 16 / 4 atoms at a time, kernels::thread_mapped_batched_spmv) adds a row's products in the
     row's order with the same fused multiply-adds as the reference-shaped loop (schedule-API entry): identical bits on
