@@ -38,8 +38,8 @@ struct rowband_t {
     const int err = kernels::rowband_create<index_t, offset_t, type_t>(
         stream, static_cast<int>(rows), static_cast<int>(cols), static_cast<int>(nnzs), csr.offsets.data().get(), csr.indices.data().get(),
         csr.values.data().get(), band_rows, target_chunks, arrays);
-    error::throw_if_exception(err == kernels::rowband_e_badarg,
-                              "rowband_t: band_rows must be a power of two in [64, 16384] and every column index inside [0, cols)");
+    if (err == kernels::rowband_e_badarg)
+      throw error::bad_argument_t("rowband_t: band_rows must be a power of two in [64, 16384] and every column index inside [0, cols)");
     error::throw_if_exception(err == kernels::rowband_e_range, "rowband_t: nnz + padding (bands x (cols / 255 + 256)) must stay below 2^31");
     error::throw_if_exception(err != 0, "rowband_t: build failed");
   }

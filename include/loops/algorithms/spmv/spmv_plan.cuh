@@ -72,6 +72,8 @@ struct spmv_plan_t {
             band = std::make_unique<band_t>(csr, 0, 0, stream);
             layout = row_band_layout;
           }
+        } catch (const error::bad_argument_t&) {
+          throw;  // (the caller's mistake -- a column outside the matrix --, not a missing resource: LOOPS_E_BADARG of the C ABI)
         } catch (const std::exception&) {
           (void)hipGetLastError();  // clear the sticky error of the failed allocation
           panel.reset();

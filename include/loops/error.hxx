@@ -22,6 +22,13 @@ struct exception_t : std::exception {
   const char* what() const noexcept override { return report.c_str(); }
 };
 
+/// An argument the caller got wrong (an index outside the matrix, a size outside the documented range) -- as opposed to a
+/// resource that ran out: callers that treat a failed OPTIONAL step as "do without" (algorithms::spmv::spmv_plan_t and its
+/// re-ordered copies) let this one through, as the C ABI returns LOOPS_E_BADARG for the same input.
+struct bad_argument_t : exception_t {
+  explicit bad_argument_t(std::string message = "") : exception_t(std::move(message)) {}
+};
+
 inline void throw_if_exception(error_t status, std::string message = "") {
   if (status != xpu::success) throw exception_t(status, std::move(message));
 }

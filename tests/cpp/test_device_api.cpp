@@ -321,6 +321,35 @@ static void misc() {
       for (std::size_t i = 0; i < g0.size(); ++i) same = same && std::fabs(g0[i] - g1[i]) <= 1e-9 + 1e-12 * std::fabs(g0[i]);
       CHECK(same);
     }
+  // A column index outside the matrix is the caller's mistake, not a missing resource: the row-band copy's build reports it and
+  // spmv_plan_t lets it through in the structural AND the measured path (error::bad_argument_t; the C ABI returns LOOPS_E_BADARG
+  // for the same input) instead of quietly staying on the CSR.
+  {
+    const std::size_t rows = 2048, cols = 700000, per = 12;  // x = 2.8 MB, mean row 12: the structural rule takes the row-band copy
+    hcsr_t<float> h(rows, cols, rows * per);
+    for (std::size_t r = 0; r <= rows; ++r) h.offsets[r] = static_cast<int>(r * per);
+    for (std::size_t r = 0; r < rows; ++r)
+      for (std::size_t k = 0; k < per; ++k) {
+        h.indices[r * per + k] = static_cast<int>((r * 131 + k * 50021) % cols);
+        h.values[r * per + k] = 1.0f;
+      }
+    for (int measure = 0; measure < 2; ++measure) {
+      hcsr_t<float> bad = h;
+      bad.indices[777] = static_cast<int>(cols);  // one past the last column
+      csr_t<int, int, float> good_dev(h), bad_dev(bad);
+      bool threw = false, other = false;
+      try {
+        algorithms::spmv::spmv_plan_t<int, int, float> plan(bad_dev, /*allow_copy=*/true, measure != 0, 2);
+      } catch (const error::bad_argument_t&) {
+        threw = true;
+      } catch (const std::exception&) {
+        other = true;
+      }
+      CHECK(threw && !other);
+      algorithms::spmv::spmv_plan_t<int, int, float> plan(good_dev, /*allow_copy=*/true, measure != 0, 2);  // (the same matrix without the mistake builds)
+      CHECK(measure != 0 || plan.layout == algorithms::spmv::spmv_plan_t<int, int, float>::row_band_layout);
+    }
+  }
   // how the phased-gather kernels are configured (host logic, kernels::phased_config_for): parts by |x|, the shift that maps
   // every column below `cols` to a part below `parts`, at most 16 parts for 8-byte values
   for (long long cols : {1ll, 2ll, 9ll, 1000ll, 1ll << 20, (1ll << 20) + 1, 1ll << 21, 1ll << 23, (1ll << 24) - 3, (1ll << 31) - 1}) {
