@@ -190,6 +190,7 @@ def context_c3_standins(G, S, O, torch, iters=10):
         # columns are scattered and LOSES where they are local; another template instantiation than the headline's, 512 x 8 / 8 parts)
         pplan = S.MergePathPlan(csr, "256x16")
         runs = {"group_mapped": lambda: S.spmv("group_mapped", csr, x, y), "work_oriented": lambda: S.spmv("work_oriented", csr, x, y),
+                "merge_path_flat_plan_less": lambda: S.spmv("merge_path_flat", csr, x, y),
                 "merge_path_flat": lambda: S.merge_path_flat(csr, x, y, plan=mplan),
                 "merge_path_flat_phased_gathers": lambda: S.merge_path_flat(csr, x, y, plan=pplan, variant=VARIANT_PHASED)}
         # which kernels an entry launches on a matrix of this size (the one-shot entries decide by size: abi_csr.inc)
@@ -197,7 +198,9 @@ def context_c3_standins(G, S, O, torch, iters=10):
                                     "the entry's memo says nothing was published)",
                     "work_oriented": "shares of ONE tile through merge_path_flat's one-shot launch (sampled columns, merge_path_spmv_fused_auto: plain or "
                                      "phased gathers decided on the device) -- the persistent work_oriented_spmv_fused only below the sampling threshold (x < 3 MB)",
-                    "merge_path_flat": "merge_path_spmv_fused_planned<256, 8> (held plan) + fix-up",
+                    "merge_path_flat_plan_less": "what algorithms::spmv::merge_path_flat(csr, x, y) / loops_spmv_csr_f32(MERGE_PATH_FLAT) give: coordinate pre-pass + "
+                                                 "merge_path_spmv_fused_auto<256, 16, 32> (gather order decided on the device from the remembered column sample) + fix-up",
+                    "merge_path_flat": "merge_path_spmv_fused_planned<256, 8> (held plan, PLAIN gathers: variant 0 as asked for) + fix-up",
                     "merge_path_flat_phased_gathers": "merge_path_spmv_fused_phased_planned<256, 16, 32> (held plan) + fix-up"}
         for sched, fn in runs.items():
             ms = timed_ms(torch, fn, iters)
