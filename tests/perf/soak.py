@@ -341,6 +341,8 @@ for name, (deg, window) in cases.items():
     kernels = {f"merge_path_flat {t} (self={int(p.self_complete)})": (lambda y, p=p: S.merge_path_flat(csr, x, y, plan=p)) for t, p in plans.items()}
     kernels["work_oriented"] = lambda y: S.spmv("work_oriented", csr, x, y)
     kernels["group_mapped"] = lambda y: S.spmv("group_mapped", csr, x, y)
+    kernels["thread_mapped (assisted long rows)"] = lambda y: S.spmv("thread_mapped", csr, x, y)
+    kernels["work_oriented, held plan"] = lambda y, p=plans["256x8"]: S.work_oriented(csr, x, y, plan=p)
     kernels["row_band"] = lambda y: cb.spmv(x, y)
     kernels["row_band, cut bands, 16 wavefronts"] = lambda y: cb16.spmv(x, y)
     for label, fn in kernels.items():
