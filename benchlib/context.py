@@ -236,7 +236,8 @@ def context_schedules(S, torch, csr, x, ref_y, abytes, iters=50):
     # the plan-less entries, whole calls (coordinates rebuilt per call as the reference's wrappers do; the column sample behind the choice
     # of gather order is remembered per matrix) -- "merge_path_flat_one_shot" is what a caller of the reference's API gets without a plan
     for key, sched in (("merge_path_flat_one_shot", "merge_path_flat"), ("work_oriented", "work_oriented"), ("group_mapped", "group_mapped"),
-                       ("thread_mapped", "thread_mapped")):   # (thread_mapped: a thread owns whole rows, sums in the row's order -- the reference loop's bits)
+                       ("thread_mapped", "thread_mapped"),   # (a thread owns whole rows, sums in the row's order -- the reference loop's bits)
+                       ("flat_partitioned", "flat_partitioned")):  # (runs stitched per wavefront, one atomic per row and wavefront; y zero-filled by the entry)
         ms = timed_ms(torch, lambda: S.spmv(sched, csr, x, y), iters)
         out[key] = {"ms_per_spmv": round(ms, 5), "GFLOPs": round(2.0 * csr.nnzs / ms / 1e6, 1),
                     "frac": round(abytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "equals_merge_path_y": bool(torch.equal(y, ref_y))}
