@@ -17,6 +17,7 @@
 #include <cstdint>
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <loops/kernels/merge_path_spmv.hxx>
 #include <loops/util/math.hxx>
@@ -181,6 +182,151 @@ __global__ void __launch_bounds__(256)
 gather_values(const int n, const int* __restrict__ perm, const type_t* __restrict__ from, type_t* __restrict__ to) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) to[i] = from[perm[i]];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BINNED one-shot CSC product.  csc_nonzero_split_spmv pays one memory-side atomic per nonzero (the rows of a column are
+// scattered; C2: 1.1 ms = 15 G atomics/s, the reference's shape 1.15 ms).  Here the products travel instead:
+//   1. csc_products: p[k] = values[k] * x[column of k] (x is a broadcast read: no gather at all);
+//   2. ONE radix pass per 8 bits of (row / 4096) -- hipcub SortPairs over the row indices as they are, bits 12 and up -- moves
+//      (row, product) into bins of 4 096 consecutive rows, stably;
+//   3. csc_bin_bounds + csc_reduce_bins: a workgroup adds a bin's products up in LDS (fp64 words, one ds_add_f64 per product) and stores
+//      adds them to the bin's 4 096 rows of y (zero-filled by the caller, like the atomic kernels' y).  A bin of more than `csc_bin_chunk`
+//      products is shared by up to 8 workgroups, which add their sums with one atomic per row and workgroup.
+// Sums: unordered fp64 in LDS, rounded once (several workgroups: once each) -- exact on exactly summable inputs, within an ulp of the
+// fp64 sum otherwise; the reference's kernel adds with fp32 atomics in an order that varies from run to run.
+constexpr int csc_bin_rows = 4096, csc_bin_shift = 12, csc_bin_chunk = 1 << 17;
+
+template <int IPT, typename index_t, typename offset_t, typename type_t>
+__global__ void __launch_bounds__(256)
+csc_products(const int cols, const int nnz, const offset_t* __restrict__ offsets, const type_t* __restrict__ values, const type_t* __restrict__ x,
+             type_t* __restrict__ products) {
+  const long long base_ll = (static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x) * IPT;
+  if (base_ll >= nnz) return;
+  const int base = static_cast<int>(base_ll);
+  int col = 0, count = cols;  // column of nonzero `base`: last c with offsets[c] <= base
+  while (count > 0) {
+    const int half = count >> 1;
+    const int mid = col + half;
+    if (offsets[mid + 1] <= base) {
+      col = mid + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  int next = static_cast<int>(offsets[col + 1]);
+  type_t xc = x[col];
+#pragma unroll
+  for (int i = 0; i < IPT; ++i) {
+    const int k = base + i;
+    if (k >= nnz) break;
+    while (k >= next) {  // (empty columns are stepped over)
+      ++col;
+      next = static_cast<int>(offsets[col + 1]);
+      xc = x[col];
+    }
+    products[k] = values[k] * xc;
+  }
+}
+
+/// bounds[b] = first position of the sorted rows that lies in bin b or later (b in [0, bins]): a lane per bound, a halving search.
+template <typename index_t>
+__global__ void __launch_bounds__(256)
+csc_bin_bounds(const int nnz, const int bins, const index_t* __restrict__ sorted_rows, int* __restrict__ bounds) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b > bins) return;
+  const long long first_row = static_cast<long long>(b) << csc_bin_shift;
+  int lo = 0, count = nnz;
+  while (count > 0) {
+    const int half = count >> 1;
+    if (static_cast<long long>(sorted_rows[lo + half]) < first_row) {
+      lo += half + 1;
+      count -= half + 1;
+    } else {
+      count = half;
+    }
+  }
+  bounds[b] = lo;
+}
+
+/// Workgroup (bin, share): a bin of at most csc_bin_chunk products is added up by share 0 alone, which adds its sums to the bin's rows
+/// of y with plain read-modify-writes; a larger bin is cut into chunks of csc_bin_chunk products dealt to the gridDim.y shares in
+/// turn, each of which adds its LDS sums to y with one atomic per row it touched.  Shares without work return at once.
+template <typename index_t, typename type_t>
+__global__ void __launch_bounds__(512)
+csc_reduce_bins(const int rows, const int* __restrict__ bounds, const index_t* __restrict__ sorted_rows, const type_t* __restrict__ sorted_products,
+                type_t* __restrict__ y) {
+  __shared__ double s_acc[csc_bin_rows];
+  const int bin = blockIdx.x;
+  const long long bin_begin = bounds[bin], bin_end = bounds[bin + 1];
+  const bool shared = bin_end - bin_begin > csc_bin_chunk;                            // (workgroup-uniform)
+  if (!shared && blockIdx.y > 0) return;
+  if (shared && bin_begin + static_cast<long long>(blockIdx.y) * csc_bin_chunk >= bin_end) return;
+  for (int i = threadIdx.x; i < csc_bin_rows; i += 512) s_acc[i] = 0.0;
+  __syncthreads();
+  for (long long begin = bin_begin + static_cast<long long>(blockIdx.y) * csc_bin_chunk; begin < bin_end;
+       begin += static_cast<long long>(gridDim.y) * csc_bin_chunk) {
+    const long long end = begin + csc_bin_chunk < bin_end ? begin + csc_bin_chunk : bin_end;
+    for (long long k = begin + threadIdx.x; k < end; k += 512)
+      atomicAdd(&s_acc[static_cast<int>(sorted_rows[k]) & (csc_bin_rows - 1)], static_cast<double>(sorted_products[k]));
+  }
+  __syncthreads();
+  const long long row0 = static_cast<long long>(bin) << csc_bin_shift;
+  for (int i = threadIdx.x; i < csc_bin_rows; i += 512) {
+    if (row0 + i >= rows) break;
+    if (s_acc[i] == 0.0) continue;
+    if (shared) atomicAdd(&y[row0 + i], static_cast<type_t>(s_acc[i]));
+    else y[row0 + i] = y[row0 + i] + static_cast<type_t>(s_acc[i]);  // (this workgroup alone touches the bin's rows)
+  }
+}
+
+/// Scratch of launch_csc_binned: products + sorted rows + sorted products + bin bounds + the sort's own.
+template <typename index_t, typename type_t>
+inline std::size_t csc_binned_scratch_bytes(int rows, int nnz) {
+  const std::size_t n = static_cast<std::size_t>(nnz > 0 ? nnz : 1), bins = static_cast<std::size_t>(rows) / csc_bin_rows + 2;
+  std::size_t sort_bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, static_cast<const unsigned int*>(nullptr), static_cast<unsigned int*>(nullptr),
+                                            static_cast<const type_t*>(nullptr), static_cast<type_t*>(nullptr), nnz, csc_bin_shift, 32);
+  auto up = [](std::size_t b) { return (b + 255) & ~std::size_t(255); };
+  return up(sizeof(type_t) * n) * 2 + up(sizeof(index_t) * n) + up(sizeof(int) * (bins + 1)) + up(sort_bytes) + 256;
+}
+
+/// y += A x for a CSC matrix by binned products (file section above): y zero-filled by the caller, as for the atomic kernels (a row's
+/// sum is ADDED to what y holds).  int row indices.
+template <typename offset_t, typename type_t>
+int launch_csc_binned(hipStream_t stream, int rows, int cols, int nnz, const offset_t* offsets, const int* row_indices, const type_t* values,
+                      const type_t* x, type_t* y, void* scratch) {
+  if (rows <= 0) return 0;
+  if (nnz <= 0) return 0;
+  auto up = [](std::size_t b) { return (b + 255) & ~std::size_t(255); };
+  const std::size_t n = static_cast<std::size_t>(nnz);
+  const int bins = (rows + csc_bin_rows - 1) / csc_bin_rows;
+  char* p = static_cast<char*>(scratch);
+  type_t* products = reinterpret_cast<type_t*>(p); p += up(sizeof(type_t) * n);
+  type_t* sorted_products = reinterpret_cast<type_t*>(p); p += up(sizeof(type_t) * n);
+  unsigned int* sorted_rows = reinterpret_cast<unsigned int*>(p); p += up(sizeof(int) * n);
+  int* bounds = reinterpret_cast<int*>(p); p += up(sizeof(int) * (static_cast<std::size_t>(rows) / csc_bin_rows + 3));
+  void* sort_temp = p;
+  constexpr int IPT = 8;
+  hipLaunchKernelGGL((csc_products<IPT, int, offset_t, type_t>), dim3(math::ceil_div(math::ceil_div(nnz, IPT), 256)), dim3(256), 0, stream, cols, nnz, offsets,
+                     values, x, products);
+  int top = csc_bin_shift;  // bits of (rows - 1) above the bin: one 8-bit radix pass for up to 2^20 rows
+  while (top < 32 && ((static_cast<unsigned int>(rows - 1)) >> top) != 0u) ++top;
+  if (top == csc_bin_shift) top = csc_bin_shift + 1;
+  std::size_t sort_bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, reinterpret_cast<const unsigned int*>(row_indices), sorted_rows, products,
+                                                    sorted_products, nnz, csc_bin_shift, top, stream);
+  if (e == hipSuccess)
+    e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_bytes, reinterpret_cast<const unsigned int*>(row_indices), sorted_rows, products, sorted_products,
+                                           nnz, csc_bin_shift, top, stream);
+  if (e != hipSuccess) return static_cast<int>(e);
+  hipLaunchKernelGGL((csc_bin_bounds<unsigned int>), dim3(math::ceil_div(bins + 1, 256)), dim3(256), 0, stream, nnz, bins, sorted_rows, bounds);
+  // (8 shares per bin: the host does not know the bins' sizes; a bin beyond 8 chunks -- an eighth of C2 in ONE bin of 4 096 rows -- has its
+  //  chunks dealt to the 8 shares in turn)
+  hipLaunchKernelGGL((csc_reduce_bins<unsigned int, type_t>), dim3(bins, nnz > csc_bin_chunk ? 8 : 1), dim3(512), 0, stream, rows, bounds, sorted_rows,
+                     sorted_products, y);
+  return static_cast<int>(hipGetLastError());
 }
 
 }  // namespace kernels

@@ -321,6 +321,35 @@ static void misc() {
       for (std::size_t i = 0; i < g0.size(); ++i) same = same && std::fabs(g0[i] - g1[i]) <= 1e-9 + 1e-12 * std::fabs(g0[i]);
       CHECK(same);
     }
+  // csc_thread_mapped from 2^20 nonzeros on: the binned product (kernels::launch_csc_binned) instead of one atomic per nonzero; exactly
+  // summable values, so the result is bit for bit the CSR product of the same matrix.  One hub row (a bin shared by several workgroups).
+  {
+    const std::size_t rows = 150001, cols = 40000, per = 7, hub = 30000;
+    std::size_t nnz = rows * per + (hub - per);
+    hcsr_t<float> h(rows, cols, nnz);
+    std::size_t k = 0;
+    for (std::size_t r = 0; r < rows; ++r) {
+      h.offsets[r] = static_cast<int>(k);
+      const std::size_t deg = r == 777 ? hub : per;
+      for (std::size_t j = 0; j < deg; ++j, ++k) {
+        h.indices[k] = static_cast<int>(deg == hub ? j : (r * 37 + j * 5003) % cols);  // (distinct within a row)
+        h.values[k] = static_cast<float>((static_cast<int>((r + 3 * j) % 17) - 8)) / 8.0f;
+      }
+    }
+    h.offsets[rows] = static_cast<int>(k);
+    CHECK(k == nnz && nnz >= (std::size_t(1) << 20));
+    vector_t<float, H> hx(cols);
+    for (std::size_t c = 0; c < cols; ++c) hx[c] = static_cast<float>(1 + c % 9);
+    csr_t<int, int, float> a(h);
+    csc_t<int, int, float> c(a);
+    vector_t<float> x(hx), y0(rows, -1.f), y1(rows, 0.f);
+    algorithms::spmv::merge_path_flat(a, x, y0);
+    algorithms::spmv::csc_thread_mapped(c, x, y1);
+    vector_t<float, H> g0(y0), g1(y1);
+    bool same = true;
+    for (std::size_t i = 0; i < rows; ++i) same = same && g0[i] == g1[i];
+    CHECK(same);
+  }
   // A column index outside the matrix is the caller's mistake, not a missing resource: the row-band copy's build reports it and
   // spmv_plan_t lets it through in the structural AND the measured path (error::bad_argument_t; the C ABI returns LOOPS_E_BADARG
   // for the same input) instead of quietly staying on the CSR.

@@ -105,3 +105,30 @@ def test_spmm_plan_f64(n):
     want = np.stack([O.spmv_f64(off, idx, val, np.ascontiguousarray(B[:, j])) for j in range(n)], axis=1)
     assert np.array_equal(got, want)
     assert np.array_equal(S.spmm(csr, torch.from_numpy(B).cuda()).cpu().numpy(), want)  # plan-less f64 entry
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_csc_one_shot_binned_product(dtype):
+    """loops_spmv_csc_* mode 1 from 2^20 nonzeros on: the binned product (kernels::launch_csc_binned -- products, one radix pass into bins
+    of 4 096 rows, fp64 LDS sums) instead of one atomic per nonzero.  Exactly summable inputs: BIT-EXACT against the CSR product of the
+    same matrix; a hub row (a bin shared by several workgroups), empty columns, a row count that is no multiple of the bin, repeated
+    calls on one stream (the scratch is reused), and a matrix below the threshold (the atomic kernel) beside it."""
+    import scipy.sparse as sp
+    from loops_amd import generate as G, spmv as S
+    rng = np.random.default_rng(3)
+    for rows, cols, nnz_target, hub in ((70_001, 90_000, 1_300_000, 60_000), (300_000, 50_000, 1_100_000, 0), (3000, 4000, 40_000, 0)):
+        deg = G.powerlaw_degrees(rows, nnz_target, cap=min(1 << 12, cols)).astype(np.int64)
+        if hub:
+            deg[12345] = hub                                                   # (two thirds of the columns: its bin is shared by several workgroups)
+        off, idx, val = G.csr_from_degrees(deg, cols, 5, 0, True)
+        m = sp.csr_matrix((val.astype(np.float64), idx, off), shape=(rows, cols))
+        xh = G.uniform_distribution_int(cols)
+        want = (m @ xh.astype(np.float64)).astype(dtype)
+        c = m.tocsc(); c.sort_indices()
+        coff, ridx, cval = c.indptr.astype(np.int32), c.indices.astype(np.int32), c.data.astype(dtype)
+        assert (ridx.size >= 1 << 20) == (nnz_target > 1 << 20)
+        d = [torch.from_numpy(a).cuda() for a in (coff, ridx, cval, xh.astype(dtype))]
+        for _ in range(3):
+            y = torch.full((rows,), 9.0, dtype=d[2].dtype, device="cuda")
+            S.csc_spmv(rows, cols, d[0], d[1], d[2], d[3], y, tuned=True)
+            assert np.array_equal(y.cpu().numpy(), want), (rows, cols, ridx.size)
