@@ -40,7 +40,7 @@ template <typename index_t, typename offset_t, typename type_t>
 util::timer_t csc_thread_mapped(csc_t<index_t, offset_t, type_t>& csc, vector_t<type_t>& x, vector_t<type_t>& y,
                                 xpu::stream_t stream = 0) {
   // From 2^20 nonzeros on the products TRAVEL instead of one memory-side atomic each (kernels::launch_csc_binned: products, one radix
-  // pass into bins of 4 096 rows, LDS sums -- C2 0.38 against 1.03 ms, a hub row of 2^19 nonzeros 0.32 against 6.6); its scratch is
+  // pass into bins of 4 096 rows, LDS sums -- C2 0.26 against 1.03 ms, a hub row of 2^19 nonzeros 0.21 against 6.6); its scratch is
   // this call's (allocated outside the timed region).
   constexpr bool binnable = std::is_same<index_t, int>::value && (std::is_same<type_t, float>::value || std::is_same<type_t, double>::value);
   vector_t<unsigned char> scratch;

@@ -516,8 +516,8 @@ int loops_autotune_merge_path_variants_f32(int rows, int cols, int nnz, const in
  * mode 0: lane per column (reference shape), y zero-filled by the CALLER; mode 1: tuned -- the nonzeros
  * are split evenly over the lanes (8 consecutive ones each, 16-byte loads, column found by a search over
  * the column offsets), one atomicAdd per nonzero, y zero-filled here; from 2^20 nonzeros on the BINNED product instead
- * (include/loops/kernels/csc_spmv.hxx: products, one radix pass into bins of 4 096 rows, fp64 LDS sums -- no atomic per nonzero:
- * C2 0.38 against 1.03 ms, a hub row of 2^19 nonzeros 0.32 against 6.6 ms; sums exact on exactly summable inputs, within an ulp
+ * (include/loops/kernels/csc_spmv.hxx: products counted and scattered into bins of 4 096 rows, fp64 LDS sums -- no atomic per nonzero:
+ * C2 0.26 against 1.03 ms, a hub row of 2^19 nonzeros 0.21 against 6.6 ms; sums exact on exactly summable inputs, within an ulp
  * of the fp64 sum otherwise; uses a per-stream scratch block of ~3 x 4 bytes per nonzero that loops_release_scratch frees). */
 int loops_spmv_csc_f32(int mode, int rows, int cols, int nnz, const int* col_offsets, const int* row_indices,
                        const float* values, const float* x, float* y, void* stream);

@@ -5,6 +5,7 @@
 using namespace loops;
 extern "C" long long csc_binned_bytes(int rows, int nnz) { return (long long)kernels::csc_binned_scratch_bytes<int, float>(rows, nnz); }
 extern "C" int csc_binned(int rows, int cols, int nnz, const int* off, const int* ridx, const float* val, const float* x, float* y, void* scratch, void* st) {
+  (void)hipMemsetAsync(y, 0, sizeof(float) * rows, static_cast<hipStream_t>(st));  // (the product ADDS to y, like the atomic kernels)
   return kernels::launch_csc_binned(static_cast<hipStream_t>(st), rows, cols, nnz, off, ridx, val, x, y, scratch);
 }
 extern "C" int csc_atomic(int rows, int cols, int nnz, const int* off, const int* ridx, const float* val, const float* x, float* y, void* st) {

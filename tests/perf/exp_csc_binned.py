@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np, scipy.sparse as sp, torch
 from loops_amd import generate as G
-L = C.CDLL(os.path.join(ROOT, "build", "variants", "libcsc_binned.so"))
+L = C.CDLL(os.environ.get("CSC_LIB", os.path.join(ROOT, "build", "variants", "libcsc_binned.so")))
 L.csc_binned_bytes.restype = C.c_longlong
 vp = C.c_void_p
 
