@@ -193,6 +193,14 @@ def round6():
     for sched in ("group_mapped", "merge_path_flat"):
         soak("c2x8", sched + " plan-less, x = 8 MB, one hub row", lambda y, sched=sched: (S.spmv(sched, csr8, x8, y), None)[1], ref8, rows)
     del csr8
+    # one-shot CSC: the binned product (count / scan / scatter into bins of 4 096 rows, fp64 LDS sums) on C2's matrix and on R-MAT (shared bins)
+    import scipy.sparse as sp
+    for tag, (o_, i_, v_) in (("c2csc", G.powerlaw_csr(rows, cols, 1 << 24)), ("rmatcsc", G.rmat_csr(20, 16, relabel="none"))):
+        m = sp.csr_matrix((v_.astype(np.float64), i_, o_), shape=(rows, cols))
+        refc = torch.from_numpy((m @ xh.astype(np.float64)).astype(np.float32)).cuda()
+        c = m.tocsc(); c.sort_indices()
+        dc = [torch.from_numpy(a).cuda() for a in (c.indptr.astype(np.int32), c.indices.astype(np.int32), c.data.astype(np.float32))]
+        soak(tag, "csc one-shot, binned products", lambda y: (S.csc_spmv(rows, cols, dc[0], dc[1], dc[2], x, y, tuned=True), None)[1], refc, rows)
     off3, idx3, val3 = G.csr_from_degrees(G.powerlaw_degrees(rows, 1 << 24), cols, 1)
     csr3 = S.CSR.from_numpy(rows, cols, off3, idx3, val3.astype(np.float64))
     x64 = torch.from_numpy(xh.astype(np.float64)).cuda()
