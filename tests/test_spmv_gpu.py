@@ -1032,3 +1032,27 @@ def test_planless_device_decided_kernel(schedule, window, dtype, log2_cols):
         torch.cuda.synchronize()
         assert torch.equal(yg, w)
     plan.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("window", [None, 4096], ids=["scattered", "banded"])
+def test_work_oriented_over_a_held_plan_on_a_large_x(window, dtype):
+    """loops_spmv_work_oriented_* over an x of 3 MB or more (8-byte values: 6 MB): shares of ONE tile through merge_path_flat's launch over the
+    plan's 256 x 8 tiles, the gather order decided on the device from a sample of the columns the plan remembers (first call) -- 16 parts at
+    this |x|.  Both decisions give the bits of the plain held-plan merge_path_flat, call after call, and after the plan has served another
+    matrix of the same shape (the remembered sample is then stale: the ORDER of the gathers only)."""
+    from loops_amd import spmv as S, generate as G
+    rows, cols = 1 << 17, 1 << 21                                   # x = 8 MB (f32) / 16 MB (f64)
+    deg = G.powerlaw_degrees(rows, 1 << 21, cap=1 << 12)
+    mats = []
+    for seed in (1, 2):
+        off, idx, val = G.csr_from_degrees(deg, cols, seed, 0, True, window)
+        mats.append(_dev(off, idx, val.astype(dtype), rows, cols))
+    x = torch.from_numpy(G.uniform_distribution_int(cols).astype(dtype)).cuda()
+    plan = S.MergePathPlan(mats[0], "256x8")                        # (same offsets for both matrices: one plan serves both)
+    want = [S.merge_path_flat(m, x, plan=plan).clone() for m in mats]
+    for which in (0, 0, 1, 0, 1, 1):
+        y = torch.full((rows,), -2.0, dtype=x.dtype, device="cuda")
+        S.work_oriented(mats[which], x, y, plan=plan)
+        assert torch.equal(y, want[which]), which
+    plan.close()
